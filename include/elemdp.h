@@ -1,0 +1,149 @@
+/* elemdp.h -- C ABI of libelemdp.so, the MI355X-native inside/outside/CYK engine.
+ *
+ * The reference (iyak/RNAelem @ 2024_08_07) has no FFI: its de-facto operator interface for this
+ * path is C++ duck typing,
+ *     int  RNAelemTrainer::operator()(V const& x, double& fn, V& gr)   RNAelem/motif_trainer.hpp:595
+ *     void RNAelemScanner::scan(RNAelem& model)                        RNAelem/motif_scanner.hpp:938
+ * consumed by Lbfgsb::minimize / Adam::minimize (RNAelem/optimizer.hpp:146, :298) and main()
+ * (RNAelem/main.cpp:47-130).  This header is the boundary a maintainer would bind instead
+ * (INTEGRATION.md shows the C++ shim that drops into motif_trainer.hpp / motif_scanner.hpp).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success, a negative
+ * ELEMDP_E* code otherwise (elemdp_last_error() gives the message); no exceptions cross the
+ * boundary.  Caller owns every buffer it passes; inputs are copied during the call.  One handle =
+ * one GPU = one caller thread.  The library has NO CPU fallback: without a usable HIP device
+ * elemdp_create fails with ELEMDP_ENODEV.
+ */
+#ifndef ELEMDP_H
+#define ELEMDP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELEMDP_ABI_VERSION 1
+
+enum { /* status codes */
+  ELEMDP_OK = 0,
+  ELEMDP_EINVAL = -1,  /* bad argument / malformed pattern or parameter text */
+  ELEMDP_ENODEV = -2,  /* no HIP device */
+  ELEMDP_EHIP = -3,    /* HIP runtime error */
+  ELEMDP_ESTATE = -4,  /* call order (e.g. train_eval before load_batch) */
+  ELEMDP_ENOMEM = -5,
+};
+
+enum { /* elemdp_model_desc.flags */
+  ELEMDP_NO_RSS = 1 << 0,        /* --no-rss       RNAelem/application.hpp:259, motif_model.hpp:171-206 */
+  ELEMDP_NO_PROFILE = 1 << 1,    /* --no-profile   RNAelem/application.hpp:265 */
+  ELEMDP_NO_ENERGY = 1 << 2,     /* --no-energy    RNAelem/application.hpp:271 */
+  ELEMDP_THETA_SOFTMAX = 1 << 3, /* --theta-softmax RNAelem/application.hpp:289 */
+  /* runtime forms of the reference's compile-time test switches (RNAelem/const_options.hpp:12-24) */
+  ELEMDP_DBG_FIX_RSS = 1 << 9,   /* structure fixed per sequence (elemdp_load_batch `fix_rss`) */
+  ELEMDP_DBG_NO_TURN = 1 << 10,  /* hairpins of any size */
+};
+
+/* Model description == what main.cpp:89-101 / RNAelemReader::read_model (motif_io.hpp:118-262)
+ * put into an `RNAelem` object before the optimizer / scanner is started. */
+typedef struct {
+  const char* pattern;      /* search pattern, e.g. "((.*.))"         --motif-pattern        */
+  const char* energy_param; /* ViennaRNA-2.0 parameter TEXT, or NULL / "~T2004~" / "~A2007~"
+                               for the shipped tables (data dir: elemdp_set_data_dir)      */
+  int32_t max_span;         /* --max-span           (default 50)                            */
+  int32_t max_iloop;        /* --max-internal-loop  (default 30)                            */
+  double min_bpp;           /* --min-bpp            (default 1e-4; 0 = no BPP filter)       */
+  double tau;               /* --tau                (default 0.1)                           */
+  int32_t flags;            /* ELEMDP_* bits                                                */
+  int32_t device;           /* HIP device ordinal; -1 = current                             */
+} elemdp_model_desc;
+
+typedef struct elemdp_handle elemdp_handle;
+
+const char* elemdp_last_error(void);
+int elemdp_abi_version(void);
+/* directory holding turner2004.elempar / andronescu2007.elempar (default: next to the library) */
+int elemdp_set_data_dir(const char* dir);
+
+/* Builds the pattern automaton (RNAelem::set_motif_pattern, motif_model.hpp:80-97) and the energy
+ * tables (EnergyModel::set_param_file, energy_model.hpp:153-161), uploads them, creates streams. */
+int elemdp_create(const elemdp_model_desc* desc, elemdp_handle** out);
+int elemdp_destroy(elemdp_handle* h);
+
+/* Sizes: n_param = #theta entries + 2 (pack_params order, motif_model.hpp:147-157);
+ * n_state = S interval states; n_node = M pattern nodes (incl. 'z' and 'o'). */
+int elemdp_n_param(const elemdp_handle* h);
+int elemdp_n_state(const elemdp_handle* h);
+int elemdp_n_node(const elemdp_handle* h);
+/* x0 exactly as the reference CLI builds it: uniform log-probability rows (profile_hmm.hpp:286-313;
+ * zeros when theta-softmax), then lambda_init twice (motif_trainer.hpp:565). */
+int elemdp_initial_params(const elemdp_handle* h, double lambda_init, double* x, int32_t n_param);
+/* JSON description of the automaton (states, transition lists) for inspection / host-logic tests. */
+int elemdp_describe(const elemdp_handle* h, char* buf, int32_t cap);
+
+/* Replaces the resident batch (== FastqReader contents, fastq_io.hpp:64-108):
+ *   seq_codes : concatenated base codes N,A,C,G,U -> 0..4 (bio_sequence.hpp:28-39)
+ *   seq_off   : n_seq+1 offsets;   qual : char-33 values, L+1 per sequence;   qual_off likewise
+ *   fix_rss   : NULL, or concatenated dot-bracket strings (seq_off indexing) with ELEMDP_DBG_FIX_RSS
+ * Runs the parameter-independent part once on the GPU and keeps it resident:
+ * the BPP filter (EnergyModel::set_seq .. fill_bpp_tables, energy_model.hpp:211-276) and the
+ * structural energy terms of every admissible rule (energy_param.hpp:686-795). */
+int elemdp_load_batch(elemdp_handle* h, const uint8_t* seq_codes, const int32_t* seq_off, const uint8_t* qual,
+                      const int32_t* qual_off, const char* fix_rss, int32_t n_seq);
+/* per-sequence results of the BPP filter: bpp_eff[n_seq] (energy_model.hpp:265) */
+int elemdp_batch_bpp_eff(elemdp_handle* h, double* bpp_eff, int32_t n_seq);
+/* kept[(L+1)*(W+1)] (index i*(W+1)+d) of one sequence after the filter; lnbpp may be NULL */
+int elemdp_batch_pairs(elemdp_handle* h, int32_t seq_index, uint8_t* kept, double* lnbpp, int32_t cap);
+
+/* == RNAelemTrainer::operator()(x, fn, gr) over the whole resident batch with --no-shuffle
+ * (motif_trainer.hpp:595-633 + RNAelemTrainDP::operator() :124-272).  fn/gr are the UNREGULARISED
+ * sums (the optimizer adds rho*x^2/2, optimizer.hpp:246-260).  sum_eff = sum of bpp_eff over used
+ * sequences (:227); n_skipped = sequences with non-finite Z (:211-215). */
+int elemdp_train_eval(elemdp_handle* h, const double* x, int32_t n_param, double* fn, double* gr,
+                      double* sum_eff, int32_t* n_skipped);
+
+/* Multi-GPU form: the same evaluation, but stops before the cross-rank sum.  `partial` (device or
+ * host pointer, elemdp_partial_len(h) doubles) receives this rank's
+ *   [fn, sum_eff, n_used, n_skipped, ENo[n_theta], ENx[n_theta], EHo[2], EHx[2]]
+ * The caller all-reduces (sum) it over RCCL -- the MI355X replacement of the reference's
+ * file-based array-job sum (motif_array_trainer.hpp:20-58) -- and then calls
+ * elemdp_train_finish on the reduced vector (host pointer) to obtain fn / gr. */
+int elemdp_partial_len(const elemdp_handle* h);
+int elemdp_train_partial(elemdp_handle* h, const double* x, int32_t n_param, void* partial, int32_t partial_is_device);
+int elemdp_train_finish(elemdp_handle* h, const double* reduced, double* fn, double* gr, double* sum_eff,
+                        int32_t* n_skipped);
+
+/* per-sequence diagnostics of the last train evaluation: 5 doubles per sequence
+ * [Z(ari,nasi), Z(ari), Z(nasi), f_n, skipped] (motif_trainer.hpp:108-112, 204-227) */
+int elemdp_train_seq_stats(elemdp_handle* h, double* out, int32_t n_seq);
+/* debug: tables of ONE sequence after a train evaluation of a batch holding only that sequence:
+ * inside_o/outside_o [(L+1)*S]; inside/outside [(L+1)*(W+1)*7*S] in the reference's index order
+ * [i][d][e][s] (motif_trainer.hpp:62-65); outside = the first (full-terminal) pass.  Any may be NULL.
+ * ENo/ENx [n_theta], EH [4] = EHo,EHx. */
+int elemdp_debug_tables(elemdp_handle* h, double* inside, double* outside, double* inside_o, double* outside_o,
+                        double* ENo, double* ENx, double* EH);
+
+/* == RNAelemScanner::scan (motif_scanner.hpp:938-949, per-sequence worker :215-260), input order
+ * preserved.  Caller-provided arrays use the batch offsets: start/inner at seq_off[n] (L values),
+ * end at qual_off[n] (L+1 values), psihat/rss at seq_off[n]; per-sequence scalars indexed by n. */
+typedef struct {
+  double* start;      /* log P(motif starts at p)                  "start:"  */
+  double* end;        /* log P(motif ends at p | start = Ys)       "end:"    */
+  double* inner;      /* log P(p inside motif)                     "inner:"  */
+  int32_t* psihat;    /* CYK motif node per position               "psihat:" */
+  char* rss;          /* CYK structure letters O L R H B I M       "rss:"    */
+  int32_t* ys;        /* argmax start (last maximum, util.hpp:232) "motif region:" */
+  int32_t* ye;
+  double* exist_prob; /* exp(logsumexp(start))                     "exist prob:" */
+  double* en;         /* n_theta expected emission counts summed over the batch ("E[N]:"), may be NULL */
+} elemdp_scan_out;
+int elemdp_scan(elemdp_handle* h, const double* x, int32_t n_param, elemdp_scan_out* out);
+
+/* timing of the last train evaluation, measured with HIP events on the engine's stream:
+ * ms[0] = whole evaluation, ms[1] = the fused inside/outside kernel only */
+int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n);
+/* name of the dominant kernel (for matching rocprofv3 rows) */
+const char* elemdp_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELEMDP_H */

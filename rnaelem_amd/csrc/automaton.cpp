@@ -1,0 +1,318 @@
+// automaton.cpp -- see automaton.h.  Host only.
+#include "automaton.h"
+
+#include <algorithm>
+#include <sstream>
+#include <stdexcept>
+
+namespace elemdp {
+namespace {
+
+bool is_background(char c) { return c == 'z' || c == '*' || c == 'o'; }
+bool emits_single(char c) { return c == 'z' || c == '.' || c == '*' || c == 'o'; }
+bool is_weighted(char c) { return c == '.' || c == '(' || c == ')'; }  // motif_model.hpp:131-134
+
+void transitive_closure(std::vector<char>& m, int n) {  // Warshall, profile_hmm.hpp:357-366
+  for (int k = 0; k < n; ++k)
+    for (int i = 0; i < n; ++i)
+      if (m[i * n + k])
+        for (int j = 0; j < n; ++j)
+          if (m[k * n + j]) m[i * n + j] = 1;
+}
+
+// CSR builder over S keys
+struct Csr {
+  std::vector<std::vector<int32_t>> rows;
+  int width;
+  Csr(int S, int w) : rows(S), width(w) {}
+  void add(int key, std::initializer_list<int32_t> v) { rows[key].insert(rows[key].end(), v); }
+  // appends offsets (S+1) then entries to the blob; returns {off_pos, ent_pos}
+  std::pair<int32_t, int32_t> emit(std::vector<int32_t>* blob) const {
+    int32_t off_pos = (int32_t)blob->size();
+    int32_t n = 0;
+    for (auto const& r : rows) { blob->push_back(n); n += (int32_t)r.size() / width; }
+    blob->push_back(n);
+    int32_t ent_pos = (int32_t)blob->size();
+    for (auto const& r : rows) blob->insert(blob->end(), r.begin(), r.end());
+    return {off_pos, ent_pos};
+  }
+};
+
+}  // namespace
+
+Automaton::Automaton(const std::string& pattern) : pattern_(pattern) {
+  if (pattern.empty()) throw std::runtime_error("empty motif");
+  // regularise: runs of '*' collapse to one, leading / trailing '*' are dropped (profile_hmm.hpp:188-204)
+  for (char c : pattern) {
+    if (c == '*' && !reg_.empty() && reg_.back() == '*') continue;
+    reg_.push_back(c);
+  }
+  size_t b = reg_.find_first_not_of('*');
+  reg_ = (b == std::string::npos) ? std::string() : reg_.substr(b);
+  size_t e = reg_.find_last_not_of('*');
+  if (e != std::string::npos) reg_.erase(e + 1);
+
+  node_.push_back('z');
+  for (char c : reg_) node_.push_back(c);
+  node_.push_back('o');
+  const int m = M();
+
+  // bracket mates
+  mate_.assign(m, -1);
+  {
+    std::vector<int> open;
+    for (int h = 0; h < m; ++h) {
+      if (node_[h] == '(') open.push_back(h);
+      else if (node_[h] == ')') {
+        if (open.empty()) throw std::runtime_error("unmatched brackets");
+        mate_[h] = open.back();
+        mate_[open.back()] = h;
+        open.pop_back();
+      }
+    }
+    if (!open.empty()) throw std::runtime_error("unmatched brackets");
+  }
+
+  // node edges: h -> h-1, h -> h (self), and h -> h-2 across a '*' (profile_hmm.hpp:257-283)
+  edge_to_.assign(m, {});
+  edge_from_.assign(m, {});
+  for (int h = 0; h < m; ++h) {
+    if (h > 0) {
+      if (node_[h - 1] == '*') { edge_to_[h].push_back(h - 2); edge_from_[h - 2].push_back(h); }
+      edge_to_[h].push_back(h - 1);
+      edge_from_[h - 1].push_back(h);
+    }
+    edge_to_[h].push_back(h);
+    edge_from_[h].push_back(h);
+  }
+
+  // theta rows: row 0 = shared background (z, *, o); one row per '.', one 6-wide row per ')'
+  theta_row_.assign(m, -1);
+  row_width_.assign(1, 4);
+  for (int h = 0; h < m; ++h) {
+    switch (node_[h]) {
+      case ')': theta_row_[h] = (int)row_width_.size(); row_width_.push_back(6); break;
+      case '.': theta_row_[h] = (int)row_width_.size(); row_width_.push_back(4); break;
+      case '*': case 'z': case 'o': theta_row_[h] = 0; break;
+      case '(': break;
+      default: throw std::runtime_error(std::string("bad motif char: ") + node_[h]);
+    }
+  }
+  row_off_.assign(1, 0);
+  for (int w : row_width_) row_off_.push_back(row_off_.back() + w);
+
+  // reachability between nodes (profile_hmm.hpp:316-354)
+  reach_.assign(m * m, 0);
+  reach_loop_.assign(m * m, 0);
+  for (int h = 0; h < m; ++h) {
+    if (node_[h] == ')') {
+      for (int h1 : edge_to_[mate_[h]]) reach_[h1 * m + h] = 1;
+    } else if (node_[h] != '(') {
+      for (int h1 : edge_to_[h]) { reach_[h1 * m + h] = 1; reach_loop_[h1 * m + h] = 1; }
+    }
+    reach_[h * m + h] = 1;
+    reach_loop_[h * m + h] = 1;
+  }
+  transitive_closure(reach_, m);
+  transitive_closure(reach_loop_, m);
+
+  // interval states ordered by r ascending, l descending (profile_hmm.hpp:369-384)
+  n2s_.assign(m * m, -1);
+  for (int r = 0; r < m; ++r)
+    for (int l = r; l >= 0; --l)
+      if (reach_[l * m + r]) {
+        n2s_[l * m + r] = (int)states_.size();
+        states_.push_back(IntervalState{(int)states_.size(), l, r});
+      }
+  const int S_ = S();
+  loop_flag_.assign(S_, 0);
+  for (auto const& s : states_) loop_flag_[s.id] = reach_loop_[s.l * m + s.r];
+
+  // transitions (profile_hmm.hpp:387-449)
+  right_.assign(S_, {});
+  left_.assign(S_, {});
+  pair_.assign(S_, {});
+  for (auto const& s : states_) {
+    if (emits_single(node_[s.r]))
+      for (int h : edge_to_[s.r])
+        if (s.l <= h && reach_[s.l * m + h]) right_[s.id].push_back(state_id(s.l, h));
+  }
+  for (auto const& s : states_) {
+    if (emits_single(node_[s.l]))
+      for (int h : edge_to_[s.l])
+        if (h <= s.r && reach_[h * m + s.r]) left_[state_id(h, s.r)].push_back(s.id);
+  }
+  for (int hr = 0; hr < m; ++hr) {
+    if (node_[hr] != ')') continue;
+    const int kl = mate_[hr];
+    for (int hl : edge_to_[kl]) {
+      const int parent = state_id(hl, hr);
+      for (int kr : edge_to_[hr])
+        if (reach_[kl * m + kr]) pair_[parent].push_back(state_id(kl, kr));
+    }
+  }
+  for (auto const& s : states_) {  // background "pairs": both ends emitted by z / * / o
+    if (!is_background(node_[s.r])) continue;
+    for (int hl : edge_from_[s.l]) {
+      if (!is_background(node_[hl])) continue;
+      for (int hr : edge_to_[s.r])
+        if (reach_[hl * m + hr]) pair_[s.id].push_back(state_id(hl, hr));
+    }
+  }
+
+  // interior-loop quadruples {s, s1, s2, s3} (profile_hmm.hpp:451-463)
+  for (auto const& s2 : states_) {
+    if (!loop_flag_[s2.id]) continue;
+    for (auto const& s3 : states_) {
+      if (!loop_flag_[s3.id]) continue;
+      if (s3.r < s2.l || !reach_[s2.r * m + s3.l] || !reach_[s2.l * m + s3.r]) continue;
+      quads_.push_back({state_id(s2.l, s3.r), state_id(s2.r, s3.l), s2.id, s3.id});
+    }
+  }
+}
+
+std::vector<std::array<int, 2>> Automaton::splits(int s) const {
+  std::vector<std::array<int, 2>> out;
+  const IntervalState& st = states_[s];
+  const int m = M();
+  for (int h = st.l; h <= st.r; ++h)
+    if (reach_[st.l * m + h] && reach_[h * m + st.r]) out.push_back({state_id(st.l, h), state_id(h, st.r)});
+  return out;
+}
+
+std::string Automaton::to_json() const {
+  std::ostringstream o;
+  auto list = [&](const std::vector<int>& v) {
+    o << "[";
+    for (size_t i = 0; i < v.size(); ++i) o << (i ? "," : "") << v[i];
+    o << "]";
+  };
+  const int m = M();
+  o << "{\"reg_pattern\":\"" << reg_ << "\",\"M\":" << m << ",\"S\":" << S() << ",\"node\":\"";
+  for (char c : node_) o << c;
+  o << "\",\"theta_id\":";
+  list(theta_row_);
+  o << ",\"theta_sizes\":";
+  list(row_width_);
+  o << ",\"state\":[";
+  for (int s = 0; s < S(); ++s) o << (s ? "," : "") << "[" << states_[s].l << "," << states_[s].r << "]";
+  o << "],\"loop_state\":[";
+  {
+    bool first = true;
+    for (int s = 0; s < S(); ++s)
+      if (loop_flag_[s]) { o << (first ? "" : ",") << s; first = false; }
+  }
+  o << "],\"reachable\":[";
+  for (int a = 0; a < m; ++a) {
+    o << (a ? "," : "") << "[";
+    for (int b = 0; b < m; ++b) o << (b ? "," : "") << int(reach_[a * m + b]);
+    o << "]";
+  }
+  o << "],\"right\":[";
+  for (int s = 0; s < S(); ++s) { if (s) o << ","; list(right_[s]); }
+  o << "],\"left\":[";
+  for (int s = 0; s < S(); ++s) { if (s) o << ","; list(left_[s]); }
+  o << "],\"pair\":[";
+  for (int s = 0; s < S(); ++s) { if (s) o << ","; list(pair_[s]); }
+  o << "],\"loop_loop\":[";
+  for (size_t i = 0; i < quads_.size(); ++i)
+    o << (i ? "," : "") << "[" << quads_[i][0] << "," << quads_[i][1] << "," << quads_[i][2] << "," << quads_[i][3] << "]";
+  o << "]}";
+  return o.str();
+}
+
+void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints) const {
+  const int S_ = S(), m = M();
+  AutomatonLayout& A = *lay;
+  ints->clear();
+  A.S = S_;
+  A.M = m;
+  A.n_theta = n_theta();
+  A.n_rows = n_rows();
+  A.s00 = state_id(0, 0);
+  A.s0m1 = state_id(0, m - 1);
+  A.s0m2 = state_id(0, m - 2);
+  auto per_state = [&](auto fn) {
+    int32_t pos = (int32_t)ints->size();
+    for (int s = 0; s < S_; ++s) ints->push_back(fn(states_[s]));
+    return pos;
+  };
+  A.st_l = per_state([&](const IntervalState& s) { return s.l; });
+  A.st_r = per_state([&](const IntervalState& s) { return s.r; });
+  A.st_is_loop = per_state([&](const IntervalState& s) { return (int)loop_flag_[s.id]; });
+  A.st_row_r = per_state([&](const IntervalState& s) { return theta_row_[s.r]; });
+  A.st_row_l = per_state([&](const IntervalState& s) { return theta_row_[s.l]; });
+  A.st_pair_r = per_state([&](const IntervalState& s) { return (int)(node_[s.r] == ')'); });
+  A.st_w_r = per_state([&](const IntervalState& s) { return (int)is_weighted(node_[s.r]); });
+  A.st_w_l = per_state([&](const IntervalState& s) { return (int)is_weighted(node_[s.l]); });
+  A.st_lam = per_state([&](const IntervalState& s) { return s.l == s.r ? 0 : 1; });
+  A.row_off = (int32_t)ints->size();
+  for (int v : row_off_) ints->push_back(v);
+
+  // tau applies to a self-loop on the emitting node (motif_model.hpp:250-251, 278-279, 352-353)
+  auto tau_right = [&](int par, int ch) { return (int)(states_[par].r == states_[ch].r && node_[states_[par].r] == '.'); };
+  auto tau_left = [&](int par, int ch) { return (int)(states_[par].l == states_[ch].l && node_[states_[par].l] == '.'); };
+  auto tau_pair = [&](int par, int ch) { return (int)(states_[par].r == states_[ch].r && node_[states_[ch].r] == ')'); };
+
+  Csr right(S_, 2), left(S_, 2), pair(S_, 2), rright(S_, 2), rleft(S_, 2), rpair(S_, 2);
+  for (int s = 0; s < S_; ++s) {
+    for (int c : right_[s]) { right.add(s, {c, tau_right(s, c)}); rright.add(c, {s, tau_right(s, c)}); }
+    for (int c : left_[s]) { left.add(s, {c, tau_left(s, c)}); rleft.add(c, {s, tau_left(s, c)}); }
+    for (int c : pair_[s]) { pair.add(s, {c, tau_pair(s, c)}); rpair.add(c, {s, tau_pair(s, c)}); }
+  }
+  Csr split(S_, 2), split1(S_, 2), split2(S_, 2);
+  for (int s = 0; s < S_; ++s)
+    for (auto const& p : splits(s)) {
+      split.add(s, {p[0], p[1]});
+      split1.add(p[0], {s, p[1]});
+      split2.add(p[1], {s, p[0]});
+    }
+  Csr quad(S_, 3), quad1(S_, 3), quad2(S_, 3), quad3(S_, 3);
+  for (auto const& q : quads_) {
+    quad.add(q[0], {q[1], q[2], q[3]});
+    quad1.add(q[1], {q[0], q[2], q[3]});
+    quad2.add(q[2], {q[0], q[1], q[3]});
+    quad3.add(q[3], {q[0], q[1], q[2]});
+  }
+  auto put = [&](const Csr& c, int32_t* off, int32_t* ent) { auto p = c.emit(ints); *off = p.first; *ent = p.second; };
+  put(right, &A.right_off, &A.right_ent);
+  put(left, &A.left_off, &A.left_ent);
+  put(pair, &A.pair_off, &A.pair_ent);
+  put(split, &A.split_off, &A.split_ent);
+  put(quad, &A.quad_off, &A.quad_ent);
+  put(rright, &A.rright_off, &A.rright_ent);
+  put(rleft, &A.rleft_off, &A.rleft_ent);
+  put(rpair, &A.rpair_off, &A.rpair_ent);
+  put(split1, &A.split1_off, &A.split1_ent);
+  put(split2, &A.split2_off, &A.split2_ent);
+  put(quad1, &A.quad1_off, &A.quad1_ent);
+  put(quad2, &A.quad2_off, &A.quad2_ent);
+  put(quad3, &A.quad3_off, &A.quad3_ent);
+  A.n_ints = (int32_t)ints->size();
+}
+
+void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
+  AutomatonLayout& A = *lay;
+  ints->clear();
+  A.S = 1; A.M = 1; A.n_theta = 0; A.n_rows = 0;
+  A.s00 = A.s0m1 = A.s0m2 = 0;
+  auto one = [&](int32_t v) { int32_t p = (int32_t)ints->size(); ints->push_back(v); return p; };
+  A.st_l = one(0); A.st_r = one(0); A.st_is_loop = one(1);
+  A.st_row_r = one(-1); A.st_row_l = one(-1); A.st_pair_r = one(0);
+  A.st_w_r = one(0); A.st_w_l = one(0); A.st_lam = one(0);
+  A.row_off = one(0);
+  auto csr = [&](int width, int32_t* off, int32_t* ent) {
+    *off = (int32_t)ints->size();
+    ints->push_back(0); ints->push_back(1);
+    *ent = (int32_t)ints->size();
+    for (int k = 0; k < width; ++k) ints->push_back(0);  // (state 0, flag 0) / (0,0) / (0,0,0)
+  };
+  csr(2, &A.right_off, &A.right_ent); csr(2, &A.left_off, &A.left_ent); csr(2, &A.pair_off, &A.pair_ent);
+  csr(2, &A.split_off, &A.split_ent); csr(3, &A.quad_off, &A.quad_ent);
+  csr(2, &A.rright_off, &A.rright_ent); csr(2, &A.rleft_off, &A.rleft_ent); csr(2, &A.rpair_off, &A.rpair_ent);
+  csr(2, &A.split1_off, &A.split1_ent); csr(2, &A.split2_off, &A.split2_ent);
+  csr(3, &A.quad1_off, &A.quad1_ent); csr(3, &A.quad2_off, &A.quad2_ent); csr(3, &A.quad3_off, &A.quad3_ent);
+  A.n_ints = (int32_t)ints->size();
+}
+
+}  // namespace elemdp

@@ -1,0 +1,89 @@
+// device_layout.h -- PODs shared by the host engine and the HIP kernels.
+//
+// Naming follows the reference's domain: structural states P,E,M,B,1,2,L(,O) (energy_model.hpp:58-70),
+// interval states s=(l,r) of the pattern automaton (profile_hmm.hpp:21-29), rules numbered as in
+// SURVEY.md Appendix A.
+#pragma once
+#include <cstdint>
+
+namespace elemdp {
+
+enum StructState : int { ST_P = 0, ST_E = 1, ST_M = 2, ST_B = 3, ST_1 = 4, ST_2 = 5, ST_L = 6, ST_O = 7 };
+constexpr int kNumBandStates = 7;  // P,E,M,B,1,2,L live in the banded tables; O is the exterior prefix
+
+// Transition codes stored in CYK trace records (values follow energy_model.hpp:72-91)
+enum TransType : int {
+  TT_E_H = 0, TT_P_E, TT_P_P, TT_O_O, TT_O_OP, TT_E_P, TT_E_M, TT_M_M, TT_M_B, TT_B_12, TT_1_B, TT_1_2, TT_2_2,
+  TT_2_P, TT_L_L
+};
+
+// ---- flattened pattern automaton ------------------------------------------------------------
+// All lists are CSR over interval-state ids: entries of state s are [off[s], off[s+1]).
+// "fwd" lists enumerate children of a parent (inside direction), "rev" lists enumerate parents
+// of a child (outside direction, gather form).  Offsets below index ModelBlob::ints.
+struct AutomatonLayout {
+  int32_t S;        // interval states
+  int32_t M;        // pattern nodes incl. 'z' and 'o'
+  int32_t n_theta;  // total theta entries (n_param - 2)
+  int32_t n_rows;   // theta rows
+  int32_t s00, s0m1, s0m2;  // ids of (0,0), (0,M-1), (0,M-2)  (terminal states, motif_trainer.hpp:100-112)
+  // per-state attributes
+  int32_t st_l, st_r;        // node indices
+  int32_t st_is_loop;        // reachable as loop (profile_hmm.hpp:380-383)
+  int32_t st_row_r;          // theta row of node r (-1: none)
+  int32_t st_row_l;          // theta row of node l (-1: none)
+  int32_t st_pair_r;         // node r is ')'
+  int32_t st_w_r, st_w_l;    // position weight applies to node r / l ('.', '(' or ')': motif_model.hpp:131-134)
+  int32_t st_lam;            // 0 if l==r else 1 (motif_model.hpp:117-121)
+  int32_t row_off;           // n_rows+1 offsets of theta rows in the parameter vector
+  // forward lists: (child, tau_flag) pairs, 2 ints per entry
+  int32_t right_off, right_ent;  // loop_right_trans  (profile_hmm.hpp:389-401)
+  int32_t left_off, left_ent;    // loop_left_trans   (:403-415)
+  int32_t pair_off, pair_ent;    // pair_trans        (:417-448)
+  // splits s -> (s1=(l,h), s2=(h,r)), 2 ints per entry (motif_model.hpp:368-381, 315-327)
+  int32_t split_off, split_ent;
+  // interior-loop quadruples grouped by parent s: (s1, s2, s3), 3 ints (profile_hmm.hpp:451-463)
+  int32_t quad_off, quad_ent;
+  // reverse lists (grouped by CHILD): (parent, tau_flag)
+  int32_t rright_off, rright_ent;
+  int32_t rleft_off, rleft_ent;
+  int32_t rpair_off, rpair_ent;
+  // splits grouped by s1 (the "1" / prefix child): (parent, s2); by s2 (the "2" / pair-part child): (parent, s1)
+  int32_t split1_off, split1_ent;
+  int32_t split2_off, split2_ent;
+  // quadruples grouped by s1 (P child): (s, s2, s3); by s2 (left loop): (s, s1, s3); by s3: (s, s1, s2)
+  int32_t quad1_off, quad1_ent;
+  int32_t quad2_off, quad2_ent;
+  int32_t quad3_off, quad3_ent;
+  int32_t n_ints;  // total length of the int blob
+};
+
+// Per-evaluation parameters (changes every optimizer step)
+struct ParamBlock {
+  double lambda[2];
+  double log_tau;
+  int32_t lam_same;  // lambda[0]==lambda[1] bitwise-equal as doubles (motif_trainer.hpp:380-381 quirk)
+  int32_t pad;
+  // followed in memory by theta[n_theta] (log-probabilities; rows per row_off)
+};
+
+// ---- per-sequence plan (parameter independent, built once per batch on the GPU) -------------
+struct SeqPlan {
+  int32_t L, W, C;
+  int32_t positive;     // last quality == 0  <=>  ws[L] == -inf  ("has motif", motif_model.hpp:69)
+  int64_t cell_base;    // offset of this sequence in the per-cell arrays ((L+1)*(W+1) entries)
+  int64_t pos_base;     // offset in per-position arrays (L+1 entries)
+  int64_t item_base;    // offset of the interior-loop item arrays
+  int32_t n_items;      // number of interior-loop items (outside set; inside set is flagged)
+  int32_t n_pairs;      // kept base pairs
+  int64_t seq_base;     // offset into concatenated base codes
+  double bpp_eff;
+};
+
+// interior-loop item: outer cell E(i,j), inner pair P(k,l), tsc = loop_energy(i-1,j,k,l-1)
+struct LoopItem {
+  double tsc;
+  int16_t i, j, k, l;
+};
+
+}  // namespace elemdp

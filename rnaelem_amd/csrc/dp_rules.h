@@ -1,0 +1,758 @@
+// dp_rules.h -- the per-target ("gather") form of the RNAelem inside / outside / CYK recurrences.
+//
+// One *target* = one (cell (i,d), interval state s): the function computes every structural state
+// P,E,M,B,1,2,L of that target from cells of strictly smaller span (inside) or strictly larger
+// span (outside), so all targets of one anti-diagonal d are independent -- that is the unit the
+// HIP kernels (dp_kernels.hip) distribute over the lanes of a workgroup, one diagonal per barrier.
+// The exterior chain O(j) is a second, sequential phase with S independent targets per step.
+//
+// The reference evaluates the same rules as a *scatter* driven by the structural sweep
+// (RNAelem/energy_model.hpp:340-547 x RNAelem/motif_model.hpp:230-613 x the functors in
+// RNAelem/motif_trainer.hpp:274-458 and RNAelem/motif_scanner.hpp:364-913).  Rule numbers in the
+// comments are those of SURVEY.md Appendix A.  Summation order differs from the reference, so
+// parity is to tolerance (1e-9 rel on log Z), not bitwise; CYK keeps the reference's candidate
+// order per target because ties are broken by "first strictly greater" (motif_scanner.hpp:821).
+//
+// The code is plain C++ (no HIP intrinsics) so that tests/emul can run the *same* functions on
+// the CPU against the oracle; the product only ever calls them from device code.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "device_layout.h"
+
+#if defined(__HIPCC__)
+#define ELEMDP_HD __host__ __device__ __forceinline__
+#else
+#define ELEMDP_HD inline
+#endif
+
+namespace elemdp {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ELEMDP_NEG_INF (-__builtin_huge_val())
+#else
+#define ELEMDP_NEG_INF (-HUGE_VAL)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// log-semiring accumulators
+// ---------------------------------------------------------------------------------------------
+// streaming log-sum-exp: value = m + log(s); one exp per term, one log per target
+struct LseAcc {
+  double m, s;
+  ELEMDP_HD LseAcc() : m(ELEMDP_NEG_INF), s(0.) {}
+  ELEMDP_HD void add(double x) {
+    if (x == ELEMDP_NEG_INF) return;
+    if (x > m) { s = s * exp(m - x) + 1.; m = x; }
+    else s += exp(x - m);
+  }
+  ELEMDP_HD double value() const { return (m == ELEMDP_NEG_INF) ? ELEMDP_NEG_INF : m + log(s); }
+};
+
+// CYK trace record (motif_scanner.hpp:51-59); t < 0 = leaf
+struct TraceRec { int16_t k, l; int8_t t, e1; int16_t s1; };
+
+// ---------------------------------------------------------------------------------------------
+// views
+// ---------------------------------------------------------------------------------------------
+struct ModelView {
+  AutomatonLayout lay;
+  const int32_t* ints;   // automaton blob
+  const double* theta;   // n_theta log-probabilities
+  double lambda[2];
+  double log_tau;
+  int32_t lam_same;      // lambda[0] == lambda[1]
+  int32_t no_prf;        // --no-profile: theta terms are 0 and no emission counts
+  int32_t m_min;         // minimal span of a multiloop cell M: 2*(2+turn)=10, or 4 with NO_TURN
+
+  ELEMDP_HD int st_l(int s) const { return ints[lay.st_l + s]; }
+  ELEMDP_HD int st_r(int s) const { return ints[lay.st_r + s]; }
+  ELEMDP_HD double lam(int s) const { return lambda[ints[lay.st_lam + s]]; }
+  // index of the EH accumulator a transition with parent s feeds (motif_trainer.hpp:380-381)
+  ELEMDP_HD int eh_index(int s) const { return lam_same ? 0 : ints[lay.st_lam + s]; }
+  ELEMDP_HD double theta_at(int row, int col) const { return theta[ints[lay.row_off + row] + col]; }
+  ELEMDP_HD int param_index(int row, int col) const { return ints[lay.row_off + row] + col; }
+};
+
+struct SeqView {
+  int32_t L, W, C;
+  const uint8_t* seq;        // L base codes 0..4
+  const double* ws;          // L+1 position weights (motif_model.hpp:62-70)
+  const uint32_t* okbits;    // kept pairs, bit (i*(W+1)+d)
+  const int16_t* dmin;       // L+1: smallest kept span starting at i, 0 = none  (left_bp_ok, energy_model.hpp:203-209)
+  const uint8_t* unp;        // L: position may be emitted unpaired (all 1 unless FIX_RSS)
+  // structural terms keyed by the PAIR cell (i,d): index i*(W+1)+d
+  const double* e_stack;     // rule 1b: loop_energy(i,j-1,i+1,j-2); -inf if inner pair not kept
+  const double* e_ext;       // rule 7 : sum_ext_m(i,j-1,true)
+  const double* e_ml;        // rule 3b: sum_ext_m(i,j-1,false) + mlintern
+  const double* e_close;     // rule 6a for E(i+1,j-1): sum_ext_m(j-1,i,false)+mlclosing+mlintern
+  const double* e_hp;        // rule 6b for E(i+1,j-1): hairpin_energy(i,j-1)
+  // rule 6c items; CSR by outer E cell, by inner P cell, by left loop cell (i,k), by right loop cell (l,j)
+  const LoopItem* items;
+  const int32_t* by_outer_off;
+  const int32_t* by_inner_off; const int32_t* by_inner_idx;
+  const int32_t* by_left_off;  const int32_t* by_left_idx;
+  const int32_t* by_right_off; const int32_t* by_right_idx;
+  const uint8_t* item_in;    // item belongs to the inside enumeration (u1+u2 <= C; see SURVEY §7 quirk ii)
+
+  ELEMDP_HD int cell(int i, int d) const { return i * (W + 1) + d; }
+  ELEMDP_HD bool pair_ok(int i, int d) const {  // is_parsable<ST_P>
+    if (i < 0 || d < 0 || d > W || i + d > L) return false;
+    int c = i * (W + 1) + d;
+    return (okbits[c >> 5] >> (c & 31)) & 1u;
+  }
+  ELEMDP_HD bool left_ok(int i, int d) const {  // is_parsable<ST_B/1/2>
+    if (d > W || d < 0 || i + d > L) return false;
+    int dm = dmin[i];
+    return dm > 0 && d >= dm;
+  }
+  ELEMDP_HD bool e_ok(int i, int d) const { return i > 0 && d + 2 <= W && pair_ok(i - 1, d + 2); }  // is_parsable<ST_E>
+};
+
+// banded tables [e][d][i][s] and exterior table [j][s]
+struct TableView {
+  double* band;
+  double* ext;
+  int32_t L, W, S;
+  ELEMDP_HD size_t idx(int e, int d, int i, int s) const {
+    return (((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s;
+  }
+  ELEMDP_HD double& at(int e, int d, int i, int s) const { return band[idx(e, d, i, s)]; }
+  ELEMDP_HD double& o(int j, int s) const { return ext[(size_t)j * S + s]; }
+};
+
+ELEMDP_HD bool m_ok(const ModelView& m, const SeqView& q, int i, int d) {  // is_parsable<ST_M>
+  return 0 < i && i + d < q.L && d <= q.W && m.m_min <= d;
+}
+
+// base-pair type (bio_sequence.hpp:20-26): CG=1 GC=2 GU=3 UG=4 AU=5 UA=6
+ELEMDP_HD int bp_type(int a, int b) {
+  // rows N,A,C,G,U
+  const int t = a * 5 + b;
+  return t == 9 ? 5 : t == 13 ? 1 : t == 17 ? 2 : t == 19 ? 3 : t == 21 ? 6 : t == 23 ? 4 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// emission weights  wt = theta + (tau + position weight)   (motif_model.hpp:243-421)
+// ---------------------------------------------------------------------------------------------
+// right emission of base at `pos` by the r-node of `par` (rules 3a, 8, L<-L)
+ELEMDP_HD double w_right(const ModelView& m, const SeqView& q, int par, int tau_flag, int pos) {
+  const int b = q.seq[pos];
+  double w = (m.no_prf || b == 0) ? 0. : m.theta_at(m.ints[m.lay.st_row_r + par], b - 1);
+  double ws = m.ints[m.lay.st_w_r + par] ? q.ws[pos] : 0.;
+  double t = tau_flag ? m.log_tau : 0.;
+  return w + (t + ws);
+}
+// left emission of base at `pos` by the l-node of `child` (rule 5a)
+ELEMDP_HD double w_left(const ModelView& m, const SeqView& q, int child, int tau_flag, int pos) {
+  const int b = q.seq[pos];
+  double w = (m.no_prf || b == 0) ? 0. : m.theta_at(m.ints[m.lay.st_row_l + child], b - 1);
+  double ws = m.ints[m.lay.st_w_l + child] ? q.ws[pos] : 0.;
+  double t = tau_flag ? m.log_tau : 0.;
+  return w + (t + ws);
+}
+// pair emission: l-node of `child` at pos pi, r-node of `par` at pos pj (rules 1a, 1b; profile_hmm.hpp:113-135)
+ELEMDP_HD double w_pair(const ModelView& m, const SeqView& q, int par, int child, int tau_flag, int pi, int pj) {
+  const int bi = q.seq[pi], bj = q.seq[pj];
+  double w = 0.;
+  if (!m.no_prf) {
+    if (m.ints[m.lay.st_pair_r + par]) {
+      int t = bp_type(bi, bj);
+      w = t ? m.theta_at(m.ints[m.lay.st_row_r + par], t - 1) : 0.;
+    } else {
+      w = (bi ? m.theta_at(m.ints[m.lay.st_row_l + child], bi - 1) : 0.) +
+          (bj ? m.theta_at(m.ints[m.lay.st_row_r + par], bj - 1) : 0.);
+    }
+  }
+  double ws = (m.ints[m.lay.st_w_l + child] ? q.ws[pi] : 0.) + (m.ints[m.lay.st_w_r + par] ? q.ws[pj] : 0.);
+  double t = tau_flag ? m.log_tau : 0.;
+  return w + (t + ws);
+}
+
+// ---------------------------------------------------------------------------------------------
+// constraints of the scan passes (motif_scanner.hpp:594-622, 839-873)
+// ---------------------------------------------------------------------------------------------
+struct Constraint {
+  int32_t ys;  // motif must start at ys (-1 = off)
+  int32_t ye;  // motif must end at ye   (-1 = off; CYK only)
+  int32_t use_end;
+};
+// pair emission: parent P(i,j,par), child (i+1,j-1,ch); emits positions i and j-1
+ELEMDP_HD bool allow_pair(const ModelView& m, const Constraint& c, int L, int i, int j, int par, int ch) {
+  const int pl = m.st_l(par), pr = m.st_r(par), cl = m.st_l(ch), cr = m.st_r(ch);
+  if (i == c.ys && !(pl == 0 && cl == 1)) return false;
+  if (j - 1 == c.ys && !(cr == 0 && pr == 1)) return false;
+  if (c.use_end) {
+    const int M = m.lay.M;
+    if (i == c.ye && !(pl == M - 2 && cl == M - 1)) return false;
+    if (j - 1 == c.ye && !(cr == M - 2 && pr == M - 1)) return false;
+    if (j == c.ye && L == j && pr != M - 2) return false;
+  }
+  return true;
+}
+// right emission: parent (.,j,par), child (.,j-1,ch); emits position j-1
+ELEMDP_HD bool allow_right(const ModelView& m, const Constraint& c, int L, int j, int par, int ch) {
+  const int pr = m.st_r(par), cr = m.st_r(ch);
+  if (j - 1 == c.ys && !(cr == 0 && pr == 1)) return false;
+  if (c.use_end) {
+    const int M = m.lay.M;
+    if (j - 1 == c.ye && !(cr == M - 2 && pr == M - 1)) return false;
+    if (j == c.ye && L == j && pr != M - 2) return false;
+  }
+  return true;
+}
+// left emission: parent M(i,j,par), child M(i+1,j,ch); emits position i
+ELEMDP_HD bool allow_left(const ModelView& m, const Constraint& c, int i, int par, int ch) {
+  const int pl = m.st_l(par), cl = m.st_l(ch);
+  if (i == c.ys && !(pl == 0 && cl == 1)) return false;
+  if (c.use_end) {
+    const int M = m.lay.M;
+    if (i == c.ye && !(pl == M - 2 && cl == M - 1)) return false;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// INSIDE, sum semiring, optional start constraint (train K2, scan K4/K5 inside halves)
+// ---------------------------------------------------------------------------------------------
+// Computes and stores P,E,M,B,1,2,L of target (i, d, s).  CONSTRAINED=false compiles the checks away.
+template <bool CONSTRAINED>
+ELEMDP_HD void inside_target(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, int d,
+                             int i, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const int j = i + d;
+  const double NEG = ELEMDP_NEG_INF;
+  const double lam = m.lam(s);
+  const bool isloop = I[A.st_is_loop + s] != 0;
+
+  // ---- L(i,j,s): loop emission chain (motif_model.hpp:243-257; init motif_trainer.hpp:89-95)
+  double vL = NEG;
+  if (isloop) {
+    if (d == 0) vL = (m.st_l(s) == m.st_r(s)) ? 0. : NEG;
+    else {
+      LseAcc a;
+      for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+        const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+        if (CONSTRAINED && !allow_right(m, c, q.L, j, s, s1)) continue;
+        a.add(T.at(ST_L, d - 1, i, s1) + w_right(m, q, s, tf, j - 1));
+      }
+      vL = a.value();
+    }
+  }
+  T.at(ST_L, d, i, s) = vL;
+
+  // ---- P(i,j,s): rules 1a, 1b
+  const bool pok = q.pair_ok(i, d);
+  double vP = NEG;
+  if (pok) {
+    LseAcc a;
+    const double est = q.e_stack[q.cell(i, d)];
+    for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {
+      const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
+      if (CONSTRAINED && !allow_pair(m, c, q.L, i, j, s, s1)) continue;
+      const double w = w_pair(m, q, s, s1, tf, i, j - 1);
+      a.add(T.at(ST_E, d - 2, i + 1, s1) + w);                       // 1a (tsc = 0)
+      if (est != NEG) a.add(T.at(ST_P, d - 2, i + 1, s1) + (w + lam * est));  // 1b
+    }
+    vP = a.value();
+  }
+  T.at(ST_P, d, i, s) = vP;
+
+  // ---- B(i,j,s): rule 2  (bifurcation)
+  const bool lok = q.left_ok(i, d);
+  double vB = NEG;
+  if (lok) {
+    LseAcc a;
+    const int k0 = i + q.dmin[i];
+    for (int k = k0; k < j; ++k) {
+      const int dk = q.dmin[k];
+      if (dk == 0 || j - k < dk) continue;
+      for (int t = I[A.split_off + s]; t < I[A.split_off + s + 1]; ++t) {
+        const int s1 = I[A.split_ent + 2 * t], s2 = I[A.split_ent + 2 * t + 1];
+        a.add(T.at(ST_1, k - i, i, s1) + T.at(ST_2, j - k, k, s2));
+      }
+    }
+    vB = a.value();
+  }
+  T.at(ST_B, d, i, s) = vB;
+
+  // ---- 2(i,j,s): rules 3a, 3b ; 1(i,j,s): rules 4a, 4b
+  double v2 = NEG, v1 = NEG;
+  if (lok) {
+    LseAcc a;
+    if (q.left_ok(i, d - 1) && q.unp[j - 1]) {
+      for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+        const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+        if (CONSTRAINED && !allow_right(m, c, q.L, j, s, s1)) continue;
+        a.add(T.at(ST_2, d - 1, i, s1) + w_right(m, q, s, tf, j - 1));
+      }
+    }
+    if (pok) {
+      const double eml = q.e_ml[q.cell(i, d)];
+      if (eml != NEG) a.add(vP + lam * eml);
+    }
+    v2 = a.value();
+    LseAcc b;
+    b.add(v2);
+    b.add(vB);
+    v1 = b.value();
+  }
+  T.at(ST_2, d, i, s) = v2;
+  T.at(ST_1, d, i, s) = v1;
+
+  // ---- M(i,j,s): rules 5a, 5b
+  const bool mok = m_ok(m, q, i, d);
+  double vM = NEG;
+  if (mok) {
+    LseAcc a;
+    if (m_ok(m, q, i + 1, d - 1) && q.unp[i]) {
+      for (int t = I[A.left_off + s]; t < I[A.left_off + s + 1]; ++t) {
+        const int s1 = I[A.left_ent + 2 * t], tf = I[A.left_ent + 2 * t + 1];
+        if (CONSTRAINED && !allow_left(m, c, i, s, s1)) continue;
+        a.add(T.at(ST_M, d - 1, i + 1, s1) + w_left(m, q, s1, tf, i));
+      }
+    }
+    if (lok) a.add(vB);
+    vM = a.value();
+  }
+  T.at(ST_M, d, i, s) = vM;
+
+  // ---- E(i,j,s): rules 6a, 6b, 6c ; closing pair is the cell (i-1, d+2)
+  double vE = NEG;
+  if (q.e_ok(i, d)) {
+    LseAcc a;
+    const int pc = q.cell(i - 1, d + 2);
+    if (mok) { const double t = q.e_close[pc]; if (t != NEG) a.add(vM + lam * t); }
+    if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) a.add(vL + lam * t); }
+    const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
+    for (int it = c0; it < c1; ++it) {
+      if (!q.item_in[it]) continue;
+      const LoopItem x = q.items[it];
+      const double lt = lam * x.tsc;
+      for (int t = I[A.quad_off + s]; t < I[A.quad_off + s + 1]; ++t) {
+        const int s1 = I[A.quad_ent + 3 * t], s2 = I[A.quad_ent + 3 * t + 1], s3 = I[A.quad_ent + 3 * t + 2];
+        a.add(T.at(ST_P, x.l - x.k, x.k, s1) + (T.at(ST_L, x.k - i, i, s2) + (T.at(ST_L, j - x.l, x.l, s3) + lt)));
+      }
+    }
+    vE = a.value();
+  }
+  T.at(ST_E, d, i, s) = vE;
+}
+
+// exterior chain, one step: O(j,s) from O(<j,.) and P(.,j,.)  (rules 7, 8).  j >= 1.
+template <bool CONSTRAINED>
+ELEMDP_HD void inside_ext_target(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, int j,
+                                 int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const double NEG = ELEMDP_NEG_INF;
+  const double lam = m.lam(s);
+  LseAcc a;
+  const int i0 = (j - q.W > 0) ? j - q.W : 0;
+  for (int i = j - 1; i >= i0; --i) {  // rule 7
+    const int d = j - i;
+    if (!q.pair_ok(i, d)) continue;
+    const double t = q.e_ext[q.cell(i, d)];
+    if (t == NEG) continue;
+    const double lt = lam * t;
+    for (int u = I[A.split_off + s]; u < I[A.split_off + s + 1]; ++u) {
+      const int s2 = I[A.split_ent + 2 * u];      // prefix part (l,h)
+      const int s1 = I[A.split_ent + 2 * u + 1];  // pair part   (h,r)
+      a.add(T.o(i, s2) + (T.at(ST_P, d, i, s1) + lt));
+    }
+  }
+  if (q.unp[j - 1]) {  // rule 8
+    for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+      const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+      if (CONSTRAINED && !allow_right(m, c, q.L, j, s, s1)) continue;
+      a.add(T.o(j - 1, s1) + w_right(m, q, s, tf, j - 1));
+    }
+  }
+  T.o(j, s) = a.value();
+}
+
+// Z(ari, nasi) (motif_trainer.hpp:108-112)
+ELEMDP_HD double lse2(double x, double y) {
+  if (y == ELEMDP_NEG_INF) return x;
+  if (x == ELEMDP_NEG_INF) return y;
+  return x < y ? y + log1p(exp(x - y)) : x + log1p(exp(y - x));
+}
+ELEMDP_HD double part_func(const ModelView& m, const TableView& T, bool ari, bool nasi) {
+  const double a = nasi ? T.o(T.L, m.lay.s00) : ELEMDP_NEG_INF;
+  const double b = ari ? T.o(T.L, m.lay.s0m2) : ELEMDP_NEG_INF;
+  const double c = ari ? T.o(T.L, m.lay.s0m1) : ELEMDP_NEG_INF;
+  return lse2(a, lse2(b, c));
+}
+
+// ---------------------------------------------------------------------------------------------
+// OUTSIDE (gather form) with expected counts / posteriors
+// ---------------------------------------------------------------------------------------------
+enum OutsideMode : int { OUT_TRAIN = 0, OUT_SCAN = 1, OUT_END = 2, OUT_NONE = 3 };  // NONE: tables only (BPP filter)
+
+// Sink for the statistics of one transition; implementations: LDS atomics on the GPU, plain adds in
+// the CPU emulation.  en(idx, w): EN[idx] += w ; eh(k, w): EH[k] += w ;
+// pos(which, p, z): log-space position posteriors, which: 0 = start (PysL), 1 = inner (PyiL), 2 = end (PyeL)
+template <class Sink> struct OutCtx {
+  const ModelView& m;
+  const SeqView& q;
+  const TableView& in;
+  const TableView& out;
+  double Z;
+  Constraint c;
+  Sink& sink;
+};
+
+// statistics of a pair-emission transition: parent P(i-1,j+1,par), child (i,j,ch) -- positions i-1 and j
+template <int MODE, class Sink>
+ELEMDP_HD bool stat_pair(OutCtx<Sink>& x, int i, int j, int par, int ch, double z) {
+  if (MODE == OUT_NONE) return true;
+  const ModelView& m = x.m;
+  const int k = i - 1;
+  const int pl = m.st_l(par), pr = m.st_r(par), cl = m.st_l(ch), cr = m.st_r(ch);
+  const int M = m.lay.M;
+  if (MODE == OUT_END) {  // motif_scanner.hpp:715-724
+    if (x.c.ys == k && !(pl == 0 && cl == 1)) return false;
+    if (x.c.ys == j && !(cr == 0 && pr == 1)) return false;
+    if (pl == M - 2 && cl == M - 1) x.sink.pos(2, k, z);
+    if (cr == M - 2 && pr == M - 1) x.sink.pos(2, j, z);
+    if (pr == M - 2 && x.q.L == j + 1) x.sink.pos(2, x.q.L, z);
+    return true;
+  }
+  if (!m.no_prf) {  // motif_trainer.hpp:384-388 / profile_hmm.hpp:144-179
+    const double w = exp(z);
+    const int bi = x.q.seq[k], bj = x.q.seq[j];
+    if (m.ints[m.lay.st_pair_r + par]) {
+      const int t = bp_type(bi, bj);
+      if (t) x.sink.en(m.param_index(m.ints[m.lay.st_row_r + par], t - 1), w);
+    } else {
+      if (bi) x.sink.en(m.param_index(m.ints[m.lay.st_row_l + ch], bi - 1), w);
+      if (bj) x.sink.en(m.param_index(m.ints[m.lay.st_row_r + par], bj - 1), w);
+    }
+  }
+  if (MODE == OUT_SCAN) {  // motif_scanner.hpp:546-553
+    if (pl == 0 && cl == 1) x.sink.pos(0, k, z);
+    if (cr == 0 && pr == 1) x.sink.pos(0, j, z);
+    if (cl != 0 && cl != M - 1) x.sink.pos(1, k, z);
+    if (pr != 0 && pr != M - 1) x.sink.pos(1, j, z);
+  }
+  return true;
+}
+// right-emission transition: parent (.,j+1,par), child (.,j,ch) -- position j
+template <int MODE, class Sink>
+ELEMDP_HD bool stat_right(OutCtx<Sink>& x, int j, int par, int ch, double z) {
+  if (MODE == OUT_NONE) return true;
+  const ModelView& m = x.m;
+  const int pr = m.st_r(par), cr = m.st_r(ch);
+  const int M = m.lay.M;
+  if (MODE == OUT_END) {  // motif_scanner.hpp:730-738
+    if (x.c.ys == j && !(cr == 0 && pr == 1)) return false;
+    if (cr == M - 2 && pr == M - 1) x.sink.pos(2, j, z);
+    if (pr == M - 2 && x.q.L == j + 1) x.sink.pos(2, x.q.L, z);
+    return true;
+  }
+  if (!m.no_prf) {
+    const int b = x.q.seq[j];
+    if (b) x.sink.en(m.param_index(m.ints[m.lay.st_row_r + par], b - 1), exp(z));
+  }
+  if (MODE == OUT_SCAN) {  // :559-564
+    if (cr == 0 && pr == 1) x.sink.pos(0, j, z);
+    if (pr != 0 && pr != M - 1) x.sink.pos(1, j, z);
+  }
+  return true;
+}
+// left-emission transition: parent M(i-1,j,par), child M(i,j,ch) -- position i-1
+template <int MODE, class Sink>
+ELEMDP_HD bool stat_left(OutCtx<Sink>& x, int i, int par, int ch, double z) {
+  if (MODE == OUT_NONE) return true;
+  const ModelView& m = x.m;
+  const int k = i - 1;
+  const int pl = m.st_l(par), cl = m.st_l(ch);
+  const int M = m.lay.M;
+  if (MODE == OUT_END) {  // :741-747
+    if (x.c.ys == k && !(pl == 0 && cl == 1)) return false;
+    if (pl == M - 2 && cl == M - 1) x.sink.pos(2, k, z);
+    return true;
+  }
+  if (!m.no_prf) {
+    const int b = x.q.seq[k];
+    if (b) x.sink.en(m.param_index(m.ints[m.lay.st_row_l + ch], b - 1), exp(z));
+  }
+  if (MODE == OUT_SCAN) {  // :568-573
+    if (pl == 0 && cl == 1) x.sink.pos(0, k, z);
+    if (cl != 0 && cl != M - 1) x.sink.pos(1, k, z);
+  }
+  return true;
+}
+// energy-gradient statistic: EH[idx(parent)] += tsc * e^z (motif_trainer.hpp:380-381)
+template <int MODE, class Sink> ELEMDP_HD void stat_energy(OutCtx<Sink>& x, int par, double tsc, double z) {
+  if (MODE == OUT_TRAIN) x.sink.eh(x.m.eh_index(par), tsc * exp(z));
+}
+
+// exterior chain backwards, one step: outside_o(i, s) for i < L from outside_o(>i,.) (rules 8, 7 reversed).
+// Also accounts the statistics of those transitions.
+template <int MODE, class Sink> ELEMDP_HD void outside_ext_target(OutCtx<Sink>& x, int i, int s) {
+  const ModelView& m = x.m;
+  const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const double NEG = ELEMDP_NEG_INF;
+  const double in_c = x.in.o(i, s);
+  if (in_c == NEG) { x.out.o(i, s) = NEG; return; }
+  LseAcc a;
+  // rule 8: parent O(i+1, par) with s in right(par); emits position i
+  if (q.unp[i]) {
+    for (int t = I[A.rright_off + s]; t < I[A.rright_off + s + 1]; ++t) {
+      const int par = I[A.rright_ent + 2 * t], tf = I[A.rright_ent + 2 * t + 1];
+      const double term = x.out.o(i + 1, par) + w_right(m, q, par, tf, i);
+      const double z = term + in_c - x.Z;
+      if (z == NEG) continue;
+      if (!stat_right<MODE>(x, i, par, s, z)) continue;
+      a.add(term);
+    }
+  }
+  // rule 7: parent O(j, par), this = prefix part s2=(l,h), sibling P(i,j,(h,r))
+  const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+  for (int j = i + 1; j <= jmax; ++j) {
+    const int d = j - i;
+    if (!q.pair_ok(i, d)) continue;
+    const double t = q.e_ext[q.cell(i, d)];
+    if (t == NEG) continue;
+    for (int u = I[A.split1_off + s]; u < I[A.split1_off + s + 1]; ++u) {
+      const int par = I[A.split1_ent + 2 * u], s1 = I[A.split1_ent + 2 * u + 1];
+      const double term = x.out.o(j, par) + (x.in.at(ST_P, d, i, s1) + m.lam(par) * t);
+      const double z = term + in_c - x.Z;
+      if (z == NEG) continue;
+      stat_energy<MODE>(x, par, t, z);
+      a.add(term);
+    }
+  }
+  x.out.o(i, s) = a.value();
+}
+
+// band target (i,d,s), outside direction.  Requires every larger diagonal and the whole exterior
+// chain outside_o to be final.
+template <int MODE, class Sink> ELEMDP_HD void outside_target(OutCtx<Sink>& x, int d, int i, int s) {
+  const ModelView& m = x.m;
+  const SeqView& q = x.q;
+  const TableView& in = x.in;
+  const TableView& out = x.out;
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const double NEG = ELEMDP_NEG_INF;
+  const double Z = x.Z;
+  const int j = i + d;
+  const bool isloop = I[A.st_is_loop + s] != 0;
+  const bool pok = q.pair_ok(i, d);
+  const bool lok = q.left_ok(i, d);
+  const bool mok = m_ok(m, q, i, d);
+  const bool eok = q.e_ok(i, d);
+  const bool up_ok = q.pair_ok(i - 1, d + 2);  // enclosing pair cell (i-1, j+1)
+
+  // ---- E(i,j,s) as child of P(i-1,j+1,par): rule 1a
+  // NB every transition's posterior z contains inside(child); the reference drops transitions with
+  // z == log 0 *before* touching the outside table (motif_trainer.hpp:378), so a child whose inside
+  // value is log 0 keeps outside = log 0 -- hence the `in_c != NEG` guards below.
+  double oE = NEG;
+  const double inE = eok ? in.at(ST_E, d, i, s) : NEG;
+  if (inE != NEG) {
+    LseAcc a;
+    const double in_c = inE;
+    for (int t = I[A.rpair_off + s]; t < I[A.rpair_off + s + 1]; ++t) {
+      const int par = I[A.rpair_ent + 2 * t], tf = I[A.rpair_ent + 2 * t + 1];
+      const double term = out.at(ST_P, d + 2, i - 1, par) + w_pair(m, q, par, s, tf, i - 1, j);
+      const double z = term + in_c - Z;
+      if (z == NEG) continue;
+      if (!stat_pair<MODE>(x, i, j, par, s, z)) continue;
+      a.add(term);
+    }
+    oE = a.value();
+  }
+  out.at(ST_E, d, i, s) = oE;
+
+  // ---- M(i,j,s): child of E(i,j,s) (6a) and of M(i-1,j,par) (5a)
+  double oM = NEG;
+  const double inM = mok ? in.at(ST_M, d, i, s) : NEG;
+  if (inM != NEG) {
+    LseAcc a;
+    const double in_c = inM;
+    if (eok) {
+      const double t = q.e_close[q.cell(i - 1, d + 2)];
+      if (t != NEG) {
+        const double term = oE + m.lam(s) * t;
+        const double z = term + in_c - Z;
+        if (z != NEG) { stat_energy<MODE>(x, s, t, z); a.add(term); }
+      }
+    }
+    if (m_ok(m, q, i - 1, d + 1) && q.unp[i - 1]) {
+      for (int t = I[A.rleft_off + s]; t < I[A.rleft_off + s + 1]; ++t) {
+        const int par = I[A.rleft_ent + 2 * t], tf = I[A.rleft_ent + 2 * t + 1];
+        const double term = out.at(ST_M, d + 1, i - 1, par) + w_left(m, q, s, tf, i - 1);
+        const double z = term + in_c - Z;
+        if (z == NEG) continue;
+        if (!stat_left<MODE>(x, i, par, s, z)) continue;
+        a.add(term);
+      }
+    }
+    oM = a.value();
+  }
+  out.at(ST_M, d, i, s) = oM;
+
+  // ---- 1(i,j,s): the "1" child of B(i,j',par) for j' > j (rule 2)
+  double o1 = NEG, oB = NEG, o2 = NEG;
+  if (lok) {
+    if (in.at(ST_1, d, i, s) != NEG) {
+      LseAcc a;
+      const int dj = q.dmin[j];
+      if (j < q.L && dj > 0) {
+        const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+        for (int jj = j + dj; jj <= jmax; ++jj) {
+          for (int u = I[A.split1_off + s]; u < I[A.split1_off + s + 1]; ++u) {
+            const int par = I[A.split1_ent + 2 * u], s2 = I[A.split1_ent + 2 * u + 1];
+            a.add(out.at(ST_B, jj - i, i, par) + in.at(ST_2, jj - j, j, s2));
+          }
+        }
+      }
+      o1 = a.value();
+    }
+    // ---- B(i,j,s): child of M (5b) and of 1 (4b)
+    if (in.at(ST_B, d, i, s) != NEG) {
+      LseAcc a;
+      if (mok) a.add(oM);
+      a.add(o1);
+      oB = a.value();
+    }
+    // ---- 2(i,j,s): child of 1 (4a), of 2(i,j+1,par) (3a), and the "2" child of B(i',j,par), i' < i (rule 2)
+    const double in2 = in.at(ST_2, d, i, s);
+    if (in2 != NEG) {
+      LseAcc a;
+      a.add(o1);
+      const double in_c = in2;
+      if (q.left_ok(i, d + 1) && q.unp[j]) {
+        for (int t = I[A.rright_off + s]; t < I[A.rright_off + s + 1]; ++t) {
+          const int par = I[A.rright_ent + 2 * t], tf = I[A.rright_ent + 2 * t + 1];
+          const double term = out.at(ST_2, d + 1, i, par) + w_right(m, q, par, tf, j);
+          const double z = term + in_c - Z;
+          if (z == NEG) continue;
+          if (!stat_right<MODE>(x, j, par, s, z)) continue;
+          a.add(term);
+        }
+      }
+      const int imin = (j - q.W > 0) ? j - q.W : 0;
+      for (int ii = i - 1; ii >= imin; --ii) {
+        const int di = q.dmin[ii];
+        if (di == 0 || i - ii < di) continue;
+        for (int u = I[A.split2_off + s]; u < I[A.split2_off + s + 1]; ++u) {
+          const int par = I[A.split2_ent + 2 * u], s1 = I[A.split2_ent + 2 * u + 1];
+          a.add(out.at(ST_B, j - ii, ii, par) + in.at(ST_1, i - ii, ii, s1));
+        }
+      }
+      o2 = a.value();
+    }
+  }
+  out.at(ST_1, d, i, s) = o1;
+  out.at(ST_B, d, i, s) = oB;
+  out.at(ST_2, d, i, s) = o2;
+
+  // ---- P(i,j,s): child of 2 (3b), of P(i-1,j+1,par) (1b), of O (7), inner pair of E(i',j') (6c)
+  double oP = NEG;
+  const double inP = pok ? in.at(ST_P, d, i, s) : NEG;
+  if (inP != NEG) {
+    LseAcc a;
+    const double in_c = inP;
+    const int pc = q.cell(i, d);
+    {  // rule 7: parent O(j, par), sibling prefix O(i, s2); this = pair part (h,r)
+      const double t = q.e_ext[pc];
+      if (t != NEG)
+        for (int u = I[A.split2_off + s]; u < I[A.split2_off + s + 1]; ++u) {
+          const int par = I[A.split2_ent + 2 * u], s2 = I[A.split2_ent + 2 * u + 1];
+          a.add(out.o(j, par) + (in.o(i, s2) + m.lam(par) * t));
+        }
+    }
+    if (up_ok) {  // rule 1b
+      const double t = q.e_stack[q.cell(i - 1, d + 2)];
+      if (t != NEG)
+        for (int u = I[A.rpair_off + s]; u < I[A.rpair_off + s + 1]; ++u) {
+          const int par = I[A.rpair_ent + 2 * u], tf = I[A.rpair_ent + 2 * u + 1];
+          const double term = out.at(ST_P, d + 2, i - 1, par) + (w_pair(m, q, par, s, tf, i - 1, j) + m.lam(par) * t);
+          const double z = term + in_c - Z;
+          if (z == NEG) continue;
+          if (!stat_pair<MODE>(x, i, j, par, s, z)) continue;
+          stat_energy<MODE>(x, par, t, z);
+          a.add(term);
+        }
+    }
+    {  // rule 3b
+      const double t = q.e_ml[pc];
+      if (t != NEG) {
+        const double term = o2 + m.lam(s) * t;
+        const double z = term + in_c - Z;
+        if (z != NEG) { stat_energy<MODE>(x, s, t, z); a.add(term); }
+      }
+    }
+    // rule 6c: outer E(i',j',par) with loops L(i',i,s2), L(j,j',s3)
+    for (int n = q.by_inner_off[pc]; n < q.by_inner_off[pc + 1]; ++n) {
+      const LoopItem it = q.items[q.by_inner_idx[n]];
+      for (int u = I[A.quad1_off + s]; u < I[A.quad1_off + s + 1]; ++u) {
+        const int par = I[A.quad1_ent + 3 * u], s2 = I[A.quad1_ent + 3 * u + 1], s3 = I[A.quad1_ent + 3 * u + 2];
+        const double term = out.at(ST_E, it.j - it.i, it.i, par) +
+                            (in.at(ST_L, i - it.i, it.i, s2) + (in.at(ST_L, it.j - j, j, s3) + m.lam(par) * it.tsc));
+        const double z = term + in_c - Z;
+        if (z == NEG) continue;
+        stat_energy<MODE>(x, par, it.tsc, z);
+        a.add(term);
+      }
+    }
+    oP = a.value();
+  }
+  out.at(ST_P, d, i, s) = oP;
+
+  // ---- L(i,j,s): child of E (6b), of L(i,j+1,par), left / right loop of an interior loop (6c)
+  double oL = NEG;
+  const double inL = isloop ? in.at(ST_L, d, i, s) : NEG;
+  if (inL != NEG) {
+    LseAcc a;
+    const double in_c = inL;
+    if (eok) {
+      const double t = q.e_hp[q.cell(i - 1, d + 2)];
+      if (t != NEG) {
+        const double term = oE + m.lam(s) * t;
+        const double z = term + in_c - Z;
+        if (z != NEG) { stat_energy<MODE>(x, s, t, z); a.add(term); }
+      }
+    }
+    if (j < q.L && d + 1 <= q.W) {
+      for (int t = I[A.rright_off + s]; t < I[A.rright_off + s + 1]; ++t) {
+        const int par = I[A.rright_ent + 2 * t], tf = I[A.rright_ent + 2 * t + 1];
+        if (!I[A.st_is_loop + par]) continue;
+        const double term = out.at(ST_L, d + 1, i, par) + w_right(m, q, par, tf, j);
+        const double z = term + in_c - Z;
+        if (z == NEG) continue;
+        if (!stat_right<MODE>(x, j, par, s, z)) continue;
+        a.add(term);
+      }
+    }
+    const int lc = q.cell(i, d);
+    for (int n = q.by_left_off[lc]; n < q.by_left_off[lc + 1]; ++n) {  // this = L(i', k): i'=i, k=j
+      const LoopItem it = q.items[q.by_left_idx[n]];
+      for (int u = I[A.quad2_off + s]; u < I[A.quad2_off + s + 1]; ++u) {
+        const int par = I[A.quad2_ent + 3 * u], s1 = I[A.quad2_ent + 3 * u + 1], s3 = I[A.quad2_ent + 3 * u + 2];
+        a.add(out.at(ST_E, it.j - it.i, it.i, par) +
+              (in.at(ST_P, it.l - it.k, it.k, s1) + (in.at(ST_L, it.j - it.l, it.l, s3) + m.lam(par) * it.tsc)));
+      }
+    }
+    for (int n = q.by_right_off[lc]; n < q.by_right_off[lc + 1]; ++n) {  // this = L(l, j'): l=i, j'=j
+      const LoopItem it = q.items[q.by_right_idx[n]];
+      for (int u = I[A.quad3_off + s]; u < I[A.quad3_off + s + 1]; ++u) {
+        const int par = I[A.quad3_ent + 3 * u], s1 = I[A.quad3_ent + 3 * u + 1], s2 = I[A.quad3_ent + 3 * u + 2];
+        a.add(out.at(ST_E, it.j - it.i, it.i, par) +
+              (in.at(ST_P, it.l - it.k, it.k, s1) + (in.at(ST_L, it.k - it.i, it.i, s2) + m.lam(par) * it.tsc)));
+      }
+    }
+    oL = a.value();
+  }
+  out.at(ST_L, d, i, s) = oL;
+}
+
+}  // namespace elemdp

@@ -1,0 +1,67 @@
+// plan_rules.h -- parameter-independent per-sequence preparation ("plan"), host/device agnostic.
+//
+// Everything the reference recomputes inside its sweep on every optimizer step although it does
+// not depend on theta / lambda is computed once per batch and kept resident in HBM:
+//   * which cells may hold a base pair      EnergyModel::fill_bpp_tables  energy_model.hpp:211-266
+//   * the structural term of every rule     the tsc arguments at          energy_model.hpp:346-437
+//   * the interior-loop candidates (k,l)    the double loop at            energy_model.hpp:413-426
+//     (inside enumeration) and :527-541 (outside enumeration, a superset when C < 30)
+#pragma once
+#include "dp_rules.h"
+#include "energy_rules.h"
+
+namespace elemdp {
+
+struct PlanCfg {
+  int32_t no_ene;    // --no-energy: every structural term is 0 (energy_model.hpp:351,372,399,...)
+  int32_t min_span;  // smallest span of a base-pair cell: turn+2 = 5, or 1 with NO_TURN (:217)
+  int32_t fix_rss;   // structure given per sequence
+};
+
+// ndot[p] = number of non-'.' characters in fix[0..p); segment [a,b) is all dots iff equal counts
+ELEMDP_HD bool all_dots(const int32_t* ndot, int a, int b) { return ndot == nullptr || ndot[b] == ndot[a]; }
+
+// canonical candidate: cell (i,d) may pair by sequence alone (energy_model.hpp:216-219)
+ELEMDP_HD bool canonical_pair(const uint8_t* seq, int L, int W, int min_span, int i, int d) {
+  return d >= min_span && d <= W && i + d <= L && bp_type(seq[i], seq[i + d - 1]) > 0;
+}
+
+struct PairTerms { double stack, ext, ml, close, hp; };
+
+// structural terms of a kept pair cell (i,d); `inner_ok` = cell (i+1,d-2) is kept too
+ELEMDP_HD PairTerms pair_terms(const EnergyTables& e, const PlanCfg& cfg, const uint8_t* seq, int L, const int32_t* ndot,
+                               int i, int d, bool inner_ok) {
+  const int j = i + d;
+  PairTerms t;
+  const double NEG = ELEMDP_NEG_INF;
+  t.stack = inner_ok ? (cfg.no_ene ? 0. : loop_energy(e, seq, i, j - 1, i + 1, j - 2)) : NEG;     // :351-352
+  t.ext = cfg.no_ene ? 0. : sum_ext_m(e, seq, L, i, j - 1, true);                                  // :429-430
+  t.ml = cfg.no_ene ? 0. : sum_ext_m(e, seq, L, i, j - 1, false) + e.ml_intern;                    // :372-373
+  t.close = cfg.no_ene ? 0. : sum_ext_m(e, seq, L, j - 1, i, false) + (e.ml_closing + e.ml_intern);  // :399-402
+  t.hp = cfg.no_ene ? 0. : hairpin_energy(e, seq, i, j - 1);                                       // :407-408
+  if (!all_dots(ndot, i + 1, j - 1)) t.hp = NEG;                                                   // :409-410
+  return t;
+}
+
+// Enumerates the interior-loop candidates of the E cell (i,d) (closing pair = cell (i-1,d+2)) in the
+// reference's inside order (l descending, k ascending) over the OUTSIDE set
+//   i <= k <= min(j-2, i+C),  k+2 <= l <= j,  (k,l) != (i,j),  P(k,l) kept,  tsc finite
+// and calls f(k, l, tsc, in_inside_set) for each; in_inside_set <=> (k-i)+(j-l) <= C.
+template <class OkFn, class F>
+ELEMDP_HD void enum_interior(const EnergyTables& e, const PlanCfg& cfg, const uint8_t* seq, int L, int W, int C,
+                             const int32_t* ndot, const OkFn& ok, int i, int d, F&& f) {
+  const int j = i + d;
+  for (int l = j; l >= i + 2; --l) {
+    const int kmax = (l - 2 < i + C) ? l - 2 : i + C;
+    for (int k = i; k <= kmax; ++k) {
+      if (k == i && l == j) continue;
+      if (l - k > W || !ok(k, l - k)) continue;
+      const double tsc = cfg.no_ene ? 0. : loop_energy(e, seq, i - 1, j, k, l - 1);
+      if (tsc == ELEMDP_NEG_INF) continue;
+      if (!all_dots(ndot, i, k) || !all_dots(ndot, l, j)) continue;  // :419-421
+      f(k, l, tsc, (k - i) + (j - l) <= C);
+    }
+  }
+}
+
+}  // namespace elemdp

@@ -1,0 +1,248 @@
+// scan_rules.h -- CYK (max-product) targets with traceback records, and the traceback itself.
+//
+// Per-target form of RNAelemScanDP::CYKFun (RNAelem/motif_scanner.hpp:802-913) and trace_back
+// (:262-362).  The candidate order inside one target follows the reference's sweep order
+// (energy_model.hpp:346-437 x motif_model.hpp:262-421) because `compare` keeps the first strictly
+// greatest candidate (:821): ties -- frequent with uniform theta -- must resolve identically.
+#pragma once
+#include "dp_rules.h"
+
+namespace elemdp {
+
+struct TraceView {
+  TraceRec* band;  // same indexing as TableView::band
+  TraceRec* ext;   // [j][s]
+};
+
+struct MaxAcc {
+  double best;
+  TraceRec tr;
+  ELEMDP_HD MaxAcc() : best(ELEMDP_NEG_INF) { tr.k = tr.l = -1; tr.t = -1; tr.e1 = -1; tr.s1 = -1; }
+  ELEMDP_HD void offer(double y, int k, int l, int t, int e1, int s1) {
+    if (best < y) {
+      best = y;
+      tr.k = (int16_t)k; tr.l = (int16_t)l; tr.t = (int8_t)t; tr.e1 = (int8_t)e1; tr.s1 = (int16_t)s1;
+    }
+  }
+};
+
+// last index of the maximum (max_index, util.hpp:232-241)
+ELEMDP_HD int last_argmax(const double* v, int n) {
+  int s = 0;
+  double m = -1.7976931348623157e308;
+  for (int i = 0; i < n; ++i)
+    if (m <= v[i]) { s = i; m = v[i]; }
+  return s;
+}
+
+ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
+                          const Constraint& c, int d, int i, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const int j = i + d;
+  const double NEG = ELEMDP_NEG_INF;
+  const double lam = m.lam(s);
+  const bool isloop = I[A.st_is_loop + s] != 0;
+
+  MaxAcc aL;
+  if (isloop) {
+    if (d == 0) { if (m.st_l(s) == m.st_r(s)) aL.best = 0.; }
+    else
+      for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+        const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+        if (!allow_right(m, c, q.L, j, s, s1)) continue;
+        aL.offer(T.at(ST_L, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_L_L, ST_L, s1);
+      }
+  }
+  T.at(ST_L, d, i, s) = aL.best;
+  R.band[T.idx(ST_L, d, i, s)] = aL.tr;
+
+  const bool pok = q.pair_ok(i, d);
+  MaxAcc aP;
+  if (pok) {
+    const double est = q.e_stack[q.cell(i, d)];
+    for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {  // all 1a candidates first ...
+      const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
+      if (!allow_pair(m, c, q.L, i, j, s, s1)) continue;
+      aP.offer(T.at(ST_E, d - 2, i + 1, s1) + w_pair(m, q, s, s1, tf, i, j - 1), i + 1, j - 1, TT_P_E, ST_E, s1);
+    }
+    if (est != NEG)
+      for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {  // ... then 1b
+        const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
+        if (!allow_pair(m, c, q.L, i, j, s, s1)) continue;
+        aP.offer(T.at(ST_P, d - 2, i + 1, s1) + (w_pair(m, q, s, s1, tf, i, j - 1) + lam * est), i + 1, j - 1, TT_P_P,
+                 ST_P, s1);
+      }
+  }
+  T.at(ST_P, d, i, s) = aP.best;
+  R.band[T.idx(ST_P, d, i, s)] = aP.tr;
+
+  const bool lok = q.left_ok(i, d);
+  MaxAcc aB;
+  if (lok) {
+    for (int k = i + q.dmin[i]; k < j; ++k) {
+      const int dk = q.dmin[k];
+      if (dk == 0 || j - k < dk) continue;
+      for (int t = I[A.split_off + s]; t < I[A.split_off + s + 1]; ++t) {
+        const int s1 = I[A.split_ent + 2 * t], s2 = I[A.split_ent + 2 * t + 1];
+        aB.offer(T.at(ST_1, k - i, i, s1) + T.at(ST_2, j - k, k, s2), i, k, TT_B_12, ST_1, s1);
+      }
+    }
+  }
+  T.at(ST_B, d, i, s) = aB.best;
+  R.band[T.idx(ST_B, d, i, s)] = aB.tr;
+
+  MaxAcc a2, a1;
+  if (lok) {
+    if (q.left_ok(i, d - 1) && q.unp[j - 1])
+      for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+        const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+        if (!allow_right(m, c, q.L, j, s, s1)) continue;
+        a2.offer(T.at(ST_2, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_2_2, ST_2, s1);
+      }
+    if (pok) {
+      const double eml = q.e_ml[q.cell(i, d)];
+      if (eml != NEG) a2.offer(aP.best + lam * eml, i, j, TT_2_P, ST_P, s);
+    }
+    a1.offer(a2.best, i, j, TT_1_2, ST_2, s);
+    a1.offer(aB.best, i, j, TT_1_B, ST_B, s);
+  }
+  T.at(ST_2, d, i, s) = a2.best;
+  R.band[T.idx(ST_2, d, i, s)] = a2.tr;
+  T.at(ST_1, d, i, s) = a1.best;
+  R.band[T.idx(ST_1, d, i, s)] = a1.tr;
+
+  const bool mok = m_ok(m, q, i, d);
+  MaxAcc aM;
+  if (mok) {
+    if (m_ok(m, q, i + 1, d - 1) && q.unp[i])
+      for (int t = I[A.left_off + s]; t < I[A.left_off + s + 1]; ++t) {
+        const int s1 = I[A.left_ent + 2 * t], tf = I[A.left_ent + 2 * t + 1];
+        if (!allow_left(m, c, i, s, s1)) continue;
+        aM.offer(T.at(ST_M, d - 1, i + 1, s1) + w_left(m, q, s1, tf, i), i + 1, j, TT_M_M, ST_M, s1);
+      }
+    if (lok) aM.offer(aB.best, i, j, TT_M_B, ST_B, s);
+  }
+  T.at(ST_M, d, i, s) = aM.best;
+  R.band[T.idx(ST_M, d, i, s)] = aM.tr;
+
+  MaxAcc aE;
+  if (q.e_ok(i, d)) {
+    const int pc = q.cell(i - 1, d + 2);
+    if (mok) { const double t = q.e_close[pc]; if (t != NEG) aE.offer(aM.best + lam * t, i, j, TT_E_M, ST_M, s); }
+    if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) aE.offer(aL.best + lam * t, i, j, TT_E_H, ST_L, s); }
+    const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
+    for (int it = c0; it < c1; ++it) {
+      if (!q.item_in[it]) continue;
+      const LoopItem x = q.items[it];
+      const double lt = lam * x.tsc;
+      for (int t = I[A.quad_off + s]; t < I[A.quad_off + s + 1]; ++t) {
+        const int s1 = I[A.quad_ent + 3 * t], s2 = I[A.quad_ent + 3 * t + 1], s3 = I[A.quad_ent + 3 * t + 2];
+        aE.offer(T.at(ST_P, x.l - x.k, x.k, s1) + (T.at(ST_L, x.k - i, i, s2) + (T.at(ST_L, j - x.l, x.l, s3) + lt)), x.k,
+                 x.l, TT_E_P, ST_P, s1);
+      }
+    }
+  }
+  T.at(ST_E, d, i, s) = aE.best;
+  R.band[T.idx(ST_E, d, i, s)] = aE.tr;
+}
+
+ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
+                              const Constraint& c, int j, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const double NEG = ELEMDP_NEG_INF;
+  const double lam = m.lam(s);
+  MaxAcc a;
+  const int i0 = (j - q.W > 0) ? j - q.W : 0;
+  for (int i = j - 1; i >= i0; --i) {
+    const int d = j - i;
+    if (!q.pair_ok(i, d)) continue;
+    const double t = q.e_ext[q.cell(i, d)];
+    if (t == NEG) continue;
+    const double lt = lam * t;
+    for (int u = I[A.split_off + s]; u < I[A.split_off + s + 1]; ++u) {
+      const int s2 = I[A.split_ent + 2 * u], s1 = I[A.split_ent + 2 * u + 1];
+      a.offer(T.o(i, s2) + (T.at(ST_P, d, i, s1) + lt), i, j, TT_O_OP, ST_P, s1);
+    }
+  }
+  if (q.unp[j - 1])
+    for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+      const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+      if (!allow_right(m, c, q.L, j, s, s1)) continue;
+      a.offer(T.o(j - 1, s1) + w_right(m, q, s, tf, j - 1), 0, j - 1, TT_O_O, ST_O, s1);
+    }
+  T.o(j, s) = a.best;
+  R.ext[(size_t)j * T.S + s] = a.tr;
+}
+
+struct TraceFrame { int16_t i, j; int8_t e; int16_t s; };
+
+// Walks the trace from O(L, s0) and writes the motif node per position (`path`, psihat) and the
+// structure letters (`rss`: O L R H B I M, blank where nothing was written).  `stack` is caller
+// scratch; returns false on overflow.
+ELEMDP_HD bool trace_back(const ModelView& m, const TableView& T, const TraceView& R, int L, int s0, int32_t* path,
+                          char* rss, TraceFrame* stack, int cap) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const int M = A.M;
+  // (l, r) -> state id by search (only used a few times per sequence)
+  auto find_state = [&](int l, int r) {
+    for (int s = 0; s < A.S; ++s) if (I[A.st_l + s] == l && I[A.st_r + s] == r) return s;
+    return -1;
+  };
+  (void)M;
+  int top = 0;
+  stack[top++] = TraceFrame{0, (int16_t)L, (int8_t)ST_O, (int16_t)s0};
+  auto fill = [&](int from, int n, char ch) { for (int p = from; p < from + n; ++p) rss[p] = ch; };
+  while (top > 0) {
+    const TraceFrame f = stack[--top];
+    const TraceRec t = (f.e == ST_O) ? R.ext[(size_t)f.j * T.S + f.s] : R.band[T.idx(f.e, f.j - f.i, f.i, f.s)];
+    if (t.t < 0) continue;  // leaf
+    if (top + 3 > cap) return false;
+    const int s1 = t.s1;
+    const int fr = I[A.st_r + f.s], fl = I[A.st_l + f.s];
+    const int s1l = I[A.st_l + s1], s1r = I[A.st_r + s1];
+    switch (t.t) {
+      case TT_L_L: path[t.l] = fr; stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1}; break;
+      case TT_O_O: path[t.l] = fr; rss[t.l] = 'O'; stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1}; break;
+      case TT_2_2: path[t.l] = fr; rss[t.l] = 'M'; stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1}; break;
+      case TT_E_H: fill(f.i, f.j - f.i, 'H'); stack[top++] = TraceFrame{t.k, t.l, t.e1, f.s}; break;
+      case TT_E_M: case TT_M_B: case TT_2_P: case TT_1_2: case TT_1_B:
+        stack[top++] = TraceFrame{t.k, t.l, t.e1, f.s};
+        break;
+      case TT_P_E: case TT_P_P:
+        path[f.i] = s1l; rss[f.i] = 'L'; path[t.l] = fr; rss[t.l] = 'R';
+        stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1};
+        break;
+      case TT_O_OP: {
+        const int s2 = find_state(fl, s1l);
+        stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1};
+        stack[top++] = TraceFrame{(int16_t)fl, t.k, (int8_t)ST_O, (int16_t)s2};
+        break;
+      }
+      case TT_E_P: {
+        const int s2 = find_state(fl, s1l), s3 = find_state(s1r, fr);
+        const int n1 = f.j - t.l, n2 = t.k - f.i;
+        if (0 == n1) fill(f.i, n2, 'B');
+        else if (0 == n2) fill(t.l, n1, 'B');
+        else { fill(f.i, n2, 'I'); fill(t.l, n1, 'I'); }
+        stack[top++] = TraceFrame{t.l, f.j, (int8_t)ST_L, (int16_t)s3};
+        stack[top++] = TraceFrame{f.i, t.k, (int8_t)ST_L, (int16_t)s2};
+        stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1};
+        break;
+      }
+      case TT_B_12: {
+        const int s2 = find_state(s1r, fr);
+        stack[top++] = TraceFrame{t.l, f.j, (int8_t)ST_2, (int16_t)s2};
+        stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1};
+        break;
+      }
+      case TT_M_M: path[f.i] = s1l; rss[f.i] = 'M'; stack[top++] = TraceFrame{t.k, t.l, (int8_t)ST_M, (int16_t)s1}; break;
+      default: break;
+    }
+  }
+  return true;
+}
+
+}  // namespace elemdp

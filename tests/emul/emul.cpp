@@ -1,0 +1,441 @@
+// emul.cpp -- TEST-ONLY serial driver around the product's host/device-agnostic rule headers.
+//
+// Built by tests (tests/emul/build.py) into tests/emul/libelemdp_emul.so; it is NOT part of
+// libelemdp.so and nothing in rnaelem_amd/ can reach it.  It runs the very same per-target
+// functions the HIP kernels run (rnaelem_amd/csrc/dp_rules.h, plan_rules.h, energy_rules.h),
+// one target after the other on the CPU, so that the gather formulation, the plan builder, the
+// automaton flattening and the energy parser can be checked against the oracle without a GPU
+// (pytest -m "not gpu").  The thread mapping, LDS staging, barriers and reductions of the real
+// kernels are covered by the -m gpu tests.
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../rnaelem_amd/csrc/automaton.h"
+#include "../../rnaelem_amd/csrc/dp_rules.h"
+#include "../../rnaelem_amd/csrc/energy_rules.h"
+#include "../../rnaelem_amd/csrc/energy_tables.h"
+#include "../../rnaelem_amd/csrc/host_prep.h"
+#include "../../rnaelem_amd/csrc/plan_rules.h"
+#include "../../rnaelem_amd/csrc/scan_rules.h"
+
+using namespace elemdp;
+
+namespace {
+
+const double NEG = -HUGE_VAL;
+
+enum { F_NO_RSS = 1, F_NO_PRF = 2, F_NO_ENE = 4, F_SOFTMAX = 8, F_FIX_RSS = 1 << 9, F_NO_TURN = 1 << 10 };
+
+struct Emu {
+  Automaton* au = nullptr;
+  EnergyTables et;
+  AutomatonLayout lay, lay0;
+  std::vector<int32_t> ints, ints0;
+  int max_span, max_iloop, flags;
+  double min_bpp, tau;
+  ~Emu() { delete au; }
+};
+
+// CPU-side plan of one sequence (what plan kernels build on the GPU)
+struct HostPlan {
+  int L, W, C;
+  std::vector<uint8_t> seq, unp, item_in;
+  std::vector<double> ws;
+  std::vector<uint32_t> okbits;
+  std::vector<int16_t> dmin;
+  std::vector<double> e_stack, e_ext, e_ml, e_close, e_hp;
+  std::vector<LoopItem> items;
+  std::vector<int32_t> by_outer_off, by_inner_off, by_inner_idx, by_left_off, by_left_idx, by_right_off, by_right_idx;
+  std::vector<int32_t> ndot;
+  bool have_fix = false;
+  int n_pairs = 0;
+
+  bool ok(int i, int d) const {
+    if (i < 0 || d < 0 || d > W || i + d > L) return false;
+    int c = i * (W + 1) + d;
+    return (okbits[c >> 5] >> (c & 31)) & 1u;
+  }
+  void set_ok(int i, int d) { int c = i * (W + 1) + d; okbits[c >> 5] |= 1u << (c & 31); }
+
+  SeqView view() const {
+    SeqView q;
+    q.L = L; q.W = W; q.C = C;
+    q.seq = seq.data(); q.ws = ws.data(); q.okbits = okbits.data(); q.dmin = dmin.data(); q.unp = unp.data();
+    q.e_stack = e_stack.data(); q.e_ext = e_ext.data(); q.e_ml = e_ml.data(); q.e_close = e_close.data(); q.e_hp = e_hp.data();
+    q.items = items.data(); q.by_outer_off = by_outer_off.data();
+    q.by_inner_off = by_inner_off.data(); q.by_inner_idx = by_inner_idx.data();
+    q.by_left_off = by_left_off.data(); q.by_left_idx = by_left_idx.data();
+    q.by_right_off = by_right_off.data(); q.by_right_idx = by_right_idx.data();
+    q.item_in = item_in.data();
+    return q;
+  }
+};
+
+void plan_init(const Emu& E, HostPlan& P, const uint8_t* seq, int L, const uint8_t* qual, const char* fix) {
+  P.L = L;
+  P.W = std::min(L, E.max_span);
+  P.C = std::min(P.W - 2 - ((E.flags & F_NO_TURN) ? 2 : 5), E.max_iloop);  // energy_model.hpp:271-273
+  P.seq.assign(seq, seq + L);
+  P.ws.assign(L + 1, 0.);
+  if (qual) position_weights(qual, L + 1, P.ws.data());
+  P.unp.assign(L + 1, 1);
+  P.have_fix = (E.flags & F_FIX_RSS) && fix;
+  if (P.have_fix) {
+    P.ndot.assign(L + 1, 0);
+    nondot_prefix(fix, L, P.ndot.data());
+    for (int p = 0; p < L; ++p) P.unp[p] = fix[p] == '.';
+  }
+  P.okbits.assign(((size_t)(L + 1) * (P.W + 1) + 31) / 32, 0u);
+}
+
+// canonical mask / fixed structure (energy_model.hpp:213-247)
+int plan_mask(const Emu& E, HostPlan& P, const char* fix) {
+  const int min_span = (E.flags & F_NO_TURN) ? 1 : 5;
+  int total = 0;
+  for (int i = 0; i <= P.L; ++i)
+    for (int d = min_span; d <= P.W && i + d <= P.L; ++d)
+      if (canonical_pair(P.seq.data(), P.L, P.W, min_span, i, d)) { ++total; if (!P.have_fix) P.set_ok(i, d); }
+  if (P.have_fix) {
+    std::vector<int> st;
+    for (int p = 0; p < P.L; ++p) {
+      if (fix[p] == '(') st.push_back(p);
+      else if (fix[p] == ')') {
+        if (st.empty()) throw std::runtime_error("bad rss");
+        int o = st.back(); st.pop_back();
+        if (p + 1 - o > P.W) throw std::runtime_error("fixed pair exceeds max span");
+        P.set_ok(o, p + 1 - o);
+      } else if (fix[p] != '.') throw std::runtime_error("bad rss char");
+    }
+  }
+  return total;
+}
+
+// everything derived from the pair mask
+void plan_finish(const Emu& E, HostPlan& P) {
+  const int L = P.L, W = P.W;
+  const size_t nc = (size_t)(L + 1) * (W + 1);
+  PlanCfg cfg{(E.flags & F_NO_ENE) ? 1 : 0, (E.flags & F_NO_TURN) ? 1 : 5, P.have_fix ? 1 : 0};
+  const int32_t* ndot = P.have_fix ? P.ndot.data() : nullptr;
+  P.dmin.assign(L + 1, 0);
+  P.n_pairs = 0;
+  for (int i = 0; i <= L; ++i)
+    for (int d = 1; d <= W && i + d <= L; ++d)
+      if (P.ok(i, d)) { if (!P.dmin[i]) P.dmin[i] = (int16_t)d; ++P.n_pairs; }
+  P.e_stack.assign(nc, NEG); P.e_ext.assign(nc, NEG); P.e_ml.assign(nc, NEG); P.e_close.assign(nc, NEG); P.e_hp.assign(nc, NEG);
+  for (int i = 0; i <= L; ++i)
+    for (int d = 1; d <= W && i + d <= L; ++d)
+      if (P.ok(i, d)) {
+        PairTerms t = pair_terms(E.et, cfg, P.seq.data(), L, ndot, i, d, P.ok(i + 1, d - 2));
+        size_t c = (size_t)i * (W + 1) + d;
+        P.e_stack[c] = t.stack; P.e_ext[c] = t.ext; P.e_ml[c] = t.ml; P.e_close[c] = t.close; P.e_hp[c] = t.hp;
+      }
+  // interior-loop items, CSR by outer E cell
+  P.items.clear(); P.item_in.clear();
+  P.by_outer_off.assign(nc + 1, 0);
+  auto okfn = [&](int i, int d) { return P.ok(i, d); };
+  for (int i = 0; i <= L; ++i)
+    for (int d = 0; d <= W; ++d) {
+      size_t c = (size_t)i * (W + 1) + d;
+      P.by_outer_off[c] = (int32_t)P.items.size();
+      if (i + d > L) continue;
+      if (!(i > 0 && d + 2 <= W && P.ok(i - 1, d + 2))) continue;
+      enum_interior(E.et, cfg, P.seq.data(), L, W, P.C, ndot, okfn, i, d, [&](int k, int l, double tsc, bool in) {
+        LoopItem it; it.tsc = tsc; it.i = (int16_t)i; it.j = (int16_t)(i + d); it.k = (int16_t)k; it.l = (int16_t)l;
+        P.items.push_back(it); P.item_in.push_back(in ? 1 : 0);
+      });
+    }
+  P.by_outer_off[nc] = (int32_t)P.items.size();
+  // secondary orderings (ascending item index inside a key)
+  auto build = [&](std::vector<int32_t>& off, std::vector<int32_t>& idx, auto key) {
+    off.assign(nc + 1, 0);
+    for (auto const& it : P.items) off[key(it) + 1]++;
+    for (size_t c = 0; c < nc; ++c) off[c + 1] += off[c];
+    idx.assign(P.items.size(), 0);
+    std::vector<int32_t> cur(off.begin(), off.end() - 1);
+    for (size_t n = 0; n < P.items.size(); ++n) idx[cur[key(P.items[n])]++] = (int32_t)n;
+  };
+  build(P.by_inner_off, P.by_inner_idx, [&](const LoopItem& it) { return (size_t)it.k * (W + 1) + (it.l - it.k); });
+  build(P.by_left_off, P.by_left_idx, [&](const LoopItem& it) { return (size_t)it.i * (W + 1) + (it.k - it.i); });
+  build(P.by_right_off, P.by_right_idx, [&](const LoopItem& it) { return (size_t)it.l * (W + 1) + (it.j - it.l); });
+}
+
+ModelView make_view(const AutomatonLayout& lay, const std::vector<int32_t>& ints, const double* theta, double l0, double l1,
+                    double log_tau, bool no_prf, bool no_turn) {
+  ModelView m;
+  m.lay = lay; m.ints = ints.data(); m.theta = theta;
+  m.lambda[0] = l0; m.lambda[1] = l1; m.log_tau = log_tau;
+  m.lam_same = (l0 == l1);
+  m.no_prf = no_prf;
+  m.m_min = no_turn ? 4 : 10;
+  return m;
+}
+
+struct Tab {
+  std::vector<double> band, ext;
+  TableView v;
+  Tab(int L, int W, int S) : band((size_t)7 * (W + 1) * (L + 1) * S, NEG), ext((size_t)(L + 1) * S, NEG) {
+    v.band = band.data(); v.ext = ext.data(); v.L = L; v.W = W; v.S = S;
+  }
+};
+
+template <bool CON> void run_inside(const ModelView& m, const SeqView& q, Tab& T, const Constraint& c) {
+  const int S = m.lay.S;
+  for (int d = 0; d <= q.W; ++d)
+    for (int i = 0; i + d <= q.L; ++i)
+      for (int s = 0; s < S; ++s) inside_target<CON>(m, q, T.v, c, d, i, s);
+  for (int s = 0; s < S; ++s) T.v.o(0, s) = (s == m.lay.s00) ? 0. : NEG;
+  for (int j = 1; j <= q.L; ++j)
+    for (int s = 0; s < S; ++s) inside_ext_target<CON>(m, q, T.v, c, j, s);
+}
+
+struct CpuSink {
+  double* EN; double* EH; double* post[3];
+  void en(int idx, double w) { EN[idx] += w; }
+  void eh(int k, double w) { EH[k] += w; }
+  void pos(int which, int p, double z) { if (post[which]) post[which][p] = lse2(post[which][p], z); }
+};
+
+template <int MODE>
+void run_outside(const ModelView& m, const SeqView& q, Tab& in, Tab& out, double Z, const Constraint& c, CpuSink& sink,
+                 bool ari, bool nasi) {
+  const int S = m.lay.S;
+  OutCtx<CpuSink> x{m, q, in.v, out.v, Z, c, sink};
+  for (int s = 0; s < S; ++s) out.v.o(q.L, s) = NEG;
+  if (nasi) out.v.o(q.L, m.lay.s00) = 0.;
+  if (ari) { out.v.o(q.L, m.lay.s0m1) = 0.; out.v.o(q.L, m.lay.s0m2) = 0.; }
+  for (int i = q.L - 1; i >= 0; --i)
+    for (int s = 0; s < S; ++s) outside_ext_target<MODE>(x, i, s);
+  for (int d = q.W; d >= 0; --d)
+    for (int i = 0; i + d <= q.L; ++i)
+      for (int s = 0; s < S; ++s) outside_target<MODE>(x, d, i, s);
+}
+
+// BPP filter through the one-state automaton (energy_model.hpp:188-266)
+void bpp_filter(const Emu& E, HostPlan& P, int total, std::vector<double>* lnbpp_out, double* lnZ, double* eff) {
+  plan_finish(E, P);
+  ModelView m0 = make_view(E.lay0, E.ints0, nullptr, 1., 1., 0., true, E.flags & F_NO_TURN);
+  SeqView q = P.view();
+  std::vector<double> ws0(P.L + 1, 0.);
+  q.ws = ws0.data();
+  Tab in(P.L, P.W, 1), out(P.L, P.W, 1);
+  Constraint c{-1, -1, 0};
+  run_inside<false>(m0, q, in, c);
+  double Z = in.v.o(P.L, 0);
+  double en[1] = {0}, eh[2] = {0, 0};
+  CpuSink sink{en, eh, {nullptr, nullptr, nullptr}};
+  run_outside<OUT_NONE>(m0, q, in, out, Z, Constraint{-1, -1, 0}, sink, false, true);
+  const double thr = std::log(E.min_bpp);
+  std::vector<uint32_t> keep(P.okbits.size(), 0u);
+  int nbp = 0;
+  if (lnbpp_out) lnbpp_out->assign((size_t)(P.L + 1) * (P.W + 1), NEG);
+  for (int i = 0; i <= P.L; ++i)
+    for (int d = 1; d <= P.W && i + d <= P.L; ++d)
+      if (P.ok(i, d)) {
+        double ln = (in.v.at(ST_P, d, i, 0) + out.v.at(ST_P, d, i, 0)) - Z;  // energy_model.hpp:195-201
+        if (lnbpp_out) (*lnbpp_out)[(size_t)i * (P.W + 1) + d] = ln;
+        if (thr <= ln) { int c2 = i * (P.W + 1) + d; keep[c2 >> 5] |= 1u << (c2 & 31); ++nbp; }
+      }
+  if (lnZ) *lnZ = Z;
+  if (E.min_bpp > 0) { P.okbits.swap(keep); if (eff) *eff = (double)nbp / (double)total; }
+  else if (eff) *eff = 1.0;
+}
+
+// full preparation of one sequence as elemdp_load_batch does it
+double prepare(const Emu& E, HostPlan& P, const uint8_t* seq, int L, const uint8_t* qual, const char* fix) {
+  plan_init(E, P, seq, L, qual, fix);
+  int total = plan_mask(E, P, fix);
+  double eff = 1.0;
+  if (P.have_fix) {
+    int nbp = 0;
+    for (int i = 0; i <= L; ++i) for (int d = 1; d <= P.W && i + d <= L; ++d) nbp += P.ok(i, d);
+    eff = (double)nbp / (double)total;
+  } else if (E.min_bpp > 0) {
+    bpp_filter(E, P, total, nullptr, nullptr, &eff);
+  }
+  plan_finish(E, P);
+  return eff;
+}
+
+thread_local std::string g_err;
+
+}  // namespace
+
+extern "C" {
+
+const char* emu_last_error() { return g_err.c_str(); }
+
+void* emu_create(const char* pattern, const char* par_text, int max_span, int max_iloop, double min_bpp, double tau,
+                 int flags) {
+  try {
+    Emu* E = new Emu();
+    E->au = new Automaton(pattern);
+    parse_energy_text(par_text, &E->et);
+    E->au->flatten(&E->lay, &E->ints);
+    flatten_trivial(&E->lay0, &E->ints0);
+    E->max_span = max_span; E->max_iloop = max_iloop; E->min_bpp = min_bpp; E->tau = tau; E->flags = flags;
+    return E;
+  } catch (std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void emu_destroy(void* h) { delete (Emu*)h; }
+int emu_n_param(void* h) { return ((Emu*)h)->au->n_theta() + 2; }
+int emu_n_state(void* h) { return ((Emu*)h)->au->S(); }
+int emu_describe(void* h, char* buf, int cap) {
+  std::string s = ((Emu*)h)->au->to_json();
+  if ((int)s.size() + 1 > cap) return -1;
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+int emu_energy_table(void* h, const char* name, double* out, int cap) {
+  EnergyTables& e = ((Emu*)h)->et;
+  struct Ent { const char* n; double* p; int c; };
+  Ent tab[] = {{"stack", e.stack, 49}, {"hairpin", e.hairpin, 31}, {"bulge", e.bulge, 31}, {"internal", e.interior, 31},
+               {"ninio", e.ninio, 31}, {"mismatch_h", e.mismatch_h, 175}, {"mismatch_i", e.mismatch_i, 175},
+               {"mismatch_m", e.mismatch_m, 175}, {"mismatch_1ni", e.mismatch_1ni, 175}, {"mismatch_23i", e.mismatch_23i, 175},
+               {"mismatch_ext", e.mismatch_ext, 175}, {"dangle5", e.dangle5, 40}, {"dangle3", e.dangle3, 40},
+               {"int_11", e.int11, 1600}, {"int_21", e.int21, 8000}, {"int_22", e.int22, 40000}, {"triloop", e.triloop, 40},
+               {"tetraloop", e.tetraloop, 40}, {"hexaloop", e.hexaloop, 40}, {"term_au", &e.term_au, 1},
+               {"mlintern", &e.ml_intern, 1}, {"mlclosing", &e.ml_closing, 1}, {"ml_base", &e.ml_base, 1}, {"lxc37", &e.lxc37, 1}};
+  for (auto& t : tab) if (!strcmp(t.n, name)) { if (cap < t.c) return -t.c; std::copy(t.p, t.p + t.c, out); return t.c; }
+  return 0;
+}
+double emu_hairpin_energy(void* h, const uint8_t* seq, int L, int i, int j) { return hairpin_energy(((Emu*)h)->et, seq, i, j); }
+double emu_loop_energy(void* h, const uint8_t* seq, int L, int i, int j, int p, int q) { return loop_energy(((Emu*)h)->et, seq, i, j, p, q); }
+double emu_sum_ext_m(void* h, const uint8_t* seq, int L, int i, int j, int ext) { return sum_ext_m(((Emu*)h)->et, seq, L, i, j, ext); }
+
+int emu_bpp(void* h, const uint8_t* seq, int L, double* lnbpp, uint8_t* kept, double* bpp_eff, double* lnZ) {
+  try {
+    Emu& E = *(Emu*)h;
+    HostPlan P;
+    plan_init(E, P, seq, L, nullptr, nullptr);
+    int total = plan_mask(E, P, nullptr);
+    std::vector<double> ln;
+    double eff = 1.0;
+    bpp_filter(E, P, total, &ln, lnZ, &eff);
+    if (lnbpp) std::copy(ln.begin(), ln.end(), lnbpp);
+    if (kept) for (int i = 0; i <= L; ++i) for (int d = 0; d <= P.W; ++d) kept[i * (P.W + 1) + d] = P.ok(i, d);
+    if (bpp_eff) *bpp_eff = eff;
+    return 0;
+  } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// out9: Zo, Zari, Znasi, f, bpp_eff, skipped, L, W, n_items
+int emu_train_seq(void* h, const double* x, const uint8_t* seq, int L, const uint8_t* qual, const char* fix, double* out9,
+                  double* ENo, double* EHo, double* ENx, double* EHx, double* inside_o, double* inside, double* outside,
+                  double* outside_o) {
+  try {
+    Emu& E = *(Emu*)h;
+    const int nt = E.au->n_theta();
+    std::vector<double> theta(x, x + nt);
+    if (E.flags & F_SOFTMAX)  // theta = log-softmax of the rows (profile_hmm.hpp:103-111)
+      for (int r = 0; r < E.au->n_rows(); ++r) {
+        double tot = NEG;
+        for (int c = 0; c < E.au->row_width(r); ++c) tot = lse2(tot, x[E.au->row_offset(r) + c]);
+        for (int c = 0; c < E.au->row_width(r); ++c) theta[E.au->row_offset(r) + c] = x[E.au->row_offset(r) + c] - tot;
+      }
+    ModelView m = make_view(E.lay, E.ints, theta.data(), x[nt], x[nt + 1], std::log(E.tau), E.flags & F_NO_PRF,
+                            E.flags & F_NO_TURN);
+    HostPlan P;
+    double eff = prepare(E, P, seq, L, qual, fix);
+    SeqView q = P.view();
+    const int S = m.lay.S;
+    Tab in(L, P.W, S), out(L, P.W, S);
+    Constraint c{-1, -1, 0};
+    run_inside<false>(m, q, in, c);
+    double Zo = part_func(m, in.v, true, true), Za = part_func(m, in.v, true, false), Zn = part_func(m, in.v, false, true);
+    out9[0] = Zo; out9[1] = Za; out9[2] = Zn; out9[3] = 0; out9[4] = eff; out9[5] = 0; out9[6] = L; out9[7] = P.W;
+    out9[8] = (double)P.items.size();
+    auto copy_tab = [&](Tab& T, double* dst) {  // -> reference index order [i][d][e][s]
+      for (int i = 0; i <= L; ++i) for (int d = 0; d <= P.W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s)
+        dst[(((size_t)i * (P.W + 1) + d) * 7 + e) * S + s] = (i + d <= L) ? T.v.at(e, d, i, s) : NEG;
+    };
+    if (inside_o) std::copy(in.ext.begin(), in.ext.end(), inside_o);
+    if (inside) copy_tab(in, inside);
+    if (!(std::isfinite(Zo) && std::isfinite(Za))) { out9[5] = 1; return 0; }
+    std::vector<double> eno(nt + 1, 0.), enx(nt + 1, 0.);
+    double eho[2] = {0, 0}, ehx[2] = {0, 0};
+    CpuSink s1{eno.data(), eho, {nullptr, nullptr, nullptr}};
+    run_outside<OUT_TRAIN>(m, q, in, out, Zo, c, s1, true, true);
+    if (outside) copy_tab(out, outside);
+    if (outside_o) std::copy(out.ext.begin(), out.ext.end(), outside_o);
+    const bool positive = !(P.ws[L] > NEG);
+    CpuSink s2{enx.data(), ehx, {nullptr, nullptr, nullptr}};
+    double Zx = positive ? Za : Zn;
+    run_outside<OUT_TRAIN>(m, q, in, out, Zx, c, s2, positive, !positive);
+    out9[3] = Zo - Zx;
+    if (ENo) std::copy(eno.begin(), eno.begin() + nt, ENo);
+    if (ENx) std::copy(enx.begin(), enx.begin() + nt, ENx);
+    if (EHo) { EHo[0] = eho[0]; EHo[1] = eho[1]; }
+    if (EHx) { EHx[0] = ehx[0]; EHx[1] = ehx[1]; }
+    return 0;
+  } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// scan of one sequence: out6 = Ys, Ye, exist_prob, ZL, ZeL, PyNL
+int emu_scan_seq(void* h, const double* x, const uint8_t* seq, int L, const uint8_t* qual, double* out6, double* start,
+                 double* end, double* inner, int32_t* psihat, char* rss, double* EN) {
+  try {
+    Emu& E = *(Emu*)h;
+    const int nt = E.au->n_theta();
+    std::vector<double> theta(x, x + nt);
+    if (E.flags & F_SOFTMAX)
+      for (int r = 0; r < E.au->n_rows(); ++r) {
+        double tot = NEG;
+        for (int c = 0; c < E.au->row_width(r); ++c) tot = lse2(tot, x[E.au->row_offset(r) + c]);
+        for (int c = 0; c < E.au->row_width(r); ++c) theta[E.au->row_offset(r) + c] = x[E.au->row_offset(r) + c] - tot;
+      }
+    ModelView m = make_view(E.lay, E.ints, theta.data(), x[nt], x[nt + 1], std::log(E.tau), E.flags & F_NO_PRF,
+                            E.flags & F_NO_TURN);
+    HostPlan P;
+    prepare(E, P, seq, L, qual, nullptr);
+    SeqView q = P.view();
+    const int S = m.lay.S;
+    Tab in(L, P.W, S), out(L, P.W, S);
+    std::vector<double> Pys(L, NEG), Pyi(L, NEG), Pye(L + 1, NEG), en(nt + 1, 0.);
+    double eh[2] = {0, 0};
+    // start / inner posteriors (motif_scanner.hpp:186-193)
+    Constraint c0{-1, -1, 0};
+    run_inside<false>(m, q, in, c0);
+    double ZL = part_func(m, in.v, true, true);
+    CpuSink s1{en.data(), eh, {Pys.data(), Pyi.data(), nullptr}};
+    run_outside<OUT_SCAN>(m, q, in, out, ZL, c0, s1, true, true);
+    int Ys = last_argmax(Pys.data(), L);
+    double PyNL = in.v.o(L, m.lay.s00) - ZL;
+    // end posterior given the start (:195-202)
+    Constraint c1{Ys, -1, 0};
+    run_inside<true>(m, q, in, c1);
+    double ZeL = part_func(m, in.v, true, true);
+    CpuSink s2{en.data(), eh, {nullptr, nullptr, Pye.data()}};
+    run_outside<OUT_END>(m, q, in, out, ZeL, c1, s2, true, true);
+    int Ye = last_argmax(Pye.data(), L + 1);
+    // Viterbi parse (:172-184, 262-362)
+    std::vector<TraceRec> tr((size_t)7 * (P.W + 1) * (L + 1) * S), tro((size_t)(L + 1) * S);
+    TraceView tv{tr.data(), tro.data()};
+    Constraint c2{Ys, Ye, 1};
+    for (int d = 0; d <= q.W; ++d)
+      for (int i = 0; i + d <= q.L; ++i)
+        for (int s = 0; s < S; ++s) cyk_target(m, q, in.v, tv, c2, d, i, s);
+    for (int s = 0; s < S; ++s) { in.v.o(0, s) = (s == m.lay.s00) ? 0. : NEG; tro[s] = TraceRec{-1, -1, -1, -1, -1}; }
+    for (int j = 1; j <= L; ++j)
+      for (int s = 0; s < S; ++s) cyk_ext_target(m, q, in.v, tv, c2, j, s);
+    std::vector<int32_t> path(L, 0);
+    std::string r(L, ' ');
+    std::vector<TraceFrame> stack((size_t)4 * (L + 2));
+    int s0 = in.v.o(L, m.lay.s0m2) < in.v.o(L, m.lay.s0m1) ? m.lay.s0m1 : m.lay.s0m2;
+    trace_back(m, in.v, tv, L, s0, path.data(), &r[0], stack.data(), (int)stack.size());
+    double tot = NEG;
+    for (double v : Pys) tot = lse2(tot, v);
+    out6[0] = Ys; out6[1] = Ye; out6[2] = std::exp(tot); out6[3] = ZL; out6[4] = ZeL; out6[5] = PyNL;
+    if (start) std::copy(Pys.begin(), Pys.end(), start);
+    if (end) std::copy(Pye.begin(), Pye.end(), end);
+    if (inner) std::copy(Pyi.begin(), Pyi.end(), inner);
+    if (psihat) std::copy(path.begin(), path.end(), psihat);
+    if (rss) memcpy(rss, r.data(), L);
+    if (EN) for (int k = 0; k < nt; ++k) EN[k] += en[k];
+    return 0;
+  } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+}  // extern "C"
