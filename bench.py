@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: train-iteration sequences / second (BASELINE.json metric).
+
+One "step" = one evaluation of (fn, gr) over the whole batch = per sequence K2 (inside) + 2 x K3
+(outside + expected counts), the cached K1 (BPP filter) excluded, then ONE RCCL all-reduce of the
+partial sums when N > 1.  Workload = BASELINE config C/D: 10 000 synthetic RNAs of L = 200, pattern
+'((.*.))', x0 with lambda = (1,1) so the energy terms are exercised; the 10 000 sequences are sharded
+over the N ranks (strong scaling, as the metric is quoted).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PATTERN = "((.*.))"
+N_SEQ, SEQ_LEN, MAX_SPAN, MAX_ILOOP = 10000, 200, 50, 30
+PEAK_HBM_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_seq(L, S, W=MAX_SPAN):
+    """5*T per sequence with the BPP filter cached, T = (L+1)(W+1)*7*S*8 + (L+1)*S*8."""
+    T = (L + 1) * (W + 1) * 7 * S * 8 + (L + 1) * S * 8
+    return 5 * T
+
+
+def cpu_baseline(seqs, quals, x, n_theta):
+    """Reference CPU path (oracle/_ref, kind 'reference') or the oracle port, on a bounded sample."""
+    cores = len(os.sched_getaffinity(0))
+    sample = min(len(seqs), max(8, cores * 6))
+    from rnaelem_amd import synth
+    ref = os.path.join(REPO, "oracle", "_ref", "ref_dump")
+    if os.path.exists(ref):
+        with tempfile.TemporaryDirectory() as td:
+            fq, mdl = os.path.join(td, "s.fq"), os.path.join(td, "m.model")
+            synth.write_fastq(fq, seqs[:sample], quals[:sample])
+            rows, k = [], 0
+            for w in [4, 4, 4, 6, 6]:
+                rows.append(list(x[k:k + w]))
+                k += w
+            with open(mdl, "w") as f:
+                f.write("pattern: %s\ntheta: [%s]\n" % (PATTERN, ",".join("[" + ",".join("%.17g" % v for v in r) + "]" for r in rows)))
+                f.write("ene-param: ~T2004~\nmax-span: %d\nmax-internal-loop: %d\ntheta-softmax: 0\nrho-theta: 0.1\n" % (MAX_SPAN, MAX_ILOOP))
+                f.write("rho-lambda: 0.1\ntau: 0.1\nlambda: [%.17g,%.17g]\nlambda-prior: 0\nmin-bpp: 0.0001\n" % (x[-2], x[-1]))
+            out = subprocess.run([ref, "time", fq, str(cores), "1", mdl], capture_output=True, text=True, timeout=900)
+            if out.returncode == 0:
+                r = json.loads(out.stdout.strip().split("\n")[-1])
+                return {"value": r["seq_per_sec"], "unit": "seq/s", "cores": cores, "kind": "reference",
+                        "sample": "%d of the %d sequences, 1 eval, %d threads (RNAelemTrainer::operator(), BPP filter included)" % (sample, len(seqs), cores)}
+    from oracle import pyoracle as po
+    o = po.make_oracle(PATTERN, MAX_SPAN, MAX_ILOOP, min_bpp=1e-4, tau=0.1)
+    t0 = time.time()
+    o.train_eval(x, seqs[:sample], quals[:sample], n_threads=cores)
+    dt = time.time() - t0
+    return {"value": sample / dt, "unit": "seq/s", "cores": cores, "kind": "port",
+            "sample": "%d of the %d sequences, 1 eval, %d threads (oracle port, BPP filter included)" % (sample, len(seqs), cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-seq", type=int, default=N_SEQ)
+    ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from rnaelem_amd import api, synth
+    from rnaelem_amd.distributed import ShardedTrainer
+    eng = api.Engine(PATTERN, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, local_rank)
+    seqs, quals = synth.synth_batch(args.n_seq, args.seq_len)
+    x = eng.initial_params(1.0)
+    t_load = time.time()
+    trainer = ShardedTrainer(eng, seqs, quals, rank, world)
+    t_load = time.time() - t_load
+    n_local = trainer.range[1] - trainer.range[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer(x)
+    barrier()
+    t0 = time.perf_counter()
+    kern_ms = []
+    for _ in range(args.steps):
+        fn, gr, eff, nsk = trainer(x)
+        kern_ms.append(eng.last_timing()[1])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    S = eng.n_state
+    alg = algorithmic_bytes_per_seq(args.seq_len, S) * n_local
+    k_s = float(np.mean(kern_ms)) / 1e3
+    achieved = alg / k_s / 1e9
+    line = {
+        "metric": "train-iter seqs/sec (inside+outside)", "value": args.n_seq * args.steps / dt, "unit": "seq/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%d synthetic RNAs L=%d, pattern %s, W=%d C=%d min_bpp=1e-4 T2004, x0 lambda=(1,1), one (fn,gr) eval per step" % (
+            args.n_seq, args.seq_len, PATTERN, MAX_SPAN, MAX_ILOOP), "n_seq": args.n_seq, "seq_len": args.seq_len, "pattern": PATTERN,
+            "sharding": "contiguous ranges per rank, 1 all-reduce of %d doubles per step" % eng.partial_len(),
+            "bpp_filter": "cached (computed once at load_batch, %.1f s incl. plan)" % t_load, "fn": fn, "n_skipped": nsk},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                     "traffic": None, "kernel": eng.kernel_name(), "kernel_ms": k_s * 1e3,
+                     "algorithmic_bytes_per_launch": alg},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(seqs, quals, x, eng.n_param - 2)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,11 @@ int elemdp_initial_params(const elemdp_handle* h, double lambda_init, double* x,
 /* JSON description of the automaton (states, transition lists) for inspection / host-logic tests. */
 int elemdp_describe(const elemdp_handle* h, char* buf, int32_t cap);
 
+/* Engine knobs (not part of the reference interface): "slots" = number of persistent workgroups /
+ * table slots (default 2 per CU), "keep_lnbpp" = keep ln BPP of the filter for elemdp_batch_pairs,
+ * "first_pass_only" = debug: stop a train evaluation after the first outside pass. */
+int elemdp_set_option(elemdp_handle* h, const char* key, double value);
+
 /* Replaces the resident batch (== FastqReader contents, fastq_io.hpp:64-108):
  *   seq_codes : concatenated base codes N,A,C,G,U -> 0..4 (bio_sequence.hpp:28-39)
  *   seq_off   : n_seq+1 offsets;   qual : char-33 values, L+1 per sequence;   qual_off likewise
@@ -110,6 +115,9 @@ int elemdp_partial_len(const elemdp_handle* h);
 int elemdp_train_partial(elemdp_handle* h, const double* x, int32_t n_param, void* partial, int32_t partial_is_device);
 int elemdp_train_finish(elemdp_handle* h, const double* reduced, double* fn, double* gr, double* sum_eff,
                         int32_t* n_skipped);
+/* Host-only: tells the handle which x a following elemdp_train_finish refers to (needed for the
+ * softmax chain rule, motif_trainer.hpp:251-261) when elemdp_train_partial ran in another handle. */
+int elemdp_set_finish_params(elemdp_handle* h, const double* x, int32_t n_param);
 
 /* per-sequence diagnostics of the last train evaluation: 5 doubles per sequence
  * [Z(ari,nasi), Z(ari), Z(nasi), f_n, skipped] (motif_trainer.hpp:108-112, 204-227) */

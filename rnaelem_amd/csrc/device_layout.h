@@ -71,19 +71,32 @@ struct ParamBlock {
 struct SeqPlan {
   int32_t L, W, C;
   int32_t positive;     // last quality == 0  <=>  ws[L] == -inf  ("has motif", motif_model.hpp:69)
-  int64_t cell_base;    // offset of this sequence in the per-cell arrays ((L+1)*(W+1) entries)
-  int64_t pos_base;     // offset in per-position arrays (L+1 entries)
-  int64_t item_base;    // offset of the interior-loop item arrays
-  int32_t n_items;      // number of interior-loop items (outside set; inside set is flagged)
-  int32_t n_pairs;      // kept base pairs
-  int64_t seq_base;     // offset into concatenated base codes
-  double bpp_eff;
+  // batch-level (static) arrays
+  int64_t seq_base;     // base codes (L entries)
+  int64_t pos_base;     // per-position arrays ws / unp (L+1 entries)
+  int64_t bits_base;    // pair-mask words (ceil((L+1)*(W+1)/32) words)
+  // plan-level arrays (relative to the plan set the sequence belongs to)
+  int64_t dmin_base;    // L+1 entries
+  int64_t cell_base;    // per-cell terms ((L+1)*(W+1) entries)
+  int64_t off_base;     // CSR offsets ((L+1)*(W+1)+1 entries)
+  int64_t item_base;    // interior-loop items
+  int32_t n_items;      // outside set; members of the inside set are flagged
+  int32_t n_canonical;  // base pairs possible by sequence alone (denominator of bpp_eff)
+  double bpp_eff;       // kept / possible pairs (energy_model.hpp:265)
 };
 
 // interior-loop item: outer cell E(i,j), inner pair P(k,l), tsc = loop_energy(i-1,j,k,l-1)
 struct LoopItem {
   double tsc;
   int16_t i, j, k, l;
+};
+
+// CYK trace record (motif_scanner.hpp:51-59): child cell (k,l), transition type t (< 0 = leaf),
+// child structural state e1 and child interval state s1
+struct TraceRec {
+  int16_t k, l;
+  int8_t t, e1;
+  int16_t s1;
 };
 
 }  // namespace elemdp

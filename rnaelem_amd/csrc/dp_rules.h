@@ -21,8 +21,10 @@
 
 #include "device_layout.h"
 
+// Under hipcc (the product build) the rules exist as DEVICE code only: the shipped library has no
+// host instantiation of the recurrences, hence no CPU path.  Plain g++ (tests/emul) sees inline functions.
 #if defined(__HIPCC__)
-#define ELEMDP_HD __host__ __device__ __forceinline__
+#define ELEMDP_HD __device__ __forceinline__
 #else
 #define ELEMDP_HD inline
 #endif
@@ -49,9 +51,6 @@ struct LseAcc {
   }
   ELEMDP_HD double value() const { return (m == ELEMDP_NEG_INF) ? ELEMDP_NEG_INF : m + log(s); }
 };
-
-// CYK trace record (motif_scanner.hpp:51-59); t < 0 = leaf
-struct TraceRec { int16_t k, l; int8_t t, e1; int16_t s1; };
 
 // ---------------------------------------------------------------------------------------------
 // views

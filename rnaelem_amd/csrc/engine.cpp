@@ -1,0 +1,907 @@
+// engine.cpp -- host side of libelemdp.so: model set-up, batch residency, kernel launches, C ABI.
+//
+// Mirrors the part of the reference that sits directly around the hot path:
+//   RNAelem::set_motif_pattern / set_energy_params      RNAelem/motif_model.hpp:72-97
+//   RNAelem::pack_params / unpack_params                 RNAelem/motif_model.hpp:147-168
+//   RNAelemTrainer::operator()  (fn / gr assembly)       RNAelem/motif_trainer.hpp:248-271, 595-633
+//   RNAelemScanner::scan                                 RNAelem/motif_scanner.hpp:938-949
+// There is deliberately no CPU implementation of the DP in this library.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <dlfcn.h>
+
+#include "../../include/elemdp.h"
+#include "automaton.h"
+#include "device_layout.h"
+#include "energy_tables.h"
+#include "host_prep.h"
+#include "kernels.h"
+
+namespace elemdp {
+namespace {
+
+thread_local std::string g_error;
+std::string g_data_dir;
+
+struct HipError : std::runtime_error {
+  explicit HipError(const std::string& m) : std::runtime_error(m) {}
+};
+struct ArgError : std::runtime_error {
+  explicit ArgError(const std::string& m) : std::runtime_error(m) {}
+};
+struct StateError : std::runtime_error {
+  explicit StateError(const std::string& m) : std::runtime_error(m) {}
+};
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+// owning device buffer
+class DevBuf {
+ public:
+  DevBuf() = default;
+  ~DevBuf() { reset(); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  void alloc(size_t bytes) {
+    reset();
+    bytes_ = bytes ? bytes : 8;
+    HIP_OK(hipMalloc(&p_, bytes_));
+  }
+  void reset() { if (p_) { hipFree(p_); p_ = nullptr; bytes_ = 0; } }
+  template <class T> T* as() const { return static_cast<T*>(p_); }
+  size_t bytes() const { return bytes_; }
+  template <class T> void upload(const std::vector<T>& v, hipStream_t st) {
+    alloc(v.size() * sizeof(T));
+    if (!v.empty()) HIP_OK(hipMemcpyAsync(p_, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+  }
+
+ private:
+  void* p_ = nullptr;
+  size_t bytes_ = 0;
+};
+
+std::string default_data_dir() {
+  if (!g_data_dir.empty()) return g_data_dir;
+  if (const char* e = std::getenv("ELEMDP_DATA_DIR")) return e;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<void*>(&default_data_dir), &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    size_t k = p.find_last_of('/');
+    return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/data";
+  }
+  return "data";
+}
+
+std::string read_file(const std::string& path) {
+  std::ifstream f(path);
+  if (!f) throw ArgError("cannot open energy parameter file: " + path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+// one set of plan arrays (for a subset of the batch)
+struct PlanSet {
+  int first = 0, count = 0;
+  std::vector<SeqPlan> h;
+  DevBuf d_plans, dmin, e_stack, e_ext, e_ml, e_close, e_hp, off_outer, off_inner, off_left, off_right, cursor, items,
+      item_in, idx_inner, idx_left, idx_right;
+  int64_t n_items = 0;
+  PlanArrays arrays() const {
+    PlanArrays a;
+    a.dmin = dmin.as<int16_t>();
+    a.e_stack = e_stack.as<double>(); a.e_ext = e_ext.as<double>(); a.e_ml = e_ml.as<double>();
+    a.e_close = e_close.as<double>(); a.e_hp = e_hp.as<double>();
+    a.by_outer_off = off_outer.as<int32_t>(); a.by_inner_off = off_inner.as<int32_t>();
+    a.by_left_off = off_left.as<int32_t>(); a.by_right_off = off_right.as<int32_t>();
+    a.cursor = cursor.as<int32_t>();
+    a.items = items.as<LoopItem>(); a.item_in = item_in.as<uint8_t>();
+    a.by_inner_idx = idx_inner.as<int32_t>(); a.by_left_idx = idx_left.as<int32_t>(); a.by_right_idx = idx_right.as<int32_t>();
+    return a;
+  }
+};
+
+}  // namespace
+
+class Engine {
+ public:
+  explicit Engine(const elemdp_model_desc& d);
+  ~Engine();
+
+  int n_param() const { return au_.n_theta() + 2; }
+  int n_state() const { return au_.S(); }
+  int n_node() const { return au_.M(); }
+  const Automaton& automaton() const { return au_; }
+  bool softmax() const { return flags_ & ELEMDP_THETA_SOFTMAX; }
+
+  void load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* qual, const int32_t* qoff, const char* fix, int n);
+  void train_partial(const double* x, int n_param, void* partial, bool device_ptr);
+  void train_finish(const double* reduced, double* fn, double* gr, double* sum_eff, int32_t* n_skipped);
+  void scan(const double* x, int n_param, elemdp_scan_out* out);
+  int partial_len() const { return 4 + 2 * au_.n_theta() + 4; }
+  void set_option(const std::string& key, double v);
+
+  int n_seq() const { return n_seq_; }
+  const std::vector<SeqPlan>& plans() const { return h_plans_; }
+  void seq_stats(double* out, int n);
+  void debug_tables(double* inside, double* outside, double* inside_o, double* outside_o, double* ENo, double* ENx, double* EH);
+  void batch_pairs(int idx, uint8_t* kept, double* lnbpp, int cap);
+  double last_ms[2] = {0, 0};
+
+ private:
+  void upload_params(const double* x, const AutomatonLayout& lay, bool trivial);
+ public:
+  void set_theta_from(const double* x);  // host: theta (log-softmax of x when theta-softmax)
+ private:
+  void build_planset(PlanSet& ps, int first, int count, const uint32_t* d_okbits);
+  LdsLayout lds_layout(const AutomatonLayout& lay, int Lmax, int nword_max, bool scan) const;
+  DpArgs base_args(const AutomatonLayout& lay, const int32_t* d_ints, const double* d_params, const PlanSet& ps,
+                   const uint32_t* d_okbits, int S);
+  void ensure_slots(int S, bool scan, int n_want);
+  void run_train(bool first_pass_only);
+  void init_device();
+  void require_device() const;
+  bool has_device_ = false;
+  int want_device_ = -1;
+
+  Automaton au_;
+  EnergyTables et_;
+  AutomatonLayout lay_, lay0_;
+  std::vector<int32_t> ints_, ints0_;
+  int flags_, max_span_, max_iloop_;
+  double min_bpp_, tau_;
+  int device_ = 0, n_cu_ = 256;
+  hipStream_t st_ = nullptr;
+  hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+  DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_;
+  std::vector<double> theta_;  // log-probabilities of the last evaluation (softmax Jacobian)
+
+  // batch
+  int n_seq_ = 0, Lmax_ = 0, Wmax_ = 0, nword_max_ = 0;
+  std::vector<SeqPlan> h_plans_;
+  std::vector<int32_t> h_order_, h_seq_off_, h_qual_off_;
+  DevBuf d_seq_, d_ws_, d_unp_, d_ndot_, d_okbits0_, d_okbits1_, d_order_, d_ncanon_;
+  std::vector<double> h_lnbpp_;          // optional (keep_lnbpp)
+  std::vector<int64_t> h_lnbpp_base_;
+  PlanSet plan_;
+  // slots
+  int n_slots_ = 0, slots_S_ = 0;
+  bool slots_scan_ = false;
+  size_t band_stride_ = 0, ext_stride_ = 0;
+  DevBuf d_band_in_, d_band_out_, d_ext_in_, d_ext_out_, d_tr_band_, d_tr_ext_, d_tr_stack_;
+  DevBuf d_seq_out_, d_partial_;
+  int out_stride_ = 0;
+  // options
+  int opt_slots_ = 0;
+  bool opt_keep_lnbpp_ = false;
+  bool opt_first_pass_only_ = false;
+};
+
+Engine::Engine(const elemdp_model_desc& d)
+    : au_(d.pattern ? d.pattern : ""), flags_(d.flags), max_span_(d.max_span), max_iloop_(d.max_iloop), min_bpp_(d.min_bpp),
+      tau_(d.tau) {
+  if ((flags_ & ELEMDP_NO_RSS) && (flags_ & ELEMDP_NO_PROFILE)) throw ArgError("no-rss, no-profile are exclusive.");
+  if ((flags_ & ELEMDP_NO_RSS) && au_.reg_pattern().find(')') != std::string::npos)
+    throw ArgError("search pattern must not include pair when no-rss mode");
+  if (max_span_ < 1) throw ArgError("max_span must be positive");
+  if (!(tau_ > 0)) throw ArgError("tau must be positive");
+  std::string par = d.energy_param ? d.energy_param : "~T2004~";
+  if (par == "~T2004~") par = read_file(default_data_dir() + "/turner2004.elempar");
+  else if (par == "~A2007~") par = read_file(default_data_dir() + "/andronescu2007.elempar");
+  parse_energy_text(par, &et_);
+  au_.flatten(&lay_, &ints_);
+  flatten_trivial(&lay0_, &ints0_);
+
+  int ndev = 0;
+  has_device_ = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+  want_device_ = d.device;
+  // Without a GPU the handle still serves the host-only calls (describe, initial_params,
+  // train_finish); everything that computes raises ELEMDP_ENODEV -- there is no CPU path.
+  if (has_device_) init_device();
+}
+
+void Engine::require_device() const {
+  if (!has_device_) throw HipError("no HIP device available (libelemdp has no CPU path)");
+}
+
+void Engine::init_device() {
+  if (want_device_ >= 0) { device_ = want_device_; HIP_OK(hipSetDevice(device_)); }
+  else HIP_OK(hipGetDevice(&device_));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, device_));
+  n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_OK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  for (auto& e : ev_) HIP_OK(hipEventCreate(&e));
+  d_et_.alloc(sizeof(EnergyTables));
+  HIP_OK(hipMemcpyAsync(d_et_.as<void>(), &et_, sizeof(EnergyTables), hipMemcpyHostToDevice, st_));
+  d_ints_.upload(ints_, st_);
+  d_ints0_.upload(ints0_, st_);
+  d_params_.alloc(sizeof(ParamBlock) + sizeof(double) * (au_.n_theta() + 1));
+  d_params0_.alloc(sizeof(ParamBlock) + sizeof(double));
+  d_counter_.alloc(sizeof(int32_t));
+  d_partial_.alloc(sizeof(double) * partial_len());
+  {  // parameters of the one-state automaton of the BPP filter: lambda = 1, no emissions
+    ParamBlock pb;
+    pb.lambda[0] = pb.lambda[1] = 1.;
+    pb.log_tau = 0.;
+    pb.lam_same = 1;
+    pb.pad = 0;
+    HIP_OK(hipMemcpyAsync(d_params0_.as<void>(), &pb, sizeof(pb), hipMemcpyHostToDevice, st_));
+  }
+  HIP_OK(hipStreamSynchronize(st_));
+}
+
+Engine::~Engine() {
+  if (st_) hipStreamSynchronize(st_);
+  for (auto& e : ev_) if (e) hipEventDestroy(e);
+  if (st_) hipStreamDestroy(st_);
+}
+
+void Engine::set_option(const std::string& key, double v) {
+  if (key == "slots") opt_slots_ = (int)v;
+  else if (key == "keep_lnbpp") opt_keep_lnbpp_ = v != 0;
+  else if (key == "first_pass_only") opt_first_pass_only_ = v != 0;
+  else throw ArgError("unknown option: " + key);
+}
+
+void Engine::set_theta_from(const double* x) {
+  const int nt = au_.n_theta();
+  theta_.assign(x, x + nt);
+  if (softmax()) {  // theta = log-softmax of the score rows (ProfileHMM::calc_theta, profile_hmm.hpp:103-111)
+    for (int r = 0; r < au_.n_rows(); ++r) {
+      const int o = au_.row_offset(r), w = au_.row_width(r);
+      double tot = -std::numeric_limits<double>::infinity();
+      for (int c = 0; c < w; ++c) {  // logsumexp by sequential log1p(exp()) like util.hpp:195-209
+        const double a = tot, b = x[o + c];
+        tot = (b == -INFINITY) ? a : (a == -INFINITY) ? b : (a < b ? b + std::log1p(std::exp(a - b)) : a + std::log1p(std::exp(b - a)));
+      }
+      for (int c = 0; c < w; ++c) theta_[o + c] = x[o + c] - tot;
+    }
+  }
+}
+
+void Engine::upload_params(const double* x, const AutomatonLayout& lay, bool) {
+  const int nt = au_.n_theta();
+  set_theta_from(x);
+  std::vector<double> blob(sizeof(ParamBlock) / sizeof(double) + nt + 1, 0.);
+  ParamBlock pb;
+  pb.lambda[0] = x[nt];
+  pb.lambda[1] = x[nt + 1];
+  pb.log_tau = std::log(tau_);
+  pb.lam_same = (x[nt] == x[nt + 1]) ? 1 : 0;
+  pb.pad = 0;
+  std::memcpy(blob.data(), &pb, sizeof(pb));
+  std::copy(theta_.begin(), theta_.end(), blob.begin() + sizeof(ParamBlock) / sizeof(double));
+  HIP_OK(hipMemcpyAsync(d_params_.as<void>(), blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+  HIP_OK(hipStreamSynchronize(st_));  // blob is a local
+  (void)lay;
+}
+
+LdsLayout Engine::lds_layout(const AutomatonLayout& lay, int Lmax, int nword_max, bool scan) const {
+  LdsLayout l;
+  int o = 0;
+  auto take = [&](int bytes) { int p = o; o += (bytes + 15) & ~15; return p; };
+  l.theta = take(8 * (lay.n_theta + 1));
+  l.en_o = take(8 * (lay.n_theta + 1));
+  l.en_x = take(8 * (lay.n_theta + 1));
+  l.eh = take(8 * 4);
+  l.zs = take(8 * 8);
+  l.ws = take(8 * (Lmax + 1));
+  l.post = take(scan ? 8 * 3 * (Lmax + 1) : 16);
+  l.ints = take(4 * lay.n_ints);
+  l.okbits = take(4 * nword_max);
+  l.dmin = take(2 * (Lmax + 1));
+  l.seq = take(Lmax + 1);
+  l.unp = take(Lmax + 1);
+  l.total = o;
+  if (l.total > 160 * 1024) throw ArgError("sequence / pattern too large for the LDS staging of this build");
+  return l;
+}
+
+void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_okbits) {
+  ps.first = first;
+  ps.count = count;
+  ps.h.assign(h_plans_.begin() + first, h_plans_.begin() + first + count);
+  int64_t dmin_b = 0, cell_b = 0, off_b = 0;
+  for (auto& p : ps.h) {
+    const int64_t nc = (int64_t)(p.L + 1) * (p.W + 1);
+    p.dmin_base = dmin_b; p.cell_base = cell_b; p.off_base = off_b; p.item_base = 0; p.n_items = 0;
+    dmin_b += p.L + 1; cell_b += nc; off_b += nc + 1;
+  }
+  ps.d_plans.upload(ps.h, st_);
+  ps.dmin.alloc(sizeof(int16_t) * dmin_b);
+  for (DevBuf* b : {&ps.e_stack, &ps.e_ext, &ps.e_ml, &ps.e_close, &ps.e_hp}) b->alloc(sizeof(double) * cell_b);
+  for (DevBuf* b : {&ps.off_outer, &ps.off_inner, &ps.off_left, &ps.off_right, &ps.cursor}) b->alloc(sizeof(int32_t) * off_b);
+  DevBuf d_nitems;
+  d_nitems.alloc(sizeof(int32_t) * count);
+  PlanKernelArgs a;
+  a.et = d_et_.as<EnergyTables>();
+  a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>();
+  a.b.ndot = (flags_ & ELEMDP_DBG_FIX_RSS) ? d_ndot_.as<int32_t>() : nullptr;
+  a.okbits = d_okbits;
+  a.plans = ps.d_plans.as<SeqPlan>();
+  a.first = 0; a.count = count;
+  a.p = ps.arrays();
+  a.no_ene = (flags_ & ELEMDP_NO_ENERGY) ? 1 : 0;
+  a.min_span = (flags_ & ELEMDP_DBG_NO_TURN) ? 1 : 5;
+  a.fix_rss = (flags_ & ELEMDP_DBG_FIX_RSS) ? 1 : 0;
+  HIP_OK(launch_plan_cells(a, d_nitems.as<int32_t>(), st_));
+  std::vector<int32_t> n_items(count);
+  HIP_OK(hipMemcpyAsync(n_items.data(), d_nitems.as<void>(), sizeof(int32_t) * count, hipMemcpyDeviceToHost, st_));
+  HIP_OK(hipStreamSynchronize(st_));
+  int64_t ib = 0;
+  for (int k = 0; k < count; ++k) { ps.h[k].n_items = n_items[k]; ps.h[k].item_base = ib; ib += n_items[k]; }
+  ps.n_items = ib;
+  ps.d_plans.upload(ps.h, st_);
+  ps.items.alloc(sizeof(LoopItem) * ib);
+  ps.item_in.alloc(ib);
+  for (DevBuf* b : {&ps.idx_inner, &ps.idx_left, &ps.idx_right}) b->alloc(sizeof(int32_t) * ib);
+  a.plans = ps.d_plans.as<SeqPlan>();
+  a.p = ps.arrays();
+  HIP_OK(launch_plan_items(a, st_));
+  HIP_OK(hipStreamSynchronize(st_));
+}
+
+void Engine::ensure_slots(int S, bool scan, int n_want) {
+  const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;
+  const size_t ext = (size_t)(Lmax_ + 1) * S;
+  int want = opt_slots_ > 0 ? opt_slots_ : 2 * n_cu_;
+  want = std::max(1, std::min(want, n_want));
+  size_t free_b = 0, total_b = 0;
+  HIP_OK(hipMemGetInfo(&free_b, &total_b));
+  const size_t per_slot = (band + ext) * 2 * sizeof(double) + (scan ? (band + ext) * sizeof(TraceRec) + 16 * (Lmax_ + 2) : 0);
+  if (n_slots_ >= want && slots_S_ == S && band_stride_ == band && (slots_scan_ || !scan)) return;
+  d_band_in_.reset(); d_band_out_.reset(); d_ext_in_.reset(); d_ext_out_.reset(); d_tr_band_.reset(); d_tr_ext_.reset();
+  d_tr_stack_.reset();
+  HIP_OK(hipMemGetInfo(&free_b, &total_b));
+  const size_t budget = free_b / 2;
+  while (want > 1 && per_slot * want > budget) want /= 2;
+  if (per_slot * want > free_b) throw HipError("not enough device memory for one table slot");
+  n_slots_ = want; slots_S_ = S; slots_scan_ = scan;
+  band_stride_ = band; ext_stride_ = ext;
+  d_band_in_.alloc(band * want * sizeof(double));
+  d_band_out_.alloc(band * want * sizeof(double));
+  d_ext_in_.alloc(ext * want * sizeof(double));
+  d_ext_out_.alloc(ext * want * sizeof(double));
+  if (scan) {
+    d_tr_band_.alloc(band * want * sizeof(TraceRec));
+    d_tr_ext_.alloc(ext * want * sizeof(TraceRec));
+    d_tr_stack_.alloc((size_t)want * 4 * (4 * (Lmax_ + 2)) * sizeof(int32_t));
+  }
+}
+
+DpArgs Engine::base_args(const AutomatonLayout& lay, const int32_t* d_ints, const double* d_params, const PlanSet& ps,
+                         const uint32_t* d_okbits, int S) {
+  DpArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.lay = lay;
+  a.ints = d_ints;
+  a.params = d_params;
+  a.no_prf = (flags_ & ELEMDP_NO_PROFILE) ? 1 : 0;
+  a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
+  a.no_rss = (flags_ & ELEMDP_NO_RSS) ? 1 : 0;
+  a.plans = ps.d_plans.as<SeqPlan>();
+  a.n_seq = ps.count;
+  a.counter = d_counter_.as<int32_t>();
+  a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>();
+  a.b.ndot = nullptr;
+  a.okbits = d_okbits;
+  a.p = ps.arrays();
+  a.band_in = d_band_in_.as<double>(); a.band_out = d_band_out_.as<double>();
+  a.ext_in = d_ext_in_.as<double>(); a.ext_out = d_ext_out_.as<double>();
+  a.band_stride = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;
+  a.ext_stride = (size_t)(Lmax_ + 1) * S;
+  return a;
+}
+
+void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* qual, const int32_t* qoff, const char* fix,
+                        int n) {
+  require_device();
+  if (n <= 0 || !seq || !off || !qual || !qoff) throw ArgError("load_batch: empty batch or null pointer");
+  const bool fixmode = flags_ & ELEMDP_DBG_FIX_RSS;
+  if (fixmode && !fix) throw ArgError("load_batch: ELEMDP_DBG_FIX_RSS needs fix_rss strings");
+  const bool no_rss = flags_ & ELEMDP_NO_RSS;
+  n_seq_ = n;
+  h_plans_.assign(n, SeqPlan());
+  h_seq_off_.assign(off, off + n + 1);
+  h_qual_off_.assign(qoff, qoff + n + 1);
+  int64_t seq_b = 0, pos_b = 0, bits_b = 0;
+  Lmax_ = Wmax_ = nword_max_ = 0;
+  for (int k = 0; k < n; ++k) {
+    const int L = off[k + 1] - off[k];
+    if (L <= 0) throw ArgError("load_batch: empty sequence");
+    if (L > 32000) throw ArgError("load_batch: sequence longer than 32000");
+    if (qoff[k + 1] - qoff[k] != L + 1) throw ArgError("bad seq format. (quality must have L+1 entries)");  // motif_trainer.hpp:139
+    SeqPlan& p = h_plans_[k];
+    p.L = L;
+    p.W = std::min(L, max_span_);
+    p.C = std::min(p.W - 2 - ((flags_ & ELEMDP_DBG_NO_TURN) ? 2 : 5), max_iloop_);  // energy_model.hpp:271-273
+    p.positive = qual[qoff[k + 1] - 1] == 0;
+    p.seq_base = seq_b; p.pos_base = pos_b; p.bits_base = bits_b;
+    const int nword = (int)(((int64_t)(L + 1) * (p.W + 1) + 31) / 32);
+    seq_b += L; pos_b += L + 1; bits_b += nword;
+    Lmax_ = std::max(Lmax_, L); Wmax_ = std::max(Wmax_, p.W); nword_max_ = std::max(nword_max_, nword);
+    p.bpp_eff = 0.;
+  }
+  // static arrays
+  std::vector<uint8_t> h_seq((size_t)seq_b), h_unp((size_t)pos_b, 1);
+  std::vector<double> h_ws((size_t)pos_b);
+  std::vector<int32_t> h_ndot;
+  std::vector<uint32_t> h_bits;
+  if (fixmode) { h_ndot.assign((size_t)pos_b, 0); h_bits.assign((size_t)bits_b, 0u); }
+  for (int k = 0; k < n; ++k) {
+    const SeqPlan& p = h_plans_[k];
+    for (int t = 0; t < p.L; ++t) {
+      const uint8_t c = seq[off[k] + t];
+      if (c > 4) throw ArgError("load_batch: base code out of range");
+      h_seq[p.seq_base + t] = c;
+    }
+    position_weights(qual + qoff[k], p.L + 1, &h_ws[p.pos_base]);
+    if (fixmode) {
+      const char* f = fix + off[k];
+      nondot_prefix(f, p.L, &h_ndot[p.pos_base]);
+      std::vector<int> open;
+      for (int t = 0; t < p.L; ++t) {
+        h_unp[p.pos_base + t] = f[t] == '.';
+        if (f[t] == '(') open.push_back(t);
+        else if (f[t] == ')') {
+          if (open.empty()) throw ArgError("bad rss: unbalanced");
+          const int o = open.back();
+          open.pop_back();
+          const int d = t + 1 - o;
+          if (d > p.W) throw ArgError("bad rss: pair wider than max_span");
+          const int64_t c = (int64_t)o * (p.W + 1) + d;
+          h_bits[p.bits_base + (c >> 5)] |= 1u << (c & 31);
+        } else if (f[t] != '.') throw ArgError(std::string("bad rss char: ") + f[t]);
+      }
+      if (!open.empty()) throw ArgError("bad rss: unbalanced");
+    }
+  }
+  h_order_.resize(n);
+  std::iota(h_order_.begin(), h_order_.end(), 0);
+  std::stable_sort(h_order_.begin(), h_order_.end(), [&](int a, int b) { return h_plans_[a].L > h_plans_[b].L; });
+  d_seq_.upload(h_seq, st_);
+  d_ws_.upload(h_ws, st_);
+  d_unp_.upload(h_unp, st_);
+  if (fixmode) d_ndot_.upload(h_ndot, st_);
+  d_okbits0_.alloc(sizeof(uint32_t) * bits_b);
+  d_okbits1_.alloc(sizeof(uint32_t) * bits_b);
+  d_ncanon_.alloc(sizeof(int32_t) * n);
+  DevBuf d_plans_all;
+  d_plans_all.upload(h_plans_, st_);
+  BatchArrays b;
+  b.seq = d_seq_.as<uint8_t>(); b.ws = d_ws_.as<double>(); b.unp = d_unp_.as<uint8_t>(); b.ndot = nullptr;
+  const int min_span = (flags_ & ELEMDP_DBG_NO_TURN) ? 1 : 5;
+  // ---- canonical mask (also counts the possible pairs = denominator of bpp_eff)
+  HIP_OK(launch_mask(b, d_plans_all.as<SeqPlan>(), n, min_span, !fixmode && !no_rss, d_okbits0_.as<uint32_t>(),
+                     d_ncanon_.as<int32_t>(), st_));
+  std::vector<int32_t> ncanon(n);
+  HIP_OK(hipMemcpyAsync(ncanon.data(), d_ncanon_.as<void>(), sizeof(int32_t) * n, hipMemcpyDeviceToHost, st_));
+  HIP_OK(hipStreamSynchronize(st_));
+  for (int k = 0; k < n; ++k) h_plans_[k].n_canonical = ncanon[k];
+  h_lnbpp_.clear();
+  h_lnbpp_base_.clear();
+
+  const uint32_t* final_bits = d_okbits0_.as<uint32_t>();
+  if (no_rss) {
+    HIP_OK(hipMemsetAsync(d_okbits0_.as<void>(), 0, sizeof(uint32_t) * bits_b, st_));
+    for (auto& p : h_plans_) p.bpp_eff = 0.;  // em.set_seq is never called in --no-rss mode (motif_model.hpp:57)
+  } else if (fixmode) {
+    HIP_OK(hipMemcpyAsync(d_okbits0_.as<void>(), h_bits.data(), sizeof(uint32_t) * bits_b, hipMemcpyHostToDevice, st_));
+    HIP_OK(hipStreamSynchronize(st_));
+    for (int k = 0; k < n; ++k) {
+      int nbp = 0;
+      const SeqPlan& p = h_plans_[k];
+      const int nword = (int)(((int64_t)(p.L + 1) * (p.W + 1) + 31) / 32);
+      for (int w = 0; w < nword; ++w) nbp += __builtin_popcount(h_bits[p.bits_base + w]);
+      h_plans_[k].bpp_eff = (double)nbp / (double)ncanon[k];
+    }
+  } else if (min_bpp_ > 0) {
+    // ---- K1: BPP filter, in chunks (the plan of the unfiltered mask is large and only needed here)
+    final_bits = d_okbits1_.as<uint32_t>();
+    if (opt_keep_lnbpp_) h_lnbpp_base_.assign(n + 1, 0);
+    int64_t cells_cap = 24LL * 1000 * 1000;
+    int first = 0;
+    while (first < n) {
+      int count = 0;
+      int64_t cells = 0;
+      while (first + count < n && (count == 0 || cells + (int64_t)(h_plans_[first + count].L + 1) * (h_plans_[first + count].W + 1) <= cells_cap)) {
+        cells += (int64_t)(h_plans_[first + count].L + 1) * (h_plans_[first + count].W + 1);
+        ++count;
+      }
+      PlanSet tmp;
+      build_planset(tmp, first, count, d_okbits0_.as<uint32_t>());
+      // table slots for S = 1
+      ensure_slots(1, false, count);
+      std::vector<int32_t> order(count);
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return tmp.h[a2].L > tmp.h[b2].L; });
+      DevBuf d_order, d_out, d_lnbpp;
+      d_order.upload(order, st_);
+      d_out.alloc(sizeof(double) * 2 * count);
+      DpArgs a = base_args(lay0_, d_ints0_.as<int32_t>(), d_params0_.as<double>(), tmp, d_okbits0_.as<uint32_t>(), 1);
+      a.no_prf = 1;
+      a.no_rss = 0;
+      a.order = d_order.as<int32_t>();
+      a.seq_out = d_out.as<double>();
+      a.out_stride = 2;
+      a.okbits_out = d_okbits1_.as<uint32_t>();
+      a.log_min_bpp = std::log(min_bpp_);
+      if (opt_keep_lnbpp_) { d_lnbpp.alloc(sizeof(double) * cells); a.lnbpp_out = d_lnbpp.as<double>(); }
+      a.lds = lds_layout(lay0_, Lmax_, nword_max_, false);
+      HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
+      HIP_OK(launch_dp(DP_BPP, a, std::min(n_slots_, count), st_));
+      std::vector<double> out(2 * (size_t)count);
+      HIP_OK(hipMemcpyAsync(out.data(), d_out.as<void>(), sizeof(double) * 2 * count, hipMemcpyDeviceToHost, st_));
+      HIP_OK(hipStreamSynchronize(st_));
+      for (int k = 0; k < count; ++k) h_plans_[first + k].bpp_eff = out[2 * k + 1] / (double)ncanon[first + k];
+      if (opt_keep_lnbpp_) {
+        const size_t base = h_lnbpp_.size();
+        h_lnbpp_.resize(base + cells);
+        HIP_OK(hipMemcpy(h_lnbpp_.data() + base, d_lnbpp.as<void>(), sizeof(double) * cells, hipMemcpyDeviceToHost));
+        for (int k = 0; k < count; ++k) h_lnbpp_base_[first + k] = (int64_t)base + tmp.h[k].cell_base;
+      }
+      first += count;
+    }
+    n_slots_ = 0;  // S = 1 slots are not reusable for the motif DP
+  } else {
+    for (auto& p : h_plans_) p.bpp_eff = 1.;  // 0 == min_BPP: nbp = total (energy_model.hpp:249-251)
+  }
+  // ---- resident plan of the filtered mask
+  if (final_bits != d_okbits1_.as<uint32_t>())
+    HIP_OK(hipMemcpyAsync(d_okbits1_.as<void>(), d_okbits0_.as<void>(), sizeof(uint32_t) * bits_b, hipMemcpyDeviceToDevice, st_));
+  build_planset(plan_, 0, n, d_okbits1_.as<uint32_t>());
+  for (int k = 0; k < n; ++k) { plan_.h[k].bpp_eff = h_plans_[k].bpp_eff; plan_.h[k].n_canonical = h_plans_[k].n_canonical; }
+  plan_.d_plans.upload(plan_.h, st_);
+  for (int k = 0; k < n; ++k) h_plans_[k] = plan_.h[k];
+  d_order_.upload(h_order_, st_);
+  out_stride_ = 6 + 2 * au_.n_theta() + 4;
+  d_seq_out_.alloc(sizeof(double) * (size_t)out_stride_ * n);
+  n_slots_ = 0;
+  HIP_OK(hipStreamSynchronize(st_));
+}
+
+void Engine::run_train(bool) {
+  ensure_slots(au_.S(), false, n_seq_);
+  DpArgs a = base_args(lay_, d_ints_.as<int32_t>(), d_params_.as<double>(), plan_, d_okbits1_.as<uint32_t>(), au_.S());
+  a.order = d_order_.as<int32_t>();
+  a.seq_out = d_seq_out_.as<double>();
+  a.out_stride = out_stride_;
+  a.lds = lds_layout(lay_, Lmax_, nword_max_, false);
+  a.first_pass_only = opt_first_pass_only_ ? 1 : 0;
+  HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
+  HIP_OK(hipEventRecord(ev_[1], st_));
+  HIP_OK(launch_dp(DP_TRAIN, a, std::min(n_slots_, n_seq_), st_));
+  HIP_OK(hipEventRecord(ev_[2], st_));
+  HIP_OK(launch_reduce(d_seq_out_.as<double>(), out_stride_, n_seq_, au_.n_theta(), d_partial_.as<double>(), st_));
+}
+
+void Engine::train_partial(const double* x, int n_param_in, void* partial, bool device_ptr) {
+  require_device();
+  if (n_seq_ <= 0) throw StateError("train_eval before load_batch");
+  if (n_param_in != n_param()) throw ArgError("n_param mismatch");
+  HIP_OK(hipEventRecord(ev_[0], st_));
+  upload_params(x, lay_, false);
+  run_train(false);
+  HIP_OK(hipMemcpyAsync(partial, d_partial_.as<void>(), sizeof(double) * partial_len(),
+                        device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st_));
+  HIP_OK(hipEventRecord(ev_[3], st_));
+  HIP_OK(hipStreamSynchronize(st_));
+  float ms_all = 0, ms_k = 0;
+  HIP_OK(hipEventElapsedTime(&ms_all, ev_[0], ev_[3]));
+  HIP_OK(hipEventElapsedTime(&ms_k, ev_[1], ev_[2]));
+  last_ms[0] = ms_all;
+  last_ms[1] = ms_k;
+}
+
+void Engine::train_finish(const double* r, double* fn, double* gr, double* sum_eff, int32_t* n_skipped) {
+  const int nt = au_.n_theta();
+  if (fn) *fn = r[0];
+  if (sum_eff) *sum_eff = r[1];
+  if (n_skipped) *n_skipped = (int32_t)std::llround(r[3]);
+  if (!gr) return;
+  const double* ENo = r + 4;
+  const double* ENx = r + 4 + nt;
+  const double* EHo = r + 4 + 2 * nt;
+  const double* EHx = EHo + 2;
+  int k = 0;
+  if (softmax()) {  // chain rule through the row-wise softmax (motif_trainer.hpp:251-261)
+    if ((int)theta_.size() != nt) throw StateError("train_finish before any evaluation");
+    for (int row = 0; row < au_.n_rows(); ++row) {
+      const int o = au_.row_offset(row), w = au_.row_width(row);
+      double tot = 0.;
+      for (int c = 0; c < w; ++c) tot += ENo[o + c] - ENx[o + c];
+      for (int c = 0; c < w; ++c) {
+        const double tmp = ENo[o + c] - ENx[o + c];
+        const double p = std::exp(theta_[o + c]);
+        gr[k++] = (1 - p) * tmp - p * (tot - tmp);
+      }
+    }
+  } else {
+    for (int t = 0; t < nt; ++t) gr[k++] = ENo[t] - ENx[t];
+  }
+  gr[k++] = EHo[0] - EHx[0];
+  gr[k++] = EHo[1] - EHx[1];
+}
+
+void Engine::seq_stats(double* out, int n) {
+  if (n != n_seq_) throw ArgError("seq_stats: n_seq mismatch");
+  std::vector<double> h((size_t)out_stride_ * n);
+  HIP_OK(hipMemcpy(h.data(), d_seq_out_.as<void>(), sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+  for (int k = 0; k < n; ++k)
+    for (int c = 0; c < 5; ++c) out[5 * k + c] = h[(size_t)k * out_stride_ + c];
+}
+
+void Engine::debug_tables(double* inside, double* outside, double* inside_o, double* outside_o, double* ENo, double* ENx,
+                          double* EH) {
+  if (n_seq_ != 1) throw StateError("debug_tables needs a batch of exactly one sequence");
+  if (n_slots_ < 1) throw StateError("debug_tables before train_eval");
+  const SeqPlan& p = h_plans_[0];
+  const int S = au_.S(), L = p.L, W = p.W;
+  const size_t band = (size_t)7 * (W + 1) * (L + 1) * S, ext = (size_t)(L + 1) * S;
+  auto fetch = [&](const DevBuf& src, size_t cnt) {
+    std::vector<double> h(cnt);
+    HIP_OK(hipMemcpy(h.data(), src.as<void>(), sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    return h;
+  };
+  auto reorder = [&](const std::vector<double>& t, double* dst) {  // [e][d][i][s] -> [i][d][e][s]
+    for (int i = 0; i <= L; ++i) for (int d = 0; d <= W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s)
+      dst[(((size_t)i * (W + 1) + d) * 7 + e) * S + s] =
+          (i + d <= L) ? t[(((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s] : -std::numeric_limits<double>::infinity();
+  };
+  if (inside) reorder(fetch(d_band_in_, band), inside);
+  if (outside) reorder(fetch(d_band_out_, band), outside);
+  if (inside_o) { auto h = fetch(d_ext_in_, ext); std::copy(h.begin(), h.end(), inside_o); }
+  if (outside_o) { auto h = fetch(d_ext_out_, ext); std::copy(h.begin(), h.end(), outside_o); }
+  std::vector<double> o = fetch(d_seq_out_, out_stride_);
+  const int nt = au_.n_theta();
+  if (ENo) std::copy(o.begin() + 6, o.begin() + 6 + nt, ENo);
+  if (ENx) std::copy(o.begin() + 6 + nt, o.begin() + 6 + 2 * nt, ENx);
+  if (EH) std::copy(o.begin() + 6 + 2 * nt, o.begin() + 6 + 2 * nt + 4, EH);
+}
+
+void Engine::batch_pairs(int idx, uint8_t* kept, double* lnbpp, int cap) {
+  if (idx < 0 || idx >= n_seq_) throw ArgError("batch_pairs: bad sequence index");
+  const SeqPlan& p = h_plans_[idx];
+  const int nc = (p.L + 1) * (p.W + 1);
+  if (cap < nc) throw ArgError("batch_pairs: buffer too small");
+  const int nword = (nc + 31) / 32;
+  std::vector<uint32_t> w(nword);
+  HIP_OK(hipMemcpy(w.data(), d_okbits1_.as<uint32_t>() + p.bits_base, sizeof(uint32_t) * nword, hipMemcpyDeviceToHost));
+  for (int c = 0; c < nc; ++c) kept[c] = (w[c >> 5] >> (c & 31)) & 1u;
+  if (lnbpp) {
+    if (h_lnbpp_base_.empty()) throw StateError("ln BPP was not kept (set option keep_lnbpp before load_batch)");
+    std::vector<uint32_t> w0(nword);
+    HIP_OK(hipMemcpy(w0.data(), d_okbits0_.as<uint32_t>() + p.bits_base, sizeof(uint32_t) * nword, hipMemcpyDeviceToHost));
+    for (int c = 0; c < nc; ++c)
+      lnbpp[c] = ((w0[c >> 5] >> (c & 31)) & 1u) ? h_lnbpp_[h_lnbpp_base_[idx] + c] : -std::numeric_limits<double>::infinity();
+  }
+}
+
+void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
+  require_device();
+  if (n_seq_ <= 0) throw StateError("scan before load_batch");
+  if (n_param_in != n_param()) throw ArgError("n_param mismatch");
+  if (flags_ & ELEMDP_NO_RSS) throw ArgError("scan is not available in --no-rss mode");
+  if (!out) throw ArgError("scan: null output");
+  upload_params(x, lay_, false);
+  ensure_slots(au_.S(), true, n_seq_);
+  const int nt = au_.n_theta(), n = n_seq_;
+  const size_t n_seqpos = (size_t)h_seq_off_[n], n_pos = n_seqpos + n;
+  DevBuf d_start, d_end, d_inner, d_psi, d_rss, d_ys, d_ye, d_exist, d_en;
+  d_start.alloc(8 * n_seqpos); d_inner.alloc(8 * n_seqpos); d_end.alloc(8 * n_pos);
+  d_psi.alloc(4 * n_seqpos); d_rss.alloc(n_seqpos);
+  d_ys.alloc(4 * n); d_ye.alloc(4 * n); d_exist.alloc(8 * n); d_en.alloc(8 * (size_t)n * (nt + 1));
+  DpArgs a = base_args(lay_, d_ints_.as<int32_t>(), d_params_.as<double>(), plan_, d_okbits1_.as<uint32_t>(), au_.S());
+  a.order = d_order_.as<int32_t>();
+  a.tr_band = d_tr_band_.as<TraceRec>();
+  a.tr_ext = d_tr_ext_.as<TraceRec>();
+  a.trace_stack = d_tr_stack_.as<int32_t>();
+  a.trace_stack_stride = 4 * (4 * (Lmax_ + 2));
+  a.sc_start = d_start.as<double>(); a.sc_end = d_end.as<double>(); a.sc_inner = d_inner.as<double>();
+  a.sc_psihat = d_psi.as<int32_t>(); a.sc_rss = d_rss.as<char>();
+  a.sc_ys = d_ys.as<int32_t>(); a.sc_ye = d_ye.as<int32_t>(); a.sc_exist = d_exist.as<double>(); a.sc_en = d_en.as<double>();
+  a.lds = lds_layout(lay_, Lmax_, nword_max_, true);
+  HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
+  HIP_OK(hipEventRecord(ev_[1], st_));
+  HIP_OK(launch_dp(DP_SCAN, a, std::min(n_slots_, n), st_));
+  HIP_OK(hipEventRecord(ev_[2], st_));
+  HIP_OK(hipStreamSynchronize(st_));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, ev_[1], ev_[2]));
+  last_ms[0] = last_ms[1] = ms;
+  auto get = [&](void* dst, const DevBuf& src, size_t bytes) { if (dst) HIP_OK(hipMemcpy(dst, src.as<void>(), bytes, hipMemcpyDeviceToHost)); };
+  get(out->start, d_start, 8 * n_seqpos);
+  get(out->inner, d_inner, 8 * n_seqpos);
+  get(out->end, d_end, 8 * n_pos);
+  get(out->psihat, d_psi, 4 * n_seqpos);
+  get(out->rss, d_rss, n_seqpos);
+  get(out->ys, d_ys, 4 * n);
+  get(out->ye, d_ye, 4 * n);
+  get(out->exist_prob, d_exist, 8 * n);
+  if (out->en) {  // E[N] summed over the batch in input order (motif_scanner.hpp:253-259)
+    std::vector<double> h((size_t)n * nt);
+    HIP_OK(hipMemcpy(h.data(), d_en.as<void>(), 8 * h.size(), hipMemcpyDeviceToHost));
+    for (int t = 0; t < nt; ++t) out->en[t] = 0.;
+    for (int k = 0; k < n; ++k) for (int t = 0; t < nt; ++t) out->en[t] += h[(size_t)k * nt + t];
+  }
+}
+
+}  // namespace elemdp
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+struct elemdp_handle { elemdp::Engine* e; };
+
+namespace {
+int fail(const std::exception& ex) {
+  elemdp::g_error = ex.what();
+  if (dynamic_cast<const elemdp::HipError*>(&ex)) {
+    if (elemdp::g_error.find("no HIP device") != std::string::npos) return ELEMDP_ENODEV;
+    return ELEMDP_EHIP;
+  }
+  if (dynamic_cast<const elemdp::StateError*>(&ex)) return ELEMDP_ESTATE;
+  if (dynamic_cast<const std::bad_alloc*>(&ex)) return ELEMDP_ENOMEM;
+  return ELEMDP_EINVAL;
+}
+}  // namespace
+
+#define ELEMDP_TRY try {
+#define ELEMDP_CATCH                        \
+  return ELEMDP_OK;                         \
+  }                                         \
+  catch (const std::exception& ex) {        \
+    return fail(ex);                        \
+  }
+
+extern "C" {
+
+const char* elemdp_last_error(void) { return elemdp::g_error.c_str(); }
+int elemdp_abi_version(void) { return ELEMDP_ABI_VERSION; }
+int elemdp_set_data_dir(const char* dir) {
+  elemdp::g_data_dir = dir ? dir : "";
+  return ELEMDP_OK;
+}
+
+int elemdp_create(const elemdp_model_desc* desc, elemdp_handle** out) {
+  ELEMDP_TRY
+  if (!desc || !out) throw elemdp::ArgError("elemdp_create: null argument");
+  *out = nullptr;
+  std::unique_ptr<elemdp::Engine> e(new elemdp::Engine(*desc));
+  *out = new elemdp_handle{e.release()};
+  ELEMDP_CATCH
+}
+int elemdp_destroy(elemdp_handle* h) {
+  if (h) { delete h->e; delete h; }
+  return ELEMDP_OK;
+}
+int elemdp_n_param(const elemdp_handle* h) { return h ? h->e->n_param() : ELEMDP_EINVAL; }
+int elemdp_n_state(const elemdp_handle* h) { return h ? h->e->n_state() : ELEMDP_EINVAL; }
+int elemdp_n_node(const elemdp_handle* h) { return h ? h->e->n_node() : ELEMDP_EINVAL; }
+
+int elemdp_initial_params(const elemdp_handle* h, double lambda_init, double* x, int32_t n_param) {
+  ELEMDP_TRY
+  if (!h || !x || n_param != h->e->n_param()) throw elemdp::ArgError("elemdp_initial_params: bad argument");
+  const elemdp::Automaton& au = h->e->automaton();
+  int k = 0;
+  for (int r = 0; r < au.n_rows(); ++r)
+  {
+    // log-softmax of an all-zero score row, summed the way ProfileHMM::calc_theta does (profile_hmm.hpp:103-111)
+    double tot = -INFINITY;
+    for (int c = 0; c < au.row_width(r); ++c) tot = (tot == -INFINITY) ? 0. : tot + std::log1p(std::exp(0. - tot));
+    for (int c = 0; c < au.row_width(r); ++c) x[k++] = h->e->softmax() ? 0. : 0. - tot;
+  }
+  x[k++] = lambda_init;
+  x[k++] = lambda_init;
+  ELEMDP_CATCH
+}
+int elemdp_describe(const elemdp_handle* h, char* buf, int32_t cap) {
+  if (!h || !buf) return ELEMDP_EINVAL;
+  std::string s = h->e->automaton().to_json();
+  if ((int)s.size() + 1 > cap) return ELEMDP_EINVAL;
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+int elemdp_set_option(elemdp_handle* h, const char* key, double value) {
+  ELEMDP_TRY
+  if (!h || !key) throw elemdp::ArgError("elemdp_set_option: null argument");
+  h->e->set_option(key, value);
+  ELEMDP_CATCH
+}
+
+int elemdp_load_batch(elemdp_handle* h, const uint8_t* seq_codes, const int32_t* seq_off, const uint8_t* qual,
+                      const int32_t* qual_off, const char* fix_rss, int32_t n_seq) {
+  ELEMDP_TRY
+  if (!h) throw elemdp::ArgError("null handle");
+  h->e->load_batch(seq_codes, seq_off, qual, qual_off, fix_rss, n_seq);
+  ELEMDP_CATCH
+}
+int elemdp_batch_bpp_eff(elemdp_handle* h, double* bpp_eff, int32_t n_seq) {
+  ELEMDP_TRY
+  if (!h || !bpp_eff || n_seq != h->e->n_seq()) throw elemdp::ArgError("elemdp_batch_bpp_eff: bad argument");
+  for (int k = 0; k < n_seq; ++k) bpp_eff[k] = h->e->plans()[k].bpp_eff;
+  ELEMDP_CATCH
+}
+int elemdp_batch_pairs(elemdp_handle* h, int32_t seq_index, uint8_t* kept, double* lnbpp, int32_t cap) {
+  ELEMDP_TRY
+  if (!h || !kept) throw elemdp::ArgError("elemdp_batch_pairs: null argument");
+  h->e->batch_pairs(seq_index, kept, lnbpp, cap);
+  ELEMDP_CATCH
+}
+
+int elemdp_partial_len(const elemdp_handle* h) { return h ? h->e->partial_len() : ELEMDP_EINVAL; }
+int elemdp_train_partial(elemdp_handle* h, const double* x, int32_t n_param, void* partial, int32_t partial_is_device) {
+  ELEMDP_TRY
+  if (!h || !x || !partial) throw elemdp::ArgError("elemdp_train_partial: null argument");
+  h->e->train_partial(x, n_param, partial, partial_is_device != 0);
+  ELEMDP_CATCH
+}
+int elemdp_train_finish(elemdp_handle* h, const double* reduced, double* fn, double* gr, double* sum_eff,
+                        int32_t* n_skipped) {
+  ELEMDP_TRY
+  if (!h || !reduced) throw elemdp::ArgError("elemdp_train_finish: null argument");
+  h->e->train_finish(reduced, fn, gr, sum_eff, n_skipped);
+  ELEMDP_CATCH
+}
+int elemdp_set_finish_params(elemdp_handle* h, const double* x, int32_t n_param) {
+  ELEMDP_TRY
+  if (!h || !x || n_param != h->e->n_param()) throw elemdp::ArgError("elemdp_set_finish_params: bad argument");
+  h->e->set_theta_from(x);
+  ELEMDP_CATCH
+}
+int elemdp_train_eval(elemdp_handle* h, const double* x, int32_t n_param, double* fn, double* gr, double* sum_eff,
+                      int32_t* n_skipped) {
+  ELEMDP_TRY
+  if (!h || !x) throw elemdp::ArgError("elemdp_train_eval: null argument");
+  std::vector<double> partial(h->e->partial_len());
+  h->e->train_partial(x, n_param, partial.data(), false);
+  h->e->train_finish(partial.data(), fn, gr, sum_eff, n_skipped);
+  ELEMDP_CATCH
+}
+int elemdp_train_seq_stats(elemdp_handle* h, double* out, int32_t n_seq) {
+  ELEMDP_TRY
+  if (!h || !out) throw elemdp::ArgError("elemdp_train_seq_stats: null argument");
+  h->e->seq_stats(out, n_seq);
+  ELEMDP_CATCH
+}
+int elemdp_debug_tables(elemdp_handle* h, double* inside, double* outside, double* inside_o, double* outside_o,
+                        double* ENo, double* ENx, double* EH) {
+  ELEMDP_TRY
+  if (!h) throw elemdp::ArgError("null handle");
+  h->e->debug_tables(inside, outside, inside_o, outside_o, ENo, ENx, EH);
+  ELEMDP_CATCH
+}
+int elemdp_scan(elemdp_handle* h, const double* x, int32_t n_param, elemdp_scan_out* out) {
+  ELEMDP_TRY
+  if (!h || !x) throw elemdp::ArgError("elemdp_scan: null argument");
+  h->e->scan(x, n_param, out);
+  ELEMDP_CATCH
+}
+int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n) {
+  if (!h || !ms) return ELEMDP_EINVAL;
+  for (int k = 0; k < n && k < 2; ++k) ms[k] = h->e->last_ms[k];
+  return ELEMDP_OK;
+}
+const char* elemdp_kernel_name(void) { return elemdp::dp_kernel_name(elemdp::DP_TRAIN); }
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// kernels.h -- launch interface between the host engine (engine.cpp) and the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device_layout.h"
+#include "energy_tables.h"
+
+namespace elemdp {
+
+constexpr int kThreads = 256;  // workgroup size of every kernel (4 waves of 64: one per SIMD of a CU)
+
+// device arrays of one plan set (see SeqPlan for the per-sequence bases)
+struct PlanArrays {
+  int16_t* dmin = nullptr;
+  double* e_stack = nullptr; double* e_ext = nullptr; double* e_ml = nullptr; double* e_close = nullptr; double* e_hp = nullptr;
+  int32_t* by_outer_off = nullptr; int32_t* by_inner_off = nullptr; int32_t* by_left_off = nullptr; int32_t* by_right_off = nullptr;
+  int32_t* cursor = nullptr;  // scratch, one int per CSR offset entry
+  LoopItem* items = nullptr;
+  uint8_t* item_in = nullptr;
+  int32_t* by_inner_idx = nullptr; int32_t* by_left_idx = nullptr; int32_t* by_right_idx = nullptr;
+};
+
+// static per-batch arrays
+struct BatchArrays {
+  const uint8_t* seq = nullptr;     // base codes
+  const double* ws = nullptr;       // position weights
+  const uint8_t* unp = nullptr;     // position may be emitted unpaired
+  const int32_t* ndot = nullptr;    // FIX_RSS prefix counts (or null)
+};
+
+struct PlanKernelArgs {
+  const EnergyTables* et;
+  BatchArrays b;
+  const uint32_t* okbits;
+  SeqPlan* plans;       // plans[first .. first+count)
+  int32_t first, count;
+  PlanArrays p;
+  int32_t no_ene, min_span, fix_rss;
+};
+
+// byte offsets of the dynamic LDS regions of the DP kernels
+struct LdsLayout {
+  int32_t ints, theta, en_o, en_x, eh, zs, ws, post, okbits, dmin, seq, unp, total;
+};
+
+enum DpKind : int { DP_TRAIN = 0, DP_BPP = 1, DP_SCAN = 2 };
+
+struct DpArgs {
+  AutomatonLayout lay;
+  const int32_t* ints;     // automaton blob (global)
+  const double* params;    // ParamBlock followed by theta[n_theta]
+  int32_t no_prf, m_min, no_rss;
+  int32_t first_pass_only;  // debug: TRAIN stops after the full-terminal outside pass
+  const SeqPlan* plans;
+  const int32_t* order;    // processing order (longest first)
+  int32_t n_seq;
+  int32_t* counter;        // work queue head
+  BatchArrays b;
+  const uint32_t* okbits;
+  PlanArrays p;
+  // table slots, one per workgroup
+  double* band_in; double* band_out; double* ext_in; double* ext_out;
+  size_t band_stride, ext_stride;  // in doubles
+  TraceRec* tr_band; TraceRec* tr_ext;
+  // TRAIN: per-sequence results [n][out_stride] = Zo, Zari, Znasi, f, skipped, bpp_eff, ENo[nt], ENx[nt], EHo[2], EHx[2]
+  double* seq_out;
+  int32_t out_stride;
+  // BPP: filtered mask + efficiency
+  uint32_t* okbits_out;
+  double log_min_bpp;
+  double* lnbpp_out;   // optional per-cell ln BPP (debug), indexed by cell_base
+  // SCAN outputs (batch offsets: seq_base for start/inner/psihat/rss, pos_base for end)
+  double* sc_start; double* sc_end; double* sc_inner; int32_t* sc_psihat; char* sc_rss;
+  int32_t* sc_ys; int32_t* sc_ye; double* sc_exist; double* sc_en;  // sc_en: [n][n_theta]
+  int32_t* trace_stack; int32_t trace_stack_stride;
+  LdsLayout lds;
+};
+
+hipError_t launch_mask(const BatchArrays& b, const SeqPlan* plans, int n_seq, int min_span, bool write_bits, uint32_t* okbits,
+                       int32_t* n_canonical, hipStream_t st);
+hipError_t launch_plan_cells(const PlanKernelArgs& a, int32_t* n_items_out, hipStream_t st);
+hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st);
+hipError_t launch_dp(int kind, const DpArgs& a, int n_blocks, hipStream_t st);
+hipError_t launch_reduce(const double* seq_out, int out_stride, int n_seq, int n_theta, double* partial, hipStream_t st);
+const char* dp_kernel_name(int kind);
+
+}  // namespace elemdp

@@ -1,0 +1,574 @@
+// kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4).
+//
+// Execution model: ONE WORKGROUP PER SEQUENCE (256 lanes = 4 waves, one per SIMD of a CU), the
+// workgroups are persistent and pull sequences from a device-side queue (longest first).  A
+// sequence's banded tables live in the workgroup's private HBM slot in the layout [e][d][i][s]
+// (structural state, span, start, interval state): the lanes of a workgroup own the targets
+// (i, s) of the current anti-diagonal d with s fastest, so every table access of a diagonal is a
+// contiguous run of (L+1-d)*S doubles -- coalesced loads of the smaller diagonals, coalesced
+// stores of the new one.  One barrier per diagonal; the exterior chain O(j) runs as S lanes.
+// The automaton, theta, the pair mask, the sequence and its weights are staged in LDS; expected
+// counts are accumulated with LDS fp64 atomics and leave the kernel once per sequence.
+// No MFMA: this is a log-semiring recurrence, not a contraction (fp64 VALU + HBM bound).
+//
+// The arithmetic of every rule is in dp_rules.h / scan_rules.h / plan_rules.h (device code here).
+#include <hip/hip_runtime.h>
+
+#include "dp_rules.h"
+#include "energy_rules.h"
+#include "kernels.h"
+#include "plan_rules.h"
+#include "scan_rules.h"
+
+namespace elemdp {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_sum_int(int v, int* lds_tmp) {
+  // wave reduction, then one LDS slot per wave
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds_tmp[wave] = v;
+  __syncthreads();
+  int tot = 0;
+  for (int w = 0; w < kThreads / 64; ++w) tot += lds_tmp[w];
+  __syncthreads();
+  return tot;
+}
+
+// exclusive prefix sum of data[0..n) in place; data[n] receives the total.  One workgroup.
+__device__ void block_exclusive_scan(int32_t* data, int n, int* lds_tmp /* kThreads+1 ints */) {
+  const int tid = threadIdx.x;
+  const int chunk = (n + kThreads - 1) / kThreads;
+  const int a = tid * chunk;
+  const int b = (a + chunk < n) ? a + chunk : n;
+  int sum = 0;
+  for (int t = a; t < b; ++t) sum += data[t];
+  lds_tmp[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < kThreads; ++t) { int v = lds_tmp[t]; lds_tmp[t] = run; run += v; }
+    lds_tmp[kThreads] = run;
+  }
+  __syncthreads();
+  int run = lds_tmp[tid];
+  for (int t = a; t < b; ++t) { int v = data[t]; data[t] = run; run += v; }
+  if (tid == 0) data[n] = lds_tmp[kThreads];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void lse_atomic(double* addr, double z) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(addr);
+  unsigned long long old = *p, assumed;
+  do {
+    assumed = old;
+    const double nv = lse2(__longlong_as_double((long long)assumed), z);
+    old = atomicCAS(p, assumed, (unsigned long long)__double_as_longlong(nv));
+  } while (old != assumed);
+}
+
+struct OkBits {
+  const uint32_t* bits; int L, W;
+  __device__ __forceinline__ bool operator()(int i, int d) const {
+    if (i < 0 || d < 0 || d > W || i + d > L) return false;
+    const int c = i * (W + 1) + d;
+    return (bits[c >> 5] >> (c & 31)) & 1u;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// K0: canonical pair mask (energy_model.hpp:213-219), one workgroup per sequence, one lane per word
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_mask(BatchArrays b, const SeqPlan* plans, int min_span, int write_bits,
+                                                   uint32_t* okbits, int32_t* n_canonical) {
+  __shared__ int tmp[kThreads / 64];
+  const SeqPlan p = plans[blockIdx.x];
+  const uint8_t* seq = b.seq + p.seq_base;
+  const int ncell = (p.L + 1) * (p.W + 1);
+  const int nword = (ncell + 31) / 32;
+  int cnt = 0;
+  for (int w = threadIdx.x; w < nword; w += kThreads) {
+    uint32_t bits = 0;
+    for (int k = 0; k < 32; ++k) {
+      const int c = w * 32 + k;
+      if (c >= ncell) break;
+      const int i = c / (p.W + 1), d = c - i * (p.W + 1);
+      if (canonical_pair(seq, p.L, p.W, min_span, i, d)) { bits |= 1u << k; ++cnt; }
+    }
+    if (write_bits) okbits[p.bits_base + w] = bits;
+  }
+  const int tot = block_sum_int(cnt, tmp);
+  if (threadIdx.x == 0) n_canonical[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-plan 1: dmin, structural terms of every kept pair, interior-loop counts per E cell
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_plan_cells(PlanKernelArgs a, int32_t* n_items_out) {
+  __shared__ int tmp[kThreads / 64];
+  SeqPlan& pl = a.plans[a.first + blockIdx.x];
+  const SeqPlan p = pl;
+  const int L = p.L, W = p.W;
+  const uint8_t* seq = a.b.seq + p.seq_base;
+  const int32_t* ndot = a.fix_rss ? a.b.ndot + p.pos_base : nullptr;
+  const OkBits ok{a.okbits + p.bits_base, L, W};
+  const PlanCfg cfg{a.no_ene, a.min_span, a.fix_rss};
+  int16_t* dmin = a.p.dmin + p.dmin_base;
+  for (int i = threadIdx.x; i <= L; i += kThreads) {
+    int dm = 0;
+    for (int d = 1; d <= W && i + d <= L; ++d)
+      if (ok(i, d)) { dm = d; break; }
+    dmin[i] = (int16_t)dm;
+  }
+  const int ncell = (L + 1) * (W + 1);
+  int32_t* cnt = a.p.by_outer_off + p.off_base;
+  int total = 0;
+  for (int c = threadIdx.x; c < ncell; c += kThreads) {
+    const int i = c / (W + 1), d = c - i * (W + 1);
+    if (ok(i, d)) {
+      const PairTerms t = pair_terms(*a.et, cfg, seq, L, ndot, i, d, ok(i + 1, d - 2));
+      const size_t g = p.cell_base + c;
+      a.p.e_stack[g] = t.stack; a.p.e_ext[g] = t.ext; a.p.e_ml[g] = t.ml; a.p.e_close[g] = t.close; a.p.e_hp[g] = t.hp;
+    }
+    int n = 0;
+    if (i + d <= L && i > 0 && d + 2 <= W && ok(i - 1, d + 2))
+      enum_interior(*a.et, cfg, seq, L, W, p.C, ndot, ok, i, d, [&](int, int, double, bool) { ++n; });
+    cnt[c] = n;
+    total += n;
+  }
+  const int tot = block_sum_int(total, tmp);
+  if (threadIdx.x == 0) { n_items_out[blockIdx.x] = tot; pl.n_items = tot; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-plan 2: item lists.  CSR by outer cell (deterministic enumeration), then three index lists
+// (by inner pair, by left loop, by right loop) via counting sort; segments are sorted by item
+// index so that the summation order of the gathers is reproducible.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int role_key(const LoopItem& it, int role, int W) {
+  switch (role) {
+    case 0: return it.k * (W + 1) + (it.l - it.k);  // inner pair cell (k, l)
+    case 1: return it.i * (W + 1) + (it.k - it.i);  // left loop cell (i, k)
+    default: return it.l * (W + 1) + (it.j - it.l); // right loop cell (l, j)
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_plan_items(PlanKernelArgs a) {
+  __shared__ int tmp[kThreads + 1];
+  const SeqPlan p = a.plans[a.first + blockIdx.x];
+  const int L = p.L, W = p.W;
+  const uint8_t* seq = a.b.seq + p.seq_base;
+  const int32_t* ndot = a.fix_rss ? a.b.ndot + p.pos_base : nullptr;
+  const OkBits ok{a.okbits + p.bits_base, L, W};
+  const PlanCfg cfg{a.no_ene, a.min_span, a.fix_rss};
+  const int ncell = (L + 1) * (W + 1);
+  int32_t* off = a.p.by_outer_off + p.off_base;
+  block_exclusive_scan(off, ncell, tmp);
+  LoopItem* items = a.p.items + p.item_base;
+  uint8_t* item_in = a.p.item_in + p.item_base;
+  for (int c = threadIdx.x; c < ncell; c += kThreads) {
+    const int i = c / (W + 1), d = c - i * (W + 1);
+    if (!(i + d <= L && i > 0 && d + 2 <= W && ok(i - 1, d + 2))) continue;
+    int pos = off[c];
+    enum_interior(*a.et, cfg, seq, L, W, p.C, ndot, ok, i, d, [&](int k, int l, double tsc, bool in) {
+      LoopItem it;
+      it.tsc = tsc; it.i = (int16_t)i; it.j = (int16_t)(i + d); it.k = (int16_t)k; it.l = (int16_t)l;
+      items[pos] = it;
+      item_in[pos] = in ? 1 : 0;
+      ++pos;
+    });
+  }
+  __syncthreads();
+  const int n_items = p.n_items;
+  int32_t* cursor = a.p.cursor + p.off_base;
+  for (int role = 0; role < 3; ++role) {
+    int32_t* roff = (role == 0 ? a.p.by_inner_off : role == 1 ? a.p.by_left_off : a.p.by_right_off) + p.off_base;
+    int32_t* ridx = (role == 0 ? a.p.by_inner_idx : role == 1 ? a.p.by_left_idx : a.p.by_right_idx) + p.item_base;
+    for (int c = threadIdx.x; c <= ncell; c += kThreads) roff[c] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_items; t += kThreads) atomicAdd(&roff[role_key(items[t], role, W)], 1);
+    __syncthreads();
+    block_exclusive_scan(roff, ncell, tmp);
+    for (int c = threadIdx.x; c < ncell; c += kThreads) cursor[c] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_items; t += kThreads) {
+      const int key = role_key(items[t], role, W);
+      const int pos = atomicAdd(&cursor[key], 1);
+      ridx[roff[key] + pos] = t;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncell; c += kThreads) {  // insertion sort of each (short) segment
+      const int s0 = roff[c], s1 = roff[c + 1];
+      for (int x = s0 + 1; x < s1; ++x) {
+        const int v = ridx[x];
+        int y = x - 1;
+        while (y >= s0 && ridx[y] > v) { ridx[y + 1] = ridx[y]; --y; }
+        ridx[y + 1] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// statistics sinks
+// ---------------------------------------------------------------------------------------------
+struct GpuSink {
+  double* en_;       // LDS: expected emission counts of the running pass
+  double* post_[3];  // LDS: log-space position posteriors (start, inner, end) or null
+  double eh0, eh1;   // lane-private energy statistics
+  __device__ __forceinline__ void en(int idx, double w) { atomicAdd(&en_[idx], w); }
+  __device__ __forceinline__ void eh(int k, double w) { if (k) eh1 += w; else eh0 += w; }
+  __device__ __forceinline__ void pos(int which, int p, double z) { if (post_[which]) lse_atomic(&post_[which][p], z); }
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one sequence worth of sweeps (all lanes of the workgroup call these together)
+// ---------------------------------------------------------------------------------------------
+template <bool CONSTRAINED>
+__device__ void sweep_inside(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, bool no_rss) {
+  const int S = m.lay.S, tid = threadIdx.x;
+  if (!no_rss) {
+    for (int d = 0; d <= q.W; ++d) {
+      const int n = (q.L - d + 1) * S;
+      for (int t = tid; t < n; t += kThreads) {
+        const int i = t / S, s = t - i * S;
+        inside_target<CONSTRAINED>(m, q, T, c, d, i, s);
+      }
+      __syncthreads();
+    }
+  }
+  for (int s = tid; s < S; s += kThreads) T.o(0, s) = (s == m.lay.s00) ? 0. : ELEMDP_NEG_INF;
+  __syncthreads();
+  for (int j = 1; j <= q.L; ++j) {
+    for (int s = tid; s < S; s += kThreads) inside_ext_target<CONSTRAINED>(m, q, T, c, j, s);
+    __syncthreads();
+  }
+}
+
+template <int MODE>
+__device__ void sweep_outside(const ModelView& m, const SeqView& q, const TableView& in, const TableView& out, double Z,
+                              const Constraint& c, bool ari, bool nasi, GpuSink& sink, double* lds_eh, bool no_rss) {
+  const int S = m.lay.S, tid = threadIdx.x;
+  OutCtx<GpuSink> x{m, q, in, out, Z, c, sink};
+  sink.eh0 = sink.eh1 = 0.;
+  for (int s = tid; s < S; s += kThreads) {
+    double v = ELEMDP_NEG_INF;
+    if (nasi && s == m.lay.s00) v = 0.;
+    if (ari && (s == m.lay.s0m1 || s == m.lay.s0m2)) v = 0.;
+    out.o(q.L, s) = v;
+  }
+  __syncthreads();
+  for (int i = q.L - 1; i >= 0; --i) {
+    for (int s = tid; s < S; s += kThreads) outside_ext_target<MODE>(x, i, s);
+    __syncthreads();
+  }
+  if (!no_rss) {
+    for (int d = q.W; d >= 0; --d) {
+      const int n = (q.L - d + 1) * S;
+      for (int t = tid; t < n; t += kThreads) {
+        const int i = t / S, s = t - i * S;
+        outside_target<MODE>(x, d, i, s);
+      }
+      __syncthreads();
+    }
+  }
+  if (MODE == OUT_TRAIN) {
+    const double a = wave_sum(sink.eh0), b = wave_sum(sink.eh1);
+    if ((tid & 63) == 0) { atomicAdd(&lds_eh[0], a); atomicAdd(&lds_eh[1], b); }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the DP kernel: TRAIN = K2 + 2 x K3 fused, BPP = K1, SCAN = K4 + K5 + K6
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  __shared__ int l_cur;
+  int32_t* l_ints = reinterpret_cast<int32_t*>(lds + a.lds.ints);
+  double* l_theta = reinterpret_cast<double*>(lds + a.lds.theta);
+  double* l_en_o = reinterpret_cast<double*>(lds + a.lds.en_o);
+  double* l_en_x = reinterpret_cast<double*>(lds + a.lds.en_x);
+  double* l_eh = reinterpret_cast<double*>(lds + a.lds.eh);   // EHo[2], EHx[2]
+  double* l_zs = reinterpret_cast<double*>(lds + a.lds.zs);   // Zo, Zari, Znasi, skip, Ys, Ye
+  double* l_ws = reinterpret_cast<double*>(lds + a.lds.ws);
+  double* l_post = reinterpret_cast<double*>(lds + a.lds.post);
+  uint32_t* l_ok = reinterpret_cast<uint32_t*>(lds + a.lds.okbits);
+  int16_t* l_dmin = reinterpret_cast<int16_t*>(lds + a.lds.dmin);
+  uint8_t* l_seq = lds + a.lds.seq;
+  uint8_t* l_unp = lds + a.lds.unp;
+  const int tid = threadIdx.x;
+  const int S = a.lay.S, nt = a.lay.n_theta;
+
+  for (int t = tid; t < a.lay.n_ints; t += kThreads) l_ints[t] = a.ints[t];
+  const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
+  const double* g_theta = a.params + sizeof(ParamBlock) / sizeof(double);
+  for (int t = tid; t < nt; t += kThreads) l_theta[t] = g_theta[t];
+
+  ModelView m;
+  m.lay = a.lay;
+  m.ints = l_ints;
+  m.theta = l_theta;
+  m.lambda[0] = pb->lambda[0];
+  m.lambda[1] = pb->lambda[1];
+  m.log_tau = pb->log_tau;
+  m.lam_same = pb->lam_same;
+  m.no_prf = a.no_prf;
+  m.m_min = a.m_min;
+  const bool no_rss = a.no_rss != 0;
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) l_cur = atomicAdd(a.counter, 1);
+    __syncthreads();
+    const int w = l_cur;
+    if (w >= a.n_seq) break;
+    const int n = a.order[w];
+    const SeqPlan p = a.plans[n];
+    const int L = p.L, W = p.W;
+    const int ncell = (L + 1) * (W + 1);
+    const int nword = (ncell + 31) / 32;
+
+    // ---- stage the sequence in LDS
+    for (int t = tid; t < nword; t += kThreads) l_ok[t] = a.okbits[p.bits_base + t];
+    for (int t = tid; t <= L; t += kThreads) {
+      l_dmin[t] = a.p.dmin[p.dmin_base + t];
+      l_ws[t] = (KIND == DP_BPP) ? 0. : a.b.ws[p.pos_base + t];
+      l_unp[t] = a.b.unp[p.pos_base + t];
+      l_seq[t] = (t < L) ? a.b.seq[p.seq_base + t] : 0;
+    }
+    for (int t = tid; t < nt; t += kThreads) { l_en_o[t] = 0.; l_en_x[t] = 0.; }
+    if (tid < 4) l_eh[tid] = 0.;
+    if (KIND == DP_SCAN)
+      for (int t = tid; t < 3 * (L + 1); t += kThreads) l_post[t] = ELEMDP_NEG_INF;
+    __syncthreads();
+
+    SeqView q;
+    q.L = L; q.W = W; q.C = p.C;
+    q.seq = l_seq; q.ws = l_ws; q.okbits = l_ok; q.dmin = l_dmin; q.unp = l_unp;
+    q.e_stack = a.p.e_stack + p.cell_base; q.e_ext = a.p.e_ext + p.cell_base; q.e_ml = a.p.e_ml + p.cell_base;
+    q.e_close = a.p.e_close + p.cell_base; q.e_hp = a.p.e_hp + p.cell_base;
+    q.items = a.p.items + p.item_base; q.item_in = a.p.item_in + p.item_base;
+    q.by_outer_off = a.p.by_outer_off + p.off_base;
+    q.by_inner_off = a.p.by_inner_off + p.off_base; q.by_inner_idx = a.p.by_inner_idx + p.item_base;
+    q.by_left_off = a.p.by_left_off + p.off_base; q.by_left_idx = a.p.by_left_idx + p.item_base;
+    q.by_right_off = a.p.by_right_off + p.off_base; q.by_right_idx = a.p.by_right_idx + p.item_base;
+
+    TableView Tin, Tout;
+    Tin.band = a.band_in + blockIdx.x * a.band_stride;
+    Tin.ext = a.ext_in + blockIdx.x * a.ext_stride;
+    Tout.band = a.band_out + blockIdx.x * a.band_stride;
+    Tout.ext = a.ext_out + blockIdx.x * a.ext_stride;
+    Tin.L = Tout.L = L; Tin.W = Tout.W = W; Tin.S = Tout.S = S;
+
+    const Constraint c0{-1, -1, 0};
+    GpuSink sink;
+    sink.en_ = l_en_o;
+    sink.post_[0] = sink.post_[1] = sink.post_[2] = nullptr;
+
+    if (KIND == DP_TRAIN) {
+      // ---- schedule of RNAelemTrainDP::operator() (motif_trainer.hpp:204-227)
+      sweep_inside<false>(m, q, Tin, c0, no_rss);
+      if (tid == 0) {
+        const double Zo = part_func(m, Tin, true, true), Za = part_func(m, Tin, true, false),
+                     Zn = part_func(m, Tin, false, true);
+        l_zs[0] = Zo; l_zs[1] = Za; l_zs[2] = Zn;
+        l_zs[3] = (isfinite(Zo) && isfinite(Za)) ? 0. : 1.;
+      }
+      __syncthreads();
+      const double Zo = l_zs[0], Za = l_zs[1], Zn = l_zs[2];
+      const bool skip = l_zs[3] != 0.;
+      double* o = a.seq_out + (size_t)n * a.out_stride;
+      if (!skip) {
+        sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, Zo, c0, true, true, sink, l_eh, no_rss);
+        const bool positive = p.positive != 0;
+        sink.en_ = l_en_x;
+        if (!a.first_pass_only)
+          sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, positive ? Za : Zn, c0, positive, !positive, sink, l_eh + 2, no_rss);
+      }
+      if (tid == 0) {
+        o[0] = Zo; o[1] = Za; o[2] = Zn;
+        o[3] = skip ? 0. : Zo - (p.positive ? Za : Zn);
+        o[4] = skip ? 1. : 0.;
+        o[5] = skip ? 0. : p.bpp_eff;
+      }
+      for (int t = tid; t < nt; t += kThreads) { o[6 + t] = skip ? 0. : l_en_o[t]; o[6 + nt + t] = skip ? 0. : l_en_x[t]; }
+      if (tid < 4) o[6 + 2 * nt + tid] = skip ? 0. : l_eh[tid];
+    } else if (KIND == DP_BPP) {
+      // ---- K1: plain McCaskill through the one-state automaton, then the BPP threshold
+      // (EnergyModel::calc_BPP / fill_bpp_tables, energy_model.hpp:188-266)
+      sweep_inside<false>(m, q, Tin, c0, false);
+      const double Z = Tin.o(L, 0);
+      sweep_outside<OUT_NONE>(m, q, Tin, Tout, Z, c0, false, true, sink, l_eh, false);
+      __shared__ int tmp[kThreads / 64];
+      int kept = 0;
+      for (int wd = tid; wd < nword; wd += kThreads) {
+        const uint32_t in_bits = l_ok[wd];
+        uint32_t out_bits = 0;
+        for (int k = 0; k < 32; ++k) {
+          if (!((in_bits >> k) & 1u)) continue;
+          const int cc = wd * 32 + k;
+          const int i = cc / (W + 1), d = cc - i * (W + 1);
+          const double ln = (Tin.at(ST_P, d, i, 0) + Tout.at(ST_P, d, i, 0)) - Z;  // lnBPP, energy_model.hpp:195-201
+          if (a.lnbpp_out) a.lnbpp_out[p.cell_base + cc] = ln;
+          if (a.log_min_bpp <= ln) { out_bits |= 1u << k; ++kept; }
+        }
+        a.okbits_out[p.bits_base + wd] = out_bits;
+      }
+      const int tot = block_sum_int(kept, tmp);
+      if (tid == 0) {
+        double* o = a.seq_out + (size_t)n * a.out_stride;
+        o[0] = Z;
+        o[1] = (double)tot;
+      }
+    } else {
+      // ---- schedule of RNAelemScanDP::operator() (motif_scanner.hpp:204-252)
+      double* Pys = l_post; double* Pyi = l_post + (L + 1); double* Pye = l_post + 2 * (L + 1);
+      sweep_inside<false>(m, q, Tin, c0, no_rss);
+      if (tid == 0) { l_zs[0] = part_func(m, Tin, true, true); l_zs[1] = Tin.o(L, m.lay.s00); }
+      __syncthreads();
+      const double ZL = l_zs[0];
+      sink.post_[0] = Pys; sink.post_[1] = Pyi;
+      sweep_outside<OUT_SCAN>(m, q, Tin, Tout, ZL, c0, true, true, sink, l_eh, no_rss);
+      if (tid == 0) l_zs[4] = (double)last_argmax(Pys, L);
+      __syncthreads();
+      const int Ys = (int)l_zs[4];
+      for (int t = tid; t < L; t += kThreads) { a.sc_start[p.seq_base + t] = Pys[t]; a.sc_inner[p.seq_base + t] = Pyi[t]; }
+      if (a.sc_en) for (int t = tid; t < nt; t += kThreads) a.sc_en[(size_t)n * nt + t] = l_en_o[t];
+      const Constraint c1{Ys, -1, 0};
+      sweep_inside<true>(m, q, Tin, c1, no_rss);
+      if (tid == 0) l_zs[2] = part_func(m, Tin, true, true);
+      __syncthreads();
+      sink.post_[0] = sink.post_[1] = nullptr; sink.post_[2] = Pye;
+      sink.en_ = l_en_x;
+      sweep_outside<OUT_END>(m, q, Tin, Tout, l_zs[2], c1, true, true, sink, l_eh, no_rss);
+      if (tid == 0) {
+        l_zs[5] = (double)last_argmax(Pye, L + 1);
+        double tot = ELEMDP_NEG_INF;
+        for (int t = 0; t < L; ++t) tot = lse2(tot, Pys[t]);
+        a.sc_exist[n] = exp(tot);
+      }
+      __syncthreads();
+      const int Ye = (int)l_zs[5];
+      for (int t = tid; t <= L; t += kThreads) a.sc_end[p.pos_base + t] = Pye[t];
+      // Viterbi parse (calc_viterbi_alignment :172-184)
+      TraceView R;
+      R.band = a.tr_band + blockIdx.x * a.band_stride;
+      R.ext = a.tr_ext + blockIdx.x * a.ext_stride;
+      const Constraint c2{Ys, Ye, 1};
+      for (int d = 0; d <= W; ++d) {
+        const int nn = (L - d + 1) * S;
+        for (int t = tid; t < nn; t += kThreads) { const int i = t / S, s = t - i * S; cyk_target(m, q, Tin, R, c2, d, i, s); }
+        __syncthreads();
+      }
+      for (int s = tid; s < S; s += kThreads) {
+        Tin.o(0, s) = (s == m.lay.s00) ? 0. : ELEMDP_NEG_INF;
+        TraceRec leaf; leaf.k = leaf.l = -1; leaf.t = -1; leaf.e1 = -1; leaf.s1 = -1;
+        R.ext[s] = leaf;
+      }
+      __syncthreads();
+      for (int j = 1; j <= L; ++j) {
+        for (int s = tid; s < S; s += kThreads) cyk_ext_target(m, q, Tin, R, c2, j, s);
+        __syncthreads();
+      }
+      int32_t* path = a.sc_psihat + p.seq_base;
+      char* rss = a.sc_rss + p.seq_base;
+      for (int t = tid; t < L; t += kThreads) { path[t] = 0; rss[t] = ' '; }
+      __syncthreads();
+      if (tid == 0) {
+        a.sc_ys[n] = Ys; a.sc_ye[n] = Ye;
+        const int s0 = Tin.o(L, m.lay.s0m2) < Tin.o(L, m.lay.s0m1) ? m.lay.s0m1 : m.lay.s0m2;
+        TraceFrame* stack = reinterpret_cast<TraceFrame*>(a.trace_stack + (size_t)blockIdx.x * a.trace_stack_stride);
+        trace_back(m, Tin, R, L, s0, path, rss, stack, (int)(a.trace_stack_stride * sizeof(int32_t) / sizeof(TraceFrame)));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic reduction over sequences: one lane per output column, sequences in input order
+// partial = [fn, sum_eff, n_used, n_skipped, ENo[nt], ENx[nt], EHo[2], EHx[2]]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_reduce(const double* seq_out, int out_stride, int n_seq, int n_theta,
+                                                     double* partial) {
+  const int ncol = 4 + 2 * n_theta + 4;
+  const int col = blockIdx.x * kThreads + threadIdx.x;
+  if (col >= ncol) return;
+  double acc = 0.;
+  for (int n = 0; n < n_seq; ++n) {
+    const double* o = seq_out + (size_t)n * out_stride;
+    double v;
+    if (col == 0) v = o[3];
+    else if (col == 1) v = o[5];
+    else if (col == 2) v = 1. - o[4];
+    else if (col == 3) v = o[4];
+    else v = o[6 + (col - 4)];
+    acc += v;
+  }
+  partial[col] = acc;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_mask(const BatchArrays& b, const SeqPlan* plans, int n_seq, int min_span, bool write_bits, uint32_t* okbits,
+                       int32_t* n_canonical, hipStream_t st) {
+  if (n_seq <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_mask, dim3(n_seq), dim3(kThreads), 0, st, b, plans, min_span, write_bits ? 1 : 0, okbits, n_canonical);
+  return hipGetLastError();
+}
+hipError_t launch_plan_cells(const PlanKernelArgs& a, int32_t* n_items_out, hipStream_t st) {
+  if (a.count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_plan_cells, dim3(a.count), dim3(kThreads), 0, st, a, n_items_out);
+  return hipGetLastError();
+}
+hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
+  if (a.count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_plan_items, dim3(a.count), dim3(kThreads), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_dp(int kind, const DpArgs& a, int n_blocks, hipStream_t st) {
+  if (a.n_seq <= 0) return hipSuccess;
+  hipError_t e = hipSuccess;
+  const size_t lds = (size_t)a.lds.total;
+#define ELEMDP_LAUNCH(K)                                                                                          \
+  do {                                                                                                            \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<K>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds);                                                                            \
+    if (e != hipSuccess) return e;                                                                                \
+    hipLaunchKernelGGL(k_dp<K>, dim3(n_blocks), dim3(kThreads), lds, st, a);                                      \
+  } while (0)
+  switch (kind) {
+    case DP_TRAIN: ELEMDP_LAUNCH(DP_TRAIN); break;
+    case DP_BPP: ELEMDP_LAUNCH(DP_BPP); break;
+    case DP_SCAN: ELEMDP_LAUNCH(DP_SCAN); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef ELEMDP_LAUNCH
+  return hipGetLastError();
+}
+hipError_t launch_reduce(const double* seq_out, int out_stride, int n_seq, int n_theta, double* partial, hipStream_t st) {
+  const int ncol = 4 + 2 * n_theta + 4;
+  hipLaunchKernelGGL(k_reduce, dim3((ncol + kThreads - 1) / kThreads), dim3(kThreads), 0, st, seq_out, out_stride, n_seq,
+                     n_theta, partial);
+  return hipGetLastError();
+}
+const char* dp_kernel_name(int kind) {
+  return kind == DP_TRAIN ? "k_dp<0>" : kind == DP_BPP ? "k_dp<1>" : "k_dp<2>";
+}
+
+}  // namespace elemdp

@@ -1,0 +1,297 @@
+"""Parity of the HIP path (through the C ABI of libelemdp.so) with the oracle and the golden vectors.
+
+Every test here needs a real MI355X (`-m gpu`).  Tolerances: |d log Z| <= 1e-9 *
+max(1,|log Z|); fn rel 1e-9; gr abs 1e-7 + rel 1e-7; log posteriors abs 1e-6 with identical -inf
+pattern; argmax positions and Viterbi strings exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from rnaelem_amd import api, io, synth
+from tests.util import arr, assert_log_close, gload, gpath
+
+pytestmark = pytest.mark.gpu
+
+PAR = "~T2004~"
+
+
+def load(model, fq):
+    m = io.read_model(gpath(model))
+    eng = io.engine_from_model(m)
+    recs = io.read_fastq(gpath(fq))
+    return m, eng, recs
+
+
+def oracle_for(model):
+    return po.oracle_from_model(gpath(model))
+
+
+def test_library_reports_native_kernel():
+    eng = api.Engine("(.)")
+    assert eng.kernel_name().startswith("k_dp")
+    assert eng.describe()["S"] == eng.n_state
+
+
+def test_initial_params_match_reference_x0():
+    for c in gload("eval.json"):
+        if c["model"] in ("trna_x0.model", "syn_x0.model"):
+            m = io.read_model(gpath(c["model"]))
+            eng = io.engine_from_model(m)
+            np.testing.assert_allclose(eng.initial_params(0.0), c["x"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("fq,W", [("1.fq", 50), ("syn_L100_n3.fq", 50), ("0.fq", 20)])
+def test_bpp_filter(fq, W):
+    """K1 on the GPU vs the oracle: ln BPP of every candidate, kept set, bpp_eff."""
+    eng = api.Engine("(.)", PAR, W, 30, 1e-4)
+    eng.set_option("keep_lnbpp", 1)
+    recs = io.read_fastq(gpath(fq))
+    eng.load_batch([s for _, s, _ in recs], [q for _, _, q in recs])
+    o = po.make_oracle("(.)", W, 30, min_bpp=1e-4)
+    eff = eng.bpp_eff()
+    for k, (rid, seq, qual) in enumerate(recs):
+        ln_o, kept_o, eff_o, lnz_o = o.bpp(seq)
+        kept, ln = eng.pairs(k, with_lnbpp=True)
+        assert np.array_equal(kept, kept_o)
+        assert eff[k] == eff_o
+        assert_log_close(ln, ln_o, rtol=1e-9, atol=1e-9, what="lnbpp")
+
+
+def test_bpp_against_rnafold_dotplot():
+    """The reference's BPP_RNAFOLD known answer (test-exact.cpp:86-138), on the GPU, 1e-5 abs."""
+    (rid, seq, qual), = io.read_fastq(gpath("1.fq"))
+    eng = api.Engine("(.)", PAR, 50, 30, 1e-300)   # threshold so low that nothing is filtered
+    eng.set_option("keep_lnbpp", 1)
+    eng.load_batch([seq], [qual])
+    kept, ln = eng.pairs(0, with_lnbpp=True)
+    n = 0
+    for line in open(gpath("rnafold_1_0_ubox.txt")):
+        if line.startswith("#"):
+            continue
+        i, j, sp = line.split()
+        i, j, sp = int(i), int(j), float(sp)
+        assert ln[i - 1, j - (i - 1)] == pytest.approx(2 * np.log(sp), abs=1e-5), (i, j)
+        n += 1
+    assert n == 1146
+
+
+TABLE_CASES = [("tiny_a.model", "tiny.fq"), ("tiny_ne.model", "tiny.fq"), ("0.model", "0.fq"), ("1.model", "0.fq"),
+               ("3.model", "0.fq"), ("syn_b.model", "syn_L40_n3.fq"), ("syn_c12.model", "syn_L40_n3.fq")]
+
+
+@pytest.mark.parametrize("model,fq", TABLE_CASES)
+def test_tables_of_single_sequences(model, fq):
+    """Full inside / outside tables, exterior chains and expected counts of one sequence at a time."""
+    m, eng, recs = load(model, fq)
+    o, x = oracle_for(model)
+    for rid, seq, qual in recs:
+        a = o.train_seq(seq, qual, tables=True)
+        eng.set_option("first_pass_only", 1)
+        eng.load_batch([seq], [qual])
+        eng.train_eval(x)
+        t = eng.debug_tables()
+        assert_log_close(t["inside"], a["inside"], rtol=1e-10, what="inside")
+        assert_log_close(t["inside_o"], a["inside_o"], rtol=1e-10, what="inside_o")
+        if not a["skipped"]:
+            assert_log_close(t["outside"], a["outside"], rtol=1e-10, what="outside")
+            assert_log_close(t["outside_o"], a["outside_o"], rtol=1e-10, what="outside_o")
+            np.testing.assert_allclose(t["ENo"], a["ENo"], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(t["EHo"], a["EHo"], rtol=1e-8, atol=1e-10)
+        eng.set_option("first_pass_only", 0)
+        eng.train_eval(x)
+        t = eng.debug_tables()
+        st = eng.seq_stats()[0]
+        for k, name in enumerate(("Zo", "Zari", "Znasi")):
+            assert_log_close(st[k], a[name], rtol=1e-10, what=name)
+        assert st[4] == a["skipped"]
+        if not a["skipped"]:
+            assert st[3] == pytest.approx(a["f"], rel=1e-9, abs=1e-10)
+            np.testing.assert_allclose(t["ENx"], a["ENx"], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(t["EHx"], a["EHx"], rtol=1e-8, atol=1e-10)
+
+
+EVAL = gload("eval.json")
+
+
+@pytest.mark.parametrize("case", EVAL, ids=["%s-%s" % (c["model"], c["fq"]) for c in EVAL])
+def test_fn_gr_against_reference_golden(case):
+    """elemdp_train_eval vs fn / gr printed by the compiled reference at 17 digits."""
+    m, eng, recs = load(case["model"], case["fq"])
+    np.testing.assert_allclose(m["x"], case["x"], rtol=0, atol=0)
+    eng.load_batch([s for _, s, _ in recs], [q for _, _, q in recs])
+    fn, gr, eff, nsk = eng.train_eval(m["x"])
+    assert fn == pytest.approx(case["fn"], rel=1e-9, abs=1e-9)
+    np.testing.assert_allclose(gr, arr(case["gr"]), rtol=1e-7, atol=1e-7)
+    assert eff == pytest.approx(case["sum_eff"], rel=1e-12)
+    assert nsk == 0
+    # the partial / finish pair used by the multi-GPU path gives the same numbers
+    part = eng.train_partial(m["x"])
+    fn2, gr2, eff2, nsk2 = eng.train_finish(part)
+    assert fn2 == fn and np.array_equal(gr2, gr) and eff2 == eff
+
+
+from tests.test_oracle_golden import EMISSION_COUNTS, PATH_COUNTS  # noqa: E402
+
+BIG = 2 ** 30
+
+
+@pytest.mark.parametrize("pattern,seq,rss,count", PATH_COUNTS)
+def test_reference_path_count_cases(pattern, seq, rss, count):
+    """PATH_COUNT_CASES (RNAelem-test/test.cpp:88-177): number of motif alignments on a fixed structure."""
+    eng = api.Engine(pattern, PAR, BIG, BIG, 0.0, 1.0, api.NO_ENERGY | api.DBG_FIX_RSS | api.DBG_NO_TURN)
+    x = np.zeros(eng.n_param)
+    x[-2:] = 1.0
+    eng.set_option("first_pass_only", 1)
+    eng.load_batch([io.encode_seq(seq)], [np.ones(len(seq) + 1, dtype=np.uint8)], fix_rss=[rss])
+    eng.train_eval(x)
+    t = eng.debug_tables()
+    Z = eng.seq_stats()[0][0]
+    assert np.exp(Z) == pytest.approx(count, rel=1e-12)
+    assert np.exp(t["outside_o"][0, 0]) == pytest.approx(count, rel=1e-12)
+
+
+@pytest.mark.parametrize("seq,rss,counts", EMISSION_COUNTS)
+def test_reference_emission_count_cases(seq, rss, counts):
+    eng = api.Engine(".", PAR, BIG, BIG, 0.0, 1.0, api.NO_ENERGY | api.DBG_FIX_RSS | api.DBG_NO_TURN)
+    x = np.zeros(eng.n_param)
+    x[-2:] = 1.0
+    eng.set_option("first_pass_only", 1)
+    eng.load_batch([io.encode_seq(seq)], [np.ones(len(seq) + 1, dtype=np.uint8)], fix_rss=[rss])
+    eng.train_eval(x)
+    t = eng.debug_tables()
+    Z = eng.seq_stats()[0][0]
+    np.testing.assert_allclose(t["ENo"] * np.exp(Z), [v for row in counts for v in row], rtol=1e-11, atol=1e-11)
+
+
+def test_skipped_sequence_and_no_motif_record():
+    """A pattern longer than the sequence makes Z(ari) = log 0 -> the sequence is skipped
+    (motif_trainer.hpp:211-215); a record whose last quality is not '!' uses the nasi mask."""
+    eng = api.Engine("(.........)", PAR, 50, 30, 1e-4)
+    o = po.make_oracle("(.........)", 50, 30, min_bpp=1e-4)
+    seqs = [io.encode_seq("GGGAAAUCCC"), io.encode_seq("GGGGAAAUCCCCAAGGGAAACCCAAAGGCAGCAAAAGCUGCC")]
+    quals = [np.r_[np.full(10, 10), 0].astype(np.uint8), np.r_[np.full(42, 10), 5].astype(np.uint8)]
+    x = eng.initial_params(0.5)
+    o.set_params(x)
+    eng.load_batch(seqs, quals)
+    fn, gr, eff, nsk = eng.train_eval(x)
+    fo, go, eo, no = o.train_eval(x, seqs, quals)
+    assert nsk == no == 1
+    assert fn == pytest.approx(fo, rel=1e-9)
+    np.testing.assert_allclose(gr, go, rtol=1e-7, atol=1e-7)
+    assert eff == pytest.approx(eo, rel=1e-12)
+
+
+SCAN = gload("scan.json")
+
+
+@pytest.mark.parametrize("case", SCAN, ids=["%s-%s" % (c["model"], c["fq"]) for c in SCAN])
+def test_scan_against_oracle_and_reference_records(case):
+    m, eng, recs = load(case["model"], case["fq"])
+    o, x = oracle_for(case["model"])
+    eng.load_batch([s for _, s, _ in recs], [q for _, _, q in recs])
+    got, en = eng.scan(m["x"])
+    byid = {r["id"]: r for r in case["records"]}
+    nodes = eng.describe()["node"]
+    en_o = np.zeros(eng.n_param - 2)
+    for (rid, seq, qual), g in zip(recs, got):
+        a = o.scan_seq(seq, qual)
+        en_o += a["EN"]
+        assert (g["Ys"], g["Ye"]) == (a["Ys"], a["Ye"])
+        for k in ("start", "end", "inner"):
+            assert_log_close(g[k], a[k], rtol=1e-8, atol=1e-6, what=k)
+        assert g["exist_prob"] == pytest.approx(a["exist_prob"], rel=1e-9)
+        assert list(g["psihat"]) == list(a["psihat"])
+        assert g["rss"] == a["rss"]
+        # and the record text equals what `RNAelem scan` printed (6 significant digits)
+        r = byid[rid]
+        assert (g["Ys"], g["Ye"]) == (r["Ys"], r["Ye"])
+        assert g["rss"] == r["rss"] and list(g["psihat"]) == r["psihat"]
+        txt = io.scan_record(rid, seq, g, nodes)
+        assert ("mot: " + r["mot"]) in txt
+    np.testing.assert_allclose(en, en_o, rtol=1e-8, atol=1e-10)
+
+
+def test_gradient_by_central_difference():
+    """The check the reference's MACHINE_DIFF_GR intends (test-exact.cpp:54-84): d = 1e-5, 1e-6 abs."""
+    for model, fq in (("0.model", "0.fq"), ("1.model", "0.fq"), ("3.model", "0.fq")):
+        m, eng, recs = load(model, fq)
+        eng.load_batch([s for _, s, _ in recs], [q for _, _, q in recs])
+        x = m["x"]
+        fn, gr, _, _ = eng.train_eval(x)
+        d = 1e-5
+        for i in range(len(x)):
+            xp, xm = x.copy(), x.copy()
+            xp[i] += d / 2
+            xm[i] -= d / 2
+            fp = eng.train_eval(xp)[0]
+            fm = eng.train_eval(xm)[0]
+            assert gr[i] == pytest.approx((fp - fm) / d, abs=1e-6), (model, i)
+
+
+def test_ragged_batch_and_batch_linearity():
+    """Mixed lengths in one batch; fn / gr of a batch equal the sums over any split of it."""
+    m = io.read_model(gpath("syn_b.model"))
+    eng = io.engine_from_model(m)
+    seqs, quals = [], []
+    for L, n in ((30, 3), (200, 2), (75, 4), (8, 2), (120, 3)):
+        s, q = synth.synth_batch(n, L, seed=1000 + L)
+        seqs += s
+        quals += q
+    quals[1][-1] = 7
+    eng.load_batch(seqs, quals)
+    fn, gr, eff, nsk = eng.train_eval(m["x"])
+    stats = eng.seq_stats()
+    assert fn == pytest.approx(stats[:, 3].sum(), rel=1e-12)
+    h = len(seqs) // 2
+    eng.load_batch(seqs[:h], quals[:h])
+    f1, g1, e1, n1 = eng.train_eval(m["x"])
+    eng.load_batch(seqs[h:], quals[h:])
+    f2, g2, e2, n2 = eng.train_eval(m["x"])
+    assert fn == pytest.approx(f1 + f2, rel=1e-11)
+    np.testing.assert_allclose(gr, g1 + g2, rtol=1e-9, atol=1e-11)
+    assert eff == pytest.approx(e1 + e2, rel=1e-12) and nsk == n1 + n2
+    # spot-check against the oracle
+    o, x = oracle_for("syn_b.model")
+    fo, go, eo, no = o.train_eval(x, seqs, quals, n_threads=8)
+    assert fn == pytest.approx(fo, rel=1e-9)
+    np.testing.assert_allclose(gr, go, rtol=1e-7, atol=1e-7)
+
+
+def test_error_behaviour():
+    with pytest.raises(api.ElemdpError):
+        api.Engine("(.")
+    eng = api.Engine("(.)")
+    with pytest.raises(api.ElemdpError) as e:
+        eng.train_eval(eng.initial_params())
+    assert e.value.code == -4      # ELEMDP_ESTATE: no batch loaded
+    with pytest.raises(api.ElemdpError):   # quality must have L+1 entries (motif_trainer.hpp:139)
+        eng.load_batch([io.encode_seq("ACGU")], [np.zeros(4, dtype=np.uint8)])
+
+
+def test_baseline_config_full_size():
+    """BASELINE configs C/D at full size: 10 000 x L=200 x '((.*.))', x0 with lambda = (1,1).
+    Size-independent properties + oracle spot checks on sampled sequences."""
+    m = io.read_model(gpath("syn_l1.model"))
+    eng = io.engine_from_model(m)
+    seqs, quals = synth.synth_batch(10000, 200)
+    eng.load_batch(seqs, quals)
+    x = m["x"]
+    fn, gr, eff, nsk = eng.train_eval(x)
+    stats = eng.seq_stats()
+    assert nsk == 0 and np.all(np.isfinite(stats[:, :4]))
+    assert fn == pytest.approx(stats[:, 3].sum(), rel=1e-11)
+    assert np.all(stats[:, 3] >= -1e-9)              # f_n = -log P(label | seq) >= 0
+    assert np.all(stats[:, 1] <= stats[:, 0] + 1e-9) and np.all(stats[:, 2] <= stats[:, 0] + 1e-9)
+    np.testing.assert_allclose(np.logaddexp(stats[:, 1], stats[:, 2]), stats[:, 0], rtol=1e-11)   # Z = Zari (+) Znasi
+    assert eff == pytest.approx(eng.bpp_eff().sum(), rel=1e-12)
+    fn2, gr2, _, _ = eng.train_eval(x)               # idempotent up to atomic summation order
+    assert fn2 == pytest.approx(fn, rel=1e-12)
+    np.testing.assert_allclose(gr2, gr, rtol=1e-9, atol=1e-9)
+    o, xo = oracle_for("syn_l1.model")
+    for k in (0, 1234, 5000, 9999):
+        a = o.train_seq(seqs[k], quals[k])
+        assert_log_close(stats[k, 0], a["Zo"], rtol=1e-10, what="Zo")
+        assert_log_close(stats[k, 1], a["Zari"], rtol=1e-10, what="Zari")
+        assert stats[k, 3] == pytest.approx(a["f"], rel=1e-8, abs=1e-10)
+        assert eng.bpp_eff()[k] == a["bpp_eff"]
