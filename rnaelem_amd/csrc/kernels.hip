@@ -290,6 +290,31 @@ __device__ void sweep_outside(const ModelView& m, const SeqView& q, const TableV
   }
 }
 
+__device__ void sweep_cyk(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
+                                       const Constraint& c) {
+  const int S = m.lay.S, tid = threadIdx.x;
+  for (int d = 0; d <= q.W; ++d) {
+    const int nn = (q.L - d + 1) * S;
+    for (int t = tid; t < nn; t += kThreads) { const int i = t / S, s = t - i * S; cyk_target(m, q, T, R, c, d, i, s); }
+    __syncthreads();
+  }
+  for (int s = tid; s < S; s += kThreads) {
+    T.o(0, s) = (s == m.lay.s00) ? 0. : ELEMDP_NEG_INF;
+    TraceRec leaf; leaf.k = leaf.l = -1; leaf.t = -1; leaf.e1 = -1; leaf.s1 = -1;
+    R.ext[s] = leaf;
+  }
+  __syncthreads();
+  for (int j = 1; j <= q.L; ++j) {
+    for (int s = tid; s < S; s += kThreads) cyk_ext_target(m, q, T, R, c, j, s);
+    __syncthreads();
+  }
+}
+
+__device__ bool run_trace_back(const ModelView& m, const TableView& T, const TraceView& R, int L, int s0,
+                                            int32_t* path, char* rss, TraceFrame* stack, int cap) {
+  return trace_back(m, T, R, L, s0, path, rss, stack, cap);
+}
+
 // ---------------------------------------------------------------------------------------------
 // the DP kernel: TRAIN = K2 + 2 x K3 fused, BPP = K1, SCAN = K4 + K5 + K6
 // ---------------------------------------------------------------------------------------------
@@ -468,21 +493,7 @@ __global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
       R.band = a.tr_band + blockIdx.x * a.band_stride;
       R.ext = a.tr_ext + blockIdx.x * a.ext_stride;
       const Constraint c2{Ys, Ye, 1};
-      for (int d = 0; d <= W; ++d) {
-        const int nn = (L - d + 1) * S;
-        for (int t = tid; t < nn; t += kThreads) { const int i = t / S, s = t - i * S; cyk_target(m, q, Tin, R, c2, d, i, s); }
-        __syncthreads();
-      }
-      for (int s = tid; s < S; s += kThreads) {
-        Tin.o(0, s) = (s == m.lay.s00) ? 0. : ELEMDP_NEG_INF;
-        TraceRec leaf; leaf.k = leaf.l = -1; leaf.t = -1; leaf.e1 = -1; leaf.s1 = -1;
-        R.ext[s] = leaf;
-      }
-      __syncthreads();
-      for (int j = 1; j <= L; ++j) {
-        for (int s = tid; s < S; s += kThreads) cyk_ext_target(m, q, Tin, R, c2, j, s);
-        __syncthreads();
-      }
+      sweep_cyk(m, q, Tin, R, c2);
       int32_t* path = a.sc_psihat + p.seq_base;
       char* rss = a.sc_rss + p.seq_base;
       for (int t = tid; t < L; t += kThreads) { path[t] = 0; rss[t] = ' '; }
@@ -491,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
         a.sc_ys[n] = Ys; a.sc_ye[n] = Ye;
         const int s0 = Tin.o(L, m.lay.s0m2) < Tin.o(L, m.lay.s0m1) ? m.lay.s0m1 : m.lay.s0m2;
         TraceFrame* stack = reinterpret_cast<TraceFrame*>(a.trace_stack + (size_t)blockIdx.x * a.trace_stack_stride);
-        trace_back(m, Tin, R, L, s0, path, rss, stack, (int)(a.trace_stack_stride * sizeof(int32_t) / sizeof(TraceFrame)));
+        run_trace_back(m, Tin, R, L, s0, path, rss, stack, (int)(a.trace_stack_stride * sizeof(int32_t) / sizeof(TraceFrame)));
       }
     }
   }

@@ -178,6 +178,15 @@ ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableV
 
 struct TraceFrame { int16_t i, j; int8_t e; int16_t s; };
 
+// structure letters by code: 0 'O', 1 'L', 2 'R', 3 'H', 4 'B', 5 'I', 6 'M'
+ELEMDP_HD char rss_letter(int code) {
+  return code == 0 ? 'O' : code == 1 ? 'L' : code == 2 ? 'R' : code == 3 ? 'H' : code == 4 ? 'B' : code == 5 ? 'I' : 'M';
+}
+ELEMDP_HD void fill_letters(char* rss, int from, int n, int code) {
+  const char ch = rss_letter(code);
+  for (int p = from; p < from + n; ++p) rss[p] = ch;
+}
+
 // Walks the trace from O(L, s0) and writes the motif node per position (`path`, psihat) and the
 // structure letters (`rss`: O L R H B I M, blank where nothing was written).  `stack` is caller
 // scratch; returns false on overflow.
@@ -194,7 +203,7 @@ ELEMDP_HD bool trace_back(const ModelView& m, const TableView& T, const TraceVie
   (void)M;
   int top = 0;
   stack[top++] = TraceFrame{0, (int16_t)L, (int8_t)ST_O, (int16_t)s0};
-  auto fill = [&](int from, int n, char ch) { for (int p = from; p < from + n; ++p) rss[p] = ch; };
+  auto fill = [&](int from, int n, int code) { fill_letters(rss, from, n, code); };
   while (top > 0) {
     const TraceFrame f = stack[--top];
     const TraceRec t = (f.e == ST_O) ? R.ext[(size_t)f.j * T.S + f.s] : R.band[T.idx(f.e, f.j - f.i, f.i, f.s)];
@@ -207,7 +216,7 @@ ELEMDP_HD bool trace_back(const ModelView& m, const TableView& T, const TraceVie
       case TT_L_L: path[t.l] = fr; stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1}; break;
       case TT_O_O: path[t.l] = fr; rss[t.l] = 'O'; stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1}; break;
       case TT_2_2: path[t.l] = fr; rss[t.l] = 'M'; stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1}; break;
-      case TT_E_H: fill(f.i, f.j - f.i, 'H'); stack[top++] = TraceFrame{t.k, t.l, t.e1, f.s}; break;
+      case TT_E_H: fill(f.i, f.j - f.i, 3); stack[top++] = TraceFrame{t.k, t.l, t.e1, f.s}; break;
       case TT_E_M: case TT_M_B: case TT_2_P: case TT_1_2: case TT_1_B:
         stack[top++] = TraceFrame{t.k, t.l, t.e1, f.s};
         break;
@@ -224,9 +233,9 @@ ELEMDP_HD bool trace_back(const ModelView& m, const TableView& T, const TraceVie
       case TT_E_P: {
         const int s2 = find_state(fl, s1l), s3 = find_state(s1r, fr);
         const int n1 = f.j - t.l, n2 = t.k - f.i;
-        if (0 == n1) fill(f.i, n2, 'B');
-        else if (0 == n2) fill(t.l, n1, 'B');
-        else { fill(f.i, n2, 'I'); fill(t.l, n1, 'I'); }
+        if (0 == n1) fill(f.i, n2, 4);
+        else if (0 == n2) fill(t.l, n1, 4);
+        else { fill(f.i, n2, 5); fill(t.l, n1, 5); }
         stack[top++] = TraceFrame{t.l, f.j, (int8_t)ST_L, (int16_t)s3};
         stack[top++] = TraceFrame{f.i, t.k, (int8_t)ST_L, (int16_t)s2};
         stack[top++] = TraceFrame{t.k, t.l, t.e1, (int16_t)s1};

@@ -128,7 +128,9 @@ def test_fn_gr_against_reference_golden(case):
     # the partial / finish pair used by the multi-GPU path gives the same numbers
     part = eng.train_partial(m["x"])
     fn2, gr2, eff2, nsk2 = eng.train_finish(part)
-    assert fn2 == fn and np.array_equal(gr2, gr) and eff2 == eff
+    # (same numbers up to the order of the LDS atomics that accumulate the expected counts)
+    assert fn2 == pytest.approx(fn, rel=1e-13) and eff2 == eff
+    np.testing.assert_allclose(gr2, gr, rtol=1e-11, atol=1e-12)
 
 
 from tests.test_oracle_golden import EMISSION_COUNTS, PATH_COUNTS  # noqa: E402
