@@ -148,6 +148,9 @@ int elemdp_scan(elemdp_handle* h, const double* x, int32_t n_param, elemdp_scan_
 /* timing of the last train evaluation, measured with HIP events on the engine's stream:
  * ms[0] = whole evaluation, ms[1] = the fused inside/outside kernel only */
 int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n);
+/* debug: summed shader-clock cycles per phase of the last train evaluation when option "profile" = 1:
+ * [stage, inside band, inside exterior, outside exterior, outside band, queue/other] */
+int elemdp_debug_profile(elemdp_handle* h, double* cycles, int32_t n);
 /* name of the dominant kernel (for matching rocprofv3 rows) */
 const char* elemdp_kernel_name(void);
 

@@ -24,7 +24,7 @@ SYMBOLS = ["elemdp_last_error", "elemdp_abi_version", "elemdp_set_data_dir", "el
            "elemdp_n_param", "elemdp_n_state", "elemdp_n_node", "elemdp_initial_params", "elemdp_describe",
            "elemdp_set_option", "elemdp_load_batch", "elemdp_batch_bpp_eff", "elemdp_batch_pairs", "elemdp_train_eval",
            "elemdp_partial_len", "elemdp_train_partial", "elemdp_train_finish", "elemdp_set_finish_params", "elemdp_train_seq_stats",
-           "elemdp_debug_tables", "elemdp_scan", "elemdp_last_timing", "elemdp_kernel_name"]
+           "elemdp_debug_tables", "elemdp_scan", "elemdp_last_timing", "elemdp_debug_profile", "elemdp_kernel_name"]
 
 
 class ModelDesc(C.Structure):
@@ -77,6 +77,7 @@ def load_library():
         L.elemdp_debug_tables.argtypes = [hp] + [dp] * 7
         L.elemdp_scan.argtypes = [hp, dp, C.c_int32, C.POINTER(ScanOut)]
         L.elemdp_last_timing.argtypes = [hp, dp, C.c_int32]
+        L.elemdp_debug_profile.argtypes = [hp, dp, C.c_int32]
         _lib = L
     return _lib
 
@@ -242,6 +243,11 @@ class Engine:
         ms = np.zeros(2)
         self._lib.elemdp_last_timing(self._h, _dp(ms), 2)
         return ms
+
+    def profile(self):
+        c = np.zeros(8)
+        self._lib.elemdp_debug_profile(self._h, _dp(c), 8)
+        return c
 
     def kernel_name(self):
         return self._lib.elemdp_kernel_name().decode()

@@ -28,7 +28,8 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-ldl"]
+    extra = os.environ.get("ELEMDP_CXXFLAGS", "").split()
+    cmd = [HIPCC] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

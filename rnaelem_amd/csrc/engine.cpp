@@ -194,6 +194,11 @@ class Engine {
   int opt_slots_ = 0;
   bool opt_keep_lnbpp_ = false;
   bool opt_first_pass_only_ = false;
+  bool opt_profile_ = false;
+  DevBuf d_prof_;
+ public:
+  std::vector<long long> last_prof;
+ private:
 };
 
 Engine::Engine(const elemdp_model_desc& d)
@@ -260,6 +265,7 @@ void Engine::set_option(const std::string& key, double v) {
   if (key == "slots") opt_slots_ = (int)v;
   else if (key == "keep_lnbpp") opt_keep_lnbpp_ = v != 0;
   else if (key == "first_pass_only") opt_first_pass_only_ = v != 0;
+  else if (key == "profile") opt_profile_ = v != 0;
   else throw ArgError("unknown option: " + key);
 }
 
@@ -588,11 +594,24 @@ void Engine::run_train(bool) {
   a.out_stride = out_stride_;
   a.lds = lds_layout(lay_, Lmax_, nword_max_, false);
   a.first_pass_only = opt_first_pass_only_ ? 1 : 0;
+  const int n_blocks = std::min(n_slots_, n_seq_);
+  if (opt_profile_) {
+    d_prof_.alloc(sizeof(long long) * 8 * n_blocks);
+    HIP_OK(hipMemsetAsync(d_prof_.as<void>(), 0, sizeof(long long) * 8 * n_blocks, st_));
+    a.prof = d_prof_.as<long long>();
+  }
   HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
   HIP_OK(hipEventRecord(ev_[1], st_));
   HIP_OK(launch_dp(DP_TRAIN, a, std::min(n_slots_, n_seq_), st_));
   HIP_OK(hipEventRecord(ev_[2], st_));
   HIP_OK(launch_reduce(d_seq_out_.as<double>(), out_stride_, n_seq_, au_.n_theta(), d_partial_.as<double>(), st_));
+  if (opt_profile_) {
+    HIP_OK(hipStreamSynchronize(st_));
+    std::vector<long long> h(8 * (size_t)n_blocks);
+    HIP_OK(hipMemcpy(h.data(), d_prof_.as<void>(), sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+    last_prof.assign(8, 0);
+    for (size_t k = 0; k < h.size(); ++k) last_prof[k % 8] += h[k];
+  }
 }
 
 void Engine::train_partial(const double* x, int n_param_in, void* partial, bool device_ptr) {
@@ -900,6 +919,11 @@ int elemdp_scan(elemdp_handle* h, const double* x, int32_t n_param, elemdp_scan_
 int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n) {
   if (!h || !ms) return ELEMDP_EINVAL;
   for (int k = 0; k < n && k < 2; ++k) ms[k] = h->e->last_ms[k];
+  return ELEMDP_OK;
+}
+int elemdp_debug_profile(elemdp_handle* h, double* cycles, int32_t n) {
+  if (!h || !cycles) return ELEMDP_EINVAL;
+  for (int k = 0; k < n && k < 8; ++k) cycles[k] = k < (int)h->e->last_prof.size() ? (double)h->e->last_prof[k] : 0.;
   return ELEMDP_OK;
 }
 const char* elemdp_kernel_name(void) { return elemdp::dp_kernel_name(elemdp::DP_TRAIN); }

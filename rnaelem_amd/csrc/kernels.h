@@ -76,6 +76,7 @@ struct DpArgs {
   double* sc_start; double* sc_end; double* sc_inner; int32_t* sc_psihat; char* sc_rss;
   int32_t* sc_ys; int32_t* sc_ye; double* sc_exist; double* sc_en;  // sc_en: [n][n_theta]
   int32_t* trace_stack; int32_t trace_stack_stride;
+  long long* prof;  // optional [n_blocks][8] cycle counters: stage, in-band, in-ext, out-ext, out-band, other
   LdsLayout lds;
 };
 

@@ -235,8 +235,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------
 // one sequence worth of sweeps (all lanes of the workgroup call these together)
 // ---------------------------------------------------------------------------------------------
+struct Prof {
+  long long* p; long long t;
+  __device__ __forceinline__ void start() { if (p && threadIdx.x == 0) t = clock64(); }
+  __device__ __forceinline__ void lap(int k) { if (p && threadIdx.x == 0) { long long n = clock64(); p[k] += n - t; t = n; } }
+};
+
 template <bool CONSTRAINED>
-__device__ void sweep_inside(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, bool no_rss) {
+__device__ void sweep_inside(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, bool no_rss,
+                             Prof& pf) {
   const int S = m.lay.S, tid = threadIdx.x;
   if (!no_rss) {
     for (int d = 0; d <= q.W; ++d) {
@@ -248,17 +255,20 @@ __device__ void sweep_inside(const ModelView& m, const SeqView& q, const TableVi
       __syncthreads();
     }
   }
+  pf.lap(1);
   for (int s = tid; s < S; s += kThreads) T.o(0, s) = (s == m.lay.s00) ? 0. : ELEMDP_NEG_INF;
   __syncthreads();
   for (int j = 1; j <= q.L; ++j) {
     for (int s = tid; s < S; s += kThreads) inside_ext_target<CONSTRAINED>(m, q, T, c, j, s);
     __syncthreads();
   }
+  pf.lap(2);
 }
 
 template <int MODE>
 __device__ void sweep_outside(const ModelView& m, const SeqView& q, const TableView& in, const TableView& out, double Z,
-                              const Constraint& c, bool ari, bool nasi, GpuSink& sink, double* lds_eh, bool no_rss) {
+                              const Constraint& c, bool ari, bool nasi, GpuSink& sink, double* lds_eh, bool no_rss,
+                              Prof& pf) {
   const int S = m.lay.S, tid = threadIdx.x;
   OutCtx<GpuSink> x{m, q, in, out, Z, c, sink};
   sink.eh0 = sink.eh1 = 0.;
@@ -273,6 +283,7 @@ __device__ void sweep_outside(const ModelView& m, const SeqView& q, const TableV
     for (int s = tid; s < S; s += kThreads) outside_ext_target<MODE>(x, i, s);
     __syncthreads();
   }
+  pf.lap(3);
   if (!no_rss) {
     for (int d = q.W; d >= 0; --d) {
       const int n = (q.L - d + 1) * S;
@@ -283,6 +294,7 @@ __device__ void sweep_outside(const ModelView& m, const SeqView& q, const TableV
       __syncthreads();
     }
   }
+  pf.lap(4);
   if (MODE == OUT_TRAIN) {
     const double a = wave_sum(sink.eh0), b = wave_sum(sink.eh1);
     if ((tid & 63) == 0) { atomicAdd(&lds_eh[0], a); atomicAdd(&lds_eh[1], b); }
@@ -318,8 +330,11 @@ __device__ bool run_trace_back(const ModelView& m, const TableView& T, const Tra
 // ---------------------------------------------------------------------------------------------
 // the DP kernel: TRAIN = K2 + 2 x K3 fused, BPP = K1, SCAN = K4 + K5 + K6
 // ---------------------------------------------------------------------------------------------
+#ifndef ELEMDP_MIN_WAVES
+#define ELEMDP_MIN_WAVES 2
+#endif
 template <int KIND>
-__global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
+__global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
   extern __shared__ __align__(16) unsigned char lds[];
   __shared__ int l_cur;
   int32_t* l_ints = reinterpret_cast<int32_t*>(lds + a.lds.ints);
@@ -353,8 +368,13 @@ __global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
   m.no_prf = a.no_prf;
   m.m_min = a.m_min;
   const bool no_rss = a.no_rss != 0;
+  Prof pf;
+  pf.p = a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr;
+  pf.t = 0;
+  pf.start();
 
   for (;;) {
+    pf.lap(5);
     __syncthreads();
     if (tid == 0) l_cur = atomicAdd(a.counter, 1);
     __syncthreads();
@@ -380,6 +400,7 @@ __global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
       for (int t = tid; t < 3 * (L + 1); t += kThreads) l_post[t] = ELEMDP_NEG_INF;
     __syncthreads();
 
+    pf.lap(0);
     SeqView q;
     q.L = L; q.W = W; q.C = p.C;
     q.seq = l_seq; q.ws = l_ws; q.okbits = l_ok; q.dmin = l_dmin; q.unp = l_unp;
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
 
     if (KIND == DP_TRAIN) {
       // ---- schedule of RNAelemTrainDP::operator() (motif_trainer.hpp:204-227)
-      sweep_inside<false>(m, q, Tin, c0, no_rss);
+      sweep_inside<false>(m, q, Tin, c0, no_rss, pf);
       if (tid == 0) {
         const double Zo = part_func(m, Tin, true, true), Za = part_func(m, Tin, true, false),
                      Zn = part_func(m, Tin, false, true);
@@ -417,11 +438,11 @@ __global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
       const bool skip = l_zs[3] != 0.;
       double* o = a.seq_out + (size_t)n * a.out_stride;
       if (!skip) {
-        sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, Zo, c0, true, true, sink, l_eh, no_rss);
+        sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, Zo, c0, true, true, sink, l_eh, no_rss, pf);
         const bool positive = p.positive != 0;
         sink.en_ = l_en_x;
         if (!a.first_pass_only)
-          sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, positive ? Za : Zn, c0, positive, !positive, sink, l_eh + 2, no_rss);
+          sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, positive ? Za : Zn, c0, positive, !positive, sink, l_eh + 2, no_rss, pf);
       }
       if (tid == 0) {
         o[0] = Zo; o[1] = Za; o[2] = Zn;
@@ -434,9 +455,9 @@ __global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
     } else if (KIND == DP_BPP) {
       // ---- K1: plain McCaskill through the one-state automaton, then the BPP threshold
       // (EnergyModel::calc_BPP / fill_bpp_tables, energy_model.hpp:188-266)
-      sweep_inside<false>(m, q, Tin, c0, false);
+      sweep_inside<false>(m, q, Tin, c0, false, pf);
       const double Z = Tin.o(L, 0);
-      sweep_outside<OUT_NONE>(m, q, Tin, Tout, Z, c0, false, true, sink, l_eh, false);
+      sweep_outside<OUT_NONE>(m, q, Tin, Tout, Z, c0, false, true, sink, l_eh, false, pf);
       __shared__ int tmp[kThreads / 64];
       int kept = 0;
       for (int wd = tid; wd < nword; wd += kThreads) {
@@ -461,24 +482,24 @@ __global__ __launch_bounds__(kThreads) void k_dp(DpArgs a) {
     } else {
       // ---- schedule of RNAelemScanDP::operator() (motif_scanner.hpp:204-252)
       double* Pys = l_post; double* Pyi = l_post + (L + 1); double* Pye = l_post + 2 * (L + 1);
-      sweep_inside<false>(m, q, Tin, c0, no_rss);
+      sweep_inside<false>(m, q, Tin, c0, no_rss, pf);
       if (tid == 0) { l_zs[0] = part_func(m, Tin, true, true); l_zs[1] = Tin.o(L, m.lay.s00); }
       __syncthreads();
       const double ZL = l_zs[0];
       sink.post_[0] = Pys; sink.post_[1] = Pyi;
-      sweep_outside<OUT_SCAN>(m, q, Tin, Tout, ZL, c0, true, true, sink, l_eh, no_rss);
+      sweep_outside<OUT_SCAN>(m, q, Tin, Tout, ZL, c0, true, true, sink, l_eh, no_rss, pf);
       if (tid == 0) l_zs[4] = (double)last_argmax(Pys, L);
       __syncthreads();
       const int Ys = (int)l_zs[4];
       for (int t = tid; t < L; t += kThreads) { a.sc_start[p.seq_base + t] = Pys[t]; a.sc_inner[p.seq_base + t] = Pyi[t]; }
       if (a.sc_en) for (int t = tid; t < nt; t += kThreads) a.sc_en[(size_t)n * nt + t] = l_en_o[t];
       const Constraint c1{Ys, -1, 0};
-      sweep_inside<true>(m, q, Tin, c1, no_rss);
+      sweep_inside<true>(m, q, Tin, c1, no_rss, pf);
       if (tid == 0) l_zs[2] = part_func(m, Tin, true, true);
       __syncthreads();
       sink.post_[0] = sink.post_[1] = nullptr; sink.post_[2] = Pye;
       sink.en_ = l_en_x;
-      sweep_outside<OUT_END>(m, q, Tin, Tout, l_zs[2], c1, true, true, sink, l_eh, no_rss);
+      sweep_outside<OUT_END>(m, q, Tin, Tout, l_zs[2], c1, true, true, sink, l_eh, no_rss, pf);
       if (tid == 0) {
         l_zs[5] = (double)last_argmax(Pye, L + 1);
         double tot = ELEMDP_NEG_INF;
