@@ -27,6 +27,14 @@ struct Csr {
   Csr(int S, int w) : rows(S), width(w) {}
   void add(int key, std::initializer_list<int32_t> v) { rows[key].insert(rows[key].end(), v); }
   // appends offsets (S+1) then entries to the blob; returns {off_pos, ent_pos}
+  // appends the grouping key of every entry; returns its position
+  int32_t emit_targets(std::vector<int32_t>* blob) const {
+    int32_t pos = (int32_t)blob->size();
+    for (size_t k = 0; k < rows.size(); ++k)
+      for (size_t e = 0; e < rows[k].size() / width; ++e) blob->push_back((int32_t)k);
+    return pos;
+  }
+  int32_t count() const { int32_t n = 0; for (auto const& r : rows) n += (int32_t)r.size() / width; return n; }
   std::pair<int32_t, int32_t> emit(std::vector<int32_t>* blob) const {
     int32_t off_pos = (int32_t)blob->size();
     int32_t n = 0;
@@ -275,19 +283,31 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints) const 
     quad3.add(q[3], {q[0], q[1], q[2]});
   }
   auto put = [&](const Csr& c, int32_t* off, int32_t* ent) { auto p = c.emit(ints); *off = p.first; *ent = p.second; };
+  // small part: unary transition lists (staged in LDS together with the per-state attributes)
   put(right, &A.right_off, &A.right_ent);
   put(left, &A.left_off, &A.left_ent);
   put(pair, &A.pair_off, &A.pair_ent);
-  put(split, &A.split_off, &A.split_ent);
-  put(quad, &A.quad_off, &A.quad_ent);
   put(rright, &A.rright_off, &A.rright_ent);
   put(rleft, &A.rleft_off, &A.rleft_ent);
   put(rpair, &A.rpair_off, &A.rpair_ent);
+  A.n_small = (int32_t)ints->size();
+  // big part: tuple lists of the bifurcation and interior-loop rules
+  put(split, &A.split_off, &A.split_ent);
+  put(quad, &A.quad_off, &A.quad_ent);
   put(split1, &A.split1_off, &A.split1_ent);
   put(split2, &A.split2_off, &A.split2_ent);
   put(quad1, &A.quad1_off, &A.quad1_ent);
   put(quad2, &A.quad2_off, &A.quad2_ent);
   put(quad3, &A.quad3_off, &A.quad3_ent);
+  A.split_tgt = split.emit_targets(ints);
+  A.split1_tgt = split1.emit_targets(ints);
+  A.split2_tgt = split2.emit_targets(ints);
+  A.quad_tgt = quad.emit_targets(ints);
+  A.quad1_tgt = quad1.emit_targets(ints);
+  A.quad2_tgt = quad2.emit_targets(ints);
+  A.quad3_tgt = quad3.emit_targets(ints);
+  A.n_split = split.count();
+  A.n_quad = quad.count();
   A.n_ints = (int32_t)ints->size();
 }
 
@@ -308,10 +328,13 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
     for (int k = 0; k < width; ++k) ints->push_back(0);  // (state 0, flag 0) / (0,0) / (0,0,0)
   };
   csr(2, &A.right_off, &A.right_ent); csr(2, &A.left_off, &A.left_ent); csr(2, &A.pair_off, &A.pair_ent);
-  csr(2, &A.split_off, &A.split_ent); csr(3, &A.quad_off, &A.quad_ent);
   csr(2, &A.rright_off, &A.rright_ent); csr(2, &A.rleft_off, &A.rleft_ent); csr(2, &A.rpair_off, &A.rpair_ent);
+  A.n_small = (int32_t)ints->size();
+  csr(2, &A.split_off, &A.split_ent); csr(3, &A.quad_off, &A.quad_ent);
   csr(2, &A.split1_off, &A.split1_ent); csr(2, &A.split2_off, &A.split2_ent);
   csr(3, &A.quad1_off, &A.quad1_ent); csr(3, &A.quad2_off, &A.quad2_ent); csr(3, &A.quad3_off, &A.quad3_ent);
+  A.split_tgt = A.split1_tgt = A.split2_tgt = A.quad_tgt = A.quad1_tgt = A.quad2_tgt = A.quad3_tgt = one(0);
+  A.n_split = 1; A.n_quad = 1;
   A.n_ints = (int32_t)ints->size();
 }
 

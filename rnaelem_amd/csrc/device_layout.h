@@ -55,7 +55,12 @@ struct AutomatonLayout {
   int32_t quad1_off, quad1_ent;
   int32_t quad2_off, quad2_ent;
   int32_t quad3_off, quad3_ent;
-  int32_t n_ints;  // total length of the int blob
+  // target (= grouping) state of every flat entry of the seven tuple lists above, for lane-per-tuple gathers
+  int32_t split_tgt, split1_tgt, split2_tgt, quad_tgt, quad1_tgt, quad2_tgt, quad3_tgt;
+  int32_t n_split, n_quad;  // entries per split* list / per quad* list
+  int32_t n_small;  // the first n_small ints (per-state attributes, unary lists) are staged in LDS;
+                    // the tuple lists behind them are read from global memory (ModelView::big)
+  int32_t n_ints;   // total length of the int blob
 };
 
 // Per-evaluation parameters (changes every optimizer step)

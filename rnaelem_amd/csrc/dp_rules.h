@@ -49,6 +49,12 @@ struct LseAcc {
     if (x > m) { s = s * exp(m - x) + 1.; m = x; }
     else s += exp(x - m);
   }
+  // merge another partial sum (m2 + log s2)
+  ELEMDP_HD void merge(double m2, double s2) {
+    if (m2 == ELEMDP_NEG_INF) return;
+    if (m2 > m) { s = s * exp(m - m2) + s2; m = m2; }
+    else s += s2 * exp(m2 - m);
+  }
   ELEMDP_HD double value() const { return (m == ELEMDP_NEG_INF) ? ELEMDP_NEG_INF : m + log(s); }
 };
 
@@ -57,7 +63,8 @@ struct LseAcc {
 // ---------------------------------------------------------------------------------------------
 struct ModelView {
   AutomatonLayout lay;
-  const int32_t* ints;   // automaton blob
+  const int32_t* ints;   // automaton blob: per-state attributes + unary lists (first lay.n_small ints; LDS on the GPU)
+  const int32_t* big;    // the whole blob incl. the tuple lists of rules 2 / 6c / 7 (global memory on the GPU)
   const double* theta;   // n_theta log-probabilities
   double lambda[2];
   double log_tau;
@@ -215,16 +222,98 @@ ELEMDP_HD bool allow_left(const ModelView& m, const Constraint& c, int i, int pa
 // ---------------------------------------------------------------------------------------------
 // INSIDE, sum semiring, optional start constraint (train K2, scan K4/K5 inside halves)
 // ---------------------------------------------------------------------------------------------
-// Computes and stores P,E,M,B,1,2,L of target (i, d, s).  CONSTRAINED=false compiles the checks away.
+// The two long-range rules -- bifurcation (2) and interior loops (6c), > 90 % of all terms -- are
+// kept apart as "heavy" sums: on the GPU a whole wave evaluates them for one cell with one lane per
+// (state tuple) and the k / item loop unrolled for memory-level parallelism (kernels.hip); the
+// serial forms below define the same sums for the CPU emulation.
+ELEMDP_HD bool bif_valid(const SeqView& q, int j, int k) {  // is_parsable<ST_2>(k, j), energy_model.hpp:360-361
+  const int dk = q.dmin[k];
+  return dk != 0 && j - k >= dk;
+}
+ELEMDP_HD double bif_term(const TableView& T, int i, int j, int k, int s1, int s2) {
+  return T.at(ST_1, k - i, i, s1) + T.at(ST_2, j - k, k, s2);
+}
+ELEMDP_HD double loop_term(const TableView& T, int i, int j, const LoopItem& x, int s1, int s2, int s3, double lt) {
+  return T.at(ST_P, x.l - x.k, x.k, s1) + (T.at(ST_L, x.k - i, i, s2) + (T.at(ST_L, j - x.l, x.l, s3) + lt));
+}
+// rule 2: B(i,j,s); requires left_ok(i,d)
+ELEMDP_HD double heavy_bif(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const int j = i + d;
+  LseAcc a;
+  for (int k = i + q.dmin[i]; k < j; ++k) {
+    if (!bif_valid(q, j, k)) continue;
+    for (int t = G[A.split_off + s]; t < G[A.split_off + s + 1]; ++t)
+      a.add(bif_term(T, i, j, k, G[A.split_ent + 2 * t], G[A.split_ent + 2 * t + 1]));
+  }
+  return a.value();
+}
+// rule 6c: interior-loop part of E(i,j,s); requires e_ok(i,d)
+ELEMDP_HD double heavy_loop(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const int j = i + d;
+  const double lam = m.lam(s);
+  LseAcc a;
+  const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
+  for (int it = c0; it < c1; ++it) {
+    if (!q.item_in[it]) continue;
+    const LoopItem x = q.items[it];
+    const double lt = lam * x.tsc;
+    for (int t = G[A.quad_off + s]; t < G[A.quad_off + s + 1]; ++t)
+      a.add(loop_term(T, i, j, x, G[A.quad_ent + 3 * t], G[A.quad_ent + 3 * t + 1], G[A.quad_ent + 3 * t + 2], lt));
+  }
+  return a.value();
+}
+
+constexpr int kUnary = 3;  // unary transition lists hold at most 3 entries (edges h, h-1, h-2); longer lists fall back to a loop
+
+// Computes and stores P,E,M,B,1,2,L of target (i, d, s) given the heavy sums HB (= B) and HE.
+// All short-range operands (diagonals d-1, d-2) are fetched first, with fixed unrolling, so that the
+// loads of one target are in flight together.  CONSTRAINED=false compiles the scan checks away.
 template <bool CONSTRAINED>
-ELEMDP_HD void inside_target(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, int d,
-                             int i, int s) {
+ELEMDP_HD void inside_target_u(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, int d,
+                               int i, int s, double HB, double HE) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
   const int j = i + d;
   const double NEG = ELEMDP_NEG_INF;
   const double lam = m.lam(s);
   const bool isloop = I[A.st_is_loop + s] != 0;
+  const bool pok = q.pair_ok(i, d);
+  const bool lok = q.left_ok(i, d);
+  const bool mok = m_ok(m, q, i, d);
+  const bool eok = q.e_ok(i, d);
+  const bool doL = isloop && d > 0;
+  const bool do2 = lok && q.left_ok(i, d - 1) && q.unp[j - 1];
+  const bool doM = mok && m_ok(m, q, i + 1, d - 1) && q.unp[i];
+
+  // ---- operand fetch
+  const int r0 = I[A.right_off + s], nR = I[A.right_off + s + 1] - r0;
+  const int p0 = I[A.pair_off + s], nP = I[A.pair_off + s + 1] - p0;
+  const int l0 = I[A.left_off + s], nL = I[A.left_off + s + 1] - l0;
+  double xL[kUnary], x2[kUnary], xE[kUnary], xP[kUnary], xM[kUnary];
+  double est = NEG, eml = NEG, ecl = NEG, ehp = NEG;
+  if (pok) { est = q.e_stack[q.cell(i, d)]; eml = q.e_ml[q.cell(i, d)]; }
+  if (eok) { const int pc = q.cell(i - 1, d + 2); ecl = q.e_close[pc]; ehp = q.e_hp[pc]; }
+#pragma unroll
+  for (int u = 0; u < kUnary; ++u) {
+    const bool vr = u < nR;
+    const int s1 = vr ? I[A.right_ent + 2 * (r0 + u)] : 0;
+    const bool okr = vr && (!CONSTRAINED || allow_right(m, c, q.L, j, s, s1));
+    xL[u] = (doL && okr) ? T.at(ST_L, d - 1, i, s1) : NEG;
+    x2[u] = (do2 && okr) ? T.at(ST_2, d - 1, i, s1) : NEG;
+    const bool vp = u < nP;
+    const int sp = vp ? I[A.pair_ent + 2 * (p0 + u)] : 0;
+    const bool okp = pok && vp && (!CONSTRAINED || allow_pair(m, c, q.L, i, j, s, sp));
+    xE[u] = okp ? T.at(ST_E, d - 2, i + 1, sp) : NEG;
+    xP[u] = (okp && est != NEG) ? T.at(ST_P, d - 2, i + 1, sp) : NEG;
+    const bool vl = u < nL;
+    const int sl = vl ? I[A.left_ent + 2 * (l0 + u)] : 0;
+    const bool okl = doM && vl && (!CONSTRAINED || allow_left(m, c, i, s, sl));
+    xM[u] = okl ? T.at(ST_M, d - 1, i + 1, sl) : NEG;
+  }
 
   // ---- L(i,j,s): loop emission chain (motif_model.hpp:243-257; init motif_trainer.hpp:89-95)
   double vL = NEG;
@@ -232,8 +321,11 @@ ELEMDP_HD void inside_target(const ModelView& m, const SeqView& q, const TableVi
     if (d == 0) vL = (m.st_l(s) == m.st_r(s)) ? 0. : NEG;
     else {
       LseAcc a;
-      for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
-        const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+#pragma unroll
+      for (int u = 0; u < kUnary; ++u)
+        if (u < nR) a.add(xL[u] + w_right(m, q, s, I[A.right_ent + 2 * (r0 + u) + 1], j - 1));
+      for (int u = kUnary; u < nR; ++u) {
+        const int s1 = I[A.right_ent + 2 * (r0 + u)], tf = I[A.right_ent + 2 * (r0 + u) + 1];
         if (CONSTRAINED && !allow_right(m, c, q.L, j, s, s1)) continue;
         a.add(T.at(ST_L, d - 1, i, s1) + w_right(m, q, s, tf, j - 1));
       }
@@ -243,55 +335,48 @@ ELEMDP_HD void inside_target(const ModelView& m, const SeqView& q, const TableVi
   T.at(ST_L, d, i, s) = vL;
 
   // ---- P(i,j,s): rules 1a, 1b
-  const bool pok = q.pair_ok(i, d);
   double vP = NEG;
   if (pok) {
     LseAcc a;
-    const double est = q.e_stack[q.cell(i, d)];
-    for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {
-      const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
+    const double lest = (est != NEG) ? lam * est : 0.;  // (0 * -inf would be NaN when lambda = 0)
+#pragma unroll
+    for (int u = 0; u < kUnary; ++u)
+      if (u < nP) {
+        const int s1 = I[A.pair_ent + 2 * (p0 + u)], tf = I[A.pair_ent + 2 * (p0 + u) + 1];
+        const double w = w_pair(m, q, s, s1, tf, i, j - 1);
+        a.add(xE[u] + w);                       // 1a (tsc = 0)
+        a.add(xP[u] + (w + lest));              // 1b (xP is log 0 when the stack term is)
+      }
+    for (int u = kUnary; u < nP; ++u) {
+      const int s1 = I[A.pair_ent + 2 * (p0 + u)], tf = I[A.pair_ent + 2 * (p0 + u) + 1];
       if (CONSTRAINED && !allow_pair(m, c, q.L, i, j, s, s1)) continue;
       const double w = w_pair(m, q, s, s1, tf, i, j - 1);
-      a.add(T.at(ST_E, d - 2, i + 1, s1) + w);                       // 1a (tsc = 0)
-      if (est != NEG) a.add(T.at(ST_P, d - 2, i + 1, s1) + (w + lam * est));  // 1b
+      a.add(T.at(ST_E, d - 2, i + 1, s1) + w);
+      if (est != NEG) a.add(T.at(ST_P, d - 2, i + 1, s1) + (w + lam * est));
     }
     vP = a.value();
   }
   T.at(ST_P, d, i, s) = vP;
 
-  // ---- B(i,j,s): rule 2  (bifurcation)
-  const bool lok = q.left_ok(i, d);
-  double vB = NEG;
-  if (lok) {
-    LseAcc a;
-    const int k0 = i + q.dmin[i];
-    for (int k = k0; k < j; ++k) {
-      const int dk = q.dmin[k];
-      if (dk == 0 || j - k < dk) continue;
-      for (int t = I[A.split_off + s]; t < I[A.split_off + s + 1]; ++t) {
-        const int s1 = I[A.split_ent + 2 * t], s2 = I[A.split_ent + 2 * t + 1];
-        a.add(T.at(ST_1, k - i, i, s1) + T.at(ST_2, j - k, k, s2));
-      }
-    }
-    vB = a.value();
-  }
+  // ---- B(i,j,s): rule 2 (heavy sum)
+  const double vB = lok ? HB : NEG;
   T.at(ST_B, d, i, s) = vB;
 
   // ---- 2(i,j,s): rules 3a, 3b ; 1(i,j,s): rules 4a, 4b
   double v2 = NEG, v1 = NEG;
   if (lok) {
     LseAcc a;
-    if (q.left_ok(i, d - 1) && q.unp[j - 1]) {
-      for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
-        const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+    if (do2) {
+#pragma unroll
+      for (int u = 0; u < kUnary; ++u)
+        if (u < nR) a.add(x2[u] + w_right(m, q, s, I[A.right_ent + 2 * (r0 + u) + 1], j - 1));
+      for (int u = kUnary; u < nR; ++u) {
+        const int s1 = I[A.right_ent + 2 * (r0 + u)], tf = I[A.right_ent + 2 * (r0 + u) + 1];
         if (CONSTRAINED && !allow_right(m, c, q.L, j, s, s1)) continue;
         a.add(T.at(ST_2, d - 1, i, s1) + w_right(m, q, s, tf, j - 1));
       }
     }
-    if (pok) {
-      const double eml = q.e_ml[q.cell(i, d)];
-      if (eml != NEG) a.add(vP + lam * eml);
-    }
+    if (pok && eml != NEG) a.add(vP + lam * eml);
     v2 = a.value();
     LseAcc b;
     b.add(v2);
@@ -302,13 +387,18 @@ ELEMDP_HD void inside_target(const ModelView& m, const SeqView& q, const TableVi
   T.at(ST_1, d, i, s) = v1;
 
   // ---- M(i,j,s): rules 5a, 5b
-  const bool mok = m_ok(m, q, i, d);
   double vM = NEG;
   if (mok) {
     LseAcc a;
-    if (m_ok(m, q, i + 1, d - 1) && q.unp[i]) {
-      for (int t = I[A.left_off + s]; t < I[A.left_off + s + 1]; ++t) {
-        const int s1 = I[A.left_ent + 2 * t], tf = I[A.left_ent + 2 * t + 1];
+    if (doM) {
+#pragma unroll
+      for (int u = 0; u < kUnary; ++u)
+        if (u < nL) {
+          const int s1 = I[A.left_ent + 2 * (l0 + u)], tf = I[A.left_ent + 2 * (l0 + u) + 1];
+          a.add(xM[u] + w_left(m, q, s1, tf, i));
+        }
+      for (int u = kUnary; u < nL; ++u) {
+        const int s1 = I[A.left_ent + 2 * (l0 + u)], tf = I[A.left_ent + 2 * (l0 + u) + 1];
         if (CONSTRAINED && !allow_left(m, c, i, s, s1)) continue;
         a.add(T.at(ST_M, d - 1, i + 1, s1) + w_left(m, q, s1, tf, i));
       }
@@ -318,26 +408,25 @@ ELEMDP_HD void inside_target(const ModelView& m, const SeqView& q, const TableVi
   }
   T.at(ST_M, d, i, s) = vM;
 
-  // ---- E(i,j,s): rules 6a, 6b, 6c ; closing pair is the cell (i-1, d+2)
+  // ---- E(i,j,s): rules 6a, 6b, 6c (heavy sum) ; closing pair is the cell (i-1, d+2)
   double vE = NEG;
-  if (q.e_ok(i, d)) {
+  if (eok) {
     LseAcc a;
-    const int pc = q.cell(i - 1, d + 2);
-    if (mok) { const double t = q.e_close[pc]; if (t != NEG) a.add(vM + lam * t); }
-    if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) a.add(vL + lam * t); }
-    const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
-    for (int it = c0; it < c1; ++it) {
-      if (!q.item_in[it]) continue;
-      const LoopItem x = q.items[it];
-      const double lt = lam * x.tsc;
-      for (int t = I[A.quad_off + s]; t < I[A.quad_off + s + 1]; ++t) {
-        const int s1 = I[A.quad_ent + 3 * t], s2 = I[A.quad_ent + 3 * t + 1], s3 = I[A.quad_ent + 3 * t + 2];
-        a.add(T.at(ST_P, x.l - x.k, x.k, s1) + (T.at(ST_L, x.k - i, i, s2) + (T.at(ST_L, j - x.l, x.l, s3) + lt)));
-      }
-    }
+    if (mok && ecl != NEG) a.add(vM + lam * ecl);
+    if (isloop && ehp != NEG) a.add(vL + lam * ehp);
+    a.add(HE);
     vE = a.value();
   }
   T.at(ST_E, d, i, s) = vE;
+}
+
+// serial form: heavy sums evaluated in place (CPU emulation, S = 1 paths)
+template <bool CONSTRAINED>
+ELEMDP_HD void inside_target(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, int d,
+                             int i, int s) {
+  const double HB = q.left_ok(i, d) ? heavy_bif(m, q, T, d, i, s) : ELEMDP_NEG_INF;
+  const double HE = q.e_ok(i, d) ? heavy_loop(m, q, T, d, i, s) : ELEMDP_NEG_INF;
+  inside_target_u<CONSTRAINED>(m, q, T, c, d, i, s, HB, HE);
 }
 
 // exterior chain, one step: O(j,s) from O(<j,.) and P(.,j,.)  (rules 7, 8).  j >= 1.
@@ -346,6 +435,7 @@ ELEMDP_HD void inside_ext_target(const ModelView& m, const SeqView& q, const Tab
                                  int s) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
+  const int32_t* G = m.big;
   const double NEG = ELEMDP_NEG_INF;
   const double lam = m.lam(s);
   LseAcc a;
@@ -356,9 +446,9 @@ ELEMDP_HD void inside_ext_target(const ModelView& m, const SeqView& q, const Tab
     const double t = q.e_ext[q.cell(i, d)];
     if (t == NEG) continue;
     const double lt = lam * t;
-    for (int u = I[A.split_off + s]; u < I[A.split_off + s + 1]; ++u) {
-      const int s2 = I[A.split_ent + 2 * u];      // prefix part (l,h)
-      const int s1 = I[A.split_ent + 2 * u + 1];  // pair part   (h,r)
+    for (int u = G[A.split_off + s]; u < G[A.split_off + s + 1]; ++u) {
+      const int s2 = G[A.split_ent + 2 * u];      // prefix part (l,h)
+      const int s1 = G[A.split_ent + 2 * u + 1];  // pair part   (h,r)
       a.add(T.o(i, s2) + (T.at(ST_P, d, i, s1) + lt));
     }
   }
@@ -496,6 +586,7 @@ template <int MODE, class Sink> ELEMDP_HD void outside_ext_target(OutCtx<Sink>& 
   const SeqView& q = x.q;
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
+  const int32_t* G = m.big;
   const double NEG = ELEMDP_NEG_INF;
   const double in_c = x.in.o(i, s);
   if (in_c == NEG) { x.out.o(i, s) = NEG; return; }
@@ -518,8 +609,8 @@ template <int MODE, class Sink> ELEMDP_HD void outside_ext_target(OutCtx<Sink>& 
     if (!q.pair_ok(i, d)) continue;
     const double t = q.e_ext[q.cell(i, d)];
     if (t == NEG) continue;
-    for (int u = I[A.split1_off + s]; u < I[A.split1_off + s + 1]; ++u) {
-      const int par = I[A.split1_ent + 2 * u], s1 = I[A.split1_ent + 2 * u + 1];
+    for (int u = G[A.split1_off + s]; u < G[A.split1_off + s + 1]; ++u) {
+      const int par = G[A.split1_ent + 2 * u], s1 = G[A.split1_ent + 2 * u + 1];
       const double term = x.out.o(j, par) + (x.in.at(ST_P, d, i, s1) + m.lam(par) * t);
       const double z = term + in_c - x.Z;
       if (z == NEG) continue;
@@ -530,15 +621,118 @@ template <int MODE, class Sink> ELEMDP_HD void outside_ext_target(OutCtx<Sink>& 
   x.out.o(i, s) = a.value();
 }
 
-// band target (i,d,s), outside direction.  Requires every larger diagonal and the whole exterior
-// chain outside_o to be final.
-template <int MODE, class Sink> ELEMDP_HD void outside_target(OutCtx<Sink>& x, int d, int i, int s) {
+// ---- heavy sums of the outside pass (gathers over strictly larger cells) -----------------------
+ELEMDP_HD double o1_term(const TableView& in, const TableView& out, int i, int j, int jj, int par, int s2) {
+  return out.at(ST_B, jj - i, i, par) + in.at(ST_2, jj - j, j, s2);
+}
+ELEMDP_HD double o2_term(const TableView& in, const TableView& out, int i, int j, int ii, int par, int s1) {
+  return out.at(ST_B, j - ii, ii, par) + in.at(ST_1, i - ii, ii, s1);
+}
+// inner pair P(i,j) of the interior loop `it` (outer cell E(it.i, it.j))
+ELEMDP_HD double oP_term(const TableView& in, const TableView& out, int i, int j, const LoopItem& it, int par, int s2,
+                         int s3, double lt) {
+  return out.at(ST_E, it.j - it.i, it.i, par) + (in.at(ST_L, i - it.i, it.i, s2) + (in.at(ST_L, it.j - j, j, s3) + lt));
+}
+// left loop L(it.i, it.k) / right loop L(it.l, it.j) of the interior loop `it`
+ELEMDP_HD double oLl_term(const TableView& in, const TableView& out, const LoopItem& it, int par, int s1, int s3, double lt) {
+  return out.at(ST_E, it.j - it.i, it.i, par) + (in.at(ST_P, it.l - it.k, it.k, s1) + (in.at(ST_L, it.j - it.l, it.l, s3) + lt));
+}
+ELEMDP_HD double oLr_term(const TableView& in, const TableView& out, const LoopItem& it, int par, int s1, int s2, double lt) {
+  return out.at(ST_E, it.j - it.i, it.i, par) + (in.at(ST_P, it.l - it.k, it.k, s1) + (in.at(ST_L, it.k - it.i, it.i, s2) + lt));
+}
+// first admissible end jj of a parent B(i,jj) of the child 1(i,j): jj >= j + dmin[j]
+ELEMDP_HD bool o2_valid(const SeqView& q, int i, int ii) {  // is_parsable<ST_1>(ii, i)
+  const int di = q.dmin[ii];
+  return di != 0 && i - ii >= di;
+}
+
+// H1: 1(i,j,s) as the "1" child of B(i,jj,par), jj > j (rule 2)
+template <class Sink> ELEMDP_HD double heavy_o1(OutCtx<Sink>& x, int d, int i, int s) {
+  const ModelView& m = x.m; const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
+  const int j = i + d;
+  LseAcc a;
+  const int dj = q.dmin[j];
+  if (j < q.L && dj > 0) {
+    const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+    for (int jj = j + dj; jj <= jmax; ++jj)
+      for (int u = G[A.split1_off + s]; u < G[A.split1_off + s + 1]; ++u)
+        a.add(o1_term(x.in, x.out, i, j, jj, G[A.split1_ent + 2 * u], G[A.split1_ent + 2 * u + 1]));
+  }
+  return a.value();
+}
+// H2: 2(i,j,s) as the "2" child of B(ii,j,par), ii < i (rule 2)
+template <class Sink> ELEMDP_HD double heavy_o2(OutCtx<Sink>& x, int d, int i, int s) {
+  const ModelView& m = x.m; const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
+  const int j = i + d;
+  LseAcc a;
+  const int imin = (j - q.W > 0) ? j - q.W : 0;
+  for (int ii = i - 1; ii >= imin; --ii) {
+    if (!o2_valid(q, i, ii)) continue;
+    for (int u = G[A.split2_off + s]; u < G[A.split2_off + s + 1]; ++u)
+      a.add(o2_term(x.in, x.out, i, j, ii, G[A.split2_ent + 2 * u], G[A.split2_ent + 2 * u + 1]));
+  }
+  return a.value();
+}
+// HP: P(i,j,s) as inner pair of the interior loops around it (rule 6c) + their energy statistic
+template <int MODE, class Sink> ELEMDP_HD double heavy_oP(OutCtx<Sink>& x, int d, int i, int s) {
+  const ModelView& m = x.m; const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
+  const int j = i + d;
+  const double in_c = x.in.at(ST_P, d, i, s);
+  LseAcc a;
+  if (in_c == ELEMDP_NEG_INF) return ELEMDP_NEG_INF;
+  const int pc = q.cell(i, d);
+  for (int n = q.by_inner_off[pc]; n < q.by_inner_off[pc + 1]; ++n) {
+    const LoopItem it = q.items[q.by_inner_idx[n]];
+    for (int u = G[A.quad1_off + s]; u < G[A.quad1_off + s + 1]; ++u) {
+      const int par = G[A.quad1_ent + 3 * u];
+      const double term = oP_term(x.in, x.out, i, j, it, par, G[A.quad1_ent + 3 * u + 1], G[A.quad1_ent + 3 * u + 2],
+                                  m.lam(par) * it.tsc);
+      const double z = term + in_c - x.Z;
+      if (z == ELEMDP_NEG_INF) continue;
+      stat_energy<MODE>(x, par, it.tsc, z);
+      a.add(term);
+    }
+  }
+  return a.value();
+}
+// HL: L(i,j,s) as left loop (cell (it.i,it.k) = (i,j)) or right loop (cell (it.l,it.j) = (i,j)) of interior loops
+template <class Sink> ELEMDP_HD double heavy_oL(OutCtx<Sink>& x, int d, int i, int s) {
+  const ModelView& m = x.m; const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
+  LseAcc a;
+  const int lc = q.cell(i, d);
+  for (int n = q.by_left_off[lc]; n < q.by_left_off[lc + 1]; ++n) {
+    const LoopItem it = q.items[q.by_left_idx[n]];
+    for (int u = G[A.quad2_off + s]; u < G[A.quad2_off + s + 1]; ++u) {
+      const int par = G[A.quad2_ent + 3 * u];
+      a.add(oLl_term(x.in, x.out, it, par, G[A.quad2_ent + 3 * u + 1], G[A.quad2_ent + 3 * u + 2], m.lam(par) * it.tsc));
+    }
+  }
+  for (int n = q.by_right_off[lc]; n < q.by_right_off[lc + 1]; ++n) {
+    const LoopItem it = q.items[q.by_right_idx[n]];
+    for (int u = G[A.quad3_off + s]; u < G[A.quad3_off + s + 1]; ++u) {
+      const int par = G[A.quad3_ent + 3 * u];
+      a.add(oLr_term(x.in, x.out, it, par, G[A.quad3_ent + 3 * u + 1], G[A.quad3_ent + 3 * u + 2], m.lam(par) * it.tsc));
+    }
+  }
+  return a.value();
+}
+
+struct HeavyOut { double H1, H2, HP, HL; };
+
+// band target (i,d,s), outside direction, given the heavy sums.  Requires every larger diagonal and the
+// whole exterior chain outside_o to be final.
+template <int MODE, class Sink> ELEMDP_HD void outside_target_u(OutCtx<Sink>& x, int d, int i, int s, const HeavyOut& H) {
   const ModelView& m = x.m;
   const SeqView& q = x.q;
   const TableView& in = x.in;
   const TableView& out = x.out;
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
+  const int32_t* G = m.big;
   const double NEG = ELEMDP_NEG_INF;
   const double Z = x.Z;
   const int j = i + d;
@@ -548,20 +742,51 @@ template <int MODE, class Sink> ELEMDP_HD void outside_target(OutCtx<Sink>& x, i
   const bool mok = m_ok(m, q, i, d);
   const bool eok = q.e_ok(i, d);
   const bool up_ok = q.pair_ok(i - 1, d + 2);  // enclosing pair cell (i-1, j+1)
+  const bool doM = mok && m_ok(m, q, i - 1, d + 1) && q.unp[i - 1];
+  const bool do2 = lok && q.left_ok(i, d + 1) && q.unp[j];
+  const bool doL = isloop && j < q.L && d + 1 <= q.W;
 
-  // ---- E(i,j,s) as child of P(i-1,j+1,par): rule 1a
+  // ---- operand fetch: inside values of this target and the parents' outside values (diagonals d+1, d+2)
+  const double inE = eok ? in.at(ST_E, d, i, s) : NEG;
+  const double inM = mok ? in.at(ST_M, d, i, s) : NEG;
+  const double in1 = lok ? in.at(ST_1, d, i, s) : NEG;
+  const double inB = lok ? in.at(ST_B, d, i, s) : NEG;
+  const double in2 = lok ? in.at(ST_2, d, i, s) : NEG;
+  const double inP = pok ? in.at(ST_P, d, i, s) : NEG;
+  const double inL = isloop ? in.at(ST_L, d, i, s) : NEG;
+  double ecl = NEG, ehp = NEG, est_up = NEG, eml = NEG, eext = NEG;
+  if (eok) { const int pc = q.cell(i - 1, d + 2); ecl = q.e_close[pc]; ehp = q.e_hp[pc]; }
+  if (up_ok && pok) est_up = q.e_stack[q.cell(i - 1, d + 2)];
+  if (pok) { eml = q.e_ml[q.cell(i, d)]; eext = q.e_ext[q.cell(i, d)]; }
+  const int rp0 = I[A.rpair_off + s], nRP = I[A.rpair_off + s + 1] - rp0;
+  const int rl0 = I[A.rleft_off + s], nRL = I[A.rleft_off + s + 1] - rl0;
+  const int rr0 = I[A.rright_off + s], nRR = I[A.rright_off + s + 1] - rr0;
+  double yP[kUnary], yM[kUnary], y2[kUnary], yL[kUnary];
+  const bool needP = (up_ok && (inE != NEG || (inP != NEG && est_up != NEG)));
+#pragma unroll
+  for (int u = 0; u < kUnary; ++u) {
+    const int par_p = (u < nRP) ? I[A.rpair_ent + 2 * (rp0 + u)] : 0;
+    yP[u] = (needP && u < nRP) ? out.at(ST_P, d + 2, i - 1, par_p) : NEG;
+    const int par_l = (u < nRL) ? I[A.rleft_ent + 2 * (rl0 + u)] : 0;
+    yM[u] = (doM && inM != NEG && u < nRL) ? out.at(ST_M, d + 1, i - 1, par_l) : NEG;
+    const int par_r = (u < nRR) ? I[A.rright_ent + 2 * (rr0 + u)] : 0;
+    y2[u] = (do2 && in2 != NEG && u < nRR) ? out.at(ST_2, d + 1, i, par_r) : NEG;
+    yL[u] = (doL && inL != NEG && u < nRR && I[A.st_is_loop + par_r]) ? out.at(ST_L, d + 1, i, par_r) : NEG;
+  }
+
   // NB every transition's posterior z contains inside(child); the reference drops transitions with
   // z == log 0 *before* touching the outside table (motif_trainer.hpp:378), so a child whose inside
-  // value is log 0 keeps outside = log 0 -- hence the `in_c != NEG` guards below.
+  // value is log 0 keeps outside = log 0 -- hence the `in != NEG` guards below.
+
+  // ---- E(i,j,s) as child of P(i-1,j+1,par): rule 1a
   double oE = NEG;
-  const double inE = eok ? in.at(ST_E, d, i, s) : NEG;
   if (inE != NEG) {
     LseAcc a;
-    const double in_c = inE;
-    for (int t = I[A.rpair_off + s]; t < I[A.rpair_off + s + 1]; ++t) {
-      const int par = I[A.rpair_ent + 2 * t], tf = I[A.rpair_ent + 2 * t + 1];
-      const double term = out.at(ST_P, d + 2, i - 1, par) + w_pair(m, q, par, s, tf, i - 1, j);
-      const double z = term + in_c - Z;
+    for (int u = 0; u < nRP; ++u) {
+      const int par = I[A.rpair_ent + 2 * (rp0 + u)], tf = I[A.rpair_ent + 2 * (rp0 + u) + 1];
+      const double op = (u < kUnary) ? yP[u < kUnary ? u : 0] : out.at(ST_P, d + 2, i - 1, par);
+      const double term = op + w_pair(m, q, par, s, tf, i - 1, j);
+      const double z = term + inE - Z;
       if (z == NEG) continue;
       if (!stat_pair<MODE>(x, i, j, par, s, z)) continue;
       a.add(term);
@@ -572,23 +797,19 @@ template <int MODE, class Sink> ELEMDP_HD void outside_target(OutCtx<Sink>& x, i
 
   // ---- M(i,j,s): child of E(i,j,s) (6a) and of M(i-1,j,par) (5a)
   double oM = NEG;
-  const double inM = mok ? in.at(ST_M, d, i, s) : NEG;
   if (inM != NEG) {
     LseAcc a;
-    const double in_c = inM;
-    if (eok) {
-      const double t = q.e_close[q.cell(i - 1, d + 2)];
-      if (t != NEG) {
-        const double term = oE + m.lam(s) * t;
-        const double z = term + in_c - Z;
-        if (z != NEG) { stat_energy<MODE>(x, s, t, z); a.add(term); }
-      }
+    if (eok && ecl != NEG) {
+      const double term = oE + m.lam(s) * ecl;
+      const double z = term + inM - Z;
+      if (z != NEG) { stat_energy<MODE>(x, s, ecl, z); a.add(term); }
     }
-    if (m_ok(m, q, i - 1, d + 1) && q.unp[i - 1]) {
-      for (int t = I[A.rleft_off + s]; t < I[A.rleft_off + s + 1]; ++t) {
-        const int par = I[A.rleft_ent + 2 * t], tf = I[A.rleft_ent + 2 * t + 1];
-        const double term = out.at(ST_M, d + 1, i - 1, par) + w_left(m, q, s, tf, i - 1);
-        const double z = term + in_c - Z;
+    if (doM) {
+      for (int u = 0; u < nRL; ++u) {
+        const int par = I[A.rleft_ent + 2 * (rl0 + u)], tf = I[A.rleft_ent + 2 * (rl0 + u) + 1];
+        const double op = (u < kUnary) ? yM[u < kUnary ? u : 0] : out.at(ST_M, d + 1, i - 1, par);
+        const double term = op + w_left(m, q, s, tf, i - 1);
+        const double z = term + inM - Z;
         if (z == NEG) continue;
         if (!stat_left<MODE>(x, i, par, s, z)) continue;
         a.add(term);
@@ -598,55 +819,32 @@ template <int MODE, class Sink> ELEMDP_HD void outside_target(OutCtx<Sink>& x, i
   }
   out.at(ST_M, d, i, s) = oM;
 
-  // ---- 1(i,j,s): the "1" child of B(i,j',par) for j' > j (rule 2)
+  // ---- 1(i,j,s): heavy sum H1 ; B(i,j,s): child of M (5b) and of 1 (4b)
   double o1 = NEG, oB = NEG, o2 = NEG;
   if (lok) {
-    if (in.at(ST_1, d, i, s) != NEG) {
-      LseAcc a;
-      const int dj = q.dmin[j];
-      if (j < q.L && dj > 0) {
-        const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
-        for (int jj = j + dj; jj <= jmax; ++jj) {
-          for (int u = I[A.split1_off + s]; u < I[A.split1_off + s + 1]; ++u) {
-            const int par = I[A.split1_ent + 2 * u], s2 = I[A.split1_ent + 2 * u + 1];
-            a.add(out.at(ST_B, jj - i, i, par) + in.at(ST_2, jj - j, j, s2));
-          }
-        }
-      }
-      o1 = a.value();
-    }
-    // ---- B(i,j,s): child of M (5b) and of 1 (4b)
-    if (in.at(ST_B, d, i, s) != NEG) {
+    if (in1 != NEG) o1 = H.H1;
+    if (inB != NEG) {
       LseAcc a;
       if (mok) a.add(oM);
       a.add(o1);
       oB = a.value();
     }
-    // ---- 2(i,j,s): child of 1 (4a), of 2(i,j+1,par) (3a), and the "2" child of B(i',j,par), i' < i (rule 2)
-    const double in2 = in.at(ST_2, d, i, s);
+    // ---- 2(i,j,s): child of 1 (4a), of 2(i,j+1,par) (3a), and heavy sum H2
     if (in2 != NEG) {
       LseAcc a;
       a.add(o1);
-      const double in_c = in2;
-      if (q.left_ok(i, d + 1) && q.unp[j]) {
-        for (int t = I[A.rright_off + s]; t < I[A.rright_off + s + 1]; ++t) {
-          const int par = I[A.rright_ent + 2 * t], tf = I[A.rright_ent + 2 * t + 1];
-          const double term = out.at(ST_2, d + 1, i, par) + w_right(m, q, par, tf, j);
-          const double z = term + in_c - Z;
+      if (do2) {
+        for (int u = 0; u < nRR; ++u) {
+          const int par = I[A.rright_ent + 2 * (rr0 + u)], tf = I[A.rright_ent + 2 * (rr0 + u) + 1];
+          const double op = (u < kUnary) ? y2[u < kUnary ? u : 0] : out.at(ST_2, d + 1, i, par);
+          const double term = op + w_right(m, q, par, tf, j);
+          const double z = term + in2 - Z;
           if (z == NEG) continue;
           if (!stat_right<MODE>(x, j, par, s, z)) continue;
           a.add(term);
         }
       }
-      const int imin = (j - q.W > 0) ? j - q.W : 0;
-      for (int ii = i - 1; ii >= imin; --ii) {
-        const int di = q.dmin[ii];
-        if (di == 0 || i - ii < di) continue;
-        for (int u = I[A.split2_off + s]; u < I[A.split2_off + s + 1]; ++u) {
-          const int par = I[A.split2_ent + 2 * u], s1 = I[A.split2_ent + 2 * u + 1];
-          a.add(out.at(ST_B, j - ii, ii, par) + in.at(ST_1, i - ii, ii, s1));
-        }
-      }
+      a.add(H.H2);
       o2 = a.value();
     }
   }
@@ -654,104 +852,76 @@ template <int MODE, class Sink> ELEMDP_HD void outside_target(OutCtx<Sink>& x, i
   out.at(ST_B, d, i, s) = oB;
   out.at(ST_2, d, i, s) = o2;
 
-  // ---- P(i,j,s): child of 2 (3b), of P(i-1,j+1,par) (1b), of O (7), inner pair of E(i',j') (6c)
+  // ---- P(i,j,s): child of O (7), of P(i-1,j+1,par) (1b), of 2 (3b), inner pair of E(i',j') (6c: heavy sum HP)
   double oP = NEG;
-  const double inP = pok ? in.at(ST_P, d, i, s) : NEG;
   if (inP != NEG) {
     LseAcc a;
-    const double in_c = inP;
-    const int pc = q.cell(i, d);
-    {  // rule 7: parent O(j, par), sibling prefix O(i, s2); this = pair part (h,r)
-      const double t = q.e_ext[pc];
-      if (t != NEG)
-        for (int u = I[A.split2_off + s]; u < I[A.split2_off + s + 1]; ++u) {
-          const int par = I[A.split2_ent + 2 * u], s2 = I[A.split2_ent + 2 * u + 1];
-          a.add(out.o(j, par) + (in.o(i, s2) + m.lam(par) * t));
-        }
-    }
-    if (up_ok) {  // rule 1b
-      const double t = q.e_stack[q.cell(i - 1, d + 2)];
-      if (t != NEG)
-        for (int u = I[A.rpair_off + s]; u < I[A.rpair_off + s + 1]; ++u) {
-          const int par = I[A.rpair_ent + 2 * u], tf = I[A.rpair_ent + 2 * u + 1];
-          const double term = out.at(ST_P, d + 2, i - 1, par) + (w_pair(m, q, par, s, tf, i - 1, j) + m.lam(par) * t);
-          const double z = term + in_c - Z;
-          if (z == NEG) continue;
-          if (!stat_pair<MODE>(x, i, j, par, s, z)) continue;
-          stat_energy<MODE>(x, par, t, z);
-          a.add(term);
-        }
-    }
-    {  // rule 3b
-      const double t = q.e_ml[pc];
-      if (t != NEG) {
-        const double term = o2 + m.lam(s) * t;
-        const double z = term + in_c - Z;
-        if (z != NEG) { stat_energy<MODE>(x, s, t, z); a.add(term); }
+    if (eext != NEG)  // rule 7: parent O(j, par), sibling prefix O(i, s2); this = pair part (h,r)
+      for (int u = G[A.split2_off + s]; u < G[A.split2_off + s + 1]; ++u) {
+        const int par = G[A.split2_ent + 2 * u], s2 = G[A.split2_ent + 2 * u + 1];
+        a.add(out.o(j, par) + (in.o(i, s2) + m.lam(par) * eext));
       }
-    }
-    // rule 6c: outer E(i',j',par) with loops L(i',i,s2), L(j,j',s3)
-    for (int n = q.by_inner_off[pc]; n < q.by_inner_off[pc + 1]; ++n) {
-      const LoopItem it = q.items[q.by_inner_idx[n]];
-      for (int u = I[A.quad1_off + s]; u < I[A.quad1_off + s + 1]; ++u) {
-        const int par = I[A.quad1_ent + 3 * u], s2 = I[A.quad1_ent + 3 * u + 1], s3 = I[A.quad1_ent + 3 * u + 2];
-        const double term = out.at(ST_E, it.j - it.i, it.i, par) +
-                            (in.at(ST_L, i - it.i, it.i, s2) + (in.at(ST_L, it.j - j, j, s3) + m.lam(par) * it.tsc));
-        const double z = term + in_c - Z;
+    if (up_ok && est_up != NEG)  // rule 1b
+      for (int u = 0; u < nRP; ++u) {
+        const int par = I[A.rpair_ent + 2 * (rp0 + u)], tf = I[A.rpair_ent + 2 * (rp0 + u) + 1];
+        const double op = (u < kUnary) ? yP[u < kUnary ? u : 0] : out.at(ST_P, d + 2, i - 1, par);
+        const double term = op + (w_pair(m, q, par, s, tf, i - 1, j) + m.lam(par) * est_up);
+        const double z = term + inP - Z;
         if (z == NEG) continue;
-        stat_energy<MODE>(x, par, it.tsc, z);
+        if (!stat_pair<MODE>(x, i, j, par, s, z)) continue;
+        stat_energy<MODE>(x, par, est_up, z);
         a.add(term);
       }
+    if (eml != NEG) {  // rule 3b
+      const double term = o2 + m.lam(s) * eml;
+      const double z = term + inP - Z;
+      if (z != NEG) { stat_energy<MODE>(x, s, eml, z); a.add(term); }
     }
+    a.add(H.HP);
     oP = a.value();
   }
   out.at(ST_P, d, i, s) = oP;
 
-  // ---- L(i,j,s): child of E (6b), of L(i,j+1,par), left / right loop of an interior loop (6c)
+  // ---- L(i,j,s): child of E (6b), of L(i,j+1,par), loops of interior loops (6c: heavy sum HL)
   double oL = NEG;
-  const double inL = isloop ? in.at(ST_L, d, i, s) : NEG;
   if (inL != NEG) {
     LseAcc a;
-    const double in_c = inL;
-    if (eok) {
-      const double t = q.e_hp[q.cell(i - 1, d + 2)];
-      if (t != NEG) {
-        const double term = oE + m.lam(s) * t;
-        const double z = term + in_c - Z;
-        if (z != NEG) { stat_energy<MODE>(x, s, t, z); a.add(term); }
-      }
+    if (eok && ehp != NEG) {
+      const double term = oE + m.lam(s) * ehp;
+      const double z = term + inL - Z;
+      if (z != NEG) { stat_energy<MODE>(x, s, ehp, z); a.add(term); }
     }
-    if (j < q.L && d + 1 <= q.W) {
-      for (int t = I[A.rright_off + s]; t < I[A.rright_off + s + 1]; ++t) {
-        const int par = I[A.rright_ent + 2 * t], tf = I[A.rright_ent + 2 * t + 1];
+    if (doL) {
+      for (int u = 0; u < nRR; ++u) {
+        const int par = I[A.rright_ent + 2 * (rr0 + u)], tf = I[A.rright_ent + 2 * (rr0 + u) + 1];
         if (!I[A.st_is_loop + par]) continue;
-        const double term = out.at(ST_L, d + 1, i, par) + w_right(m, q, par, tf, j);
-        const double z = term + in_c - Z;
+        const double op = (u < kUnary) ? yL[u < kUnary ? u : 0] : out.at(ST_L, d + 1, i, par);
+        const double term = op + w_right(m, q, par, tf, j);
+        const double z = term + inL - Z;
         if (z == NEG) continue;
         if (!stat_right<MODE>(x, j, par, s, z)) continue;
         a.add(term);
       }
     }
-    const int lc = q.cell(i, d);
-    for (int n = q.by_left_off[lc]; n < q.by_left_off[lc + 1]; ++n) {  // this = L(i', k): i'=i, k=j
-      const LoopItem it = q.items[q.by_left_idx[n]];
-      for (int u = I[A.quad2_off + s]; u < I[A.quad2_off + s + 1]; ++u) {
-        const int par = I[A.quad2_ent + 3 * u], s1 = I[A.quad2_ent + 3 * u + 1], s3 = I[A.quad2_ent + 3 * u + 2];
-        a.add(out.at(ST_E, it.j - it.i, it.i, par) +
-              (in.at(ST_P, it.l - it.k, it.k, s1) + (in.at(ST_L, it.j - it.l, it.l, s3) + m.lam(par) * it.tsc)));
-      }
-    }
-    for (int n = q.by_right_off[lc]; n < q.by_right_off[lc + 1]; ++n) {  // this = L(l, j'): l=i, j'=j
-      const LoopItem it = q.items[q.by_right_idx[n]];
-      for (int u = I[A.quad3_off + s]; u < I[A.quad3_off + s + 1]; ++u) {
-        const int par = I[A.quad3_ent + 3 * u], s1 = I[A.quad3_ent + 3 * u + 1], s2 = I[A.quad3_ent + 3 * u + 2];
-        a.add(out.at(ST_E, it.j - it.i, it.i, par) +
-              (in.at(ST_P, it.l - it.k, it.k, s1) + (in.at(ST_L, it.k - it.i, it.i, s2) + m.lam(par) * it.tsc)));
-      }
-    }
+    a.add(H.HL);
     oL = a.value();
   }
   out.at(ST_L, d, i, s) = oL;
+}
+
+// which heavy sums a target needs (the GPU skips the gathers otherwise)
+ELEMDP_HD bool needs_o1(const SeqView& q, const TableView& in, int d, int i, int s) { return q.left_ok(i, d) && in.at(ST_1, d, i, s) != ELEMDP_NEG_INF; }
+
+// serial form: heavy sums evaluated in place (CPU emulation, S = 1 paths)
+template <int MODE, class Sink> ELEMDP_HD void outside_target(OutCtx<Sink>& x, int d, int i, int s) {
+  const SeqView& q = x.q;
+  HeavyOut H;
+  const bool lok = q.left_ok(i, d);
+  H.H1 = (lok && x.in.at(ST_1, d, i, s) != ELEMDP_NEG_INF) ? heavy_o1(x, d, i, s) : ELEMDP_NEG_INF;
+  H.H2 = (lok && x.in.at(ST_2, d, i, s) != ELEMDP_NEG_INF) ? heavy_o2(x, d, i, s) : ELEMDP_NEG_INF;
+  H.HP = q.pair_ok(i, d) ? heavy_oP<MODE>(x, d, i, s) : ELEMDP_NEG_INF;
+  H.HL = (x.m.ints[x.m.lay.st_is_loop + s] && x.in.at(ST_L, d, i, s) != ELEMDP_NEG_INF) ? heavy_oL(x, d, i, s) : ELEMDP_NEG_INF;
+  outside_target_u<MODE>(x, d, i, s, H);
 }
 
 }  // namespace elemdp

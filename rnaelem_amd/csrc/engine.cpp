@@ -187,7 +187,7 @@ class Engine {
   int n_slots_ = 0, slots_S_ = 0;
   bool slots_scan_ = false;
   size_t band_stride_ = 0, ext_stride_ = 0;
-  DevBuf d_band_in_, d_band_out_, d_ext_in_, d_ext_out_, d_tr_band_, d_tr_ext_, d_tr_stack_;
+  DevBuf d_band_in_, d_band_out_, d_ext_in_, d_ext_out_, d_tr_band_, d_tr_ext_, d_tr_stack_, d_tmp_;
   DevBuf d_seq_out_, d_partial_;
   int out_stride_ = 0;
   // options
@@ -208,6 +208,7 @@ Engine::Engine(const elemdp_model_desc& d)
   if ((flags_ & ELEMDP_NO_RSS) && au_.reg_pattern().find(')') != std::string::npos)
     throw ArgError("search pattern must not include pair when no-rss mode");
   if (max_span_ < 1) throw ArgError("max_span must be positive");
+  if (au_.S() > 128) throw ArgError("pattern has more than 128 interval states (not supported by this build)");
   if (!(tau_ > 0)) throw ArgError("tau must be positive");
   std::string par = d.energy_param ? d.energy_param : "~T2004~";
   if (par == "~T2004~") par = read_file(default_data_dir() + "/turner2004.elempar");
@@ -313,7 +314,8 @@ LdsLayout Engine::lds_layout(const AutomatonLayout& lay, int Lmax, int nword_max
   l.zs = take(8 * 8);
   l.ws = take(8 * (Lmax + 1));
   l.post = take(scan ? 8 * 3 * (Lmax + 1) : 16);
-  l.ints = take(4 * lay.n_ints);
+  l.ints = take(4 * lay.n_small);
+  l.wave_scr = take(8 * 128 * (kThreads / 64));
   l.okbits = take(4 * nword_max);
   l.dmin = take(2 * (Lmax + 1));
   l.seq = take(Lmax + 1);
@@ -376,7 +378,7 @@ void Engine::ensure_slots(int S, bool scan, int n_want) {
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   const size_t per_slot = (band + ext) * 2 * sizeof(double) + (scan ? (band + ext) * sizeof(TraceRec) + 16 * (Lmax_ + 2) : 0);
   if (n_slots_ >= want && slots_S_ == S && band_stride_ == band && (slots_scan_ || !scan)) return;
-  d_band_in_.reset(); d_band_out_.reset(); d_ext_in_.reset(); d_ext_out_.reset(); d_tr_band_.reset(); d_tr_ext_.reset();
+  d_band_in_.reset(); d_band_out_.reset(); d_ext_in_.reset(); d_ext_out_.reset(); d_tr_band_.reset(); d_tr_ext_.reset(); d_tmp_.reset();
   d_tr_stack_.reset();
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   const size_t budget = free_b / 2;
@@ -388,6 +390,7 @@ void Engine::ensure_slots(int S, bool scan, int n_want) {
   d_band_out_.alloc(band * want * sizeof(double));
   d_ext_in_.alloc(ext * want * sizeof(double));
   d_ext_out_.alloc(ext * want * sizeof(double));
+  d_tmp_.alloc(ext * 3 * want * sizeof(double));
   if (scan) {
     d_tr_band_.alloc(band * want * sizeof(TraceRec));
     d_tr_ext_.alloc(ext * want * sizeof(TraceRec));
@@ -416,6 +419,8 @@ DpArgs Engine::base_args(const AutomatonLayout& lay, const int32_t* d_ints, cons
   a.ext_in = d_ext_in_.as<double>(); a.ext_out = d_ext_out_.as<double>();
   a.band_stride = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;
   a.ext_stride = (size_t)(Lmax_ + 1) * S;
+  a.tmp = d_tmp_.as<double>();
+  a.tmp_stride = a.ext_stride;
   return a;
 }
 

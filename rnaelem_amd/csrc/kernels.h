@@ -43,7 +43,7 @@ struct PlanKernelArgs {
 
 // byte offsets of the dynamic LDS regions of the DP kernels
 struct LdsLayout {
-  int32_t ints, theta, en_o, en_x, eh, zs, ws, post, okbits, dmin, seq, unp, total;
+  int32_t ints, theta, en_o, en_x, eh, zs, ws, post, okbits, dmin, seq, unp, wave_scr, total;
 };
 
 enum DpKind : int { DP_TRAIN = 0, DP_BPP = 1, DP_SCAN = 2 };
@@ -64,6 +64,7 @@ struct DpArgs {
   // table slots, one per workgroup
   double* band_in; double* band_out; double* ext_in; double* ext_out;
   size_t band_stride, ext_stride;  // in doubles
+  double* tmp; size_t tmp_stride;  // heavy-sum temporaries: 3 * tmp_stride doubles per slot, tmp_stride = (Lmax+1)*S
   TraceRec* tr_band; TraceRec* tr_ext;
   // TRAIN: per-sequence results [n][out_stride] = Zo, Zari, Znasi, f, skipped, bpp_eff, ENo[nt], ENx[nt], EHo[2], EHx[2]
   double* seq_out;

@@ -241,21 +241,331 @@ struct Prof {
   __device__ __forceinline__ void lap(int k) { if (p && threadIdx.x == 0) { long long n = clock64(); p[k] += n - t; t = n; } }
 };
 
-template <bool CONSTRAINED>
-__device__ void sweep_inside(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, bool no_rss,
-                             Prof& pf) {
-  const int S = m.lay.S, tid = threadIdx.x;
-  if (!no_rss) {
-    for (int d = 0; d <= q.W; ++d) {
-      const int n = (q.L - d + 1) * S;
-      for (int t = tid; t < n; t += kThreads) {
-        const int i = t / S, s = t - i * S;
-        inside_target<CONSTRAINED>(m, q, T, c, d, i, s);
-      }
-      __syncthreads();
+// ---------------------------------------------------------------------------------------------
+// Heavy phase: one WAVE per cell, one LANE per state tuple of the rule, the k / item loop unrolled
+// four-fold so that eight (twelve) independent table loads are in flight per lane before the first
+// exp.  Each lane keeps a streaming log-sum-exp of its tuple; the partial sums of the tuples that
+// feed the same interval state (contiguous in the grouped lists) are merged through a 1 KiB LDS
+// scratch per wave by the lanes that own the states.  Supports S <= 2 * 64 states.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWaves = kThreads / 64;
+constexpr int kStateChunks = 2;  // S <= 128
+
+struct WaveCtx {
+  double* scr_m;  // LDS, 64 doubles of this wave
+  double* scr_s;
+  int lane;
+};
+
+// merge the lanes' (m,s) partials of tuples [t0, t0+64) into the state lanes' accumulators
+__device__ __forceinline__ void merge_tuples(const WaveCtx& w, const int32_t* G, int off_list, int S, int t0, int n_tuple,
+                                             const LseAcc& lane_acc, LseAcc (&st)[kStateChunks]) {
+  w.scr_m[w.lane] = lane_acc.m;
+  w.scr_s[w.lane] = lane_acc.s;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int c = 0; c < kStateChunks; ++c) {
+    const int s = c * 64 + w.lane;
+    if (s < S) {
+      int a = G[off_list + s], b = G[off_list + s + 1];
+      a = a > t0 ? a : t0;
+      b = b < t0 + 64 ? b : t0 + 64;
+      b = b < n_tuple ? b : n_tuple;
+      for (int t = a; t < b; ++t) st[c].merge(w.scr_m[t - t0], w.scr_s[t - t0]);
     }
   }
-  pf.lap(1);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// ---- inside: B(i,j,.) (rule 2) and the interior-loop part of E(i,j,.) (rule 6c) of ONE cell
+__device__ void heavy_inside_cell(const ModelView& m, const SeqView& q, const TableView& T, const WaveCtx& w, int d, int i,
+                                  double* he_tmp) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const int S = A.S, j = i + d, lane = w.lane;
+  const double NEG = ELEMDP_NEG_INF;
+  if (q.left_ok(i, d)) {
+    LseAcc st[kStateChunks];
+    const int k_lo = i + q.dmin[i];
+    for (int t0 = 0; t0 < A.n_split; t0 += 64) {
+      const int t = t0 + lane;
+      const bool act = t < A.n_split;
+      const int s1 = act ? G[A.split_ent + 2 * t] : 0, s2 = act ? G[A.split_ent + 2 * t + 1] : 0;
+      LseAcc acc;
+      for (int kb = k_lo; kb < j; kb += 64) {
+        const int kc = kb + lane;
+        unsigned long long mask = __ballot(kc < j && bif_valid(q, j, kc));
+        while (mask) {
+          int k[4];
+          bool v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v[u] = mask != 0;
+            k[u] = v[u] ? kb + __ffsll((long long)mask) - 1 : k_lo;
+            mask &= mask - 1;
+          }
+          double x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = (act && v[u]) ? bif_term(T, i, j, k[u], s1, s2) : NEG;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc.add(x[u]);
+        }
+      }
+      merge_tuples(w, G, A.split_off, S, t0, A.n_split, acc, st);
+    }
+#pragma unroll
+    for (int c = 0; c < kStateChunks; ++c) {
+      const int s = c * 64 + lane;
+      if (s < S) T.at(ST_B, d, i, s) = st[c].value();
+    }
+  }
+  if (q.e_ok(i, d)) {
+    LseAcc st[kStateChunks];
+    const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
+    if (c1 > c0) {
+      for (int t0 = 0; t0 < A.n_quad; t0 += 64) {
+        const int t = t0 + lane;
+        const bool act = t < A.n_quad;
+        const int s1 = act ? G[A.quad_ent + 3 * t] : 0, s2 = act ? G[A.quad_ent + 3 * t + 1] : 0,
+                  s3 = act ? G[A.quad_ent + 3 * t + 2] : 0;
+        const double lam = act ? m.lam(G[A.quad_tgt + t]) : 0.;
+        LseAcc acc;
+        for (int it = c0; it < c1; it += 2) {
+          const bool v1 = it + 1 < c1;
+          const LoopItem xa = q.items[it];
+          const LoopItem xb = q.items[v1 ? it + 1 : it];
+          const bool ia = q.item_in[it] != 0, ib = v1 && q.item_in[v1 ? it + 1 : it] != 0;
+          const double ta = (act && ia) ? loop_term(T, i, j, xa, s1, s2, s3, lam * xa.tsc) : NEG;
+          const double tb = (act && ib) ? loop_term(T, i, j, xb, s1, s2, s3, lam * xb.tsc) : NEG;
+          acc.add(ta);
+          acc.add(tb);
+        }
+        merge_tuples(w, G, A.quad_off, S, t0, A.n_quad, acc, st);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kStateChunks; ++c) {
+      const int s = c * 64 + lane;
+      if (s < S) he_tmp[(size_t)i * S + s] = st[c].value();
+    }
+  }
+}
+
+// ---- outside: the four gathers of ONE cell.  H1 goes straight into the table of state 1,
+// H2 / HP / HL into the per-slot temporaries tmp[0..2][i][s].
+template <int MODE>
+__device__ void heavy_outside_cell(OutCtx<GpuSink>& x, const WaveCtx& w, int d, int i, double* tmp, size_t tmp_stride) {
+  const ModelView& m = x.m;
+  const SeqView& q = x.q;
+  const TableView& in = x.in;
+  const TableView& out = x.out;
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const int S = A.S, j = i + d, lane = w.lane;
+  const double NEG = ELEMDP_NEG_INF;
+  const bool lok = q.left_ok(i, d);
+  if (lok) {
+    // H1: child 1(i,j,s1) of B(i,jj,par) with sibling 2(j,jj,s2)
+    {
+      LseAcc st[kStateChunks];
+      const int dj = q.dmin[j];
+      const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+      if (j < q.L && dj > 0 && j + dj <= jmax) {
+        for (int t0 = 0; t0 < A.n_split; t0 += 64) {
+          const int t = t0 + lane;
+          const bool act = t < A.n_split;
+          const int par = act ? G[A.split1_ent + 2 * t] : 0, s2 = act ? G[A.split1_ent + 2 * t + 1] : 0;
+          LseAcc acc;
+          for (int jb = j + dj; jb <= jmax; jb += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (act && jb + u <= jmax) ? o1_term(in, out, i, j, jb + u, par, s2) : NEG;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc.add(v[u]);
+          }
+          merge_tuples(w, G, A.split1_off, S, t0, A.n_split, acc, st);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < kStateChunks; ++c) {
+        const int s = c * 64 + lane;
+        if (s < S) out.at(ST_1, d, i, s) = (in.at(ST_1, d, i, s) != NEG) ? st[c].value() : NEG;
+      }
+    }
+    // H2: child 2(i,j,s2) of B(ii,j,par) with sibling 1(ii,i,s1)
+    {
+      LseAcc st[kStateChunks];
+      const int imin = (j - q.W > 0) ? j - q.W : 0;
+      for (int t0 = 0; t0 < A.n_split; t0 += 64) {
+        const int t = t0 + lane;
+        const bool act = t < A.n_split;
+        const int par = act ? G[A.split2_ent + 2 * t] : 0, s1 = act ? G[A.split2_ent + 2 * t + 1] : 0;
+        LseAcc acc;
+        for (int ib = imin; ib < i; ib += 64) {
+          const int ic = ib + lane;
+          unsigned long long mask = __ballot(ic < i && o2_valid(q, i, ic));
+          while (mask) {
+            int ii[4];
+            bool v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              v[u] = mask != 0;
+              ii[u] = v[u] ? ib + __ffsll((long long)mask) - 1 : imin;
+              mask &= mask - 1;
+            }
+            double y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y[u] = (act && v[u]) ? o2_term(in, out, i, j, ii[u], par, s1) : NEG;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc.add(y[u]);
+          }
+        }
+        merge_tuples(w, G, A.split2_off, S, t0, A.n_split, acc, st);
+      }
+#pragma unroll
+      for (int c = 0; c < kStateChunks; ++c) {
+        const int s = c * 64 + lane;
+        if (s < S) tmp[0 * tmp_stride + (size_t)i * S + s] = st[c].value();
+      }
+    }
+  }
+  const int cellid = q.cell(i, d);
+  if (q.pair_ok(i, d)) {
+    // HP: inner pair P(i,j,s1) of interior loops E(i',j',par) + energy statistic
+    LseAcc st[kStateChunks];
+    const int n0 = q.by_inner_off[cellid], n1 = q.by_inner_off[cellid + 1];
+    if (n1 > n0) {
+      for (int t0 = 0; t0 < A.n_quad; t0 += 64) {
+        const int t = t0 + lane;
+        const bool act = t < A.n_quad;
+        const int par = act ? G[A.quad1_ent + 3 * t] : 0, s2 = act ? G[A.quad1_ent + 3 * t + 1] : 0,
+                  s3 = act ? G[A.quad1_ent + 3 * t + 2] : 0;
+        const double lam = act ? m.lam(par) : 0.;
+        const double in_c = act ? in.at(ST_P, d, i, G[A.quad1_tgt + t]) : NEG;
+        const bool live = act && in_c != NEG;
+        LseAcc acc;
+        for (int n = n0; n < n1; n += 2) {
+          const bool v1 = n + 1 < n1;
+          const LoopItem xa = q.items[q.by_inner_idx[n]];
+          const LoopItem xb = q.items[q.by_inner_idx[v1 ? n + 1 : n]];
+          const double ta = live ? oP_term(in, out, i, j, xa, par, s2, s3, lam * xa.tsc) : NEG;
+          const double tb = (live && v1) ? oP_term(in, out, i, j, xb, par, s2, s3, lam * xb.tsc) : NEG;
+          if (MODE == OUT_TRAIN) {
+            const double za = ta + in_c - x.Z, zb = tb + in_c - x.Z;
+            if (live && za != NEG) x.sink.eh(m.eh_index(par), xa.tsc * exp(za));
+            if (live && v1 && zb != NEG) x.sink.eh(m.eh_index(par), xb.tsc * exp(zb));
+          }
+          acc.add(ta);
+          acc.add(tb);
+        }
+        merge_tuples(w, G, A.quad1_off, S, t0, A.n_quad, acc, st);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kStateChunks; ++c) {
+      const int s = c * 64 + lane;
+      if (s < S) tmp[1 * tmp_stride + (size_t)i * S + s] = st[c].value();
+    }
+  }
+  {
+    // HL: left loop (cell = (it.i, it.k)) and right loop (cell = (it.l, it.j)) of interior loops
+    LseAcc st[kStateChunks];
+    const int l0 = q.by_left_off[cellid], l1 = q.by_left_off[cellid + 1];
+    const int r0 = q.by_right_off[cellid], r1 = q.by_right_off[cellid + 1];
+    if (l1 > l0) {
+      for (int t0 = 0; t0 < A.n_quad; t0 += 64) {
+        const int t = t0 + lane;
+        const bool act = t < A.n_quad;
+        const int par = act ? G[A.quad2_ent + 3 * t] : 0, s1 = act ? G[A.quad2_ent + 3 * t + 1] : 0,
+                  s3 = act ? G[A.quad2_ent + 3 * t + 2] : 0;
+        const double lam = act ? m.lam(par) : 0.;
+        LseAcc acc;
+        for (int n = l0; n < l1; n += 2) {
+          const bool v1 = n + 1 < l1;
+          const LoopItem xa = q.items[q.by_left_idx[n]];
+          const LoopItem xb = q.items[q.by_left_idx[v1 ? n + 1 : n]];
+          const double ta = act ? oLl_term(in, out, xa, par, s1, s3, lam * xa.tsc) : NEG;
+          const double tb = (act && v1) ? oLl_term(in, out, xb, par, s1, s3, lam * xb.tsc) : NEG;
+          acc.add(ta);
+          acc.add(tb);
+        }
+        merge_tuples(w, G, A.quad2_off, S, t0, A.n_quad, acc, st);
+      }
+    }
+    if (r1 > r0) {
+      for (int t0 = 0; t0 < A.n_quad; t0 += 64) {
+        const int t = t0 + lane;
+        const bool act = t < A.n_quad;
+        const int par = act ? G[A.quad3_ent + 3 * t] : 0, s1 = act ? G[A.quad3_ent + 3 * t + 1] : 0,
+                  s2 = act ? G[A.quad3_ent + 3 * t + 2] : 0;
+        const double lam = act ? m.lam(par) : 0.;
+        LseAcc acc;
+        for (int n = r0; n < r1; n += 2) {
+          const bool v1 = n + 1 < r1;
+          const LoopItem xa = q.items[q.by_right_idx[n]];
+          const LoopItem xb = q.items[q.by_right_idx[v1 ? n + 1 : n]];
+          const double ta = act ? oLr_term(in, out, xa, par, s1, s2, lam * xa.tsc) : NEG;
+          const double tb = (act && v1) ? oLr_term(in, out, xb, par, s1, s2, lam * xb.tsc) : NEG;
+          acc.add(ta);
+          acc.add(tb);
+        }
+        merge_tuples(w, G, A.quad3_off, S, t0, A.n_quad, acc, st);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kStateChunks; ++c) {
+      const int s = c * 64 + lane;
+      if (s < S) tmp[2 * tmp_stride + (size_t)i * S + s] = st[c].value();
+    }
+  }
+}
+
+
+// per-sequence scratch shared by the sweeps
+struct SweepScratch {
+  int* cell_counter;   // LDS: next cell of the heavy phase
+  double* wave_scr;    // LDS: kWaves * 128 doubles
+  double* tmp;         // global: 3 * tmp_stride doubles per slot
+  size_t tmp_stride;
+};
+
+template <bool CONSTRAINED>
+__device__ void sweep_inside(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, bool no_rss,
+                             const SweepScratch& sc, Prof& pf) {
+  const int S = m.lay.S, tid = threadIdx.x;
+  WaveCtx w;
+  w.lane = tid & 63;
+  w.scr_m = sc.wave_scr + (tid >> 6) * 128;
+  w.scr_s = w.scr_m + 64;
+  if (!no_rss) {
+    if (tid == 0) *sc.cell_counter = 0;
+    __syncthreads();
+    for (int d = 0; d <= q.W; ++d) {
+      // heavy phase: waves pull cells
+      const int ncell = q.L - d + 1;
+      for (;;) {
+        int i = 0;
+        if (w.lane == 0) i = atomicAdd(sc.cell_counter, 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= ncell) break;
+        heavy_inside_cell(m, q, T, w, d, i, sc.tmp);
+      }
+      __syncthreads();
+      pf.lap(6);
+      if (tid == 0) *sc.cell_counter = 0;
+      const int n = ncell * S;
+      for (int t = tid; t < n; t += kThreads) {
+        const int i = t / S, s = t - i * S;
+        const double HB = q.left_ok(i, d) ? T.at(ST_B, d, i, s) : ELEMDP_NEG_INF;
+        const double HE = q.e_ok(i, d) ? sc.tmp[(size_t)i * S + s] : ELEMDP_NEG_INF;
+        inside_target_u<CONSTRAINED>(m, q, T, c, d, i, s, HB, HE);
+      }
+      __syncthreads();
+      pf.lap(1);
+    }
+  }
   for (int s = tid; s < S; s += kThreads) T.o(0, s) = (s == m.lay.s00) ? 0. : ELEMDP_NEG_INF;
   __syncthreads();
   for (int j = 1; j <= q.L; ++j) {
@@ -268,16 +578,21 @@ __device__ void sweep_inside(const ModelView& m, const SeqView& q, const TableVi
 template <int MODE>
 __device__ void sweep_outside(const ModelView& m, const SeqView& q, const TableView& in, const TableView& out, double Z,
                               const Constraint& c, bool ari, bool nasi, GpuSink& sink, double* lds_eh, bool no_rss,
-                              Prof& pf) {
+                              const SweepScratch& sc, Prof& pf) {
   const int S = m.lay.S, tid = threadIdx.x;
   OutCtx<GpuSink> x{m, q, in, out, Z, c, sink};
   sink.eh0 = sink.eh1 = 0.;
+  WaveCtx w;
+  w.lane = tid & 63;
+  w.scr_m = sc.wave_scr + (tid >> 6) * 128;
+  w.scr_s = w.scr_m + 64;
   for (int s = tid; s < S; s += kThreads) {
     double v = ELEMDP_NEG_INF;
     if (nasi && s == m.lay.s00) v = 0.;
     if (ari && (s == m.lay.s0m1 || s == m.lay.s0m2)) v = 0.;
     out.o(q.L, s) = v;
   }
+  if (tid == 0) *sc.cell_counter = 0;
   __syncthreads();
   for (int i = q.L - 1; i >= 0; --i) {
     for (int s = tid; s < S; s += kThreads) outside_ext_target<MODE>(x, i, s);
@@ -286,15 +601,32 @@ __device__ void sweep_outside(const ModelView& m, const SeqView& q, const TableV
   pf.lap(3);
   if (!no_rss) {
     for (int d = q.W; d >= 0; --d) {
-      const int n = (q.L - d + 1) * S;
-      for (int t = tid; t < n; t += kThreads) {
-        const int i = t / S, s = t - i * S;
-        outside_target<MODE>(x, d, i, s);
+      const int ncell = q.L - d + 1;
+      for (;;) {
+        int i = 0;
+        if (w.lane == 0) i = atomicAdd(sc.cell_counter, 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= ncell) break;
+        heavy_outside_cell<MODE>(x, w, d, i, sc.tmp, sc.tmp_stride);
       }
       __syncthreads();
+      pf.lap(7);
+      if (tid == 0) *sc.cell_counter = 0;
+      const int n = ncell * S;
+      for (int t = tid; t < n; t += kThreads) {
+        const int i = t / S, s = t - i * S;
+        HeavyOut H;
+        const bool lok = q.left_ok(i, d);
+        H.H1 = lok ? out.at(ST_1, d, i, s) : ELEMDP_NEG_INF;
+        H.H2 = lok ? sc.tmp[0 * sc.tmp_stride + (size_t)i * S + s] : ELEMDP_NEG_INF;
+        H.HP = q.pair_ok(i, d) ? sc.tmp[1 * sc.tmp_stride + (size_t)i * S + s] : ELEMDP_NEG_INF;
+        H.HL = sc.tmp[2 * sc.tmp_stride + (size_t)i * S + s];
+        outside_target_u<MODE>(x, d, i, s, H);
+      }
+      __syncthreads();
+      pf.lap(4);
     }
   }
-  pf.lap(4);
   if (MODE == OUT_TRAIN) {
     const double a = wave_sum(sink.eh0), b = wave_sum(sink.eh1);
     if ((tid & 63) == 0) { atomicAdd(&lds_eh[0], a); atomicAdd(&lds_eh[1], b); }
@@ -352,7 +684,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
   const int tid = threadIdx.x;
   const int S = a.lay.S, nt = a.lay.n_theta;
 
-  for (int t = tid; t < a.lay.n_ints; t += kThreads) l_ints[t] = a.ints[t];
+  for (int t = tid; t < a.lay.n_small; t += kThreads) l_ints[t] = a.ints[t];
   const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
   const double* g_theta = a.params + sizeof(ParamBlock) / sizeof(double);
   for (int t = tid; t < nt; t += kThreads) l_theta[t] = g_theta[t];
@@ -360,6 +692,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
   ModelView m;
   m.lay = a.lay;
   m.ints = l_ints;
+  m.big = a.ints;
   m.theta = l_theta;
   m.lambda[0] = pb->lambda[0];
   m.lambda[1] = pb->lambda[1];
@@ -368,6 +701,12 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
   m.no_prf = a.no_prf;
   m.m_min = a.m_min;
   const bool no_rss = a.no_rss != 0;
+  __shared__ int l_cell_counter;
+  SweepScratch sc;
+  sc.cell_counter = &l_cell_counter;
+  sc.wave_scr = reinterpret_cast<double*>(lds + a.lds.wave_scr);
+  sc.tmp_stride = a.tmp_stride;
+  sc.tmp = a.tmp + (size_t)blockIdx.x * 3 * a.tmp_stride;
   Prof pf;
   pf.p = a.prof ? a.prof + (size_t)blockIdx.x * 8 : nullptr;
   pf.t = 0;
@@ -426,7 +765,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
 
     if (KIND == DP_TRAIN) {
       // ---- schedule of RNAelemTrainDP::operator() (motif_trainer.hpp:204-227)
-      sweep_inside<false>(m, q, Tin, c0, no_rss, pf);
+      sweep_inside<false>(m, q, Tin, c0, no_rss, sc, pf);
       if (tid == 0) {
         const double Zo = part_func(m, Tin, true, true), Za = part_func(m, Tin, true, false),
                      Zn = part_func(m, Tin, false, true);
@@ -438,11 +777,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
       const bool skip = l_zs[3] != 0.;
       double* o = a.seq_out + (size_t)n * a.out_stride;
       if (!skip) {
-        sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, Zo, c0, true, true, sink, l_eh, no_rss, pf);
+        sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, Zo, c0, true, true, sink, l_eh, no_rss, sc, pf);
         const bool positive = p.positive != 0;
         sink.en_ = l_en_x;
         if (!a.first_pass_only)
-          sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, positive ? Za : Zn, c0, positive, !positive, sink, l_eh + 2, no_rss, pf);
+          sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, positive ? Za : Zn, c0, positive, !positive, sink, l_eh + 2, no_rss, sc, pf);
       }
       if (tid == 0) {
         o[0] = Zo; o[1] = Za; o[2] = Zn;
@@ -455,9 +794,9 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
     } else if (KIND == DP_BPP) {
       // ---- K1: plain McCaskill through the one-state automaton, then the BPP threshold
       // (EnergyModel::calc_BPP / fill_bpp_tables, energy_model.hpp:188-266)
-      sweep_inside<false>(m, q, Tin, c0, false, pf);
+      sweep_inside<false>(m, q, Tin, c0, false, sc, pf);
       const double Z = Tin.o(L, 0);
-      sweep_outside<OUT_NONE>(m, q, Tin, Tout, Z, c0, false, true, sink, l_eh, false, pf);
+      sweep_outside<OUT_NONE>(m, q, Tin, Tout, Z, c0, false, true, sink, l_eh, false, sc, pf);
       __shared__ int tmp[kThreads / 64];
       int kept = 0;
       for (int wd = tid; wd < nword; wd += kThreads) {
@@ -482,24 +821,24 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
     } else {
       // ---- schedule of RNAelemScanDP::operator() (motif_scanner.hpp:204-252)
       double* Pys = l_post; double* Pyi = l_post + (L + 1); double* Pye = l_post + 2 * (L + 1);
-      sweep_inside<false>(m, q, Tin, c0, no_rss, pf);
+      sweep_inside<false>(m, q, Tin, c0, no_rss, sc, pf);
       if (tid == 0) { l_zs[0] = part_func(m, Tin, true, true); l_zs[1] = Tin.o(L, m.lay.s00); }
       __syncthreads();
       const double ZL = l_zs[0];
       sink.post_[0] = Pys; sink.post_[1] = Pyi;
-      sweep_outside<OUT_SCAN>(m, q, Tin, Tout, ZL, c0, true, true, sink, l_eh, no_rss, pf);
+      sweep_outside<OUT_SCAN>(m, q, Tin, Tout, ZL, c0, true, true, sink, l_eh, no_rss, sc, pf);
       if (tid == 0) l_zs[4] = (double)last_argmax(Pys, L);
       __syncthreads();
       const int Ys = (int)l_zs[4];
       for (int t = tid; t < L; t += kThreads) { a.sc_start[p.seq_base + t] = Pys[t]; a.sc_inner[p.seq_base + t] = Pyi[t]; }
       if (a.sc_en) for (int t = tid; t < nt; t += kThreads) a.sc_en[(size_t)n * nt + t] = l_en_o[t];
       const Constraint c1{Ys, -1, 0};
-      sweep_inside<true>(m, q, Tin, c1, no_rss, pf);
+      sweep_inside<true>(m, q, Tin, c1, no_rss, sc, pf);
       if (tid == 0) l_zs[2] = part_func(m, Tin, true, true);
       __syncthreads();
       sink.post_[0] = sink.post_[1] = nullptr; sink.post_[2] = Pye;
       sink.en_ = l_en_x;
-      sweep_outside<OUT_END>(m, q, Tin, Tout, l_zs[2], c1, true, true, sink, l_eh, no_rss, pf);
+      sweep_outside<OUT_END>(m, q, Tin, Tout, l_zs[2], c1, true, true, sink, l_eh, no_rss, sc, pf);
       if (tid == 0) {
         l_zs[5] = (double)last_argmax(Pye, L + 1);
         double tot = ELEMDP_NEG_INF;

@@ -39,6 +39,7 @@ ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView&
                           const Constraint& c, int d, int i, int s) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
+  const int32_t* G = m.big;
   const int j = i + d;
   const double NEG = ELEMDP_NEG_INF;
   const double lam = m.lam(s);
@@ -83,8 +84,8 @@ ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView&
     for (int k = i + q.dmin[i]; k < j; ++k) {
       const int dk = q.dmin[k];
       if (dk == 0 || j - k < dk) continue;
-      for (int t = I[A.split_off + s]; t < I[A.split_off + s + 1]; ++t) {
-        const int s1 = I[A.split_ent + 2 * t], s2 = I[A.split_ent + 2 * t + 1];
+      for (int t = G[A.split_off + s]; t < G[A.split_off + s + 1]; ++t) {
+        const int s1 = G[A.split_ent + 2 * t], s2 = G[A.split_ent + 2 * t + 1];
         aB.offer(T.at(ST_1, k - i, i, s1) + T.at(ST_2, j - k, k, s2), i, k, TT_B_12, ST_1, s1);
       }
     }
@@ -136,8 +137,8 @@ ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView&
       if (!q.item_in[it]) continue;
       const LoopItem x = q.items[it];
       const double lt = lam * x.tsc;
-      for (int t = I[A.quad_off + s]; t < I[A.quad_off + s + 1]; ++t) {
-        const int s1 = I[A.quad_ent + 3 * t], s2 = I[A.quad_ent + 3 * t + 1], s3 = I[A.quad_ent + 3 * t + 2];
+      for (int t = G[A.quad_off + s]; t < G[A.quad_off + s + 1]; ++t) {
+        const int s1 = G[A.quad_ent + 3 * t], s2 = G[A.quad_ent + 3 * t + 1], s3 = G[A.quad_ent + 3 * t + 2];
         aE.offer(T.at(ST_P, x.l - x.k, x.k, s1) + (T.at(ST_L, x.k - i, i, s2) + (T.at(ST_L, j - x.l, x.l, s3) + lt)), x.k,
                  x.l, TT_E_P, ST_P, s1);
       }
@@ -151,6 +152,7 @@ ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableV
                               const Constraint& c, int j, int s) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
+  const int32_t* G = m.big;
   const double NEG = ELEMDP_NEG_INF;
   const double lam = m.lam(s);
   MaxAcc a;
@@ -161,8 +163,8 @@ ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableV
     const double t = q.e_ext[q.cell(i, d)];
     if (t == NEG) continue;
     const double lt = lam * t;
-    for (int u = I[A.split_off + s]; u < I[A.split_off + s + 1]; ++u) {
-      const int s2 = I[A.split_ent + 2 * u], s1 = I[A.split_ent + 2 * u + 1];
+    for (int u = G[A.split_off + s]; u < G[A.split_off + s + 1]; ++u) {
+      const int s2 = G[A.split_ent + 2 * u], s1 = G[A.split_ent + 2 * u + 1];
       a.offer(T.o(i, s2) + (T.at(ST_P, d, i, s1) + lt), i, j, TT_O_OP, ST_P, s1);
     }
   }
@@ -194,6 +196,7 @@ ELEMDP_HD bool trace_back(const ModelView& m, const TableView& T, const TraceVie
                           char* rss, TraceFrame* stack, int cap) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
+  const int32_t* G = m.big;
   const int M = A.M;
   // (l, r) -> state id by search (only used a few times per sequence)
   auto find_state = [&](int l, int r) {

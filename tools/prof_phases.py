@@ -18,8 +18,8 @@ eng.set_option("profile", 1)
 fn, gr, eff, nsk = eng.train_eval(x)
 ms = eng.last_timing()
 c = eng.profile()
-names = ["stage", "in-band", "in-ext", "out-ext", "out-band", "other"]
-tot = c[:6].sum()
+names = ["stage", "in-U", "in-ext", "out-ext", "out-U", "other", "in-heavy", "out-heavy"]
+tot = c[:8].sum()
 print("n=%d L=%d kernel %.1f ms -> %.0f seq/s ; fn=%.6f" % (n, L, ms[1], n / ms[1] * 1e3, fn))
 for k, nm in enumerate(names):
     print("  %-9s %6.2f %%  (%.3g cycles)" % (nm, 100 * c[k] / tot, c[k]))
