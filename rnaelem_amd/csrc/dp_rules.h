@@ -40,20 +40,48 @@ namespace elemdp {
 // ---------------------------------------------------------------------------------------------
 // log-semiring accumulators
 // ---------------------------------------------------------------------------------------------
-// streaming log-sum-exp: value = m + log(s); one exp per term, one log per target
+// exp(x) for x <= 0 (any x below -746 gives 0): Cody-Waite reduction to |r| <= ln2/2, degree-12 Taylor
+// polynomial (truncation 1.7e-16 relative), one ldexp.  About a third of the instructions of the
+// generic library exp, which matters because one exp per term is the inner loop of the whole DP.
+ELEMDP_HD double exp_neg(double x) {
+  x = fmax(x, -746.);
+  const double kf = rint(x * 1.4426950408889634074);
+  double r = fma(-kf, 6.93147180369123816490e-01, x);
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  double p = 2.08767569878680989792e-09;            // 1/12!
+  p = fma(p, r, 2.50521083854417187751e-08);        // 1/11!
+  p = fma(p, r, 2.75573192239858906526e-07);        // 1/10!
+  p = fma(p, r, 2.75573192239858906526e-06);        // 1/9!
+  p = fma(p, r, 2.48015873015873015873e-05);        // 1/8!
+  p = fma(p, r, 1.98412698412698412698e-04);        // 1/7!
+  p = fma(p, r, 1.38888888888888888889e-03);        // 1/6!
+  p = fma(p, r, 8.33333333333333333333e-03);        // 1/5!
+  p = fma(p, r, 4.16666666666666666667e-02);        // 1/4!
+  p = fma(p, r, 1.66666666666666666667e-01);        // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
+}
+
+// streaming log-sum-exp: value = m + log(s); one exp per term, one log per target; branch-free
 struct LseAcc {
   double m, s;
   ELEMDP_HD LseAcc() : m(ELEMDP_NEG_INF), s(0.) {}
   ELEMDP_HD void add(double x) {
-    if (x == ELEMDP_NEG_INF) return;
-    if (x > m) { s = s * exp(m - x) + 1.; m = x; }
-    else s += exp(x - m);
+    const bool dead = (x == ELEMDP_NEG_INF);
+    const double t = dead ? 0. : exp_neg(-fabs(x - m));  // m = -inf: exp_neg(-inf) = 0
+    const bool up = x > m;
+    s = up ? fma(s, t, 1.) : s + t;
+    m = up ? x : m;
   }
   // merge another partial sum (m2 + log s2)
   ELEMDP_HD void merge(double m2, double s2) {
-    if (m2 == ELEMDP_NEG_INF) return;
-    if (m2 > m) { s = s * exp(m - m2) + s2; m = m2; }
-    else s += s2 * exp(m2 - m);
+    const bool dead = (m2 == ELEMDP_NEG_INF);
+    const double t = dead ? 0. : exp_neg(-fabs(m2 - m));
+    const bool up = m2 > m;
+    s = up ? fma(s, t, s2) : fma(s2, t, s);
+    m = up ? m2 : m;
   }
   ELEMDP_HD double value() const { return (m == ELEMDP_NEG_INF) ? ELEMDP_NEG_INF : m + log(s); }
 };
@@ -62,7 +90,8 @@ struct LseAcc {
 // views
 // ---------------------------------------------------------------------------------------------
 struct ModelView {
-  AutomatonLayout lay;
+  const AutomatonLayout& lay;  // (a reference: on the GPU it aliases the kernel argument, no per-lane copy)
+  ELEMDP_HD explicit ModelView(const AutomatonLayout& l) : lay(l) {}
   const int32_t* ints;   // automaton blob: per-state attributes + unary lists (first lay.n_small ints; LDS on the GPU)
   const int32_t* big;    // the whole blob incl. the tuple lists of rules 2 / 6c / 7 (global memory on the GPU)
   const double* theta;   // n_theta log-probabilities
@@ -74,7 +103,8 @@ struct ModelView {
 
   ELEMDP_HD int st_l(int s) const { return ints[lay.st_l + s]; }
   ELEMDP_HD int st_r(int s) const { return ints[lay.st_r + s]; }
-  ELEMDP_HD double lam(int s) const { return lambda[ints[lay.st_lam + s]]; }
+  // (a select, not an indexed read: dynamic indexing would force the whole view into scratch memory on the GPU)
+  ELEMDP_HD double lam(int s) const { return ints[lay.st_lam + s] ? lambda[1] : lambda[0]; }
   // index of the EH accumulator a transition with parent s feeds (motif_trainer.hpp:380-381)
   ELEMDP_HD int eh_index(int s) const { return lam_same ? 0 : ints[lay.st_lam + s]; }
   ELEMDP_HD double theta_at(int row, int col) const { return theta[ints[lay.row_off + row] + col]; }
@@ -121,11 +151,12 @@ struct TableView {
   double* band;
   double* ext;
   int32_t L, W, S;
-  ELEMDP_HD size_t idx(int e, int d, int i, int s) const {
-    return (((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s;
+  // (the engine rejects batches whose band table would exceed 2^31 entries)
+  ELEMDP_HD uint32_t idx(int e, int d, int i, int s) const {
+    return (((uint32_t)e * (uint32_t)(W + 1) + (uint32_t)d) * (uint32_t)(L + 1) + (uint32_t)i) * (uint32_t)S + (uint32_t)s;
   }
   ELEMDP_HD double& at(int e, int d, int i, int s) const { return band[idx(e, d, i, s)]; }
-  ELEMDP_HD double& o(int j, int s) const { return ext[(size_t)j * S + s]; }
+  ELEMDP_HD double& o(int j, int s) const { return ext[(uint32_t)j * (uint32_t)S + (uint32_t)s]; }
 };
 
 ELEMDP_HD bool m_ok(const ModelView& m, const SeqView& q, int i, int d) {  // is_parsable<ST_M>
@@ -297,22 +328,28 @@ ELEMDP_HD void inside_target_u(const ModelView& m, const SeqView& q, const Table
   double est = NEG, eml = NEG, ecl = NEG, ehp = NEG;
   if (pok) { est = q.e_stack[q.cell(i, d)]; eml = q.e_ml[q.cell(i, d)]; }
   if (eok) { const int pc = q.cell(i - 1, d + 2); ecl = q.e_close[pc]; ehp = q.e_hp[pc]; }
+  // The loads are unconditional (from clamped, always valid cells) and masked afterwards: a predicated load
+  // becomes a branch with its own wait, which would serialise the fetches of one target.
+  const int d1 = d > 0 ? d - 1 : 0, d2 = d > 1 ? d - 2 : 0, i1 = i < q.L ? i + 1 : i;
 #pragma unroll
   for (int u = 0; u < kUnary; ++u) {
     const bool vr = u < nR;
     const int s1 = vr ? I[A.right_ent + 2 * (r0 + u)] : 0;
     const bool okr = vr && (!CONSTRAINED || allow_right(m, c, q.L, j, s, s1));
-    xL[u] = (doL && okr) ? T.at(ST_L, d - 1, i, s1) : NEG;
-    x2[u] = (do2 && okr) ? T.at(ST_2, d - 1, i, s1) : NEG;
     const bool vp = u < nP;
     const int sp = vp ? I[A.pair_ent + 2 * (p0 + u)] : 0;
     const bool okp = pok && vp && (!CONSTRAINED || allow_pair(m, c, q.L, i, j, s, sp));
-    xE[u] = okp ? T.at(ST_E, d - 2, i + 1, sp) : NEG;
-    xP[u] = (okp && est != NEG) ? T.at(ST_P, d - 2, i + 1, sp) : NEG;
     const bool vl = u < nL;
     const int sl = vl ? I[A.left_ent + 2 * (l0 + u)] : 0;
     const bool okl = doM && vl && (!CONSTRAINED || allow_left(m, c, i, s, sl));
-    xM[u] = okl ? T.at(ST_M, d - 1, i + 1, sl) : NEG;
+    const double tL = T.at(ST_L, d1, i, s1), t2 = T.at(ST_2, d1, i, s1);
+    const double tE = T.at(ST_E, d2, i1, sp), tP = T.at(ST_P, d2, i1, sp);
+    const double tM = T.at(ST_M, d1, i1, sl);
+    xL[u] = (doL && okr) ? tL : NEG;
+    x2[u] = (do2 && okr) ? t2 : NEG;
+    xE[u] = okp ? tE : NEG;
+    xP[u] = (okp && est != NEG) ? tP : NEG;
+    xM[u] = okl ? tM : NEG;
   }
 
   // ---- L(i,j,s): loop emission chain (motif_model.hpp:243-257; init motif_trainer.hpp:89-95)
@@ -747,13 +784,15 @@ template <int MODE, class Sink> ELEMDP_HD void outside_target_u(OutCtx<Sink>& x,
   const bool doL = isloop && j < q.L && d + 1 <= q.W;
 
   // ---- operand fetch: inside values of this target and the parents' outside values (diagonals d+1, d+2)
-  const double inE = eok ? in.at(ST_E, d, i, s) : NEG;
-  const double inM = mok ? in.at(ST_M, d, i, s) : NEG;
-  const double in1 = lok ? in.at(ST_1, d, i, s) : NEG;
-  const double inB = lok ? in.at(ST_B, d, i, s) : NEG;
-  const double in2 = lok ? in.at(ST_2, d, i, s) : NEG;
-  const double inP = pok ? in.at(ST_P, d, i, s) : NEG;
-  const double inL = isloop ? in.at(ST_L, d, i, s) : NEG;
+  const double rE = in.at(ST_E, d, i, s), rM = in.at(ST_M, d, i, s), r1 = in.at(ST_1, d, i, s), rB = in.at(ST_B, d, i, s);
+  const double r2 = in.at(ST_2, d, i, s), rP = in.at(ST_P, d, i, s), rL = in.at(ST_L, d, i, s);
+  const double inE = eok ? rE : NEG;
+  const double inM = mok ? rM : NEG;
+  const double in1 = lok ? r1 : NEG;
+  const double inB = lok ? rB : NEG;
+  const double in2 = lok ? r2 : NEG;
+  const double inP = pok ? rP : NEG;
+  const double inL = isloop ? rL : NEG;
   double ecl = NEG, ehp = NEG, est_up = NEG, eml = NEG, eext = NEG;
   if (eok) { const int pc = q.cell(i - 1, d + 2); ecl = q.e_close[pc]; ehp = q.e_hp[pc]; }
   if (up_ok && pok) est_up = q.e_stack[q.cell(i - 1, d + 2)];
@@ -763,15 +802,18 @@ template <int MODE, class Sink> ELEMDP_HD void outside_target_u(OutCtx<Sink>& x,
   const int rr0 = I[A.rright_off + s], nRR = I[A.rright_off + s + 1] - rr0;
   double yP[kUnary], yM[kUnary], y2[kUnary], yL[kUnary];
   const bool needP = (up_ok && (inE != NEG || (inP != NEG && est_up != NEG)));
+  const int dp1 = d + 1 <= q.W ? d + 1 : q.W, dp2 = d + 2 <= q.W ? d + 2 : q.W, im1 = i > 0 ? i - 1 : 0;
 #pragma unroll
-  for (int u = 0; u < kUnary; ++u) {
+  for (int u = 0; u < kUnary; ++u) {  // unconditional loads from clamped cells, masked afterwards (see inside_target_u)
     const int par_p = (u < nRP) ? I[A.rpair_ent + 2 * (rp0 + u)] : 0;
-    yP[u] = (needP && u < nRP) ? out.at(ST_P, d + 2, i - 1, par_p) : NEG;
     const int par_l = (u < nRL) ? I[A.rleft_ent + 2 * (rl0 + u)] : 0;
-    yM[u] = (doM && inM != NEG && u < nRL) ? out.at(ST_M, d + 1, i - 1, par_l) : NEG;
     const int par_r = (u < nRR) ? I[A.rright_ent + 2 * (rr0 + u)] : 0;
-    y2[u] = (do2 && in2 != NEG && u < nRR) ? out.at(ST_2, d + 1, i, par_r) : NEG;
-    yL[u] = (doL && inL != NEG && u < nRR && I[A.st_is_loop + par_r]) ? out.at(ST_L, d + 1, i, par_r) : NEG;
+    const double tP = out.at(ST_P, dp2, im1, par_p), tM = out.at(ST_M, dp1, im1, par_l);
+    const double t2 = out.at(ST_2, dp1, i, par_r), tL = out.at(ST_L, dp1, i, par_r);
+    yP[u] = (needP && u < nRP) ? tP : NEG;
+    yM[u] = (doM && inM != NEG && u < nRL) ? tM : NEG;
+    y2[u] = (do2 && in2 != NEG && u < nRR) ? t2 : NEG;
+    yL[u] = (doL && inL != NEG && u < nRR && I[A.st_is_loop + par_r]) ? tL : NEG;
   }
 
   // NB every transition's posterior z contains inside(child); the reference drops transitions with

@@ -158,6 +158,7 @@ class Engine {
                    const uint32_t* d_okbits, int S);
   void ensure_slots(int S, bool scan, int n_want);
   void run_train(bool first_pass_only);
+  void run_train_batch();
   void init_device();
   void require_device() const;
   bool has_device_ = false;
@@ -172,7 +173,7 @@ class Engine {
   int device_ = 0, n_cu_ = 256;
   hipStream_t st_ = nullptr;
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
-  DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_;
+  DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_, d_lay_, d_lay0_;
   std::vector<double> theta_;  // log-probabilities of the last evaluation (softmax Jacobian)
 
   // batch
@@ -184,7 +185,7 @@ class Engine {
   std::vector<int64_t> h_lnbpp_base_;
   PlanSet plan_;
   // slots
-  int n_slots_ = 0, slots_S_ = 0;
+  int n_slots_ = 0, slots_S_ = 0, slot_override_ = 0;
   bool slots_scan_ = false;
   size_t band_stride_ = 0, ext_stride_ = 0;
   DevBuf d_band_in_, d_band_out_, d_ext_in_, d_ext_out_, d_tr_band_, d_tr_ext_, d_tr_stack_, d_tmp_;
@@ -195,6 +196,8 @@ class Engine {
   bool opt_keep_lnbpp_ = false;
   bool opt_first_pass_only_ = false;
   bool opt_profile_ = false;
+  int opt_pipeline_ = 3;   // 3 = diagonal-synchronous batch pipeline, 2 = fused one-workgroup-per-sequence kernel
+  int opt_group_ = 0;      // sequences swept in lockstep by the batch pipeline (0 = auto)
   DevBuf d_prof_;
  public:
   std::vector<long long> last_prof;
@@ -241,6 +244,10 @@ void Engine::init_device() {
   HIP_OK(hipMemcpyAsync(d_et_.as<void>(), &et_, sizeof(EnergyTables), hipMemcpyHostToDevice, st_));
   d_ints_.upload(ints_, st_);
   d_ints0_.upload(ints0_, st_);
+  d_lay_.alloc(sizeof(AutomatonLayout));
+  d_lay0_.alloc(sizeof(AutomatonLayout));
+  HIP_OK(hipMemcpyAsync(d_lay_.as<void>(), &lay_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
+  HIP_OK(hipMemcpyAsync(d_lay0_.as<void>(), &lay0_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   d_params_.alloc(sizeof(ParamBlock) + sizeof(double) * (au_.n_theta() + 1));
   d_params0_.alloc(sizeof(ParamBlock) + sizeof(double));
   d_counter_.alloc(sizeof(int32_t));
@@ -267,6 +274,8 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "keep_lnbpp") opt_keep_lnbpp_ = v != 0;
   else if (key == "first_pass_only") opt_first_pass_only_ = v != 0;
   else if (key == "profile") opt_profile_ = v != 0;
+  else if (key == "pipeline") opt_pipeline_ = (int)v;
+  else if (key == "group") opt_group_ = (int)v;
   else throw ArgError("unknown option: " + key);
 }
 
@@ -373,6 +382,7 @@ void Engine::ensure_slots(int S, bool scan, int n_want) {
   const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;
   const size_t ext = (size_t)(Lmax_ + 1) * S;
   int want = opt_slots_ > 0 ? opt_slots_ : 2 * n_cu_;
+  if (slot_override_ > 0) want = slot_override_;
   want = std::max(1, std::min(want, n_want));
   size_t free_b = 0, total_b = 0;
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
@@ -403,6 +413,7 @@ DpArgs Engine::base_args(const AutomatonLayout& lay, const int32_t* d_ints, cons
   DpArgs a;
   std::memset(&a, 0, sizeof(a));
   a.lay = lay;
+  a.layp = (&lay == &lay0_) ? d_lay0_.as<AutomatonLayout>() : d_lay_.as<AutomatonLayout>();
   a.ints = d_ints;
   a.params = d_params;
   a.no_prf = (flags_ & ELEMDP_NO_PROFILE) ? 1 : 0;
@@ -453,6 +464,8 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
     Lmax_ = std::max(Lmax_, L); Wmax_ = std::max(Wmax_, p.W); nword_max_ = std::max(nword_max_, nword);
     p.bpp_eff = 0.;
   }
+  if ((double)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * au_.S() >= 2147483648.0)
+    throw ArgError("load_batch: sequence too long for this pattern (band table exceeds 2^31 entries)");
   // static arrays
   std::vector<uint8_t> h_seq((size_t)seq_b), h_unp((size_t)pos_b, 1);
   std::vector<double> h_ws((size_t)pos_b);
@@ -591,7 +604,47 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   HIP_OK(hipStreamSynchronize(st_));
 }
 
+void Engine::run_train_batch() {
+  slot_override_ = opt_group_ > 0 ? opt_group_ : 4096;
+  ensure_slots(au_.S(), false, n_seq_);
+  slot_override_ = 0;
+  const int S = au_.S();
+  TrArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.lay = lay_;
+  a.layp = d_lay_.as<AutomatonLayout>();
+  a.ints = d_ints_.as<int32_t>();
+  a.params = d_params_.as<double>();
+  a.no_prf = (flags_ & ELEMDP_NO_PROFILE) ? 1 : 0;
+  a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
+  a.no_rss = (flags_ & ELEMDP_NO_RSS) ? 1 : 0;
+  a.first_pass_only = opt_first_pass_only_ ? 1 : 0;
+  a.plans = plan_.d_plans.as<SeqPlan>();
+  a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>(); a.b.ndot = nullptr;
+  a.okbits = d_okbits1_.as<uint32_t>();
+  a.p = plan_.arrays();
+  a.band_in = d_band_in_.as<double>(); a.band_out = d_band_out_.as<double>();
+  a.ext_in = d_ext_in_.as<double>(); a.ext_out = d_ext_out_.as<double>();
+  a.band_stride = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;
+  a.ext_stride = (size_t)(Lmax_ + 1) * S;
+  a.tmp = d_tmp_.as<double>();
+  a.tmp_stride = a.ext_stride;
+  a.seq_out = d_seq_out_.as<double>();
+  a.out_stride = out_stride_;
+  HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n_seq_, st_));
+  HIP_OK(hipEventRecord(ev_[1], st_));
+  for (int g0 = 0; g0 < n_seq_; g0 += n_slots_) {
+    const int G = std::min(n_slots_, n_seq_ - g0);
+    a.grp = d_order_.as<int32_t>() + g0;
+    const int Lg = h_plans_[h_order_[g0]].L;
+    HIP_OK(launch_train_group(a, G, Lg, std::min(Lg, max_span_), st_));
+  }
+  HIP_OK(hipEventRecord(ev_[2], st_));
+  HIP_OK(launch_reduce(d_seq_out_.as<double>(), out_stride_, n_seq_, au_.n_theta(), d_partial_.as<double>(), st_));
+}
+
 void Engine::run_train(bool) {
+  if (opt_pipeline_ == 3) { run_train_batch(); return; }
   ensure_slots(au_.S(), false, n_seq_);
   DpArgs a = base_args(lay_, d_ints_.as<int32_t>(), d_params_.as<double>(), plan_, d_okbits1_.as<uint32_t>(), au_.S());
   a.order = d_order_.as<int32_t>();

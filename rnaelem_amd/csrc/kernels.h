@@ -49,7 +49,8 @@ struct LdsLayout {
 enum DpKind : int { DP_TRAIN = 0, DP_BPP = 1, DP_SCAN = 2 };
 
 struct DpArgs {
-  AutomatonLayout lay;
+  AutomatonLayout lay;            // host-visible copy (launch geometry, LDS sizes)
+  const AutomatonLayout* layp;    // the same record in device memory: kernels read it through this pointer
   const int32_t* ints;     // automaton blob (global)
   const double* params;    // ParamBlock followed by theta[n_theta]
   int32_t no_prf, m_min, no_rss;
@@ -80,6 +81,26 @@ struct DpArgs {
   long long* prof;  // optional [n_blocks][8] cycle counters: stage, in-band, in-ext, out-ext, out-band, other
   LdsLayout lds;
 };
+
+// arguments of the diagonal-synchronous train pipeline (train_kernels.hip)
+struct TrArgs {
+  AutomatonLayout lay;
+  const AutomatonLayout* layp;
+  const int32_t* ints;
+  const double* params;
+  int32_t no_prf, m_min, no_rss, first_pass_only;
+  const SeqPlan* plans;
+  const int32_t* grp;   // grp[g] = batch index of the sequence in table slot g
+  BatchArrays b;
+  const uint32_t* okbits;
+  PlanArrays p;
+  double* band_in; double* band_out; double* ext_in; double* ext_out;
+  size_t band_stride, ext_stride;
+  double* tmp; size_t tmp_stride;
+  double* seq_out; int32_t out_stride;
+  int32_t pass, d;
+};
+hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hipStream_t st);
 
 hipError_t launch_mask(const BatchArrays& b, const SeqPlan* plans, int n_seq, int min_span, bool write_bits, uint32_t* okbits,
                        int32_t* n_canonical, hipStream_t st);

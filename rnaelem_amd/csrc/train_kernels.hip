@@ -1,0 +1,284 @@
+// train_kernels.hip -- the train evaluation as a diagonal-synchronous batch pipeline (gfx950).
+//
+// A group of G sequences is swept in lockstep: for every anti-diagonal d ONE launch evaluates the
+// heavy sums of all cells (d) of all G sequences (one wave per cell, one lane per state tuple) and
+// ONE launch finishes the cells (one lane per (cell, interval state), operands of diagonals d-1 /
+// d-2 fetched up front).  Dependencies between diagonals are the kernel boundaries of the stream,
+// so there is no intra-kernel barrier and every launch exposes G x (L+1-d) x S independent lanes:
+// memory latency is hidden by occupancy (small kernels, many resident waves), not by per-lane
+// pipelining.  Tables stay resident in HBM in the [e][d][i][s] layout (coalesced along (i,s)).
+// The exterior chain O(j) is inherently sequential in j: one workgroup per sequence.
+//
+// Schedule per group (RNAelemTrainDP::operator(), RNAelem/motif_trainer.hpp:204-227):
+//   inside: for d = 0..W { in_heavy(d); in_u(d) }; in_ext  -> Z(ari,nasi), Z(ari), Z(nasi), skip flag
+//   outside pass p in {full terminals, masked}: out_ext(p); for d = W..0 { out_heavy(d,p); out_u(d,p) }
+// Expected counts are accumulated per workgroup in LDS and flushed with fp64 global atomics into
+// the per-sequence result row; k_reduce (kernels.hip) sums the rows in input order.
+#include <hip/hip_runtime.h>
+
+#include "dp_rules.h"
+#include "kernels.h"
+#include "wave_gather.h"
+
+namespace elemdp {
+namespace {
+
+struct Views {
+  ModelView m;
+  __device__ explicit Views(const TrArgs& a) : m(*a.layp) {}
+  SeqView q;
+  TableView in, out;
+  int n;         // sequence index in the batch
+  double* row;   // per-sequence result row
+  double* tmp;   // heavy-sum temporaries of this slot
+};
+
+__device__ __forceinline__ bool make_views(const TrArgs& a, int g, Views& v) {
+  const int n = a.grp[g];
+  v.n = n;
+  const SeqPlan p = a.plans[n];
+  const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
+  v.m.ints = a.ints;
+  v.m.big = a.ints;
+  v.m.theta = a.params + sizeof(ParamBlock) / sizeof(double);
+  v.m.lambda[0] = pb->lambda[0];
+  v.m.lambda[1] = pb->lambda[1];
+  v.m.log_tau = pb->log_tau;
+  v.m.lam_same = pb->lam_same;
+  v.m.no_prf = a.no_prf;
+  v.m.m_min = a.m_min;
+  SeqView& q = v.q;
+  q.L = p.L; q.W = p.W; q.C = p.C;
+  q.seq = a.b.seq + p.seq_base;
+  q.ws = a.b.ws + p.pos_base;
+  q.unp = a.b.unp + p.pos_base;
+  q.okbits = a.okbits + p.bits_base;
+  q.dmin = a.p.dmin + p.dmin_base;
+  q.e_stack = a.p.e_stack + p.cell_base; q.e_ext = a.p.e_ext + p.cell_base; q.e_ml = a.p.e_ml + p.cell_base;
+  q.e_close = a.p.e_close + p.cell_base; q.e_hp = a.p.e_hp + p.cell_base;
+  q.items = a.p.items + p.item_base; q.item_in = a.p.item_in + p.item_base;
+  q.by_outer_off = a.p.by_outer_off + p.off_base;
+  q.by_inner_off = a.p.by_inner_off + p.off_base; q.by_inner_idx = a.p.by_inner_idx + p.item_base;
+  q.by_left_off = a.p.by_left_off + p.off_base; q.by_left_idx = a.p.by_left_idx + p.item_base;
+  q.by_right_off = a.p.by_right_off + p.off_base; q.by_right_idx = a.p.by_right_idx + p.item_base;
+  v.in.band = a.band_in + (size_t)g * a.band_stride;
+  v.in.ext = a.ext_in + (size_t)g * a.ext_stride;
+  v.out.band = a.band_out + (size_t)g * a.band_stride;
+  v.out.ext = a.ext_out + (size_t)g * a.ext_stride;
+  v.in.L = v.out.L = p.L; v.in.W = v.out.W = p.W; v.in.S = v.out.S = a.lay.S;
+  v.row = a.seq_out + (size_t)n * a.out_stride;
+  v.tmp = a.tmp + (size_t)g * 3 * a.tmp_stride;
+  return true;
+}
+
+// ---- inside, heavy sums of diagonal d: grid (ceil(ncell / kWaves), G), one wave per cell
+__global__ __launch_bounds__(kThreads) void k3_in_heavy(TrArgs a) {
+  __shared__ double scr[kWaves * 128];
+  Views v(a);
+  make_views(a, blockIdx.y, v);
+  const int wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * kWaves + wave;
+  if (a.d > v.q.W || i > v.q.L - a.d) return;
+  WaveCtx w;
+  w.lane = threadIdx.x & 63;
+  w.scr_m = scr + wave * 128;
+  w.scr_s = w.scr_m + 64;
+  heavy_inside_cell(v.m, v.q, v.in, w, a.d, i, v.tmp);
+}
+
+// ---- inside, finish diagonal d: grid (ceil(ncell * S / kThreads), G), one lane per (cell, state)
+__global__ __launch_bounds__(kThreads) void k3_in_u(TrArgs a) {
+  Views v(a);
+  make_views(a, blockIdx.y, v);
+  const int S = a.lay.S, d = a.d;
+  if (d > v.q.W) return;
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= (v.q.L - d + 1) * S) return;
+  const int i = t / S, s = t - i * S;
+  const double HB = v.q.left_ok(i, d) ? v.in.at(ST_B, d, i, s) : ELEMDP_NEG_INF;
+  const double HE = v.q.e_ok(i, d) ? v.tmp[(size_t)i * S + s] : ELEMDP_NEG_INF;
+  const Constraint c{-1, -1, 0};
+  inside_target_u<false>(v.m, v.q, v.in, c, d, i, s, HB, HE);
+}
+
+// ---- exterior chain of the inside pass + partition functions: one workgroup (128 lanes) per sequence
+__global__ __launch_bounds__(128) void k3_in_ext(TrArgs a) {
+  Views v(a);
+  make_views(a, blockIdx.x, v);
+  const int S = a.lay.S, tid = threadIdx.x;
+  const Constraint c{-1, -1, 0};
+  for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00) ? 0. : ELEMDP_NEG_INF;
+  __syncthreads();
+  for (int j = 1; j <= v.q.L; ++j) {
+    for (int s = tid; s < S; s += 128) inside_ext_target<false>(v.m, v.q, v.in, c, j, s);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double Zo = part_func(v.m, v.in, true, true), Za = part_func(v.m, v.in, true, false),
+                 Zn = part_func(v.m, v.in, false, true);
+    const bool skip = !(isfinite(Zo) && isfinite(Za));   // motif_trainer.hpp:211-215
+    const SeqPlan p = a.plans[v.n];
+    v.row[0] = Zo; v.row[1] = Za; v.row[2] = Zn;
+    v.row[3] = skip ? 0. : Zo - (p.positive ? Za : Zn);
+    v.row[4] = skip ? 1. : 0.;
+    v.row[5] = skip ? 0. : p.bpp_eff;
+  }
+}
+
+struct PassInfo { double Z; bool ari, nasi, skip; int en_off, eh_off; };
+__device__ __forceinline__ PassInfo pass_info(const TrArgs& a, const Views& v) {
+  PassInfo pi;
+  const int nt = a.lay.n_theta;
+  const bool positive = a.plans[v.n].positive != 0;
+  pi.skip = v.row[4] != 0.;
+  if (a.pass == 0) { pi.Z = v.row[0]; pi.ari = true; pi.nasi = true; }
+  else { pi.Z = positive ? v.row[1] : v.row[2]; pi.ari = positive; pi.nasi = !positive; }
+  pi.en_off = 6 + a.pass * nt;
+  pi.eh_off = 6 + 2 * nt + 2 * a.pass;
+  return pi;
+}
+
+// flush the workgroup's LDS statistics into the sequence's result row
+__device__ __forceinline__ void flush_stats(const TrArgs& a, const Views& v, const PassInfo& pi, GpuSink& sink, double* l_en,
+                                            double* l_eh) {
+  const double e0 = wave_sum(sink.eh0), e1 = wave_sum(sink.eh1);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&l_eh[0], e0); atomicAdd(&l_eh[1], e1); }
+  __syncthreads();
+  const int nt = a.lay.n_theta;
+  for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+    const double val = l_en[t];
+    if (val != 0.) atomicAdd(&v.row[pi.en_off + t], val);
+  }
+  if (threadIdx.x < 2 && l_eh[threadIdx.x] != 0.) atomicAdd(&v.row[pi.eh_off + threadIdx.x], l_eh[threadIdx.x]);
+}
+
+// ---- exterior chain of an outside pass (runs before the band of that pass)
+__global__ __launch_bounds__(128) void k3_out_ext(TrArgs a) {
+  extern __shared__ double l_stat[];   // n_theta + 2
+  Views v(a);
+  make_views(a, blockIdx.x, v);
+  const PassInfo pi = pass_info(a, v);
+  if (pi.skip) return;
+  const int S = a.lay.S, tid = threadIdx.x, nt = a.lay.n_theta;
+  double* l_en = l_stat;
+  double* l_eh = l_stat + nt;
+  for (int t = tid; t < nt + 2; t += 128) l_stat[t] = 0.;
+  GpuSink sink;
+  sink.en_ = l_en;
+  sink.post_[0] = sink.post_[1] = sink.post_[2] = nullptr;
+  sink.eh0 = sink.eh1 = 0.;
+  OutCtx<GpuSink> x{v.m, v.q, v.in, v.out, pi.Z, Constraint{-1, -1, 0}, sink};
+  for (int s = tid; s < S; s += 128) {
+    double t = ELEMDP_NEG_INF;
+    if (pi.nasi && s == a.lay.s00) t = 0.;
+    if (pi.ari && (s == a.lay.s0m1 || s == a.lay.s0m2)) t = 0.;
+    v.out.o(v.q.L, s) = t;
+  }
+  __syncthreads();
+  for (int i = v.q.L - 1; i >= 0; --i) {
+    for (int s = tid; s < S; s += 128) outside_ext_target<OUT_TRAIN>(x, i, s);
+    __syncthreads();
+  }
+  flush_stats(a, v, pi, sink, l_en, l_eh);
+}
+
+// ---- outside, heavy sums of diagonal d
+__global__ __launch_bounds__(kThreads) void k3_out_heavy(TrArgs a) {
+  __shared__ double scr[kWaves * 128];
+  __shared__ double l_eh[2];
+  Views v(a);
+  make_views(a, blockIdx.y, v);
+  const PassInfo pi = pass_info(a, v);
+  if (pi.skip || a.d > v.q.W) return;
+  const int wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * kWaves + wave;
+  if (threadIdx.x < 2) l_eh[threadIdx.x] = 0.;
+  __syncthreads();
+  GpuSink sink;
+  sink.en_ = nullptr;
+  sink.post_[0] = sink.post_[1] = sink.post_[2] = nullptr;
+  sink.eh0 = sink.eh1 = 0.;
+  if (i <= v.q.L - a.d) {
+    OutCtx<GpuSink> x{v.m, v.q, v.in, v.out, pi.Z, Constraint{-1, -1, 0}, sink};
+    WaveCtx w;
+    w.lane = threadIdx.x & 63;
+    w.scr_m = scr + wave * 128;
+    w.scr_s = w.scr_m + 64;
+    heavy_outside_cell<OUT_TRAIN>(x, w, a.d, i, v.tmp, a.tmp_stride);
+  }
+  const double e0 = wave_sum(sink.eh0), e1 = wave_sum(sink.eh1);
+  if ((threadIdx.x & 63) == 0) {
+    if (e0 != 0.) atomicAdd(&v.row[pi.eh_off], e0);
+    if (e1 != 0.) atomicAdd(&v.row[pi.eh_off + 1], e1);
+  }
+}
+
+// ---- outside, finish diagonal d
+__global__ __launch_bounds__(kThreads) void k3_out_u(TrArgs a) {
+  extern __shared__ double l_stat[];   // n_theta + 2
+  Views v(a);
+  make_views(a, blockIdx.y, v);
+  const PassInfo pi = pass_info(a, v);
+  const int S = a.lay.S, d = a.d, nt = a.lay.n_theta;
+  if (pi.skip || d > v.q.W) return;
+  if ((int)(blockIdx.x * kThreads) >= (v.q.L - d + 1) * S) return;
+  double* l_en = l_stat;
+  double* l_eh = l_stat + nt;
+  for (int t = threadIdx.x; t < nt + 2; t += kThreads) l_stat[t] = 0.;
+  __syncthreads();
+  GpuSink sink;
+  sink.en_ = l_en;
+  sink.post_[0] = sink.post_[1] = sink.post_[2] = nullptr;
+  sink.eh0 = sink.eh1 = 0.;
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t < (v.q.L - d + 1) * S) {
+    const int i = t / S, s = t - i * S;
+    OutCtx<GpuSink> x{v.m, v.q, v.in, v.out, pi.Z, Constraint{-1, -1, 0}, sink};
+    HeavyOut H;
+    const bool lok = v.q.left_ok(i, d);
+    H.H1 = lok ? v.out.at(ST_1, d, i, s) : ELEMDP_NEG_INF;
+    H.H2 = lok ? v.tmp[0 * a.tmp_stride + (size_t)i * S + s] : ELEMDP_NEG_INF;
+    H.HP = v.q.pair_ok(i, d) ? v.tmp[1 * a.tmp_stride + (size_t)i * S + s] : ELEMDP_NEG_INF;
+    H.HL = v.tmp[2 * a.tmp_stride + (size_t)i * S + s];
+    outside_target_u<OUT_TRAIN>(x, d, i, s, H);
+  }
+  __syncthreads();
+  flush_stats(a, v, pi, sink, l_en, l_eh);
+}
+
+}  // namespace
+
+// Enqueues one whole train evaluation of the group on `st`.
+hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hipStream_t st) {
+  if (G <= 0) return hipSuccess;
+  TrArgs a = base;
+  const int S = a.lay.S;
+  const size_t stat_lds = sizeof(double) * (a.lay.n_theta + 2);
+  if (!a.no_rss) {
+    for (int d = 0; d <= Wmax; ++d) {
+      const int ncell = Lmax - d + 1;
+      if (ncell <= 0) break;
+      a.d = d;
+      hipLaunchKernelGGL(k3_in_heavy, dim3((ncell + kWaves - 1) / kWaves, G), dim3(kThreads), 0, st, a);
+      hipLaunchKernelGGL(k3_in_u, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+    }
+  }
+  hipLaunchKernelGGL(k3_in_ext, dim3(G), dim3(128), 0, st, a);
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && a.first_pass_only) break;
+    a.pass = pass;
+    hipLaunchKernelGGL(k3_out_ext, dim3(G), dim3(128), stat_lds, st, a);
+    if (!a.no_rss) {
+      for (int d = Wmax; d >= 0; --d) {
+        const int ncell = Lmax - d + 1;
+        if (ncell <= 0) continue;
+        a.d = d;
+        hipLaunchKernelGGL(k3_out_heavy, dim3((ncell + kWaves - 1) / kWaves, G), dim3(kThreads), 0, st, a);
+        hipLaunchKernelGGL(k3_out_u, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), stat_lds, st, a);
+      }
+    }
+  }
+  return hipGetLastError();
+}
+
+}  // namespace elemdp

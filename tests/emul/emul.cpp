@@ -164,8 +164,8 @@ void plan_finish(const Emu& E, HostPlan& P) {
 
 ModelView make_view(const AutomatonLayout& lay, const std::vector<int32_t>& ints, const double* theta, double l0, double l1,
                     double log_tau, bool no_prf, bool no_turn) {
-  ModelView m;
-  m.lay = lay; m.ints = ints.data(); m.big = ints.data(); m.theta = theta;
+  ModelView m(lay);
+  m.ints = ints.data(); m.big = ints.data(); m.theta = theta;
   m.lambda[0] = l0; m.lambda[1] = l1; m.log_tau = log_tau;
   m.lam_same = (l0 == l1);
   m.no_prf = no_prf;
