@@ -229,11 +229,12 @@ std::string Automaton::to_json() const {
   return o.str();
 }
 
-void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints) const {
+void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0) const {
   const int S_ = S(), m = M();
   AutomatonLayout& A = *lay;
   ints->clear();
   A.S = S_;
+  A.n_active = only_state0 ? 1 : S_;
   A.M = m;
   A.n_theta = n_theta();
   A.n_rows = n_rows();
@@ -263,20 +264,27 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints) const 
   auto tau_pair = [&](int par, int ch) { return (int)(states_[par].r == states_[ch].r && node_[states_[ch].r] == ')'); };
 
   Csr right(S_, 2), left(S_, 2), pair(S_, 2), rright(S_, 2), rleft(S_, 2), rpair(S_, 2);
+  auto keep = [&](std::initializer_list<int> ids) {
+    if (!only_state0) return true;
+    for (int v : ids) if (v != 0) return false;
+    return true;
+  };
   for (int s = 0; s < S_; ++s) {
-    for (int c : right_[s]) { right.add(s, {c, tau_right(s, c)}); rright.add(c, {s, tau_right(s, c)}); }
-    for (int c : left_[s]) { left.add(s, {c, tau_left(s, c)}); rleft.add(c, {s, tau_left(s, c)}); }
-    for (int c : pair_[s]) { pair.add(s, {c, tau_pair(s, c)}); rpair.add(c, {s, tau_pair(s, c)}); }
+    for (int c : right_[s]) if (keep({s, c})) { right.add(s, {c, tau_right(s, c)}); rright.add(c, {s, tau_right(s, c)}); }
+    for (int c : left_[s]) if (keep({s, c})) { left.add(s, {c, tau_left(s, c)}); rleft.add(c, {s, tau_left(s, c)}); }
+    for (int c : pair_[s]) if (keep({s, c})) { pair.add(s, {c, tau_pair(s, c)}); rpair.add(c, {s, tau_pair(s, c)}); }
   }
   Csr split(S_, 2), split1(S_, 2), split2(S_, 2);
   for (int s = 0; s < S_; ++s)
     for (auto const& p : splits(s)) {
+      if (!keep({s, p[0], p[1]})) continue;
       split.add(s, {p[0], p[1]});
       split1.add(p[0], {s, p[1]});
       split2.add(p[1], {s, p[0]});
     }
   Csr quad(S_, 3), quad1(S_, 3), quad2(S_, 3), quad3(S_, 3);
   for (auto const& q : quads_) {
+    if (!keep({q[0], q[1], q[2], q[3]})) continue;
     quad.add(q[0], {q[1], q[2], q[3]});
     quad1.add(q[1], {q[0], q[2], q[3]});
     quad2.add(q[2], {q[0], q[1], q[3]});
@@ -314,7 +322,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints) const 
 void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   AutomatonLayout& A = *lay;
   ints->clear();
-  A.S = 1; A.M = 1; A.n_theta = 0; A.n_rows = 0;
+  A.S = 1; A.n_active = 1; A.M = 1; A.n_theta = 0; A.n_rows = 0;
   A.s00 = A.s0m1 = A.s0m2 = 0;
   auto one = [&](int32_t v) { int32_t p = (int32_t)ints->size(); ints->push_back(v); return p; };
   A.st_l = one(0); A.st_r = one(0); A.st_is_loop = one(1);

@@ -46,7 +46,10 @@ class Automaton {
   std::string to_json() const;
 
   // Flattened tables for the kernels
-  void flatten(AutomatonLayout* lay, std::vector<int32_t>* ints) const;
+  // only_state0: keep only transitions among state 0 = (0,0), the background state 'z'.  Outside values of an
+  // evaluation whose only terminal is O(L,(0,0)) vanish on every other state (no transition leads from (0,0) to
+  // another state), so that pass can be swept on this one-state automaton over the same tables.
+  void flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0 = false) const;
 
  private:
   std::string pattern_, reg_;

@@ -22,7 +22,8 @@ enum TransType : int {
 // "fwd" lists enumerate children of a parent (inside direction), "rev" lists enumerate parents
 // of a child (outside direction, gather form).  Offsets below index ModelBlob::ints.
 struct AutomatonLayout {
-  int32_t S;        // interval states
+  int32_t S;        // interval states (= stride of the state axis of every table)
+  int32_t n_active; // states [0, n_active) are swept: S, or 1 in the restricted automaton of the no-motif pass
   int32_t M;        // pattern nodes incl. 'z' and 'o'
   int32_t n_theta;  // total theta entries (n_param - 2)
   int32_t n_rows;   // theta rows

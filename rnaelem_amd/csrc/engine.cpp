@@ -166,14 +166,15 @@ class Engine {
 
   Automaton au_;
   EnergyTables et_;
-  AutomatonLayout lay_, lay0_;
-  std::vector<int32_t> ints_, ints0_;
+  AutomatonLayout lay_, lay0_, layr_;
+  std::vector<int32_t> ints_, ints0_, intsr_;
+  bool linear_ok_ = true;
   int flags_, max_span_, max_iloop_;
   double min_bpp_, tau_;
   int device_ = 0, n_cu_ = 256;
   hipStream_t st_ = nullptr;
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
-  DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_, d_lay_, d_lay0_;
+  DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_, d_lay_, d_lay0_, d_layr_, d_intsr_;
   std::vector<double> theta_;  // log-probabilities of the last evaluation (softmax Jacobian)
 
   // batch
@@ -197,6 +198,7 @@ class Engine {
   bool opt_first_pass_only_ = false;
   bool opt_profile_ = false;
   int opt_pipeline_ = 3;   // 3 = diagonal-synchronous batch pipeline, 2 = fused one-workgroup-per-sequence kernel
+  int opt_schedule_ = 1;   // 1 = linear (ari pass + one-state nasi pass), 0 = the reference's two full passes
   int opt_group_ = 0;      // sequences swept in lockstep by the batch pipeline (0 = auto)
   DevBuf d_prof_;
  public:
@@ -218,7 +220,15 @@ Engine::Engine(const elemdp_model_desc& d)
   else if (par == "~A2007~") par = read_file(default_data_dir() + "/andronescu2007.elempar");
   parse_energy_text(par, &et_);
   au_.flatten(&lay_, &ints_);
+  au_.flatten(&layr_, &intsr_, true);
   flatten_trivial(&lay0_, &ints0_);
+  // the linear schedule needs state 0 = (0,0) to be closed under every transition family
+  linear_ok_ = au_.state(0).l == 0 && au_.state(0).r == 0;
+  for (int c : au_.right(0)) linear_ok_ = linear_ok_ && c == 0;
+  for (int c : au_.left(0)) linear_ok_ = linear_ok_ && c == 0;
+  for (int c : au_.pair(0)) linear_ok_ = linear_ok_ && c == 0;
+  for (auto const& sp : au_.splits(0)) linear_ok_ = linear_ok_ && sp[0] == 0 && sp[1] == 0;
+  for (auto const& q : au_.quads()) if (q[0] == 0) linear_ok_ = linear_ok_ && q[1] == 0 && q[2] == 0 && q[3] == 0;
 
   int ndev = 0;
   has_device_ = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
@@ -245,6 +255,9 @@ void Engine::init_device() {
   d_ints_.upload(ints_, st_);
   d_ints0_.upload(ints0_, st_);
   d_lay_.alloc(sizeof(AutomatonLayout));
+  d_layr_.alloc(sizeof(AutomatonLayout));
+  d_intsr_.upload(intsr_, st_);
+  HIP_OK(hipMemcpyAsync(d_layr_.as<void>(), &layr_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   d_lay0_.alloc(sizeof(AutomatonLayout));
   HIP_OK(hipMemcpyAsync(d_lay_.as<void>(), &lay_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   HIP_OK(hipMemcpyAsync(d_lay0_.as<void>(), &lay0_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
@@ -276,6 +289,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "profile") opt_profile_ = v != 0;
   else if (key == "pipeline") opt_pipeline_ = (int)v;
   else if (key == "group") opt_group_ = (int)v;
+  else if (key == "schedule") opt_schedule_ = (int)v;
   else throw ArgError("unknown option: " + key);
 }
 
@@ -619,6 +633,9 @@ void Engine::run_train_batch() {
   a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
   a.no_rss = (flags_ & ELEMDP_NO_RSS) ? 1 : 0;
   a.first_pass_only = opt_first_pass_only_ ? 1 : 0;
+  a.schedule = (opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_) ? 1 : 0;
+  a.layp_r = d_layr_.as<AutomatonLayout>();
+  a.ints_r = d_intsr_.as<int32_t>();
   a.plans = plan_.d_plans.as<SeqPlan>();
   a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>(); a.b.ndot = nullptr;
   a.okbits = d_okbits1_.as<uint32_t>();

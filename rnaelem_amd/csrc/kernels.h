@@ -89,6 +89,9 @@ struct TrArgs {
   const int32_t* ints;
   const double* params;
   int32_t no_prf, m_min, no_rss, first_pass_only;
+  int32_t schedule;     // 0 = the reference's two outside passes, 1 = ari-only + restricted nasi-only (linear)
+  int32_t restricted;   // set per launch: this pass sweeps the one-state automaton
+  const AutomatonLayout* layp_r; const int32_t* ints_r;
   const SeqPlan* plans;
   const int32_t* grp;   // grp[g] = batch index of the sequence in table slot g
   BatchArrays b;

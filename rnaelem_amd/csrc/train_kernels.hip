@@ -25,7 +25,7 @@ namespace {
 
 struct Views {
   ModelView m;
-  __device__ explicit Views(const TrArgs& a) : m(*a.layp) {}
+  __device__ explicit Views(const TrArgs& a) : m(a.restricted ? *a.layp_r : *a.layp) {}
   SeqView q;
   TableView in, out;
   int n;         // sequence index in the batch
@@ -38,8 +38,8 @@ __device__ __forceinline__ bool make_views(const TrArgs& a, int g, Views& v) {
   v.n = n;
   const SeqPlan p = a.plans[n];
   const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
-  v.m.ints = a.ints;
-  v.m.big = a.ints;
+  v.m.ints = a.restricted ? a.ints_r : a.ints;
+  v.m.big = v.m.ints;
   v.m.theta = a.params + sizeof(ParamBlock) / sizeof(double);
   v.m.lambda[0] = pb->lambda[0];
   v.m.lambda[1] = pb->lambda[1];
@@ -87,17 +87,21 @@ __global__ __launch_bounds__(kThreads) void k3_in_heavy(TrArgs a) {
 }
 
 // ---- inside, finish diagonal d: grid (ceil(ncell * S / kThreads), G), one lane per (cell, state)
+// SERIAL: the heavy sums are evaluated by the lane itself (used when only one state is swept, where a wave per
+// cell would leave 63 lanes idle: the BPP filter and the no-motif pass)
+template <bool SERIAL>
 __global__ __launch_bounds__(kThreads) void k3_in_u(TrArgs a) {
   Views v(a);
   make_views(a, blockIdx.y, v);
-  const int S = a.lay.S, d = a.d;
+  const int S = v.m.lay.S, NA = v.m.lay.n_active, d = a.d;
   if (d > v.q.W) return;
   const int t = blockIdx.x * kThreads + threadIdx.x;
-  if (t >= (v.q.L - d + 1) * S) return;
-  const int i = t / S, s = t - i * S;
+  if (t >= (v.q.L - d + 1) * NA) return;
+  const int i = t / NA, s = t - i * NA;
+  const Constraint c{-1, -1, 0};
+  if (SERIAL) { inside_target<false>(v.m, v.q, v.in, c, d, i, s); return; }
   const double HB = v.q.left_ok(i, d) ? v.in.at(ST_B, d, i, s) : ELEMDP_NEG_INF;
   const double HE = v.q.e_ok(i, d) ? v.tmp[(size_t)i * S + s] : ELEMDP_NEG_INF;
-  const Constraint c{-1, -1, 0};
   inside_target_u<false>(v.m, v.q, v.in, c, d, i, s, HB, HE);
 }
 
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void k3_in_u(TrArgs a) {
 __global__ __launch_bounds__(128) void k3_in_ext(TrArgs a) {
   Views v(a);
   make_views(a, blockIdx.x, v);
-  const int S = a.lay.S, tid = threadIdx.x;
+  const int S = v.m.lay.n_active, tid = threadIdx.x;
   const Constraint c{-1, -1, 0};
   for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00) ? 0. : ELEMDP_NEG_INF;
   __syncthreads();
@@ -126,13 +130,23 @@ __global__ __launch_bounds__(128) void k3_in_ext(TrArgs a) {
 }
 
 struct PassInfo { double Z; bool ari, nasi, skip; int en_off, eh_off; };
+// schedule 0 (reference, motif_trainer.hpp:209-225): pass 0 = terminals (ari,nasi), Z = Z(ari,nasi);
+//                                                     pass 1 = the label's mask, Z = Z(ari) or Z(nasi)
+// schedule 1 (linear): pass 0 = terminals ari only, Z = Z(ari); pass 1 = nasi only on the one-state automaton,
+//                      Z = Z(nasi); k3_combine turns the two statistics into those of schedule 0.
 __device__ __forceinline__ PassInfo pass_info(const TrArgs& a, const Views& v) {
   PassInfo pi;
   const int nt = a.lay.n_theta;
   const bool positive = a.plans[v.n].positive != 0;
   pi.skip = v.row[4] != 0.;
-  if (a.pass == 0) { pi.Z = v.row[0]; pi.ari = true; pi.nasi = true; }
-  else { pi.Z = positive ? v.row[1] : v.row[2]; pi.ari = positive; pi.nasi = !positive; }
+  if (a.schedule == 0) {
+    if (a.pass == 0) { pi.Z = v.row[0]; pi.ari = true; pi.nasi = true; }
+    else { pi.Z = positive ? v.row[1] : v.row[2]; pi.ari = positive; pi.nasi = !positive; }
+  } else {
+    if (a.pass == 0) { pi.Z = v.row[1]; pi.ari = true; pi.nasi = false; }
+    else { pi.Z = v.row[2]; pi.ari = false; pi.nasi = true; }
+    if (pi.Z == ELEMDP_NEG_INF) pi.skip = true;   // that component carries no probability mass
+  }
   pi.en_off = 6 + a.pass * nt;
   pi.eh_off = 6 + 2 * nt + 2 * a.pass;
   return pi;
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(128) void k3_out_ext(TrArgs a) {
   make_views(a, blockIdx.x, v);
   const PassInfo pi = pass_info(a, v);
   if (pi.skip) return;
-  const int S = a.lay.S, tid = threadIdx.x, nt = a.lay.n_theta;
+  const int S = v.m.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
   double* l_en = l_stat;
   double* l_eh = l_stat + nt;
   for (int t = tid; t < nt + 2; t += 128) l_stat[t] = 0.;
@@ -214,14 +228,15 @@ __global__ __launch_bounds__(kThreads) void k3_out_heavy(TrArgs a) {
 }
 
 // ---- outside, finish diagonal d
+template <bool SERIAL>
 __global__ __launch_bounds__(kThreads) void k3_out_u(TrArgs a) {
   extern __shared__ double l_stat[];   // n_theta + 2
   Views v(a);
   make_views(a, blockIdx.y, v);
   const PassInfo pi = pass_info(a, v);
-  const int S = a.lay.S, d = a.d, nt = a.lay.n_theta;
+  const int S = v.m.lay.S, NA = v.m.lay.n_active, d = a.d, nt = a.lay.n_theta;
   if (pi.skip || d > v.q.W) return;
-  if ((int)(blockIdx.x * kThreads) >= (v.q.L - d + 1) * S) return;
+  if ((int)(blockIdx.x * kThreads) >= (v.q.L - d + 1) * NA) return;
   double* l_en = l_stat;
   double* l_eh = l_stat + nt;
   for (int t = threadIdx.x; t < nt + 2; t += kThreads) l_stat[t] = 0.;
@@ -231,19 +246,42 @@ __global__ __launch_bounds__(kThreads) void k3_out_u(TrArgs a) {
   sink.post_[0] = sink.post_[1] = sink.post_[2] = nullptr;
   sink.eh0 = sink.eh1 = 0.;
   const int t = blockIdx.x * kThreads + threadIdx.x;
-  if (t < (v.q.L - d + 1) * S) {
-    const int i = t / S, s = t - i * S;
+  if (t < (v.q.L - d + 1) * NA) {
+    const int i = t / NA, s = t - i * NA;
     OutCtx<GpuSink> x{v.m, v.q, v.in, v.out, pi.Z, Constraint{-1, -1, 0}, sink};
+    if (SERIAL) outside_target<OUT_TRAIN>(x, d, i, s);
     HeavyOut H;
     const bool lok = v.q.left_ok(i, d);
     H.H1 = lok ? v.out.at(ST_1, d, i, s) : ELEMDP_NEG_INF;
     H.H2 = lok ? v.tmp[0 * a.tmp_stride + (size_t)i * S + s] : ELEMDP_NEG_INF;
     H.HP = v.q.pair_ok(i, d) ? v.tmp[1 * a.tmp_stride + (size_t)i * S + s] : ELEMDP_NEG_INF;
     H.HL = v.tmp[2 * a.tmp_stride + (size_t)i * S + s];
-    outside_target_u<OUT_TRAIN>(x, d, i, s, H);
+    if (!SERIAL) outside_target_u<OUT_TRAIN>(x, d, i, s, H);
   }
   __syncthreads();
   flush_stats(a, v, pi, sink, l_en, l_eh);
+}
+
+// schedule 1: statistics of the reference's two passes from those of the ari-only (A) and nasi-only (B) passes.
+// Outside values are linear in the terminal vector, so with p_a = Z(ari)/Z, p_n = Z(nasi)/Z the full-terminal
+// statistics are p_a * A + p_n * B, and the masked pass is A (label "has motif") or B.
+__global__ __launch_bounds__(kThreads) void k3_combine(TrArgs a, int G) {
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  const int n = a.grp[g];
+  double* row = a.seq_out + (size_t)n * a.out_stride;
+  if (row[4] != 0.) return;
+  const int nt = a.lay.n_theta;
+  const bool positive = a.plans[n].positive != 0;
+  const double pa = (row[1] == ELEMDP_NEG_INF) ? 0. : exp(row[1] - row[0]);
+  const double pn = (row[2] == ELEMDP_NEG_INF) ? 0. : exp(row[2] - row[0]);
+  for (int t = threadIdx.x; t < nt + 2; t += kThreads) {
+    double* A = (t < nt) ? &row[6 + t] : &row[6 + 2 * nt + (t - nt)];
+    double* B = (t < nt) ? &row[6 + nt + t] : &row[6 + 2 * nt + 2 + (t - nt)];
+    const double va = *A, vb = *B;
+    *A = pa * va + pn * vb;
+    *B = positive ? va : vb;
+  }
 }
 
 }  // namespace
@@ -252,32 +290,46 @@ __global__ __launch_bounds__(kThreads) void k3_out_u(TrArgs a) {
 hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hipStream_t st) {
   if (G <= 0) return hipSuccess;
   TrArgs a = base;
+  a.restricted = 0;
   const int S = a.lay.S;
   const size_t stat_lds = sizeof(double) * (a.lay.n_theta + 2);
+  const bool wave_heavy = S > 1;   // one state: the lane-serial form wastes nothing
   if (!a.no_rss) {
     for (int d = 0; d <= Wmax; ++d) {
       const int ncell = Lmax - d + 1;
       if (ncell <= 0) break;
       a.d = d;
-      hipLaunchKernelGGL(k3_in_heavy, dim3((ncell + kWaves - 1) / kWaves, G), dim3(kThreads), 0, st, a);
-      hipLaunchKernelGGL(k3_in_u, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+      if (wave_heavy) {
+        hipLaunchKernelGGL(k3_in_heavy, dim3((ncell + kWaves - 1) / kWaves, G), dim3(kThreads), 0, st, a);
+        hipLaunchKernelGGL(k3_in_u<false>, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+      } else {
+        hipLaunchKernelGGL(k3_in_u<true>, dim3((ncell + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+      }
     }
   }
   hipLaunchKernelGGL(k3_in_ext, dim3(G), dim3(128), 0, st, a);
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1 && a.first_pass_only) break;
     a.pass = pass;
+    a.restricted = (a.schedule == 1 && pass == 1) ? 1 : 0;
+    const bool serial = a.restricted || !wave_heavy;
+    const int na = a.restricted ? 1 : S;
     hipLaunchKernelGGL(k3_out_ext, dim3(G), dim3(128), stat_lds, st, a);
     if (!a.no_rss) {
       for (int d = Wmax; d >= 0; --d) {
         const int ncell = Lmax - d + 1;
         if (ncell <= 0) continue;
         a.d = d;
-        hipLaunchKernelGGL(k3_out_heavy, dim3((ncell + kWaves - 1) / kWaves, G), dim3(kThreads), 0, st, a);
-        hipLaunchKernelGGL(k3_out_u, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), stat_lds, st, a);
+        if (serial) {
+          hipLaunchKernelGGL(k3_out_u<true>, dim3((ncell * na + kThreads - 1) / kThreads, G), dim3(kThreads), stat_lds, st, a);
+        } else {
+          hipLaunchKernelGGL(k3_out_heavy, dim3((ncell + kWaves - 1) / kWaves, G), dim3(kThreads), 0, st, a);
+          hipLaunchKernelGGL(k3_out_u<false>, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), stat_lds, st, a);
+        }
       }
     }
   }
+  if (a.schedule == 1 && !a.first_pass_only) hipLaunchKernelGGL(k3_combine, dim3(G), dim3(kThreads), 0, st, a, G);
   return hipGetLastError();
 }
 
