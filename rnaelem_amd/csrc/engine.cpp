@@ -181,7 +181,7 @@ class Engine {
   int n_seq_ = 0, Lmax_ = 0, Wmax_ = 0, nword_max_ = 0;
   std::vector<SeqPlan> h_plans_;
   std::vector<int32_t> h_order_, h_seq_off_, h_qual_off_;
-  DevBuf d_seq_, d_ws_, d_unp_, d_ndot_, d_okbits0_, d_okbits1_, d_order_, d_ncanon_;
+  DevBuf d_seq_, d_ws_, d_unp_, d_ndot_, d_okbits0_, d_okbits1_, d_order_, d_ncanon_, d_zero_ws_;
   std::vector<double> h_lnbpp_;          // optional (keep_lnbpp)
   std::vector<int64_t> h_lnbpp_base_;
   PlanSet plan_;
@@ -519,6 +519,8 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   std::stable_sort(h_order_.begin(), h_order_.end(), [&](int a, int b) { return h_plans_[a].L > h_plans_[b].L; });
   d_seq_.upload(h_seq, st_);
   d_ws_.upload(h_ws, st_);
+  d_zero_ws_.alloc(sizeof(double) * pos_b);
+  HIP_OK(hipMemsetAsync(d_zero_ws_.as<void>(), 0, sizeof(double) * pos_b, st_));
   d_unp_.upload(h_unp, st_);
   if (fixmode) d_ndot_.upload(h_ndot, st_);
   d_okbits0_.alloc(sizeof(uint32_t) * bits_b);
@@ -568,30 +570,54 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
       }
       PlanSet tmp;
       build_planset(tmp, first, count, d_okbits0_.as<uint32_t>());
-      // table slots for S = 1
+      // table slots for S = 1, one per sequence of the chunk
+      slot_override_ = count;
       ensure_slots(1, false, count);
+      slot_override_ = 0;
+      if (n_slots_ < count) throw HipError("not enough device memory for the BPP filter tables");
       std::vector<int32_t> order(count);
       std::iota(order.begin(), order.end(), 0);
       std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return tmp.h[a2].L > tmp.h[b2].L; });
-      DevBuf d_order, d_out, d_lnbpp;
+      DevBuf d_order, d_rows, d_kept, d_lnbpp;
       d_order.upload(order, st_);
-      d_out.alloc(sizeof(double) * 2 * count);
-      DpArgs a = base_args(lay0_, d_ints0_.as<int32_t>(), d_params0_.as<double>(), tmp, d_okbits0_.as<uint32_t>(), 1);
+      const int stride = 10;
+      d_rows.alloc(sizeof(double) * stride * count);
+      d_kept.alloc(sizeof(int32_t) * count);
+      TrArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.lay = lay0_;
+      a.layp = d_lay0_.as<AutomatonLayout>();
+      a.ints = d_ints0_.as<int32_t>();
+      a.layp_r = a.layp; a.ints_r = a.ints;
+      a.params = d_params0_.as<double>();
       a.no_prf = 1;
-      a.no_rss = 0;
-      a.order = d_order.as<int32_t>();
-      a.seq_out = d_out.as<double>();
-      a.out_stride = 2;
-      a.okbits_out = d_okbits1_.as<uint32_t>();
-      a.log_min_bpp = std::log(min_bpp_);
-      if (opt_keep_lnbpp_) { d_lnbpp.alloc(sizeof(double) * cells); a.lnbpp_out = d_lnbpp.as<double>(); }
-      a.lds = lds_layout(lay0_, Lmax_, nword_max_, false);
-      HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
-      HIP_OK(launch_dp(DP_BPP, a, std::min(n_slots_, count), st_));
-      std::vector<double> out(2 * (size_t)count);
-      HIP_OK(hipMemcpyAsync(out.data(), d_out.as<void>(), sizeof(double) * 2 * count, hipMemcpyDeviceToHost, st_));
+      a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
+      a.plans = tmp.d_plans.as<SeqPlan>();
+      a.grp = d_order.as<int32_t>();
+      a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_zero_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>(); a.b.ndot = nullptr;
+      a.okbits = d_okbits0_.as<uint32_t>();
+      a.p = tmp.arrays();
+      a.band_in = d_band_in_.as<double>(); a.band_out = d_band_out_.as<double>();
+      a.ext_in = d_ext_in_.as<double>(); a.ext_out = d_ext_out_.as<double>();
+      a.band_stride = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1);
+      a.ext_stride = (size_t)(Lmax_ + 1);
+      a.tmp = d_tmp_.as<double>();
+      a.tmp_stride = a.ext_stride;
+      a.seq_out = d_rows.as<double>();
+      a.out_stride = stride;
+      BppOut o;
+      o.okbits_out = d_okbits1_.as<uint32_t>();
+      o.kept = d_kept.as<int32_t>();
+      o.log_min_bpp = std::log(min_bpp_);
+      o.lnbpp = nullptr;
+      if (opt_keep_lnbpp_) { d_lnbpp.alloc(sizeof(double) * cells); o.lnbpp = d_lnbpp.as<double>(); }
+      HIP_OK(hipMemsetAsync(d_rows.as<void>(), 0, sizeof(double) * stride * count, st_));
+      const int Lg = tmp.h[order[0]].L;
+      HIP_OK(launch_bpp_group(a, o, count, Lg, std::min(Lg, max_span_), st_));
+      std::vector<int32_t> kept(count);
+      HIP_OK(hipMemcpyAsync(kept.data(), d_kept.as<void>(), sizeof(int32_t) * count, hipMemcpyDeviceToHost, st_));
       HIP_OK(hipStreamSynchronize(st_));
-      for (int k = 0; k < count; ++k) h_plans_[first + k].bpp_eff = out[2 * k + 1] / (double)ncanon[first + k];
+      for (int k = 0; k < count; ++k) h_plans_[first + k].bpp_eff = (double)kept[k] / (double)ncanon[first + k];
       if (opt_keep_lnbpp_) {
         const size_t base = h_lnbpp_.size();
         h_lnbpp_.resize(base + cells);

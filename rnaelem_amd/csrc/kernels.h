@@ -103,6 +103,13 @@ struct TrArgs {
   double* seq_out; int32_t out_stride;
   int32_t pass, d;
 };
+struct BppOut {
+  uint32_t* okbits_out;   // filtered pair mask (batch-level, bits_base indexing)
+  int32_t* kept;          // kept pairs per sequence (index = position in the plan array)
+  double* lnbpp;          // optional ln BPP per cell (cell_base indexing) or null
+  double log_min_bpp;
+};
+hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax, int Wmax, hipStream_t st);
 hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hipStream_t st);
 
 hipError_t launch_mask(const BatchArrays& b, const SeqPlan* plans, int n_seq, int min_span, bool write_bits, uint32_t* okbits,

@@ -167,6 +167,7 @@ __device__ __forceinline__ void flush_stats(const TrArgs& a, const Views& v, con
 }
 
 // ---- exterior chain of an outside pass (runs before the band of that pass)
+template <int MODE>
 __global__ __launch_bounds__(128) void k3_out_ext(TrArgs a) {
   extern __shared__ double l_stat[];   // n_theta + 2
   Views v(a);
@@ -190,10 +191,10 @@ __global__ __launch_bounds__(128) void k3_out_ext(TrArgs a) {
   }
   __syncthreads();
   for (int i = v.q.L - 1; i >= 0; --i) {
-    for (int s = tid; s < S; s += 128) outside_ext_target<OUT_TRAIN>(x, i, s);
+    for (int s = tid; s < S; s += 128) outside_ext_target<MODE>(x, i, s);
     __syncthreads();
   }
-  flush_stats(a, v, pi, sink, l_en, l_eh);
+  if (MODE == OUT_TRAIN) flush_stats(a, v, pi, sink, l_en, l_eh);
 }
 
 // ---- outside, heavy sums of diagonal d
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void k3_out_heavy(TrArgs a) {
 }
 
 // ---- outside, finish diagonal d
-template <bool SERIAL>
+template <bool SERIAL, int MODE>
 __global__ __launch_bounds__(kThreads) void k3_out_u(TrArgs a) {
   extern __shared__ double l_stat[];   // n_theta + 2
   Views v(a);
@@ -249,17 +250,17 @@ __global__ __launch_bounds__(kThreads) void k3_out_u(TrArgs a) {
   if (t < (v.q.L - d + 1) * NA) {
     const int i = t / NA, s = t - i * NA;
     OutCtx<GpuSink> x{v.m, v.q, v.in, v.out, pi.Z, Constraint{-1, -1, 0}, sink};
-    if (SERIAL) outside_target<OUT_TRAIN>(x, d, i, s);
+    if (SERIAL) outside_target<MODE>(x, d, i, s);
     HeavyOut H;
     const bool lok = v.q.left_ok(i, d);
     H.H1 = lok ? v.out.at(ST_1, d, i, s) : ELEMDP_NEG_INF;
     H.H2 = lok ? v.tmp[0 * a.tmp_stride + (size_t)i * S + s] : ELEMDP_NEG_INF;
     H.HP = v.q.pair_ok(i, d) ? v.tmp[1 * a.tmp_stride + (size_t)i * S + s] : ELEMDP_NEG_INF;
     H.HL = v.tmp[2 * a.tmp_stride + (size_t)i * S + s];
-    if (!SERIAL) outside_target_u<OUT_TRAIN>(x, d, i, s, H);
+    if (!SERIAL) outside_target_u<MODE>(x, d, i, s, H);
   }
   __syncthreads();
-  flush_stats(a, v, pi, sink, l_en, l_eh);
+  if (MODE == OUT_TRAIN) flush_stats(a, v, pi, sink, l_en, l_eh);
 }
 
 // schedule 1: statistics of the reference's two passes from those of the ari-only (A) and nasi-only (B) passes.
@@ -284,7 +285,65 @@ __global__ __launch_bounds__(kThreads) void k3_combine(TrArgs a, int G) {
   }
 }
 
+// ---- K1 tail: ln BPP of every candidate pair and the min_bpp threshold (energy_model.hpp:195-201, 257-261)
+__global__ __launch_bounds__(kThreads) void k3_bpp_threshold(TrArgs a, BppOut o) {
+  __shared__ int cnt[kWaves];
+  Views v(a);
+  make_views(a, blockIdx.x, v);
+  const SeqPlan p = a.plans[v.n];
+  const int L = p.L, W = p.W;
+  const int ncell = (L + 1) * (W + 1), nword = (ncell + 31) / 32;
+  const double Z = v.in.o(L, 0);
+  int kept = 0;
+  for (int wd = threadIdx.x; wd < nword; wd += kThreads) {
+    const uint32_t in_bits = v.q.okbits[wd];
+    uint32_t out_bits = 0;
+    for (int k = 0; k < 32; ++k) {
+      if (!((in_bits >> k) & 1u)) continue;
+      const int cc = wd * 32 + k;
+      const int i = cc / (W + 1), d = cc - i * (W + 1);
+      const double ln = (v.in.at(ST_P, d, i, 0) + v.out.at(ST_P, d, i, 0)) - Z;
+      if (o.lnbpp) o.lnbpp[p.cell_base + cc] = ln;
+      if (o.log_min_bpp <= ln) { out_bits |= 1u << k; ++kept; }
+    }
+    o.okbits_out[p.bits_base + wd] = out_bits;
+  }
+  for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off, 64);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = kept;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < kWaves; ++w) tot += cnt[w];
+    o.kept[v.n] = tot;
+  }
+}
+
 }  // namespace
+
+// K1 for one group: plain McCaskill inside / outside through the one-state automaton, then the threshold.
+hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax, int Wmax, hipStream_t st) {
+  if (G <= 0) return hipSuccess;
+  TrArgs a = base;
+  a.restricted = 0;
+  for (int d = 0; d <= Wmax; ++d) {
+    const int ncell = Lmax - d + 1;
+    if (ncell <= 0) break;
+    a.d = d;
+    hipLaunchKernelGGL(k3_in_u<true>, dim3((ncell + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+  }
+  hipLaunchKernelGGL(k3_in_ext, dim3(G), dim3(128), 0, st, a);
+  a.schedule = 1;   // "nasi only": terminal O(L, 0), Z = O(L, 0)
+  a.pass = 1;
+  hipLaunchKernelGGL(k3_out_ext<OUT_NONE>, dim3(G), dim3(128), sizeof(double) * 2, st, a);
+  for (int d = Wmax; d >= 0; --d) {
+    const int ncell = Lmax - d + 1;
+    if (ncell <= 0) continue;
+    a.d = d;
+    hipLaunchKernelGGL((k3_out_u<true, OUT_NONE>), dim3((ncell + kThreads - 1) / kThreads, G), dim3(kThreads), sizeof(double) * 2, st, a);
+  }
+  hipLaunchKernelGGL(k3_bpp_threshold, dim3(G), dim3(kThreads), 0, st, a, o);
+  return hipGetLastError();
+}
 
 // Enqueues one whole train evaluation of the group on `st`.
 hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hipStream_t st) {
@@ -314,17 +373,17 @@ hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hip
     a.restricted = (a.schedule == 1 && pass == 1) ? 1 : 0;
     const bool serial = a.restricted || !wave_heavy;
     const int na = a.restricted ? 1 : S;
-    hipLaunchKernelGGL(k3_out_ext, dim3(G), dim3(128), stat_lds, st, a);
+    hipLaunchKernelGGL(k3_out_ext<OUT_TRAIN>, dim3(G), dim3(128), stat_lds, st, a);
     if (!a.no_rss) {
       for (int d = Wmax; d >= 0; --d) {
         const int ncell = Lmax - d + 1;
         if (ncell <= 0) continue;
         a.d = d;
         if (serial) {
-          hipLaunchKernelGGL(k3_out_u<true>, dim3((ncell * na + kThreads - 1) / kThreads, G), dim3(kThreads), stat_lds, st, a);
+          hipLaunchKernelGGL((k3_out_u<true, OUT_TRAIN>), dim3((ncell * na + kThreads - 1) / kThreads, G), dim3(kThreads), stat_lds, st, a);
         } else {
           hipLaunchKernelGGL(k3_out_heavy, dim3((ncell + kWaves - 1) / kWaves, G), dim3(kThreads), 0, st, a);
-          hipLaunchKernelGGL(k3_out_u<false>, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), stat_lds, st, a);
+          hipLaunchKernelGGL((k3_out_u<false, OUT_TRAIN>), dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), stat_lds, st, a);
         }
       }
     }
