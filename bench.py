@@ -3,7 +3,8 @@
 
 One "step" = one evaluation of (fn, gr) over the whole batch = per sequence K2 (inside) + 2 x K3
 (outside + expected counts), the cached K1 (BPP filter) excluded, then ONE RCCL all-reduce of the
-partial sums when N > 1.  Workload = BASELINE config C/D: 10 000 synthetic RNAs of L = 200, pattern
+partial sums when N > 1.  The roofline "launch" is the whole diagonal pipeline of one evaluation (all
+k3_* launches, timed with HIP events on the engine's stream: elemdp_last_timing()[1]).  Workload = BASELINE config C/D: 10 000 synthetic RNAs of L = 200, pattern
 '((.*.))', x0 with lambda = (1,1) so the energy terms are exercised; the 10 000 sequences are sharded
 over the N ranks (strong scaling, as the metric is quoted).
 
@@ -127,6 +128,13 @@ def main():
     alg = algorithmic_bytes_per_seq(args.seq_len, S) * n_local
     k_s = float(np.mean(kern_ms)) / 1e3
     achieved = alg / k_s / 1e9
+    # HBM traffic per sequence from the committed rocprofv3 --pmc pass (profiles/), scaled to this launch
+    traffic, traffic_src = None, None
+    tf = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        t = json.load(open(tf))
+        if t.get("seq_len") == args.seq_len and t.get("pattern") == PATTERN:
+            traffic, traffic_src = t["hbm_bytes_per_seq"] * n_local, t["source"]
     line = {
         "metric": "train-iter seqs/sec (inside+outside)", "value": args.n_seq * args.steps / dt, "unit": "seq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -136,8 +144,9 @@ def main():
             "sharding": "contiguous ranges per rank, 1 all-reduce of %d doubles per step" % eng.partial_len(),
             "bpp_filter": "cached (computed once at load_batch, %.1f s incl. plan)" % t_load, "fn": fn, "n_skipped": nsk},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                     "traffic": None, "kernel": eng.kernel_name(), "kernel_ms": k_s * 1e3,
-                     "algorithmic_bytes_per_launch": alg},
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "k3_* diagonal pipeline of one evaluation (sum of all launches; dominant %s)" % eng.kernel_name(),
+                     "kernel_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg},
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(seqs, quals, x, eng.n_param - 2)

