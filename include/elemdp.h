@@ -146,7 +146,8 @@ typedef struct {
 int elemdp_scan(elemdp_handle* h, const double* x, int32_t n_param, elemdp_scan_out* out);
 
 /* timing of the last train evaluation, measured with HIP events on the engine's stream:
- * ms[0] = whole evaluation, ms[1] = the fused inside/outside kernel only */
+ * ms[0] = whole evaluation, ms[1] = the DP pipeline only (all kernels of the inside/outside sweeps),
+ * ms[2] = number of sequences the scaled-linear pipeline handed to the log-space pipeline (range check) */
 int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n);
 /* debug: summed shader-clock cycles per phase of the last train evaluation when option "profile" = 1:
  * [stage, inside band, inside exterior, outside exterior, outside band, queue/other] */

@@ -240,8 +240,9 @@ class Engine:
         return recs, en
 
     def last_timing(self):
-        ms = np.zeros(2)
-        self._lib.elemdp_last_timing(self._h, _dp(ms), 2)
+        """[ms whole evaluation, ms DP pipeline, sequences re-evaluated in log space]"""
+        ms = np.zeros(3)
+        self._lib.elemdp_last_timing(self._h, _dp(ms), 3)
         return ms
 
     def profile(self):

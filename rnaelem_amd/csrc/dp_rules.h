@@ -95,6 +95,7 @@ struct ModelView {
   const int32_t* ints;   // automaton blob: per-state attributes + unary lists (first lay.n_small ints; LDS on the GPU)
   const int32_t* big;    // the whole blob incl. the tuple lists of rules 2 / 6c / 7 (global memory on the GPU)
   const double* theta;   // n_theta log-probabilities
+  const double* lin = nullptr;  // linear parameter block of the scaled-linear train pipeline (lin_rules.h) or null
   double lambda[2];
   double log_tau;
   int32_t lam_same;      // lambda[0] == lambda[1]
@@ -131,6 +132,11 @@ struct SeqView {
   const int32_t* by_left_off;  const int32_t* by_left_idx;
   const int32_t* by_right_off; const int32_t* by_right_idx;
   const uint8_t* item_in;    // item belongs to the inside enumeration (u1+u2 <= C; see SURVEY §7 quirk ii)
+  // scaled-linear train pipeline (lin_rules.h): exp of the position weights; exp(lambda_k * term) of the structural
+  // terms [k*5+term][cell] and of the interior-loop items [k][item], recomputed per evaluation
+  const double* ews = nullptr;
+  const double* xwc = nullptr; size_t xwc_stride = 0;
+  const double* xwi = nullptr; size_t xwi_stride = 0;
 
   ELEMDP_HD int cell(int i, int d) const { return i * (W + 1) + d; }
   ELEMDP_HD bool pair_ok(int i, int d) const {  // is_parsable<ST_P>

@@ -30,6 +30,7 @@
 #include "energy_tables.h"
 #include "host_prep.h"
 #include "kernels.h"
+#include "lin_params.h"
 
 namespace elemdp {
 namespace {
@@ -145,7 +146,7 @@ class Engine {
   void seq_stats(double* out, int n);
   void debug_tables(double* inside, double* outside, double* inside_o, double* outside_o, double* ENo, double* ENx, double* EH);
   void batch_pairs(int idx, uint8_t* kept, double* lnbpp, int cap);
-  double last_ms[2] = {0, 0};
+  double last_ms[3] = {0, 0, 0};
 
  private:
   void upload_params(const double* x, const AutomatonLayout& lay, bool trivial);
@@ -159,6 +160,8 @@ class Engine {
   void ensure_slots(int S, bool scan, int n_want);
   void run_train(bool first_pass_only);
   void run_train_batch();
+  void run_lin_batch();
+  TrArgs log_pipeline_args();
   void init_device();
   void require_device() const;
   bool has_device_ = false;
@@ -197,8 +200,19 @@ class Engine {
   bool opt_keep_lnbpp_ = false;
   bool opt_first_pass_only_ = false;
   bool opt_profile_ = false;
-  int opt_pipeline_ = 3;   // 3 = diagonal-synchronous batch pipeline, 2 = fused one-workgroup-per-sequence kernel
+  // 4 = scaled-linear batch pipeline (lin_kernels.hip), 3 = log-space batch pipeline, 2 = fused one-workgroup-per-sequence kernel
+  int opt_pipeline_ = 4;
+  // scaled-linear pipeline
+  AutomatonLayout layc_;                 // the one-state automaton over compact (S = 1) tables
+  std::vector<double> h_lin_;            // linear parameter block of the last evaluation
+  std::vector<uint8_t> h_seq_;           // base codes of the batch (table export)
+  int64_t n_cells_total_ = 0;
+  bool tables_linear_ = false;           // the resident tables hold scaled linear values (debug_tables converts)
+  int n_flagged_last_ = 0;
+  DevBuf d_ews_, d_xwc_, d_xwi_, d_lin_, d_layc_, d_zs_, d_flagged_, d_band_in0_, d_band_out0_, d_ext_in0_, d_ext_out0_;
+  int lin_slots_ = 0;
   int opt_schedule_ = 1;   // 1 = linear (ari pass + one-state nasi pass), 0 = the reference's two full passes
+  int opt_dbg_ = 0;        // timing experiments (LinArgs::dbg); results are wrong when set
   int opt_group_ = 0;      // sequences swept in lockstep by the batch pipeline (0 = auto)
   DevBuf d_prof_;
  public:
@@ -222,6 +236,8 @@ Engine::Engine(const elemdp_model_desc& d)
   au_.flatten(&lay_, &ints_);
   au_.flatten(&layr_, &intsr_, true);
   flatten_trivial(&lay0_, &ints0_);
+  layc_ = layr_;
+  layc_.S = 1;   // same one-state lists, compact tables
   // the linear schedule needs state 0 = (0,0) to be closed under every transition family
   linear_ok_ = au_.state(0).l == 0 && au_.state(0).r == 0;
   for (int c : au_.right(0)) linear_ok_ = linear_ok_ && c == 0;
@@ -259,6 +275,9 @@ void Engine::init_device() {
   d_intsr_.upload(intsr_, st_);
   HIP_OK(hipMemcpyAsync(d_layr_.as<void>(), &layr_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   d_lay0_.alloc(sizeof(AutomatonLayout));
+  d_layc_.alloc(sizeof(AutomatonLayout));
+  HIP_OK(hipMemcpyAsync(d_layc_.as<void>(), &layc_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
+  d_lin_.alloc(sizeof(double) * (kLinEth + au_.n_theta() + 1));
   HIP_OK(hipMemcpyAsync(d_lay_.as<void>(), &lay_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   HIP_OK(hipMemcpyAsync(d_lay0_.as<void>(), &lay0_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   d_params_.alloc(sizeof(ParamBlock) + sizeof(double) * (au_.n_theta() + 1));
@@ -290,6 +309,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "pipeline") opt_pipeline_ = (int)v;
   else if (key == "group") opt_group_ = (int)v;
   else if (key == "schedule") opt_schedule_ = (int)v;
+  else if (key == "dbg") opt_dbg_ = (int)v;
   else throw ArgError("unknown option: " + key);
 }
 
@@ -322,6 +342,8 @@ void Engine::upload_params(const double* x, const AutomatonLayout& lay, bool) {
   std::memcpy(blob.data(), &pb, sizeof(pb));
   std::copy(theta_.begin(), theta_.end(), blob.begin() + sizeof(ParamBlock) / sizeof(double));
   HIP_OK(hipMemcpyAsync(d_params_.as<void>(), blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+  make_lin_params(lay_, ints_.data(), theta_.data(), tau_, (flags_ & ELEMDP_NO_PROFILE) != 0, &h_lin_);
+  HIP_OK(hipMemcpyAsync(d_lin_.as<void>(), h_lin_.data(), h_lin_.size() * sizeof(double), hipMemcpyHostToDevice, st_));
   HIP_OK(hipStreamSynchronize(st_));  // blob is a local
   (void)lay;
 }
@@ -519,6 +541,13 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   std::stable_sort(h_order_.begin(), h_order_.end(), [&](int a, int b) { return h_plans_[a].L > h_plans_[b].L; });
   d_seq_.upload(h_seq, st_);
   d_ws_.upload(h_ws, st_);
+  {
+    std::vector<double> h_ews(h_ws.size());
+    for (size_t k = 0; k < h_ws.size(); ++k) h_ews[k] = std::exp(h_ws[k]);
+    d_ews_.upload(h_ews, st_);
+    HIP_OK(hipStreamSynchronize(st_));
+  }
+  h_seq_ = h_seq;
   d_zero_ws_.alloc(sizeof(double) * pos_b);
   HIP_OK(hipMemsetAsync(d_zero_ws_.as<void>(), 0, sizeof(double) * pos_b, st_));
   d_unp_.upload(h_unp, st_);
@@ -638,16 +667,19 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   plan_.d_plans.upload(plan_.h, st_);
   for (int k = 0; k < n; ++k) h_plans_[k] = plan_.h[k];
   d_order_.upload(h_order_, st_);
+  n_cells_total_ = 0;
+  for (auto const& pl : h_plans_) n_cells_total_ += (int64_t)(pl.L + 1) * (pl.W + 1);
+  d_xwc_.alloc(sizeof(double) * 10 * (size_t)n_cells_total_);
+  d_xwi_.alloc(sizeof(double) * (2 * (size_t)plan_.n_items + 1));
+  d_flagged_.alloc(sizeof(int32_t) * ((size_t)n + 1));
+  lin_slots_ = 0;
   out_stride_ = 6 + 2 * au_.n_theta() + 4;
   d_seq_out_.alloc(sizeof(double) * (size_t)out_stride_ * n);
   n_slots_ = 0;
   HIP_OK(hipStreamSynchronize(st_));
 }
 
-void Engine::run_train_batch() {
-  slot_override_ = opt_group_ > 0 ? opt_group_ : 4096;
-  ensure_slots(au_.S(), false, n_seq_);
-  slot_override_ = 0;
+TrArgs Engine::log_pipeline_args() {
   const int S = au_.S();
   TrArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -674,6 +706,15 @@ void Engine::run_train_batch() {
   a.tmp_stride = a.ext_stride;
   a.seq_out = d_seq_out_.as<double>();
   a.out_stride = out_stride_;
+  return a;
+}
+
+void Engine::run_train_batch() {
+  slot_override_ = opt_group_ > 0 ? opt_group_ : 4096;
+  ensure_slots(au_.S(), false, n_seq_);
+  slot_override_ = 0;
+  TrArgs a = log_pipeline_args();
+  tables_linear_ = false;
   HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n_seq_, st_));
   HIP_OK(hipEventRecord(ev_[1], st_));
   for (int g0 = 0; g0 < n_seq_; g0 += n_slots_) {
@@ -686,8 +727,101 @@ void Engine::run_train_batch() {
   HIP_OK(launch_reduce(d_seq_out_.as<double>(), out_stride_, n_seq_, au_.n_theta(), d_partial_.as<double>(), st_));
 }
 
+// The scaled-linear pipeline (lin_kernels.hip); sequences it flags (partition function outside the double range, or a
+// structurally empty component) are re-evaluated by the log-space pipeline, which applies the reference's skip rule.
+void Engine::run_lin_batch() {
+  slot_override_ = opt_group_ > 0 ? opt_group_ : 4096;
+  ensure_slots(au_.S(), false, n_seq_);
+  slot_override_ = 0;
+  const int S = au_.S();
+  const bool sched1 = opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_ && lay_.s00 == 0;
+  const size_t band0 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext0 = (size_t)(Lmax_ + 1);
+  if (lin_slots_ != n_slots_) {
+    d_zs_.alloc(sizeof(double) * 4 * n_slots_);
+    d_band_in0_.alloc(sizeof(double) * band0 * n_slots_);
+    d_band_out0_.alloc(sizeof(double) * band0 * n_slots_);
+    d_ext_in0_.alloc(sizeof(double) * ext0 * n_slots_);
+    d_ext_out0_.alloc(sizeof(double) * ext0 * n_slots_);
+    lin_slots_ = n_slots_;
+  }
+  LinArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.lay = lay_;
+  a.layp = d_lay_.as<AutomatonLayout>();
+  a.ints = d_ints_.as<int32_t>();
+  a.params = d_params_.as<double>();
+  a.lin = d_lin_.as<double>();
+  a.no_prf = (flags_ & ELEMDP_NO_PROFILE) ? 1 : 0;
+  a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
+  a.no_rss = (flags_ & ELEMDP_NO_RSS) ? 1 : 0;
+  a.plans = plan_.d_plans.as<SeqPlan>();
+  a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>(); a.b.ndot = nullptr;
+  a.ews = d_ews_.as<double>();
+  a.okbits = d_okbits1_.as<uint32_t>();
+  a.p = plan_.arrays();
+  a.xwc = d_xwc_.as<double>(); a.xwc_stride = (size_t)n_cells_total_;
+  a.xwi = d_xwi_.as<double>(); a.xwi_stride = (size_t)plan_.n_items;
+  a.band_in = d_band_in_.as<double>(); a.band_out = d_band_out_.as<double>();
+  a.ext_in = d_ext_in_.as<double>(); a.ext_out = d_ext_out_.as<double>();
+  a.band_stride = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;
+  a.ext_stride = (size_t)(Lmax_ + 1) * S;
+  a.band_in0 = sched1 ? d_band_in0_.as<double>() : nullptr;
+  a.ext_in0 = sched1 ? d_ext_in0_.as<double>() : nullptr;
+  a.band0_stride = band0; a.ext0_stride = ext0;
+  a.zs = d_zs_.as<double>();
+  a.seq_out = d_seq_out_.as<double>();
+  a.out_stride = out_stride_;
+  a.schedule = sched1 ? 1 : 0;
+  a.flagged = d_flagged_.as<int32_t>();
+  a.dbg = opt_dbg_;
+  a.n_stage = (lay_.n_ints <= 4096) ? lay_.n_ints : lay_.n_small;
+  LinArgs c = a;   // the no-motif pass: one-state automaton, compact tables
+  c.lay = layc_;
+  c.layp = d_layc_.as<AutomatonLayout>();
+  c.ints = d_intsr_.as<int32_t>();
+  c.band_in = d_band_in0_.as<double>(); c.band_out = d_band_out0_.as<double>();
+  c.ext_in = d_ext_in0_.as<double>(); c.ext_out = d_ext_out0_.as<double>();
+  c.band_stride = band0; c.ext_stride = ext0;
+  c.band_in0 = nullptr; c.ext_in0 = nullptr;
+  c.n_stage = (layc_.n_ints <= 4096) ? layc_.n_ints : layc_.n_small;
+  HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n_seq_, st_));
+  HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
+  HIP_OK(hipEventRecord(ev_[1], st_));
+  LinWeightArgs w;
+  const PlanArrays pa = plan_.arrays();
+  w.e_stack = pa.e_stack; w.e_ext = pa.e_ext; w.e_ml = pa.e_ml; w.e_close = pa.e_close; w.e_hp = pa.e_hp;
+  w.items = pa.items;
+  w.n_cells = (size_t)n_cells_total_; w.n_items = (size_t)plan_.n_items;
+  w.params = d_params_.as<double>();
+  w.xwc = d_xwc_.as<double>(); w.xwi = d_xwi_.as<double>();
+  HIP_OK(launch_lin_weights(w, st_));
+  for (int g0 = 0; g0 < n_seq_; g0 += n_slots_) {
+    const int G = std::min(n_slots_, n_seq_ - g0);
+    a.grp = c.grp = d_order_.as<int32_t>() + g0;
+    const int Lg = h_plans_[h_order_[g0]].L;
+    HIP_OK(launch_lin_group(a, c, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, st_));
+  }
+  int32_t n_flagged = 0;
+  HIP_OK(hipMemcpyAsync(&n_flagged, d_flagged_.as<void>(), sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+  HIP_OK(hipStreamSynchronize(st_));
+  n_flagged_last_ = n_flagged;
+  tables_linear_ = n_flagged == 0;
+  if (n_flagged > 0) {
+    TrArgs t = log_pipeline_args();
+    for (int g0 = 0; g0 < n_flagged; g0 += n_slots_) {
+      const int G = std::min(n_slots_, n_flagged - g0);
+      t.grp = d_flagged_.as<int32_t>() + 1 + g0;
+      HIP_OK(launch_train_group(t, G, Lmax_, Wmax_, st_));
+    }
+  }
+  HIP_OK(hipEventRecord(ev_[2], st_));
+  HIP_OK(launch_reduce(d_seq_out_.as<double>(), out_stride_, n_seq_, au_.n_theta(), d_partial_.as<double>(), st_));
+}
+
 void Engine::run_train(bool) {
+  if (opt_pipeline_ == 4) { run_lin_batch(); return; }
   if (opt_pipeline_ == 3) { run_train_batch(); return; }
+  tables_linear_ = false;
   ensure_slots(au_.S(), false, n_seq_);
   DpArgs a = base_args(lay_, d_ints_.as<int32_t>(), d_params_.as<double>(), plan_, d_okbits1_.as<uint32_t>(), au_.S());
   a.order = d_order_.as<int32_t>();
@@ -731,6 +865,7 @@ void Engine::train_partial(const double* x, int n_param_in, void* partial, bool 
   HIP_OK(hipEventElapsedTime(&ms_k, ev_[1], ev_[2]));
   last_ms[0] = ms_all;
   last_ms[1] = ms_k;
+  last_ms[2] = (opt_pipeline_ == 4) ? (double)n_flagged_last_ : 0.;
 }
 
 void Engine::train_finish(const double* r, double* fn, double* gr, double* sum_eff, int32_t* n_skipped) {
@@ -783,15 +918,24 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
     HIP_OK(hipMemcpy(h.data(), src.as<void>(), sizeof(double) * cnt, hipMemcpyDeviceToHost));
     return h;
   };
-  auto reorder = [&](const std::vector<double>& t, double* dst) {  // [e][d][i][s] -> [i][d][e][s]
-    for (int i = 0; i <= L; ++i) for (int d = 0; d <= W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s)
+  // the scaled-linear pipeline keeps Boltzmann weights times a power-of-two scale (lin_rules.h): export logs
+  const bool lin = tables_linear_;
+  std::vector<double> cum(L + 1, 0.);   // log2 of prod_{p<j} psb[base(p)]
+  if (lin) for (int t = 0; t < L; ++t) cum[t + 1] = cum[t] + h_lin_[kLinPl2 + h_seq_[p.seq_base + t]];
+  const double ln2 = 0.69314718055994530942, NEGINF = -std::numeric_limits<double>::infinity();
+  auto conv = [&](double v, double scale_log2) { return !lin ? v : (v > 0. ? std::log(v) - scale_log2 * ln2 : NEGINF); };
+  auto reorder = [&](const std::vector<double>& t, double* dst, bool outside_tab) {  // [e][d][i][s] -> [i][d][e][s]
+    for (int i = 0; i <= L; ++i) for (int d = 0; d <= W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s) {
+      double sc = (i + d <= L) ? cum[i + d] - cum[i] : 0.;
+      if (outside_tab) sc = cum[L] - sc;
       dst[(((size_t)i * (W + 1) + d) * 7 + e) * S + s] =
-          (i + d <= L) ? t[(((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s] : -std::numeric_limits<double>::infinity();
+          (i + d <= L) ? conv(t[(((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s], sc) : NEGINF;
+    }
   };
-  if (inside) reorder(fetch(d_band_in_, band), inside);
-  if (outside) reorder(fetch(d_band_out_, band), outside);
-  if (inside_o) { auto h = fetch(d_ext_in_, ext); std::copy(h.begin(), h.end(), inside_o); }
-  if (outside_o) { auto h = fetch(d_ext_out_, ext); std::copy(h.begin(), h.end(), outside_o); }
+  if (inside) reorder(fetch(d_band_in_, band), inside, false);
+  if (outside) reorder(fetch(d_band_out_, band), outside, true);
+  if (inside_o) { auto h = fetch(d_ext_in_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) inside_o[(size_t)j * S + s] = conv(h[(size_t)j * S + s], cum[j]); }
+  if (outside_o) { auto h = fetch(d_ext_out_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) outside_o[(size_t)j * S + s] = conv(h[(size_t)j * S + s], cum[L] - cum[j]); }
   std::vector<double> o = fetch(d_seq_out_, out_stride_);
   const int nt = au_.n_theta();
   if (ENo) std::copy(o.begin() + 6, o.begin() + 6 + nt, ENo);
@@ -1019,7 +1163,7 @@ int elemdp_scan(elemdp_handle* h, const double* x, int32_t n_param, elemdp_scan_
 }
 int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n) {
   if (!h || !ms) return ELEMDP_EINVAL;
-  for (int k = 0; k < n && k < 2; ++k) ms[k] = h->e->last_ms[k];
+  for (int k = 0; k < n && k < 3; ++k) ms[k] = h->e->last_ms[k];
   return ELEMDP_OK;
 }
 int elemdp_debug_profile(elemdp_handle* h, double* cycles, int32_t n) {

@@ -109,6 +109,46 @@ struct BppOut {
   double* lnbpp;          // optional ln BPP per cell (cell_base indexing) or null
   double log_min_bpp;
 };
+// arguments of the scaled-linear train pipeline (lin_kernels.hip, rules in lin_rules.h)
+struct LinArgs {
+  AutomatonLayout lay;            // automaton swept by this launch: the full one, or the compact one-state one (S = 1)
+  const AutomatonLayout* layp;
+  const int32_t* ints;
+  const double* params;           // ParamBlock + log theta (lambda, lam_same)
+  const double* lin;              // linear parameter block (lin_rules.h: tau, psb, log2 psb, eth)
+  int32_t no_prf, m_min, no_rss;
+  const SeqPlan* plans;
+  const int32_t* grp;             // grp[g] = batch index of the sequence in table slot g
+  BatchArrays b;
+  const double* ews;              // exp of the position weights
+  const uint32_t* okbits;
+  PlanArrays p;
+  const double* xwc; size_t xwc_stride;   // exp(lambda_k * structural term): [k*5+term][cell]
+  const double* xwi; size_t xwi_stride;   // exp(lambda_k * tsc) of the interior-loop items: [k][item]
+  double* band_in; double* band_out; double* ext_in; double* ext_out;   // tables swept by this launch
+  size_t band_stride, ext_stride;
+  double* band_in0; double* ext_in0;      // compact copies of state (0,0) written by the inside kernels (or null)
+  size_t band0_stride, ext0_stride;
+  double* zs;                     // per slot: mantissas of Z(ari,nasi), Z(ari), Z(nasi), and log2 of the sequence's scale
+  double* seq_out; int32_t out_stride;
+  int32_t schedule, pass, d;
+  int32_t cpb;                    // cells per workgroup = kThreads / S
+  int32_t* flagged;               // [0] = number of flagged sequences, [1..] = their batch indices
+  int32_t n_stage;                // ints of the automaton blob staged in LDS: n_ints (whole blob) or n_small
+  int32_t dbg;                    // timing experiments only: bit 0 skip split sums, 1 skip item sums, 2 skip the unary phase
+};
+struct LinWeightArgs {
+  const double* e_stack; const double* e_ext; const double* e_ml; const double* e_close; const double* e_hp;
+  const LoopItem* items;
+  size_t n_cells, n_items;
+  const double* params;
+  double* xwc; double* xwi;
+};
+hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st);
+// one whole train evaluation of a group; `full` sweeps the pattern automaton, `compact` (schedule 1) the one-state
+// automaton of the no-motif pass over the compact tables
+hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, int Lmax, int Wmax, bool first_pass_only,
+                            hipStream_t st);
 hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax, int Wmax, hipStream_t st);
 hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hipStream_t st);
 

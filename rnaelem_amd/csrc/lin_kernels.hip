@@ -1,0 +1,629 @@
+// lin_kernels.hip -- the train evaluation in the scaled linear semiring (rules: lin_rules.h), gfx950.
+//
+// Same diagonal-synchronous batch pipeline as train_kernels.hip (a group of G sequences swept in
+// lockstep, kernel boundaries = dependencies), but a term of the O(L W^2) rules is one FMA on two
+// table loads instead of an exp, so the pipeline is bound by the table traffic, not by the VALU:
+//   k4_weights   once per evaluation: exp(lambda_k * structural term) of every pair cell / loop item
+//   k4_in(d)     ONE launch per diagonal: workgroup = cpb = 256/S consecutive cells of one sequence;
+//                heavy sums (rules 2, 6c) with one lane per (cell, state tuple) accumulated into LDS,
+//                then one lane per (cell, state) finishes P,E,M,B,1,2,L (heavy and unary phase fused:
+//                the heavy sums never touch HBM)
+//   k4_in_ext    exterior chain, partition functions, objective, range check (flags the sequence)
+//   k4_out_ext / k4_out(d)   outside pass with expected counts; pass 0 sweeps the pattern automaton with
+//                the "has motif" terminals, pass 1 the one-state automaton over COMPACT (S = 1) tables
+//                that k4_in / k4_in_ext fill on the side (coalesced instead of 1-in-S strided)
+//   k4_combine   statistics of the reference's two passes (motif_trainer.hpp:209-225) from those two
+// Reference path: RNAelemTrainDP::operator(), RNAelem/motif_trainer.hpp:124-272.
+#include <hip/hip_runtime.h>
+
+#ifndef ELEMDP_KCI
+#define ELEMDP_KCI 4
+#endif
+#ifndef ELEMDP_KCO
+#define ELEMDP_KCO 2
+#endif
+#ifndef ELEMDP_KIB
+#define ELEMDP_KIB 4
+#endif
+#include "kernels.h"
+#include "lin_rules.h"
+#include "wave_gather.h"
+
+namespace elemdp {
+namespace {
+
+// statistics sink of the linear pipeline: emission counts into LDS, energy statistics lane-private
+struct LinSink {
+  double* en_;
+  double eh0, eh1;
+  __device__ __forceinline__ void en(int idx, double w) { atomicAdd(&en_[idx], w); }
+  __device__ __forceinline__ void eh(int k, double w) { if (k) eh1 += w; else eh0 += w; }
+};
+
+struct LViews {
+  ModelView m;
+  __device__ explicit LViews(const LinArgs& a) : m(*a.layp) {}
+  SeqView q;
+  TableView in, out;
+  int n;
+  double* row;
+  double* zs;
+};
+
+__device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) {
+  const int n = a.grp[g];
+  v.n = n;
+  const SeqPlan p = a.plans[n];
+  const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
+  v.m.ints = a.ints;
+  v.m.big = a.ints;
+  v.m.theta = a.params + sizeof(ParamBlock) / sizeof(double);
+  v.m.lin = a.lin;
+  v.m.lambda[0] = pb->lambda[0];
+  v.m.lambda[1] = pb->lambda[1];
+  v.m.log_tau = pb->log_tau;
+  v.m.lam_same = pb->lam_same;
+  v.m.no_prf = a.no_prf;
+  v.m.m_min = a.m_min;
+  SeqView& q = v.q;
+  q.L = p.L; q.W = p.W; q.C = p.C;
+  q.seq = a.b.seq + p.seq_base;
+  q.ws = a.b.ws + p.pos_base;
+  q.ews = a.ews + p.pos_base;
+  q.unp = a.b.unp + p.pos_base;
+  q.okbits = a.okbits + p.bits_base;
+  q.dmin = a.p.dmin + p.dmin_base;
+  q.e_stack = a.p.e_stack + p.cell_base; q.e_ext = a.p.e_ext + p.cell_base; q.e_ml = a.p.e_ml + p.cell_base;
+  q.e_close = a.p.e_close + p.cell_base; q.e_hp = a.p.e_hp + p.cell_base;
+  q.xwc = a.xwc + p.cell_base; q.xwc_stride = a.xwc_stride;
+  q.xwi = a.xwi + p.item_base; q.xwi_stride = a.xwi_stride;
+  q.items = a.p.items + p.item_base; q.item_in = a.p.item_in + p.item_base;
+  q.by_outer_off = a.p.by_outer_off + p.off_base;
+  q.by_inner_off = a.p.by_inner_off + p.off_base; q.by_inner_idx = a.p.by_inner_idx + p.item_base;
+  q.by_left_off = a.p.by_left_off + p.off_base; q.by_left_idx = a.p.by_left_idx + p.item_base;
+  q.by_right_off = a.p.by_right_off + p.off_base; q.by_right_idx = a.p.by_right_idx + p.item_base;
+  v.in.band = a.band_in + (size_t)g * a.band_stride;
+  v.in.ext = a.ext_in + (size_t)g * a.ext_stride;
+  v.out.band = a.band_out + (size_t)g * a.band_stride;
+  v.out.ext = a.ext_out + (size_t)g * a.ext_stride;
+  v.in.L = v.out.L = p.L; v.in.W = v.out.W = p.W; v.in.S = v.out.S = a.lay.S;
+  v.row = a.seq_out + (size_t)n * a.out_stride;
+  v.zs = a.zs + (size_t)g * 4;
+}
+
+// ---- exp(lambda_k * term) of all structural terms and loop items of the batch, once per evaluation
+__global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
+  const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
+  const double l0 = pb->lambda[0], l1 = pb->lambda[1];
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t c = (size_t)blockIdx.x * kThreads + threadIdx.x; c < a.n_cells; c += stride) {
+    const double e0 = a.e_stack[c], e1 = a.e_ext[c], e2 = a.e_ml[c], e3 = a.e_close[c], e4 = a.e_hp[c];
+    a.xwc[0 * a.n_cells + c] = lin_weight(l0, e0); a.xwc[5 * a.n_cells + c] = lin_weight(l1, e0);
+    a.xwc[1 * a.n_cells + c] = lin_weight(l0, e1); a.xwc[6 * a.n_cells + c] = lin_weight(l1, e1);
+    a.xwc[2 * a.n_cells + c] = lin_weight(l0, e2); a.xwc[7 * a.n_cells + c] = lin_weight(l1, e2);
+    a.xwc[3 * a.n_cells + c] = lin_weight(l0, e3); a.xwc[8 * a.n_cells + c] = lin_weight(l1, e3);
+    a.xwc[4 * a.n_cells + c] = lin_weight(l0, e4); a.xwc[9 * a.n_cells + c] = lin_weight(l1, e4);
+  }
+  for (size_t n = (size_t)blockIdx.x * kThreads + threadIdx.x; n < a.n_items; n += stride) {
+    const double t = a.items[n].tsc;
+    a.xwi[n] = lin_weight(l0, t);
+    a.xwi[a.n_items + n] = lin_weight(l1, t);
+  }
+}
+
+// Heavy sums are evaluated from LDS: for a chunk of split points the operand rows of ALL cells of the workgroup are
+// staged with one coalesced, fully unrolled batch of loads (consecutive cells of a diagonal are contiguous in the
+// [e][d][i][s] layout: one segment of nc*S doubles per (plane, split point)), then one lane per (cell, state tuple)
+// multiplies out of LDS.  Global loads are thereby independent of the tuple structure (every element is fetched
+// once per workgroup, 2*kChunk loads in flight per lane) and the dependent chain per diagonal stays short.
+constexpr int kChunkIn = ELEMDP_KCI;    // split points per staging round, inside  (2 segments each)
+constexpr int kChunkOut = ELEMDP_KCO;   // split points per staging round, outside (4 segments each)
+
+// Item sums without serial chains: the interior-loop items of all cells of the workgroup (CSR ranges given by
+// `range(c, &first, &last)`) form one flat list; work item = (item, state tuple), tuple fastest, so the lanes of a wave
+// read the same three table rows.  Every lane takes kItemBatch work items at a time and runs them stage by stage
+// (index -> item record -> table operands -> product), so that the dependent loads of one work item overlap with those
+// of the others.  Loads of a stage are unconditional (work items past the end are clamped to the last one and dropped
+// in the final stage).  `cnts`, `pre` (cpb+1) and `base` are LDS ints.
+constexpr int kItemBatch = ELEMDP_KIB;
+struct ItemSlot {
+  int c, n, t, idx;   // cell of the workgroup, position in the CSR order, state tuple, item index
+  LoopItem it;
+  double x0, x1, x2, xw, aux;
+  bool ok;
+};
+template <class RangeFn, class F1, class F2, class F3, class F4>
+__device__ __forceinline__ void for_block_items(int nc, int cpb, int nq, int tid, int* cnts, int* pre, int* base, RangeFn range,
+                                                F1 load_index, F2 load_item, F3 load_operands, F4 finish) {
+  if (tid < cpb) {
+    int c0 = 0, c1 = 0;
+    if (tid < nc) range(tid, c0, c1);
+    base[tid] = c0;
+    cnts[tid] = (c1 > c0) ? c1 - c0 : 0;
+  }
+  __syncthreads();
+  if (tid < cpb) {
+    int p = 0;
+    for (int c = 0; c < tid; ++c) p += cnts[c];
+    pre[tid] = p;
+    if (tid == cpb - 1) pre[cpb] = p + cnts[tid];
+  }
+  __syncthreads();
+  const int total = pre[nc] * nq;
+  for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
+    ItemSlot sl[kItemBatch];
+#pragma unroll
+    for (int u = 0; u < kItemBatch; ++u) {
+      const int w = w0 + u * kThreads;
+      sl[u].ok = w < total;
+      const int wc = sl[u].ok ? w : total - 1;
+      const int il = wc / nq;
+      sl[u].t = wc - il * nq;
+      int lo = 0, hi = nc - 1;   // the cell owning item il: largest c with pre[c] <= il
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pre[mid] <= il) lo = mid; else hi = mid - 1;
+      }
+      sl[u].c = lo;
+      sl[u].n = base[lo] + (il - pre[lo]);
+    }
+#pragma unroll
+    for (int u = 0; u < kItemBatch; ++u) load_index(sl[u]);
+#pragma unroll
+    for (int u = 0; u < kItemBatch; ++u) load_item(sl[u]);
+#pragma unroll
+    for (int u = 0; u < kItemBatch; ++u) load_operands(sl[u]);
+#pragma unroll
+    for (int u = 0; u < kItemBatch; ++u) if (sl[u].ok) finish(sl[u]);
+  }
+  __syncthreads();
+}
+
+// ---- inside, diagonal d: grid (ceil(ncell / cpb), G); dynamic LDS = (2 + 2*kChunkIn) * cpb * S doubles + cpb ints
+template <bool BIG>
+__global__ __launch_bounds__(kThreads) void k4_in(LinArgs a) {
+  extern __shared__ double lds[];
+  LViews v(a);
+  make_lviews(a, blockIdx.y, v);
+  const AutomatonLayout& A = v.m.lay;
+  const int S = A.S, NA = A.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x;
+  if (d > v.q.W) return;
+  const int ncell = v.q.L - d + 1, i0 = blockIdx.x * cpb;
+  if (i0 >= ncell) return;
+  const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
+  const int CS = cpb * S, ncS = nc * S;
+  double* hb = lds;
+  double* he = hb + CS;
+  double* st1 = he + CS;               // [kChunkIn][CS]  rows 1(i, i+a, .)
+  double* st2 = st1 + kChunkIn * CS;   // [kChunkIn][CS]  rows 2(i+a, j, .)
+  int* dm = reinterpret_cast<int*>(st2 + kChunkIn * CS);
+  int* cnts = dm + cpb;
+  int* pre = cnts + cpb;
+  int* base = pre + cpb + 1;
+  int* lints = base + cpb;   // the automaton blob (or its per-state / unary part) staged in LDS
+  for (int t = tid; t < a.n_stage; t += kThreads) lints[t] = a.ints[t];
+  v.m.ints = lints;
+  if (BIG) v.m.big = lints;
+  const int32_t* G = v.m.big;
+  for (int t = tid; t < 2 * CS; t += kThreads) lds[t] = 0.;
+  if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
+  __syncthreads();
+  // rule 2: B(i,j,tgt) = sum_{a = k-i} sum_tuples 1(i,i+a,s1) * 2(i+a,j,s2);  1(i,i+a,.) = 0 for a < dmin[i]
+  int a_lo = d;
+  for (int c = 0; c < nc; ++c) { const int x = dm[c]; if (x > 0 && x < a_lo) a_lo = x; }
+  const int nsp = A.n_split;
+  const double* B = v.in.band;
+  if (a.dbg & 1) a_lo = d;
+  for (int a0 = a_lo; a0 < d; a0 += kChunkIn) {
+    const int kc = (kChunkIn < d - a0) ? kChunkIn : d - a0;
+    if (tid < ncS) {
+#pragma unroll
+      for (int u = 0; u < kChunkIn; ++u) {
+        const int aa = a0 + ((u < kc) ? u : 0);
+        const double x1 = B[v.in.idx(ST_1, aa, i0, 0) + tid];
+        const double x2 = B[v.in.idx(ST_2, d - aa, i0 + aa, 0) + tid];
+        st1[u * CS + tid] = x1;
+        st2[u * CS + tid] = x2;
+      }
+    }
+    __syncthreads();
+    for (int w = tid; w < nc * nsp; w += kThreads) {
+      const int c = w / nsp, t = w - c * nsp;
+      const int x = dm[c];
+      if (x <= 0 || x > d) continue;   // !left_ok(i, d)
+      const int o1 = c * S + G[A.split_ent + 2 * t], o2 = c * S + G[A.split_ent + 2 * t + 1];
+      double acc = 0.;
+      for (int u = 0; u < kc; ++u) acc = fma(st1[u * CS + o1], st2[u * CS + o2], acc);
+      if (acc != 0.) atomicAdd(&hb[c * S + G[A.split_tgt + t]], acc);
+    }
+    __syncthreads();
+  }
+  // rule 6c: E(i,j,tgt) += sum_items P(k,l,s1) * L(i,k,s2) * L(l,j,s3) * exp(lambda * tsc)
+  const int nq = (a.dbg & 2) ? 0 : A.n_quad;
+  for_block_items(
+      nc, cpb, nq, tid, cnts, pre, base,
+      [&](int c, int& c0, int& c1) {
+        const int i = i0 + c;
+        if (v.q.e_ok(i, d)) { const int cell = v.q.cell(i, d); c0 = v.q.by_outer_off[cell]; c1 = v.q.by_outer_off[cell + 1]; }
+      },
+      [&](ItemSlot& x) { x.idx = x.n; },
+      [&](ItemSlot& x) {
+        x.it = v.q.items[x.idx];
+        x.aux = v.q.item_in[x.idx] ? 1. : 0.;
+        x.xw = xw_item(v.q, lamk(v.m, G[A.quad_tgt + x.t]), x.idx);
+      },
+      [&](ItemSlot& x) {
+        const int i = i0 + x.c, j = i + d;
+        x.x0 = B[v.in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad_ent + 3 * x.t])];
+        x.x1 = B[v.in.idx(ST_L, x.it.k - i, i, G[A.quad_ent + 3 * x.t + 1])];
+        x.x2 = B[v.in.idx(ST_L, j - x.it.l, x.it.l, G[A.quad_ent + 3 * x.t + 2])];
+      },
+      [&](ItemSlot& x) {
+        const double term = x.x0 * (x.x1 * x.x2) * x.xw;
+        if (x.aux != 0. && term != 0.) atomicAdd(&he[x.c * S + G[A.quad_tgt + x.t]], term);
+      });
+  if (tid < nc * NA && !(a.dbg & 4)) {
+    const int c = tid / NA, s = tid - c * NA;
+    const int i = i0 + c;
+    const Cell7 r = lin_inside_target_u(v.m, v.q, v.in, d, i, s, hb[c * S + s], he[c * S + s]);
+    if (a.band_in0 != nullptr && s == A.s00) {   // compact copy of state (0,0) for the no-motif pass
+      TableView t0;
+      t0.band = a.band_in0 + (size_t)blockIdx.y * a.band0_stride;
+      t0.ext = nullptr; t0.L = v.in.L; t0.W = v.in.W; t0.S = 1;
+      t0.at(ST_P, d, i, 0) = r.vP; t0.at(ST_E, d, i, 0) = r.vE; t0.at(ST_M, d, i, 0) = r.vM; t0.at(ST_B, d, i, 0) = r.vB;
+      t0.at(ST_1, d, i, 0) = r.v1; t0.at(ST_2, d, i, 0) = r.v2; t0.at(ST_L, d, i, 0) = r.vL;
+    }
+  }
+}
+
+__device__ __forceinline__ bool out_of_range(double z) { return !(z > 0.) || !(z < HUGE_VAL); }
+
+// ---- exterior chain of the inside pass, partition functions, objective (one workgroup of 128 per sequence)
+__global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
+  LViews v(a);
+  make_lviews(a, blockIdx.x, v);
+  const int S = v.m.lay.n_active, tid = threadIdx.x, L = v.q.L;
+  double* ext0 = a.ext_in0 ? a.ext_in0 + (size_t)blockIdx.x * a.ext0_stride : nullptr;
+  for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00) ? 1. : 0.;
+  if (ext0 && tid == 0) ext0[0] = 1.;
+  __syncthreads();
+  for (int j = 1; j <= L; ++j) {
+    for (int s = tid; s < S; s += 128) {
+      lin_inside_ext_target(v.m, v.q, v.in, j, s);
+      if (ext0 && s == a.lay.s00) ext0[j] = v.in.o(j, s);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double Zo = lin_part(v.m, v.in, true, true), Za = lin_part(v.m, v.in, true, false), Zn = lin_part(v.m, v.in, false, true);
+    double sl = 0.;   // log2 of prod_p psb[base(p)]
+    for (int p = 0; p < L; ++p) sl += a.lin[kLinPl2 + v.q.seq[p]];
+    const double ln2 = 0.69314718055994530942;
+    v.zs[0] = Zo; v.zs[1] = Za; v.zs[2] = Zn; v.zs[3] = sl;
+    const SeqPlan p = a.plans[v.n];
+    v.row[0] = (Zo > 0.) ? log(Zo) - sl * ln2 : ELEMDP_NEG_INF;
+    v.row[1] = (Za > 0.) ? log(Za) - sl * ln2 : ELEMDP_NEG_INF;
+    v.row[2] = (Zn > 0.) ? log(Zn) - sl * ln2 : ELEMDP_NEG_INF;
+    if (out_of_range(Zo) || out_of_range(Za) || out_of_range(Zn)) {
+      // outside the double range (or a structurally empty component): the log-space pipeline re-evaluates the
+      // sequence and applies the reference's skip rule (motif_trainer.hpp:211-215)
+      v.row[3] = 0.; v.row[4] = 2.; v.row[5] = 0.;
+      const int k = atomicAdd(&a.flagged[0], 1);
+      a.flagged[1 + k] = v.n;
+    } else {
+      v.row[3] = p.positive ? log1p(Zn / Za) : log1p(Za / Zn);   // Z(ari,nasi) - Z(label)
+      v.row[4] = 0.;
+      v.row[5] = p.bpp_eff;
+    }
+  }
+}
+
+struct LPass { double invZ; bool ari, nasi, skip; int en_off, eh_off; };
+// schedule 0 (reference): pass 0 = terminals (ari,nasi), pass 1 = the label's mask; schedule 1: ari only / nasi only
+__device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
+  LPass pi;
+  const int nt = a.lay.n_theta;
+  const bool positive = a.plans[v.n].positive != 0;
+  pi.skip = v.row[4] != 0.;
+  double Z;
+  if (a.schedule == 0) {
+    if (a.pass == 0) { Z = v.zs[0]; pi.ari = true; pi.nasi = true; }
+    else { Z = positive ? v.zs[1] : v.zs[2]; pi.ari = positive; pi.nasi = !positive; }
+  } else {
+    if (a.pass == 0) { Z = v.zs[1]; pi.ari = true; pi.nasi = false; }
+    else { Z = v.zs[2]; pi.ari = false; pi.nasi = true; }
+  }
+  pi.invZ = 1. / Z;
+  pi.en_off = 6 + a.pass * nt;
+  pi.eh_off = 6 + 2 * nt + 2 * a.pass;
+  return pi;
+}
+
+__device__ __forceinline__ void lflush(const LinArgs& a, const LViews& v, const LPass& pi, LinSink& sink, double* l_en, double* l_eh,
+                                       int nthreads) {
+  const double e0 = wave_sum(sink.eh0), e1 = wave_sum(sink.eh1);
+  if ((threadIdx.x & 63) == 0) {
+    if (e0 != 0.) atomicAdd(&l_eh[0], e0);
+    if (e1 != 0.) atomicAdd(&l_eh[1], e1);
+  }
+  __syncthreads();
+  const int nt = a.lay.n_theta;
+  for (int t = threadIdx.x; t < nt; t += nthreads) {
+    const double val = l_en[t];
+    if (val != 0.) atomicAdd(&v.row[pi.en_off + t], val);
+  }
+  if (threadIdx.x < 2 && l_eh[threadIdx.x] != 0.) atomicAdd(&v.row[pi.eh_off + threadIdx.x], l_eh[threadIdx.x]);
+}
+
+// ---- exterior chain of an outside pass
+template <int MODE>
+__global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
+  extern __shared__ double l_stat[];   // n_theta + 2
+  LViews v(a);
+  make_lviews(a, blockIdx.x, v);
+  const LPass pi = lpass(a, v);
+  if (pi.skip) return;
+  const int S = v.m.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
+  double* l_en = l_stat;
+  double* l_eh = l_stat + nt;
+  for (int t = tid; t < nt + 2; t += 128) l_stat[t] = 0.;
+  LinSink sink;
+  sink.en_ = l_en;
+  sink.eh0 = sink.eh1 = 0.;
+  LinOutCtx<LinSink> x{v.m, v.q, v.in, v.out, pi.invZ, sink};
+  for (int s = tid; s < S; s += 128) {
+    double t = 0.;
+    if (pi.nasi && s == a.lay.s00) t = 1.;
+    if (pi.ari && (s == a.lay.s0m1 || s == a.lay.s0m2)) t = 1.;
+    v.out.o(v.q.L, s) = t;
+  }
+  __syncthreads();
+  for (int i = v.q.L - 1; i >= 0; --i) {
+    for (int s = tid; s < S; s += 128) lin_outside_ext_target<MODE>(x, i, s);
+    __syncthreads();
+  }
+  if (MODE == OUT_TRAIN) lflush(a, v, pi, sink, l_en, l_eh, 128);
+}
+
+// ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
+template <int MODE, bool BIG>
+__global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
+  extern __shared__ double lds[];
+  LViews v(a);
+  make_lviews(a, blockIdx.y, v);
+  const LPass pi = lpass(a, v);
+  const AutomatonLayout& A = v.m.lay;
+  const int S = A.S, NA = A.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = A.n_theta;
+  if (pi.skip || d > v.q.W) return;
+  const int L = v.q.L, W = v.q.W;
+  const int ncell = L - d + 1, i0 = blockIdx.x * cpb;
+  if (i0 >= ncell) return;
+  const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
+  const int CS = cpb * S, ncS = nc * S;
+  double* h1 = lds;
+  double* h2 = h1 + CS;
+  double* hp = h2 + CS;
+  double* hl = hp + CS;
+  double* l_en = hl + CS;
+  double* l_eh = l_en + nt;
+  double* sOB1 = l_eh + 2;               // [kChunkOut][CS] out B(i, i+d+b, .)      (H1)
+  double* sI2 = sOB1 + kChunkOut * CS;   //                 in  2(j, j+b, .)
+  double* sOB2 = sI2 + kChunkOut * CS;   //                 out B(i-b, j, .)        (H2)
+  double* sI1 = sOB2 + kChunkOut * CS;   //                 in  1(i-b, i, .)
+  int* dm = reinterpret_cast<int*>(sI1 + kChunkOut * CS);
+  int* cnts = dm + cpb;
+  int* pre = cnts + cpb;
+  int* base = pre + cpb + 1;
+  int* lints = base + cpb;
+  for (int t = tid; t < a.n_stage; t += kThreads) lints[t] = a.ints[t];
+  v.m.ints = lints;
+  if (BIG) v.m.big = lints;
+  const int32_t* G = v.m.big;
+  for (int t = tid; t < 4 * CS + nt + 2; t += kThreads) lds[t] = 0.;
+  if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
+  __syncthreads();
+  LinSink sink;
+  sink.en_ = l_en;
+  sink.eh0 = sink.eh1 = 0.;
+  const TableView& in = v.in;
+  const TableView& out = v.out;
+  const int nsp = A.n_split, nq = (a.dbg & 2) ? 0 : A.n_quad;
+  // H1: 1(i,j,tgt) as the "1" child of B(i,j+b,par), sibling 2(j,j+b,s2);  H2: 2(i,j,tgt) as the "2" child of
+  // B(i-b,j,par), sibling 1(i-b,i,s1);  b = 1 .. W-d.  Cells whose parent would leave [0,L] are masked.
+  bool any_lok = false;
+  for (int c = 0; c < nc; ++c) { const int x = dm[c]; any_lok = any_lok || (x > 0 && x <= d); }
+  const int bmax = (any_lok && !(a.dbg & 1)) ? W - d : 0;
+  for (int b0 = 1; b0 <= bmax; b0 += kChunkOut) {
+    const int kc = (kChunkOut < bmax - b0 + 1) ? kChunkOut : bmax - b0 + 1;
+    if (tid < ncS) {
+      const int i = i0 + tid / S;
+#pragma unroll
+      for (int u = 0; u < kChunkOut; ++u) {
+        const int bb = b0 + ((u < kc) ? u : 0);
+        const bool ok1 = i + d + bb <= L, ok2 = i - bb >= 0;
+        const int ia = ok1 ? i0 : 0, ib = ok2 ? i0 - bb : 0;   // (clamped: the load itself must stay inside the plane)
+        const int r1 = ok1 ? tid : 0, r2 = ok2 ? tid : 0;
+        const double x1 = out.band[out.idx(ST_B, d + bb, ia, 0) + r1];
+        const double x2 = in.band[in.idx(ST_2, bb, ok1 ? i0 + d : 0, 0) + r1];
+        const double x3 = out.band[out.idx(ST_B, d + bb, ib, 0) + r2];
+        const double x4 = in.band[in.idx(ST_1, bb, ib, 0) + r2];
+        sOB1[u * CS + tid] = ok1 ? x1 : 0.;
+        sI2[u * CS + tid] = ok1 ? x2 : 0.;
+        sOB2[u * CS + tid] = ok2 ? x3 : 0.;
+        sI1[u * CS + tid] = ok2 ? x4 : 0.;
+      }
+    }
+    __syncthreads();
+    for (int w = tid; w < nc * nsp; w += kThreads) {
+      const int c = w / nsp, t = w - c * nsp;
+      const int x = dm[c];
+      if (x <= 0 || x > d) continue;   // !left_ok(i, d)
+      {
+        const int o1 = c * S + G[A.split1_ent + 2 * t], o2 = c * S + G[A.split1_ent + 2 * t + 1];
+        double acc = 0.;
+        for (int u = 0; u < kc; ++u) acc = fma(sOB1[u * CS + o1], sI2[u * CS + o2], acc);
+        if (acc != 0.) atomicAdd(&h1[c * S + G[A.split1_tgt + t]], acc);
+      }
+      {
+        const int o1 = c * S + G[A.split2_ent + 2 * t], o2 = c * S + G[A.split2_ent + 2 * t + 1];
+        double acc = 0.;
+        for (int u = 0; u < kc; ++u) acc = fma(sOB2[u * CS + o1], sI1[u * CS + o2], acc);
+        if (acc != 0.) atomicAdd(&h2[c * S + G[A.split2_tgt + t]], acc);
+      }
+    }
+    __syncthreads();
+  }
+  // HP / HL: the three roles of a cell in the interior loops around it (rule 6c)
+  const double* IB = in.band;
+  const double* OB = out.band;
+  // inner pair P(i,j,tgt) of E(it.i,it.j,par), with the energy statistic of the rule
+  for_block_items(
+      nc, cpb, nq, tid, cnts, pre, base,
+      [&](int c, int& n0, int& n1) {
+        const int i = i0 + c;
+        if (v.q.pair_ok(i, d)) { const int cell = v.q.cell(i, d); n0 = v.q.by_inner_off[cell]; n1 = v.q.by_inner_off[cell + 1]; }
+      },
+      [&](ItemSlot& x) {
+        x.idx = v.q.by_inner_idx[x.n];
+        x.aux = IB[in.idx(ST_P, d, i0 + x.c, G[A.quad1_tgt + x.t])];   // inside P(i,j,tgt)
+      },
+      [&](ItemSlot& x) {
+        x.it = v.q.items[x.idx];
+        x.xw = xw_item(v.q, lamk(v.m, G[A.quad1_ent + 3 * x.t]), x.idx);
+      },
+      [&](ItemSlot& x) {
+        const int i = i0 + x.c, j = i + d;
+        x.x0 = OB[out.idx(ST_E, x.it.j - x.it.i, x.it.i, G[A.quad1_ent + 3 * x.t])];
+        x.x1 = IB[in.idx(ST_L, i - x.it.i, x.it.i, G[A.quad1_ent + 3 * x.t + 1])];
+        x.x2 = IB[in.idx(ST_L, x.it.j - j, j, G[A.quad1_ent + 3 * x.t + 2])];
+      },
+      [&](ItemSlot& x) {
+        const double term = x.x0 * (x.x1 * x.x2) * x.xw;
+        if (x.aux == 0. || term == 0.) return;
+        atomicAdd(&hp[x.c * S + G[A.quad1_tgt + x.t]], term);
+        if (MODE == OUT_TRAIN) sink.eh(v.m.eh_index(G[A.quad1_ent + 3 * x.t]), x.it.tsc * term * (x.aux * pi.invZ));
+      });
+  // left loop L(i,j,tgt) = L(it.i,it.k)
+  for_block_items(
+      nc, cpb, nq, tid, cnts, pre, base,
+      [&](int c, int& n0, int& n1) { const int cell = v.q.cell(i0 + c, d); n0 = v.q.by_left_off[cell]; n1 = v.q.by_left_off[cell + 1]; },
+      [&](ItemSlot& x) {
+        x.idx = v.q.by_left_idx[x.n];
+        x.aux = IB[in.idx(ST_L, d, i0 + x.c, G[A.quad2_tgt + x.t])];   // inside L(i,j,tgt)
+      },
+      [&](ItemSlot& x) {
+        x.it = v.q.items[x.idx];
+        x.xw = xw_item(v.q, lamk(v.m, G[A.quad2_ent + 3 * x.t]), x.idx);
+      },
+      [&](ItemSlot& x) {
+        x.x0 = OB[out.idx(ST_E, x.it.j - x.it.i, x.it.i, G[A.quad2_ent + 3 * x.t])];
+        x.x1 = IB[in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad2_ent + 3 * x.t + 1])];
+        x.x2 = IB[in.idx(ST_L, x.it.j - x.it.l, x.it.l, G[A.quad2_ent + 3 * x.t + 2])];
+      },
+      [&](ItemSlot& x) {
+        const double term = x.x0 * (x.x1 * x.x2) * x.xw;
+        if (x.aux != 0. && term != 0.) atomicAdd(&hl[x.c * S + G[A.quad2_tgt + x.t]], term);
+      });
+  // right loop L(i,j,tgt) = L(it.l,it.j)
+  for_block_items(
+      nc, cpb, nq, tid, cnts, pre, base,
+      [&](int c, int& n0, int& n1) { const int cell = v.q.cell(i0 + c, d); n0 = v.q.by_right_off[cell]; n1 = v.q.by_right_off[cell + 1]; },
+      [&](ItemSlot& x) {
+        x.idx = v.q.by_right_idx[x.n];
+        x.aux = IB[in.idx(ST_L, d, i0 + x.c, G[A.quad3_tgt + x.t])];
+      },
+      [&](ItemSlot& x) {
+        x.it = v.q.items[x.idx];
+        x.xw = xw_item(v.q, lamk(v.m, G[A.quad3_ent + 3 * x.t]), x.idx);
+      },
+      [&](ItemSlot& x) {
+        x.x0 = OB[out.idx(ST_E, x.it.j - x.it.i, x.it.i, G[A.quad3_ent + 3 * x.t])];
+        x.x1 = IB[in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad3_ent + 3 * x.t + 1])];
+        x.x2 = IB[in.idx(ST_L, x.it.k - x.it.i, x.it.i, G[A.quad3_ent + 3 * x.t + 2])];
+      },
+      [&](ItemSlot& x) {
+        const double term = x.x0 * (x.x1 * x.x2) * x.xw;
+        if (x.aux != 0. && term != 0.) atomicAdd(&hl[x.c * S + G[A.quad3_tgt + x.t]], term);
+      });
+  if (tid < nc * NA && !(a.dbg & 4)) {
+    const int c = tid / NA, s = tid - c * NA;
+    LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink};
+    HeavyOut H;
+    H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
+    lin_outside_target_u<MODE>(x, d, i0 + c, s, H);
+  }
+  if (MODE == OUT_TRAIN) lflush(a, v, pi, sink, l_en, l_eh, kThreads);
+}
+
+// schedule 1: statistics of the reference's two passes from those of the ari-only (A) and nasi-only (B) passes
+__global__ __launch_bounds__(kThreads) void k4_combine(LinArgs a, int G) {
+  const int g = blockIdx.x;
+  if (g >= G) return;
+  const int n = a.grp[g];
+  double* row = a.seq_out + (size_t)n * a.out_stride;
+  if (row[4] != 0.) return;
+  const double* zs = a.zs + (size_t)g * 4;
+  const int nt = a.lay.n_theta;
+  const bool positive = a.plans[n].positive != 0;
+  const double pa = zs[1] / zs[0], pn = zs[2] / zs[0];
+  for (int t = threadIdx.x; t < nt + 2; t += kThreads) {
+    double* A = (t < nt) ? &row[6 + t] : &row[6 + 2 * nt + (t - nt)];
+    double* B = (t < nt) ? &row[6 + nt + t] : &row[6 + 2 * nt + 2 + (t - nt)];
+    const double va = *A, vb = *B;
+    *A = pa * va + pn * vb;
+    *B = positive ? va : vb;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st) {
+  const size_t work = a.n_cells > a.n_items ? a.n_cells : a.n_items;
+  if (work == 0) return hipSuccess;
+  size_t blocks = (work + kThreads - 1) / kThreads;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k4_weights, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, int Lmax, int Wmax, bool first_pass_only,
+                            hipStream_t st) {
+  if (G <= 0) return hipSuccess;
+  LinArgs a = full;
+  const int S = a.lay.S, nt = a.lay.n_theta;
+  a.cpb = kThreads / S;
+  auto int_bytes = [](const LinArgs& x) { return sizeof(int32_t) * (size_t)(4 * x.cpb + 2 + x.n_stage + 2); };
+  const size_t lds_in = sizeof(double) * ((2 + 2 * kChunkIn) * a.cpb * S) + int_bytes(a);
+  const bool big = a.n_stage >= a.lay.n_ints;
+  const size_t lds_stat = sizeof(double) * (nt + 2);
+  if (!a.no_rss)
+    for (int d = 0; d <= Wmax; ++d) {
+      const int ncell = Lmax - d + 1;
+      if (ncell <= 0) break;
+      a.d = d;
+      if (big) hipLaunchKernelGGL(k4_in<true>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
+      else hipLaunchKernelGGL(k4_in<false>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
+    }
+  hipLaunchKernelGGL(k4_in_ext, dim3(G), dim3(128), 0, st, a);
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && first_pass_only) break;
+    LinArgs b = (a.schedule == 1 && pass == 1) ? compact : a;
+    b.pass = pass;
+    b.cpb = kThreads / b.lay.S;
+    const size_t lds_b = sizeof(double) * ((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2) + int_bytes(b);
+    const bool big_b = b.n_stage >= b.lay.n_ints;
+    hipLaunchKernelGGL(k4_out_ext<OUT_TRAIN>, dim3(G), dim3(128), lds_stat, st, b);
+    if (!b.no_rss)
+      for (int d = Wmax; d >= 0; --d) {
+        const int ncell = Lmax - d + 1;
+        if (ncell <= 0) continue;
+        b.d = d;
+        if (big_b) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
+        else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
+      }
+  }
+  if (a.schedule == 1 && !first_pass_only) hipLaunchKernelGGL(k4_combine, dim3(G), dim3(kThreads), 0, st, a, G);
+  return hipGetLastError();
+}
+
+}  // namespace elemdp

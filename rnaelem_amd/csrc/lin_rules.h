@@ -18,49 +18,16 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
-#include <vector>
 
 #include "dp_rules.h"
+#include "lin_params.h"
 
 namespace elemdp {
 
-// layout of the per-evaluation linear parameter block (doubles): tau, psb[5], log2 psb[5], eth[n_theta]
-constexpr int kLinTau = 0, kLinPsb = 1, kLinPl2 = 6, kLinEth = 11;
 // planes of the exponentiated structural terms: xwc[(k*5 + term) * stride + cell], k = lambda class of the rule's parent
 enum LinTerm : int { XT_STACK = 0, XT_EXT = 1, XT_ML = 2, XT_CLOSE = 3, XT_HP = 4 };
 
 ELEMDP_HD double lin_weight(double lam, double e) { return (e == ELEMDP_NEG_INF) ? 0. : exp(lam * e); }
-
-// bases of base-pair type t = 1..6 (inverse of bp_type)
-ELEMDP_HD int bp_left(int t) { return t == 1 ? 2 : t == 2 ? 3 : t == 3 ? 3 : t == 4 ? 4 : t == 5 ? 1 : 4; }
-ELEMDP_HD int bp_right(int t) { return t == 1 ? 3 : t == 2 ? 2 : t == 3 ? 4 : t == 4 ? 3 : t == 5 ? 4 : 1; }
-
-// Host: linear parameter block from the log-space theta (after the softmax, if any).
-inline void make_lin_params(const AutomatonLayout& lay, const int32_t* ints, const double* theta, double tau, bool no_prf,
-                            std::vector<double>* out) {
-  out->assign(kLinEth + lay.n_theta, 1.);
-  double* p = out->data();
-  p[kLinTau] = tau;
-  const int32_t* row_off = ints + lay.row_off;
-  const int bg_row = ints[lay.st_row_r + lay.s00];
-  for (int b = 0; b < 5; ++b) {
-    double e2 = 0.;
-    if (!no_prf && b > 0 && bg_row >= 0) {
-      e2 = -std::rint(theta[row_off[bg_row] + b - 1] * 1.4426950408889634);
-      if (!(e2 > -1000.)) e2 = -1000.;   // (also catches NaN)
-      if (e2 > 1000.) e2 = 1000.;
-    }
-    p[kLinPl2 + b] = e2;
-    p[kLinPsb + b] = std::ldexp(1., (int)e2);
-  }
-  for (int r = 0; r < lay.n_rows; ++r) {
-    const int w = row_off[r + 1] - row_off[r];
-    for (int c = 0; c < w; ++c) {
-      double sc = (w == 6) ? p[kLinPsb + bp_left(c + 1)] * p[kLinPsb + bp_right(c + 1)] : p[kLinPsb + c + 1];
-      p[kLinEth + row_off[r] + c] = no_prf ? 1. : std::exp(theta[row_off[r] + c]) * sc;
-    }
-  }
-}
 
 // ---- emission weights (linear forms of w_right / w_left / w_pair) --------------------------------
 ELEMDP_HD double lw_right(const ModelView& m, const SeqView& q, int par, int tau_flag, int pos) {

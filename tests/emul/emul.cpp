@@ -18,6 +18,7 @@
 #include "../../rnaelem_amd/csrc/energy_rules.h"
 #include "../../rnaelem_amd/csrc/energy_tables.h"
 #include "../../rnaelem_amd/csrc/host_prep.h"
+#include "../../rnaelem_amd/csrc/lin_rules.h"
 #include "../../rnaelem_amd/csrc/plan_rules.h"
 #include "../../rnaelem_amd/csrc/scan_rules.h"
 
@@ -32,8 +33,8 @@ enum { F_NO_RSS = 1, F_NO_PRF = 2, F_NO_ENE = 4, F_SOFTMAX = 8, F_FIX_RSS = 1 <<
 struct Emu {
   Automaton* au = nullptr;
   EnergyTables et;
-  AutomatonLayout lay, lay0;
-  std::vector<int32_t> ints, ints0;
+  AutomatonLayout lay, lay0, lay_r;
+  std::vector<int32_t> ints, ints0, ints_r;
   int max_span, max_iloop, flags;
   double min_bpp, tau;
   ~Emu() { delete au; }
@@ -274,6 +275,7 @@ void* emu_create(const char* pattern, const char* par_text, int max_span, int ma
     E->au = new Automaton(pattern);
     parse_energy_text(par_text, &E->et);
     E->au->flatten(&E->lay, &E->ints);
+    E->au->flatten(&E->lay_r, &E->ints_r, true);
     flatten_trivial(&E->lay0, &E->ints0);
     E->max_span = max_span; E->max_iloop = max_iloop; E->min_bpp = min_bpp; E->tau = tau; E->flags = flags;
     return E;
@@ -369,6 +371,109 @@ int emu_train_seq(void* h, const double* x, const uint8_t* seq, int L, const uin
     if (ENx) std::copy(enx.begin(), enx.begin() + nt, ENx);
     if (EHo) { EHo[0] = eho[0]; EHo[1] = eho[1]; }
     if (EHx) { EHx[0] = ehx[0]; EHx[1] = ehx[1]; }
+    return 0;
+  } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// ---- scaled-linear train evaluation (lin_rules.h), same outputs as emu_train_seq (tables converted to logs) ----
+// schedule 0: the reference's two outside passes; 1: ari-only pass + nasi-only pass on the one-state automaton,
+// combined as k3_combine / k4_combine do.  out9[5] = 2 when the linear range was left (sequence flagged).
+int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const uint8_t* qual, const char* fix, int schedule,
+                      double* out9, double* ENo, double* EHo, double* ENx, double* EHx, double* inside_o, double* inside,
+                      double* outside, double* outside_o) {
+  try {
+    Emu& E = *(Emu*)h;
+    const int nt = E.au->n_theta();
+    std::vector<double> theta(x, x + nt);
+    if (E.flags & F_SOFTMAX)
+      for (int r = 0; r < E.au->n_rows(); ++r) {
+        double tot = NEG;
+        for (int c = 0; c < E.au->row_width(r); ++c) tot = lse2(tot, x[E.au->row_offset(r) + c]);
+        for (int c = 0; c < E.au->row_width(r); ++c) theta[E.au->row_offset(r) + c] = x[E.au->row_offset(r) + c] - tot;
+      }
+    const bool no_prf = E.flags & F_NO_PRF;
+    std::vector<double> lin;
+    make_lin_params(E.lay, E.ints.data(), theta.data(), E.tau, no_prf, &lin);
+    ModelView m = make_view(E.lay, E.ints, theta.data(), x[nt], x[nt + 1], std::log(E.tau), no_prf, E.flags & F_NO_TURN);
+    m.lin = lin.data();
+    ModelView mr = make_view(E.lay_r, E.ints_r, theta.data(), x[nt], x[nt + 1], std::log(E.tau), no_prf, E.flags & F_NO_TURN);
+    mr.lin = lin.data();
+    HostPlan P;
+    double eff = prepare(E, P, seq, L, qual, fix);
+    SeqView q = P.view();
+    const int S = m.lay.S;
+    const size_t nc = (size_t)(L + 1) * (P.W + 1), ni = P.items.size();
+    std::vector<double> ews(L + 1), xwc(10 * nc), xwi(2 * ni + 1);
+    for (int p = 0; p <= L; ++p) ews[p] = std::exp(P.ws[p]);
+    const double* terms[5] = {P.e_stack.data(), P.e_ext.data(), P.e_ml.data(), P.e_close.data(), P.e_hp.data()};
+    for (int k = 0; k < 2; ++k) {
+      for (int t = 0; t < 5; ++t)
+        for (size_t c = 0; c < nc; ++c) xwc[(size_t)(k * 5 + t) * nc + c] = lin_weight(m.lambda[k], terms[t][c]);
+      for (size_t n = 0; n < ni; ++n) xwi[(size_t)k * ni + n] = lin_weight(m.lambda[k], P.items[n].tsc);
+    }
+    q.ews = ews.data(); q.xwc = xwc.data(); q.xwc_stride = nc; q.xwi = xwi.data(); q.xwi_stride = ni;
+    std::vector<double> cum(L + 1, 0.);   // log2 of prod_{p<j} psb
+    for (int p = 0; p < L; ++p) cum[p + 1] = cum[p] + lin[kLinPl2 + seq[p]];
+    const double ln2 = 0.69314718055994530942;
+    Tab in(L, P.W, S), out(L, P.W, S);
+    std::fill(in.band.begin(), in.band.end(), 0.); std::fill(in.ext.begin(), in.ext.end(), 0.);
+    std::fill(out.band.begin(), out.band.end(), 0.); std::fill(out.ext.begin(), out.ext.end(), 0.);
+    for (int d = 0; d <= q.W; ++d)
+      for (int i = 0; i + d <= q.L; ++i)
+        for (int s = 0; s < S; ++s) lin_inside_target(m, q, in.v, d, i, s);
+    for (int s = 0; s < S; ++s) in.v.o(0, s) = (s == m.lay.s00) ? 1. : 0.;
+    for (int j = 1; j <= L; ++j)
+      for (int s = 0; s < S; ++s) lin_inside_ext_target(m, q, in.v, j, s);
+    const double Zo = lin_part(m, in.v, true, true), Za = lin_part(m, in.v, true, false), Zn = lin_part(m, in.v, false, true);
+    auto tolog = [&](double v, double sc) { return v > 0. ? std::log(v) - sc * ln2 : NEG; };
+    out9[0] = tolog(Zo, cum[L]); out9[1] = tolog(Za, cum[L]); out9[2] = tolog(Zn, cum[L]);
+    out9[3] = 0; out9[4] = eff; out9[5] = 0; out9[6] = L; out9[7] = P.W; out9[8] = (double)P.items.size();
+    auto copy_tab = [&](Tab& T, double* dst, bool outside_tab) {
+      for (int i = 0; i <= L; ++i) for (int d = 0; d <= P.W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s) {
+        double sc = (i + d <= L) ? cum[i + d] - cum[i] : 0.;
+        if (outside_tab) sc = cum[L] - sc;
+        dst[(((size_t)i * (P.W + 1) + d) * 7 + e) * S + s] = (i + d <= L) ? tolog(T.v.at(e, d, i, s), sc) : NEG;
+      }
+    };
+    if (inside_o) for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) inside_o[(size_t)j * S + s] = tolog(in.v.o(j, s), cum[j]);
+    if (inside) copy_tab(in, inside, false);
+    auto bad = [](double z) { return !(z > 0.) || !std::isfinite(z); };
+    if (bad(Zo) || bad(Za) || (schedule == 1 && bad(Zn))) { out9[5] = 2; return 0; }
+    const bool positive = !(P.ws[L] > NEG);
+    std::vector<double> enA(nt + 1, 0.), enB(nt + 1, 0.);
+    double ehA[2] = {0, 0}, ehB[2] = {0, 0};
+    auto run_out = [&](const ModelView& mm, double Z, bool ari, bool nasi, std::vector<double>& en, double* eh) {
+      CpuSink sink{en.data(), eh, {nullptr, nullptr, nullptr}};
+      LinOutCtx<CpuSink> xo{mm, q, in.v, out.v, 1. / Z, sink};
+      const int NA = mm.lay.n_active;
+      for (int s = 0; s < S; ++s) out.v.o(L, s) = 0.;
+      if (nasi) out.v.o(L, mm.lay.s00) = 1.;
+      if (ari) { out.v.o(L, mm.lay.s0m1) = 1.; out.v.o(L, mm.lay.s0m2) = 1.; }
+      for (int i = L - 1; i >= 0; --i)
+        for (int s = 0; s < NA; ++s) lin_outside_ext_target<OUT_TRAIN>(xo, i, s);
+      for (int d = q.W; d >= 0; --d)
+        for (int i = 0; i + d <= L; ++i)
+          for (int s = 0; s < NA; ++s) lin_outside_target<OUT_TRAIN>(xo, d, i, s);
+    };
+    if (schedule == 0) {
+      run_out(m, Zo, true, true, enA, ehA);
+      if (outside) copy_tab(out, outside, true);
+      if (outside_o) for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) outside_o[(size_t)j * S + s] = tolog(out.v.o(j, s), cum[L] - cum[j]);
+      run_out(m, positive ? Za : Zn, positive, !positive, enB, ehB);
+    } else {
+      run_out(m, Za, true, false, enA, ehA);
+      if (outside) copy_tab(out, outside, true);
+      std::fill(out.band.begin(), out.band.end(), 0.); std::fill(out.ext.begin(), out.ext.end(), 0.);
+      run_out(mr, Zn, false, true, enB, ehB);
+      const double pa = Za / Zo, pn = Zn / Zo;
+      for (int t = 0; t < nt; ++t) { const double a = enA[t], b = enB[t]; enA[t] = pa * a + pn * b; enB[t] = positive ? a : b; }
+      for (int t = 0; t < 2; ++t) { const double a = ehA[t], b = ehB[t]; ehA[t] = pa * a + pn * b; ehB[t] = positive ? a : b; }
+    }
+    out9[3] = positive ? std::log1p(Zn / Za) : std::log1p(Za / Zn);
+    if (ENo) std::copy(enA.begin(), enA.begin() + nt, ENo);
+    if (ENx) std::copy(enB.begin(), enB.begin() + nt, ENx);
+    if (EHo) { EHo[0] = ehA[0]; EHo[1] = ehA[1]; }
+    if (EHx) { EHx[0] = ehB[0]; EHx[1] = ehB[1]; }
     return 0;
   } catch (std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -30,6 +30,7 @@ def lib():
         L.emu_sum_ext_m.argtypes = [C.c_void_p, u8, C.c_int, C.c_int, C.c_int, C.c_int]
         L.emu_bpp.argtypes = [C.c_void_p, u8, C.c_int, dp, u8, dp, dp]
         L.emu_train_seq.argtypes = [C.c_void_p, dp, u8, C.c_int, u8, C.c_char_p] + [dp] * 9
+        L.emu_train_seq_lin.argtypes = [C.c_void_p, dp, u8, C.c_int, u8, C.c_char_p, C.c_int] + [dp] * 9
         L.emu_scan_seq.argtypes = [C.c_void_p, dp, u8, C.c_int, u8, dp, dp, dp, dp, i32, C.c_char_p, dp]
         _lib = L
     return _lib
@@ -88,7 +89,9 @@ class Emul:
             raise RuntimeError(lib().emu_last_error().decode())
         return ln, kept, eff.value, lnz.value
 
-    def train_seq(self, x, seq, qual, fix_rss=None, tables=False):
+    def train_seq(self, x, seq, qual, fix_rss=None, tables=False, linear=None):
+        """linear=None: the log-space rules (dp_rules.h); 0 / 1: the scaled-linear rules (lin_rules.h) with the
+        reference schedule / the ari-only + one-state schedule."""
         L = len(seq)
         W = min(L, self.max_span)
         x = np.ascontiguousarray(x, dtype=np.float64)
@@ -100,8 +103,13 @@ class Emul:
         if tables:
             ins = np.zeros((L + 1) * (W + 1) * 7 * self.S)
             outs = np.zeros((L + 1) * (W + 1) * 7 * self.S)
-        rc = lib().emu_train_seq(self.h, _dp(x), _u8(seq), L, _u8(qual), fix_rss.encode() if fix_rss else None, _dp(out9),
-                                 _dp(ENo), _dp(EHo), _dp(ENx), _dp(EHx), _dp(io), _dp(ins), _dp(outs), _dp(oo))
+        fx = fix_rss.encode() if fix_rss else None
+        if linear is None:
+            rc = lib().emu_train_seq(self.h, _dp(x), _u8(seq), L, _u8(qual), fx, _dp(out9),
+                                     _dp(ENo), _dp(EHo), _dp(ENx), _dp(EHx), _dp(io), _dp(ins), _dp(outs), _dp(oo))
+        else:
+            rc = lib().emu_train_seq_lin(self.h, _dp(x), _u8(seq), L, _u8(qual), fx, int(linear), _dp(out9),
+                                         _dp(ENo), _dp(EHo), _dp(ENx), _dp(EHx), _dp(io), _dp(ins), _dp(outs), _dp(oo))
         if rc:
             raise RuntimeError(lib().emu_last_error().decode())
         r = dict(Zo=out9[0], Zari=out9[1], Znasi=out9[2], f=out9[3], bpp_eff=out9[4], skipped=int(out9[5]), L=L, W=W,

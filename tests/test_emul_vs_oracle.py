@@ -172,6 +172,51 @@ def test_reference_emission_counts(seq, rss, counts):
     np.testing.assert_allclose(r["ENo"] * np.exp(r["Zo"]), [v for row in counts for v in row], rtol=1e-12, atol=1e-12)
 
 
+# ---- the scaled-linear train rules (lin_rules.h: what the k4_* kernels run) ------------------------------------
+@pytest.mark.parametrize("model,fq", CASES)
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_linear_train_rules_match_oracle(model, fq, schedule):
+    o, e, x = model_pair(model)
+    full = fq in ("tiny.fq", "0.fq", "syn_L40_n3.fq")
+    for rid, seq, qual in po.read_fastq(gpath(fq)):
+        a = o.train_seq(seq, qual, tables=full)
+        b = e.train_seq(x, seq, qual, tables=full, linear=schedule)
+        for k in ("Zo", "Zari", "Znasi"):
+            assert_log_close(b[k], a[k], rtol=1e-11, what=k)
+        assert_log_close(b["inside_o"], a["inside_o"], rtol=1e-10, what="inside_o")
+        if full:
+            assert_log_close(b["inside"], a["inside"], rtol=1e-10, what="inside table")
+        if a["skipped"] or (schedule == 1 and not np.isfinite(a["Znasi"])):
+            assert b["skipped"] == 2          # flagged: the log-space pipeline decides
+            continue
+        assert b["skipped"] == 0
+        assert b["f"] == pytest.approx(a["f"], rel=1e-10, abs=1e-12)
+        for k in ("ENo", "ENx", "EHo", "EHx"):
+            np.testing.assert_allclose(b[k], a[k], rtol=1e-9, atol=1e-11, err_msg=k)
+        if schedule == 0:
+            assert_log_close(b["outside_o"], a["outside_o"], rtol=1e-10, what="outside_o")
+            if full:
+                assert_log_close(b["outside"], a["outside"], rtol=1e-10, what="outside table")
+
+
+@pytest.mark.parametrize("pattern,seq,rss,count", PATH_COUNTS)
+def test_reference_path_counts_linear(pattern, seq, rss, count):
+    e = Emul(pattern, PAR, BIG, BIG, 0.0, 1.0, DBG_FLAGS)
+    x = np.zeros(e.n_param)
+    x[-2:] = 1.0
+    r = e.train_seq(x, po.encode_seq(seq), np.ones(len(seq) + 1, dtype=np.uint8), fix_rss=rss, linear=0)
+    assert np.exp(r["Zo"]) == pytest.approx(count, rel=1e-13)
+
+
+@pytest.mark.parametrize("seq,rss,counts", EMISSION_COUNTS)
+def test_reference_emission_counts_linear(seq, rss, counts):
+    e = Emul(".", PAR, BIG, BIG, 0.0, 1.0, DBG_FLAGS)
+    x = np.zeros(e.n_param)
+    x[-2:] = 1.0
+    r = e.train_seq(x, po.encode_seq(seq), np.ones(len(seq) + 1, dtype=np.uint8), fix_rss=rss, linear=0)
+    np.testing.assert_allclose(r["ENo"] * np.exp(r["Zo"]), [v for row in counts for v in row], rtol=1e-12, atol=1e-12)
+
+
 SCAN = [("0.model", "0.fq"), ("1.model", "0.fq"), ("3.model", "0.fq"), ("tiny_a.model", "tiny.fq"),
         ("syn_b.model", "syn_L100_n3.fq"), ("syn_sm.model", "syn_L40_n3.fq"), ("syn_c12.model", "syn_L100_n3.fq"),
         ("trna_a.model", "positive_head6.fq")]

@@ -1,14 +1,17 @@
-import sys, time
-sys.path.insert(0, ".")
+"""Train-evaluation time against the lockstep group size.  args: n L pipeline groups..."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from rnaelem_amd import api, synth
-n = int(sys.argv[1]); L = int(sys.argv[2])
+n, L, pipeline = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+groups = [int(g) for g in sys.argv[4:]]
 eng = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+eng.set_option("pipeline", pipeline)
 seqs, quals = synth.synth_batch(n, L)
-t0 = time.time(); eng.load_batch(seqs, quals); print("load %.2fs" % (time.time() - t0))
+eng.load_batch(seqs, quals)
 x = eng.initial_params(1.0)
-for g in [int(v) for v in sys.argv[3:]]:
+for g in groups:
     eng.set_option("group", g)
     eng.train_eval(x)
     fn, gr, eff, nsk = eng.train_eval(x)
     ms = eng.last_timing()
-    print("group %5d: %.1f ms  -> %.0f seq/s  fn=%.9f" % (g, ms[1], n / ms[1] * 1e3, fn))
+    print("pipeline %d group %5d: %.1f ms -> %.0f seq/s (fn %.10g)" % (pipeline, g, ms[1], n / ms[1] * 1e3, fn), flush=True)
