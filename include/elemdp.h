@@ -150,7 +150,9 @@ int elemdp_scan(elemdp_handle* h, const double* x, int32_t n_param, elemdp_scan_
  * ms[2] = number of sequences the scaled-linear pipeline handed to the log-space pipeline (range check) */
 int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n);
 /* debug: summed shader-clock cycles per phase of the last train evaluation when option "profile" = 1:
- * [stage, inside band, inside exterior, outside exterior, outside band, queue/other] */
+ * pipeline 2: [stage, inside band, inside exterior, outside exterior, outside band, queue/other];
+ * pipeline 4 (16 values): k4_in [setup, stage split operands, split products, item sums, unary phase],
+ * k4_out [setup, stage, products, items inner, items left, items right, unary phase, statistics flush] */
 int elemdp_debug_profile(elemdp_handle* h, double* cycles, int32_t n);
 /* name of the dominant kernel (for matching rocprofv3 rows) */
 const char* elemdp_kernel_name(void);

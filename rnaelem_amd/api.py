@@ -246,8 +246,8 @@ class Engine:
         return ms
 
     def profile(self):
-        c = np.zeros(8)
-        self._lib.elemdp_debug_profile(self._h, _dp(c), 8)
+        c = np.zeros(16)
+        self._lib.elemdp_debug_profile(self._h, _dp(c), 16)
         return c
 
     def kernel_name(self):

@@ -774,6 +774,12 @@ void Engine::run_lin_batch() {
   a.schedule = sched1 ? 1 : 0;
   a.flagged = d_flagged_.as<int32_t>();
   a.dbg = opt_dbg_;
+  a.prof = nullptr;
+  if (opt_profile_) {
+    d_prof_.alloc(sizeof(long long) * 16 * 64);
+    HIP_OK(hipMemsetAsync(d_prof_.as<void>(), 0, sizeof(long long) * 16 * 64, st_));
+    a.prof = d_prof_.as<long long>();
+  }
   a.n_stage = (lay_.n_ints <= 4096) ? lay_.n_ints : lay_.n_small;
   LinArgs c = a;   // the no-motif pass: one-state automaton, compact tables
   c.lay = layc_;
@@ -805,6 +811,12 @@ void Engine::run_lin_batch() {
   HIP_OK(hipMemcpyAsync(&n_flagged, d_flagged_.as<void>(), sizeof(int32_t), hipMemcpyDeviceToHost, st_));
   HIP_OK(hipStreamSynchronize(st_));
   n_flagged_last_ = n_flagged;
+  if (opt_profile_) {
+    std::vector<long long> hp(16 * 64);
+    HIP_OK(hipMemcpy(hp.data(), d_prof_.as<void>(), sizeof(long long) * 16 * 64, hipMemcpyDeviceToHost));
+    last_prof.assign(16, 0);
+    for (size_t k = 0; k < hp.size(); ++k) last_prof[k % 16] += hp[k];
+  }
   tables_linear_ = n_flagged == 0;
   if (n_flagged > 0) {
     TrArgs t = log_pipeline_args();
@@ -1168,7 +1180,7 @@ int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n) {
 }
 int elemdp_debug_profile(elemdp_handle* h, double* cycles, int32_t n) {
   if (!h || !cycles) return ELEMDP_EINVAL;
-  for (int k = 0; k < n && k < 8; ++k) cycles[k] = k < (int)h->e->last_prof.size() ? (double)h->e->last_prof[k] : 0.;
+  for (int k = 0; k < n && k < 16; ++k) cycles[k] = k < (int)h->e->last_prof.size() ? (double)h->e->last_prof[k] : 0.;
   return ELEMDP_OK;
 }
 const char* elemdp_kernel_name(void) { return "k3_out_heavy"; }

@@ -134,6 +134,8 @@ struct LinArgs {
   int32_t schedule, pass, d;
   int32_t cpb;                    // cells per workgroup = kThreads / S
   int32_t* flagged;               // [0] = number of flagged sequences, [1..] = their batch indices
+  long long* prof;                // optional [16] shader-clock sums per phase (thread 0 of every workgroup), or null
+  int32_t wmax;                   // largest span of the launch (sizes the position window staged in LDS)
   int32_t n_stage;                // ints of the automaton blob staged in LDS: n_ints (whole blob) or n_small
   int32_t dbg;                    // timing experiments only: bit 0 skip split sums, 1 skip item sums, 2 skip the unary phase
 };

@@ -40,9 +40,37 @@ struct LinSink {
   __device__ __forceinline__ void eh(int k, double w) { if (k) eh1 += w; else eh0 += w; }
 };
 
+// phase timer (option "profile"): thread 0 of a workgroup sums the shader clocks between marks per slot and adds
+// them to one of 64 copies of the counter row when the workgroup ends (host adds the copies)
+struct PhaseClock {
+  long long* prof;
+  long long t0;
+  long long acc[13];
+  __device__ __forceinline__ void start(long long* p) {
+    prof = p;
+    if (prof && threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 13; ++k) acc[k] = 0;
+      t0 = clock64();
+    }
+  }
+  template <int SLOT> __device__ __forceinline__ void mark() {
+    if (prof && threadIdx.x == 0) { const long long t = clock64(); acc[SLOT] += t - t0; t0 = t; }
+  }
+  __device__ __forceinline__ void finish() {
+    if (prof && threadIdx.x == 0) {
+      long long* row = prof + 16 * ((blockIdx.x + 7 * blockIdx.y) & 63);
+#pragma unroll
+      for (int k = 0; k < 13; ++k) if (acc[k]) atomicAdd((unsigned long long*)&row[k], (unsigned long long)acc[k]);
+    }
+  }
+};
+
 struct LViews {
   ModelView m;
-  __device__ explicit LViews(const LinArgs& a) : m(*a.layp) {}
+  // `lay` must live in LDS (stage_layout): every field access of a layout in global memory is a vector load with its
+  // own wait, dozens of serialized round trips per target
+  __device__ explicit LViews(const AutomatonLayout& lay) : m(lay) {}
   SeqView q;
   TableView in, out;
   int n;
@@ -91,6 +119,13 @@ __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) 
   v.zs = a.zs + (size_t)g * 4;
 }
 
+// copies the automaton layout record into LDS (all threads; caller synchronises before the first use)
+__device__ __forceinline__ void stage_layout(const LinArgs& a, AutomatonLayout* dst, int nthreads) {
+  const int32_t* src = reinterpret_cast<const int32_t*>(a.layp);
+  int32_t* d32 = reinterpret_cast<int32_t*>(dst);
+  for (int t = threadIdx.x; t < (int)(sizeof(AutomatonLayout) / sizeof(int32_t)); t += nthreads) d32[t] = src[t];
+}
+
 // ---- exp(lambda_k * term) of all structural terms and loop items of the batch, once per evaluation
 __global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
   const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
@@ -109,6 +144,73 @@ __global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
     a.xwi[n] = lin_weight(l0, t);
     a.xwi[a.n_items + n] = lin_weight(l1, t);
   }
+}
+
+// LDS layout shared by k4_in / k4_out (host computes the size, kernels the pointers): nd doubles of accumulators and
+// staging buffers come first, then the per-workgroup context: linear parameter block, exp position weights of the
+// window of positions the workgroup touches, small int arrays, the automaton blob, and the dmin / base / unpaired
+// windows.  With the context in LDS the unary phase has a single level of global loads (the tables themselves).
+struct BlockLds {
+  int lin, ews, ints, dm, cnts, pre, base, blob, dmin16, seq8, unp8, total;   // byte offsets
+};
+__host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int win, int n_stage) {
+  BlockLds b;
+  int o = nd * 8;
+  b.lin = o; o += n_lin * 8;
+  b.ews = o; o += win * 8;
+  b.ints = o;
+  b.dm = o; o += cpb * 4;
+  b.cnts = o; o += cpb * 4;
+  b.pre = o; o += (cpb + 1) * 4;
+  b.base = o; o += cpb * 4;
+  b.blob = o; o += n_stage * 4;
+  b.dmin16 = o; o += ((win + 1) / 2) * 4;
+  b.seq8 = o; o += ((win + 3) / 4) * 4;
+  b.unp8 = o; o += ((win + 3) / 4) * 4;
+  b.total = o + 8;
+  return b;
+}
+struct BlockCtx { int* dm; int* cnts; int* pre; int* base; };
+
+// stages the context and redirects the views to it; positions [p0, p0+len) = [i0-1, i0+nc+d] clipped to [0, L]
+template <bool BIG>
+__device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, unsigned char* raw, const BlockLds& B, int i0, int nc,
+                                                  int d, int cpb) {
+  const int tid = threadIdx.x;
+  const int L = v.q.L;
+  const int p0 = (i0 > 0) ? i0 - 1 : 0;
+  const int p1 = (i0 + nc + d < L) ? i0 + nc + d : L;   // inclusive
+  const int len = p1 - p0 + 1;
+  double* llin = reinterpret_cast<double*>(raw + B.lin);
+  double* lews = reinterpret_cast<double*>(raw + B.ews);
+  int* blob = reinterpret_cast<int*>(raw + B.blob);
+  int16_t* ldmin = reinterpret_cast<int16_t*>(raw + B.dmin16);
+  uint8_t* lseq = raw + B.seq8;
+  uint8_t* lunp = raw + B.unp8;
+  const int n_lin = kLinEth + a.lay.n_theta;
+  for (int t = tid; t < a.n_stage; t += kThreads) blob[t] = a.ints[t];
+  for (int t = tid; t < n_lin; t += kThreads) llin[t] = a.lin[t];
+  for (int t = tid; t < len; t += kThreads) {
+    const int p = p0 + t;
+    lews[t] = v.q.ews[p];
+    ldmin[t] = v.q.dmin[p];
+    lunp[t] = v.q.unp[p];
+    lseq[t] = (p < L) ? v.q.seq[p] : (uint8_t)0;
+  }
+  BlockCtx c;
+  c.dm = reinterpret_cast<int*>(raw + B.dm);
+  c.cnts = reinterpret_cast<int*>(raw + B.cnts);
+  c.pre = reinterpret_cast<int*>(raw + B.pre);
+  c.base = reinterpret_cast<int*>(raw + B.base);
+  if (tid < cpb) c.dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
+  v.m.ints = blob;
+  if (BIG) v.m.big = blob;
+  v.m.lin = llin;
+  v.q.ews = lews - p0;
+  v.q.dmin = ldmin - p0;
+  v.q.unp = lunp - p0;
+  v.q.seq = lseq - p0;
+  return c;
 }
 
 // Heavy sums are evaluated from LDS: for a chunk of split points the operand rows of ALL cells of the workgroup are
@@ -133,23 +235,23 @@ struct ItemSlot {
   bool ok;
 };
 template <class RangeFn, class F1, class F2, class F3, class F4>
-__device__ __forceinline__ void for_block_items(int nc, int cpb, int nq, int tid, int* cnts, int* pre, int* base, RangeFn range,
+__device__ __forceinline__ void for_block_items(int nv, int nq, int tid, int* cnts, int* pre, int* base, RangeFn range,
                                                 F1 load_index, F2 load_item, F3 load_operands, F4 finish) {
-  if (tid < cpb) {
+  // nv "virtual cells" (cell x role), each with one CSR range
+  for (int vc = tid; vc < nv; vc += kThreads) {
     int c0 = 0, c1 = 0;
-    if (tid < nc) range(tid, c0, c1);
-    base[tid] = c0;
-    cnts[tid] = (c1 > c0) ? c1 - c0 : 0;
+    range(vc, c0, c1);
+    base[vc] = c0;
+    cnts[vc] = (c1 > c0) ? c1 - c0 : 0;
   }
   __syncthreads();
-  if (tid < cpb) {
+  for (int vc = tid; vc <= nv; vc += kThreads) {
     int p = 0;
-    for (int c = 0; c < tid; ++c) p += cnts[c];
-    pre[tid] = p;
-    if (tid == cpb - 1) pre[cpb] = p + cnts[tid];
+    for (int c = 0; c < vc; ++c) p += cnts[c];
+    pre[vc] = p;
   }
   __syncthreads();
-  const int total = pre[nc] * nq;
+  const int total = pre[nv] * nq;
   for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
     ItemSlot sl[kItemBatch];
 #pragma unroll
@@ -159,7 +261,7 @@ __device__ __forceinline__ void for_block_items(int nc, int cpb, int nq, int tid
       const int wc = sl[u].ok ? w : total - 1;
       const int il = wc / nq;
       sl[u].t = wc - il * nq;
-      int lo = 0, hi = nc - 1;   // the cell owning item il: largest c with pre[c] <= il
+      int lo = 0, hi = nv - 1;   // the virtual cell owning item il: largest vc with pre[vc] <= il
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (pre[mid] <= il) lo = mid; else hi = mid - 1;
@@ -179,14 +281,17 @@ __device__ __forceinline__ void for_block_items(int nc, int cpb, int nq, int tid
   __syncthreads();
 }
 
-// ---- inside, diagonal d: grid (ceil(ncell / cpb), G); dynamic LDS = (2 + 2*kChunkIn) * cpb * S doubles + cpb ints
 template <bool BIG>
 __global__ __launch_bounds__(kThreads) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
-  LViews v(a);
+  __shared__ AutomatonLayout s_lay;
+  PhaseClock pc;
+  pc.start(a.prof);
+  stage_layout(a, &s_lay, kThreads);
+  LViews v(s_lay);
   make_lviews(a, blockIdx.y, v);
-  const AutomatonLayout& A = v.m.lay;
-  const int S = A.S, NA = A.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x;
+  const AutomatonLayout& A = s_lay;   // (valid after the first barrier below)
+  const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x;
   if (d > v.q.W) return;
   const int ncell = v.q.L - d + 1, i0 = blockIdx.x * cpb;
   if (i0 >= ncell) return;
@@ -196,24 +301,35 @@ __global__ __launch_bounds__(kThreads) void k4_in(LinArgs a) {
   double* he = hb + CS;
   double* st1 = he + CS;               // [kChunkIn][CS]  rows 1(i, i+a, .)
   double* st2 = st1 + kChunkIn * CS;   // [kChunkIn][CS]  rows 2(i+a, j, .)
-  int* dm = reinterpret_cast<int*>(st2 + kChunkIn * CS);
-  int* cnts = dm + cpb;
-  int* pre = cnts + cpb;
-  int* base = pre + cpb + 1;
-  int* lints = base + cpb;   // the automaton blob (or its per-state / unary part) staged in LDS
-  for (int t = tid; t < a.n_stage; t += kThreads) lints[t] = a.ints[t];
-  v.m.ints = lints;
-  if (BIG) v.m.big = lints;
+  const BlockLds BL = block_lds((2 + 2 * kChunkIn) * CS, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, a.n_stage);
+  const BlockCtx cx = stage_context<BIG>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   for (int t = tid; t < 2 * CS; t += kThreads) lds[t] = 0.;
-  if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
   __syncthreads();
+  pc.mark<0>();
   // rule 2: B(i,j,tgt) = sum_{a = k-i} sum_tuples 1(i,i+a,s1) * 2(i+a,j,s2);  1(i,i+a,.) = 0 for a < dmin[i]
   int a_lo = d;
   for (int c = 0; c < nc; ++c) { const int x = dm[c]; if (x > 0 && x < a_lo) a_lo = x; }
   const int nsp = A.n_split;
   const double* B = v.in.band;
   if (a.dbg & 1) a_lo = d;
+  // every lane owns up to kOwn (cell, tuple) products, decoded once; the sums stay in registers over all rounds
+  constexpr int kOwn = 2;
+  int po1[kOwn], po2[kOwn], ptg[kOwn];
+  double pacc[kOwn];
+#pragma unroll
+  for (int r = 0; r < kOwn; ++r) {
+    const int w = tid + r * kThreads;
+    po1[r] = -1; po2[r] = 0; ptg[r] = 0; pacc[r] = 0.;
+    if (w < nc * nsp) {
+      const int c = w / nsp, t = w - c * nsp;
+      const int x = dm[c];
+      if (x > 0 && x <= d) {   // left_ok(i, d)
+        po1[r] = c * S + G[A.split_ent + 2 * t]; po2[r] = c * S + G[A.split_ent + 2 * t + 1]; ptg[r] = c * S + G[A.split_tgt + t];
+      }
+    }
+  }
   for (int a0 = a_lo; a0 < d; a0 += kChunkIn) {
     const int kc = (kChunkIn < d - a0) ? kChunkIn : d - a0;
     if (tid < ncS) {
@@ -222,26 +338,36 @@ __global__ __launch_bounds__(kThreads) void k4_in(LinArgs a) {
         const int aa = a0 + ((u < kc) ? u : 0);
         const double x1 = B[v.in.idx(ST_1, aa, i0, 0) + tid];
         const double x2 = B[v.in.idx(ST_2, d - aa, i0 + aa, 0) + tid];
-        st1[u * CS + tid] = x1;
-        st2[u * CS + tid] = x2;
+        st1[u * CS + tid] = (u < kc) ? x1 : 0.;
+        st2[u * CS + tid] = (u < kc) ? x2 : 0.;
       }
     }
     __syncthreads();
-    for (int w = tid; w < nc * nsp; w += kThreads) {
+    pc.mark<1>();
+#pragma unroll
+    for (int r = 0; r < kOwn; ++r)
+      if (po1[r] >= 0) {
+#pragma unroll
+        for (int u = 0; u < kChunkIn; ++u) pacc[r] = fma(st1[u * CS + po1[r]], st2[u * CS + po2[r]], pacc[r]);
+      }
+    for (int w = tid + kOwn * kThreads; w < nc * nsp; w += kThreads) {   // (patterns with more tuples than lanes)
       const int c = w / nsp, t = w - c * nsp;
       const int x = dm[c];
-      if (x <= 0 || x > d) continue;   // !left_ok(i, d)
+      if (x <= 0 || x > d) continue;
       const int o1 = c * S + G[A.split_ent + 2 * t], o2 = c * S + G[A.split_ent + 2 * t + 1];
       double acc = 0.;
       for (int u = 0; u < kc; ++u) acc = fma(st1[u * CS + o1], st2[u * CS + o2], acc);
       if (acc != 0.) atomicAdd(&hb[c * S + G[A.split_tgt + t]], acc);
     }
     __syncthreads();
+    pc.mark<2>();
   }
+#pragma unroll
+  for (int r = 0; r < kOwn; ++r) if (po1[r] >= 0 && pacc[r] != 0.) atomicAdd(&hb[ptg[r]], pacc[r]);
   // rule 6c: E(i,j,tgt) += sum_items P(k,l,s1) * L(i,k,s2) * L(l,j,s3) * exp(lambda * tsc)
   const int nq = (a.dbg & 2) ? 0 : A.n_quad;
   for_block_items(
-      nc, cpb, nq, tid, cnts, pre, base,
+      nc, nq, tid, cnts, pre, base,
       [&](int c, int& c0, int& c1) {
         const int i = i0 + c;
         if (v.q.e_ok(i, d)) { const int cell = v.q.cell(i, d); c0 = v.q.by_outer_off[cell]; c1 = v.q.by_outer_off[cell + 1]; }
@@ -262,6 +388,7 @@ __global__ __launch_bounds__(kThreads) void k4_in(LinArgs a) {
         const double term = x.x0 * (x.x1 * x.x2) * x.xw;
         if (x.aux != 0. && term != 0.) atomicAdd(&he[x.c * S + G[A.quad_tgt + x.t]], term);
       });
+  pc.mark<3>();
   if (tid < nc * NA && !(a.dbg & 4)) {
     const int c = tid / NA, s = tid - c * NA;
     const int i = i0 + c;
@@ -274,15 +401,19 @@ __global__ __launch_bounds__(kThreads) void k4_in(LinArgs a) {
       t0.at(ST_1, d, i, 0) = r.v1; t0.at(ST_2, d, i, 0) = r.v2; t0.at(ST_L, d, i, 0) = r.vL;
     }
   }
+  pc.mark<4>();
+  pc.finish();
 }
 
 __device__ __forceinline__ bool out_of_range(double z) { return !(z > 0.) || !(z < HUGE_VAL); }
 
 // ---- exterior chain of the inside pass, partition functions, objective (one workgroup of 128 per sequence)
 __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
-  LViews v(a);
+  __shared__ AutomatonLayout s_lay;
+  stage_layout(a, &s_lay, 128);
+  LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
-  const int S = v.m.lay.n_active, tid = threadIdx.x, L = v.q.L;
+  const int S = a.lay.n_active, tid = threadIdx.x, L = v.q.L;
   double* ext0 = a.ext_in0 ? a.ext_in0 + (size_t)blockIdx.x * a.ext0_stride : nullptr;
   for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00) ? 1. : 0.;
   if (ext0 && tid == 0) ext0[0] = 1.;
@@ -359,11 +490,13 @@ __device__ __forceinline__ void lflush(const LinArgs& a, const LViews& v, const 
 template <int MODE>
 __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   extern __shared__ double l_stat[];   // n_theta + 2
-  LViews v(a);
+  __shared__ AutomatonLayout s_lay;
+  stage_layout(a, &s_lay, 128);
+  LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
   const LPass pi = lpass(a, v);
   if (pi.skip) return;
-  const int S = v.m.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
+  const int S = a.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
   double* l_en = l_stat;
   double* l_eh = l_stat + nt;
   for (int t = tid; t < nt + 2; t += 128) l_stat[t] = 0.;
@@ -389,11 +522,15 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
 template <int MODE, bool BIG>
 __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
   extern __shared__ double lds[];
-  LViews v(a);
+  __shared__ AutomatonLayout s_lay;
+  PhaseClock pc;
+  pc.start(a.prof);
+  stage_layout(a, &s_lay, kThreads);
+  LViews v(s_lay);
   make_lviews(a, blockIdx.y, v);
   const LPass pi = lpass(a, v);
-  const AutomatonLayout& A = v.m.lay;
-  const int S = A.S, NA = A.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = A.n_theta;
+  const AutomatonLayout& A = s_lay;   // (valid after the first barrier below)
+  const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = a.lay.n_theta;
   if (pi.skip || d > v.q.W) return;
   const int L = v.q.L, W = v.q.W;
   const int ncell = L - d + 1, i0 = blockIdx.x * cpb;
@@ -410,18 +547,13 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
   double* sI2 = sOB1 + kChunkOut * CS;   //                 in  2(j, j+b, .)
   double* sOB2 = sI2 + kChunkOut * CS;   //                 out B(i-b, j, .)        (H2)
   double* sI1 = sOB2 + kChunkOut * CS;   //                 in  1(i-b, i, .)
-  int* dm = reinterpret_cast<int*>(sI1 + kChunkOut * CS);
-  int* cnts = dm + cpb;
-  int* pre = cnts + cpb;
-  int* base = pre + cpb + 1;
-  int* lints = base + cpb;
-  for (int t = tid; t < a.n_stage; t += kThreads) lints[t] = a.ints[t];
-  v.m.ints = lints;
-  if (BIG) v.m.big = lints;
+  const BlockLds BL = block_lds((4 + 4 * kChunkOut) * CS + nt + 2, cpb, kLinEth + nt, cpb + a.wmax + 3, a.n_stage);
+  const BlockCtx cx = stage_context<BIG>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   for (int t = tid; t < 4 * CS + nt + 2; t += kThreads) lds[t] = 0.;
-  if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
   __syncthreads();
+  pc.mark<5>();
   LinSink sink;
   sink.en_ = l_en;
   sink.eh0 = sink.eh1 = 0.;
@@ -433,6 +565,22 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
   bool any_lok = false;
   for (int c = 0; c < nc; ++c) { const int x = dm[c]; any_lok = any_lok || (x > 0 && x <= d); }
   const int bmax = (any_lok && !(a.dbg & 1)) ? W - d : 0;
+  constexpr int kOwn = 2;
+  int qa1[kOwn], qa2[kOwn], qat[kOwn], qb1[kOwn], qb2[kOwn], qbt[kOwn];
+  double acc1[kOwn], acc2[kOwn];
+#pragma unroll
+  for (int r = 0; r < kOwn; ++r) {
+    const int w = tid + r * kThreads;
+    qa1[r] = -1; qa2[r] = qat[r] = qb1[r] = qb2[r] = qbt[r] = 0; acc1[r] = acc2[r] = 0.;
+    if (w < nc * nsp) {
+      const int c = w / nsp, t = w - c * nsp;
+      const int x = dm[c];
+      if (x > 0 && x <= d) {   // left_ok(i, d)
+        qa1[r] = c * S + G[A.split1_ent + 2 * t]; qa2[r] = c * S + G[A.split1_ent + 2 * t + 1]; qat[r] = c * S + G[A.split1_tgt + t];
+        qb1[r] = c * S + G[A.split2_ent + 2 * t]; qb2[r] = c * S + G[A.split2_ent + 2 * t + 1]; qbt[r] = c * S + G[A.split2_tgt + t];
+      }
+    }
+  }
   for (int b0 = 1; b0 <= bmax; b0 += kChunkOut) {
     const int kc = (kChunkOut < bmax - b0 + 1) ? kChunkOut : bmax - b0 + 1;
     if (tid < ncS) {
@@ -440,7 +588,7 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
 #pragma unroll
       for (int u = 0; u < kChunkOut; ++u) {
         const int bb = b0 + ((u < kc) ? u : 0);
-        const bool ok1 = i + d + bb <= L, ok2 = i - bb >= 0;
+        const bool ok1 = u < kc && i + d + bb <= L, ok2 = u < kc && i - bb >= 0;
         const int ia = ok1 ? i0 : 0, ib = ok2 ? i0 - bb : 0;   // (clamped: the load itself must stay inside the plane)
         const int r1 = ok1 ? tid : 0, r2 = ok2 ? tid : 0;
         const double x1 = out.band[out.idx(ST_B, d + bb, ia, 0) + r1];
@@ -454,10 +602,20 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
       }
     }
     __syncthreads();
-    for (int w = tid; w < nc * nsp; w += kThreads) {
+    pc.mark<6>();
+#pragma unroll
+    for (int r = 0; r < kOwn; ++r)
+      if (qa1[r] >= 0) {
+#pragma unroll
+        for (int u = 0; u < kChunkOut; ++u) {
+          acc1[r] = fma(sOB1[u * CS + qa1[r]], sI2[u * CS + qa2[r]], acc1[r]);
+          acc2[r] = fma(sOB2[u * CS + qb1[r]], sI1[u * CS + qb2[r]], acc2[r]);
+        }
+      }
+    for (int w = tid + kOwn * kThreads; w < nc * nsp; w += kThreads) {   // (patterns with more tuples than lanes)
       const int c = w / nsp, t = w - c * nsp;
       const int x = dm[c];
-      if (x <= 0 || x > d) continue;   // !left_ok(i, d)
+      if (x <= 0 || x > d) continue;
       {
         const int o1 = c * S + G[A.split1_ent + 2 * t], o2 = c * S + G[A.split1_ent + 2 * t + 1];
         double acc = 0.;
@@ -472,13 +630,20 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
       }
     }
     __syncthreads();
+    pc.mark<7>();
   }
+#pragma unroll
+  for (int r = 0; r < kOwn; ++r)
+    if (qa1[r] >= 0) {
+      if (acc1[r] != 0.) atomicAdd(&h1[qat[r]], acc1[r]);
+      if (acc2[r] != 0.) atomicAdd(&h2[qbt[r]], acc2[r]);
+    }
   // HP / HL: the three roles of a cell in the interior loops around it (rule 6c)
   const double* IB = in.band;
   const double* OB = out.band;
   // inner pair P(i,j,tgt) of E(it.i,it.j,par), with the energy statistic of the rule
   for_block_items(
-      nc, cpb, nq, tid, cnts, pre, base,
+      nc, nq, tid, cnts, pre, base,
       [&](int c, int& n0, int& n1) {
         const int i = i0 + c;
         if (v.q.pair_ok(i, d)) { const int cell = v.q.cell(i, d); n0 = v.q.by_inner_off[cell]; n1 = v.q.by_inner_off[cell + 1]; }
@@ -503,9 +668,10 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
         atomicAdd(&hp[x.c * S + G[A.quad1_tgt + x.t]], term);
         if (MODE == OUT_TRAIN) sink.eh(v.m.eh_index(G[A.quad1_ent + 3 * x.t]), x.it.tsc * term * (x.aux * pi.invZ));
       });
+  pc.mark<8>();
   // left loop L(i,j,tgt) = L(it.i,it.k)
   for_block_items(
-      nc, cpb, nq, tid, cnts, pre, base,
+      nc, nq, tid, cnts, pre, base,
       [&](int c, int& n0, int& n1) { const int cell = v.q.cell(i0 + c, d); n0 = v.q.by_left_off[cell]; n1 = v.q.by_left_off[cell + 1]; },
       [&](ItemSlot& x) {
         x.idx = v.q.by_left_idx[x.n];
@@ -524,9 +690,10 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
         const double term = x.x0 * (x.x1 * x.x2) * x.xw;
         if (x.aux != 0. && term != 0.) atomicAdd(&hl[x.c * S + G[A.quad2_tgt + x.t]], term);
       });
+  pc.mark<9>();
   // right loop L(i,j,tgt) = L(it.l,it.j)
   for_block_items(
-      nc, cpb, nq, tid, cnts, pre, base,
+      nc, nq, tid, cnts, pre, base,
       [&](int c, int& n0, int& n1) { const int cell = v.q.cell(i0 + c, d); n0 = v.q.by_right_off[cell]; n1 = v.q.by_right_off[cell + 1]; },
       [&](ItemSlot& x) {
         x.idx = v.q.by_right_idx[x.n];
@@ -545,6 +712,7 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
         const double term = x.x0 * (x.x1 * x.x2) * x.xw;
         if (x.aux != 0. && term != 0.) atomicAdd(&hl[x.c * S + G[A.quad3_tgt + x.t]], term);
       });
+  pc.mark<10>();
   if (tid < nc * NA && !(a.dbg & 4)) {
     const int c = tid / NA, s = tid - c * NA;
     LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink};
@@ -552,7 +720,10 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
     H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
     lin_outside_target_u<MODE>(x, d, i0 + c, s, H);
   }
+  pc.mark<11>();
   if (MODE == OUT_TRAIN) lflush(a, v, pi, sink, l_en, l_eh, kThreads);
+  pc.mark<12>();
+  pc.finish();
 }
 
 // schedule 1: statistics of the reference's two passes from those of the ari-only (A) and nasi-only (B) passes
@@ -592,8 +763,8 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   LinArgs a = full;
   const int S = a.lay.S, nt = a.lay.n_theta;
   a.cpb = kThreads / S;
-  auto int_bytes = [](const LinArgs& x) { return sizeof(int32_t) * (size_t)(4 * x.cpb + 2 + x.n_stage + 2); };
-  const size_t lds_in = sizeof(double) * ((2 + 2 * kChunkIn) * a.cpb * S) + int_bytes(a);
+  a.wmax = Wmax;
+  const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const size_t lds_stat = sizeof(double) * (nt + 2);
   if (!a.no_rss)
@@ -610,7 +781,8 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
     LinArgs b = (a.schedule == 1 && pass == 1) ? compact : a;
     b.pass = pass;
     b.cpb = kThreads / b.lay.S;
-    const size_t lds_b = sizeof(double) * ((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2) + int_bytes(b);
+    b.wmax = Wmax;
+    const size_t lds_b = block_lds((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, b.n_stage).total;
     const bool big_b = b.n_stage >= b.lay.n_ints;
     hipLaunchKernelGGL(k4_out_ext<OUT_TRAIN>, dim3(G), dim3(128), lds_stat, st, b);
     if (!b.no_rss)
