@@ -137,6 +137,8 @@ struct SeqView {
   const double* ews = nullptr;
   const double* xwc = nullptr; size_t xwc_stride = 0;
   const double* xwi = nullptr; size_t xwi_stride = 0;
+  // items in the by_inner / by_left / by_right orders and their weights: order o (1..3) at xwi + o * 2 * xwi_stride
+  const LoopItem* items_inner = nullptr; const LoopItem* items_left = nullptr; const LoopItem* items_right = nullptr;
 
   ELEMDP_HD int cell(int i, int d) const { return i * (W + 1) + d; }
   ELEMDP_HD bool pair_ok(int i, int d) const {  // is_parsable<ST_P>

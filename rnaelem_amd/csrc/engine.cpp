@@ -105,7 +105,8 @@ struct PlanSet {
   int first = 0, count = 0;
   std::vector<SeqPlan> h;
   DevBuf d_plans, dmin, e_stack, e_ext, e_ml, e_close, e_hp, off_outer, off_inner, off_left, off_right, cursor, items,
-      item_in, idx_inner, idx_left, idx_right;
+      item_in, idx_inner, idx_left, idx_right, items_inner, items_left, items_right;
+  bool permuted = false;   // keep item copies in the secondary orders (resident plan of the train pipeline)
   int64_t n_items = 0;
   PlanArrays arrays() const {
     PlanArrays a;
@@ -117,6 +118,7 @@ struct PlanSet {
     a.cursor = cursor.as<int32_t>();
     a.items = items.as<LoopItem>(); a.item_in = item_in.as<uint8_t>();
     a.by_inner_idx = idx_inner.as<int32_t>(); a.by_left_idx = idx_left.as<int32_t>(); a.by_right_idx = idx_right.as<int32_t>();
+    a.items_inner = items_inner.as<LoopItem>(); a.items_left = items_left.as<LoopItem>(); a.items_right = items_right.as<LoopItem>();
     return a;
   }
 };
@@ -408,9 +410,11 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   ps.items.alloc(sizeof(LoopItem) * ib);
   ps.item_in.alloc(ib);
   for (DevBuf* b : {&ps.idx_inner, &ps.idx_left, &ps.idx_right}) b->alloc(sizeof(int32_t) * ib);
+  if (ps.permuted) for (DevBuf* b : {&ps.items_inner, &ps.items_left, &ps.items_right}) b->alloc(sizeof(LoopItem) * (ib + 1));
   a.plans = ps.d_plans.as<SeqPlan>();
   a.p = ps.arrays();
   HIP_OK(launch_plan_items(a, st_));
+  if (ps.permuted) HIP_OK(launch_permute_items(a, st_));
   HIP_OK(hipStreamSynchronize(st_));
 }
 
@@ -662,6 +666,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   // ---- resident plan of the filtered mask
   if (final_bits != d_okbits1_.as<uint32_t>())
     HIP_OK(hipMemcpyAsync(d_okbits1_.as<void>(), d_okbits0_.as<void>(), sizeof(uint32_t) * bits_b, hipMemcpyDeviceToDevice, st_));
+  plan_.permuted = true;
   build_planset(plan_, 0, n, d_okbits1_.as<uint32_t>());
   for (int k = 0; k < n; ++k) { plan_.h[k].bpp_eff = h_plans_[k].bpp_eff; plan_.h[k].n_canonical = h_plans_[k].n_canonical; }
   plan_.d_plans.upload(plan_.h, st_);
@@ -670,7 +675,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   n_cells_total_ = 0;
   for (auto const& pl : h_plans_) n_cells_total_ += (int64_t)(pl.L + 1) * (pl.W + 1);
   d_xwc_.alloc(sizeof(double) * 10 * (size_t)n_cells_total_);
-  d_xwi_.alloc(sizeof(double) * (2 * (size_t)plan_.n_items + 1));
+  d_xwi_.alloc(sizeof(double) * (8 * (size_t)plan_.n_items + 1));   // 4 orders x 2 lambda classes
   d_flagged_.alloc(sizeof(int32_t) * ((size_t)n + 1));
   lin_slots_ = 0;
   out_stride_ = 6 + 2 * au_.n_theta() + 4;
@@ -780,7 +785,7 @@ void Engine::run_lin_batch() {
     HIP_OK(hipMemsetAsync(d_prof_.as<void>(), 0, sizeof(long long) * 16 * 64, st_));
     a.prof = d_prof_.as<long long>();
   }
-  a.n_stage = (lay_.n_ints <= 4096) ? lay_.n_ints : lay_.n_small;
+  a.n_stage = (lay_.n_ints <= 4096 && !(opt_dbg_ & 8)) ? lay_.n_ints : lay_.n_small;
   LinArgs c = a;   // the no-motif pass: one-state automaton, compact tables
   c.lay = layc_;
   c.layp = d_layc_.as<AutomatonLayout>();
@@ -797,6 +802,7 @@ void Engine::run_lin_batch() {
   const PlanArrays pa = plan_.arrays();
   w.e_stack = pa.e_stack; w.e_ext = pa.e_ext; w.e_ml = pa.e_ml; w.e_close = pa.e_close; w.e_hp = pa.e_hp;
   w.items = pa.items;
+  w.items_inner = pa.items_inner; w.items_left = pa.items_left; w.items_right = pa.items_right;
   w.n_cells = (size_t)n_cells_total_; w.n_items = (size_t)plan_.n_items;
   w.params = d_params_.as<double>();
   w.xwc = d_xwc_.as<double>(); w.xwi = d_xwi_.as<double>();

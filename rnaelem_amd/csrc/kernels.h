@@ -21,6 +21,8 @@ struct PlanArrays {
   LoopItem* items = nullptr;
   uint8_t* item_in = nullptr;
   int32_t* by_inner_idx = nullptr; int32_t* by_left_idx = nullptr; int32_t* by_right_idx = nullptr;
+  // copies of the items in the three secondary orders (one dependent load less per term in the outside sweeps)
+  LoopItem* items_inner = nullptr; LoopItem* items_left = nullptr; LoopItem* items_right = nullptr;
 };
 
 // static per-batch arrays
@@ -140,6 +142,7 @@ struct LinArgs {
   int32_t dbg;                    // timing experiments only: bit 0 skip split sums, 1 skip item sums, 2 skip the unary phase
 };
 struct LinWeightArgs {
+  const LoopItem* items_inner; const LoopItem* items_left; const LoopItem* items_right;   // (may be null)
   const double* e_stack; const double* e_ext; const double* e_ml; const double* e_close; const double* e_hp;
   const LoopItem* items;
   size_t n_cells, n_items;
@@ -158,6 +161,7 @@ hipError_t launch_mask(const BatchArrays& b, const SeqPlan* plans, int n_seq, in
                        int32_t* n_canonical, hipStream_t st);
 hipError_t launch_plan_cells(const PlanKernelArgs& a, int32_t* n_items_out, hipStream_t st);
 hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st);
+hipError_t launch_permute_items(const PlanKernelArgs& a, hipStream_t st);
 hipError_t launch_dp(int kind, const DpArgs& a, int n_blocks, hipStream_t st);
 hipError_t launch_reduce(const double* seq_out, int out_stride, int n_seq, int n_theta, double* partial, hipStream_t st);
 const char* dp_kernel_name(int kind);

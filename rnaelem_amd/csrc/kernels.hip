@@ -563,6 +563,17 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
 // deterministic reduction over sequences: one lane per output column, sequences in input order
 // partial = [fn, sum_eff, n_used, n_skipped, ENo[nt], ENx[nt], EHo[2], EHx[2]]
 // ---------------------------------------------------------------------------------------------
+// copies of the items of one sequence in the by_inner / by_left / by_right orders
+__global__ __launch_bounds__(kThreads) void k_permute_items(PlanKernelArgs a) {
+  const SeqPlan p = a.plans[a.first + blockIdx.x];
+  const LoopItem* src = a.p.items + p.item_base;
+  for (int n = threadIdx.x; n < p.n_items; n += kThreads) {
+    a.p.items_inner[p.item_base + n] = src[a.p.by_inner_idx[p.item_base + n]];
+    a.p.items_left[p.item_base + n] = src[a.p.by_left_idx[p.item_base + n]];
+    a.p.items_right[p.item_base + n] = src[a.p.by_right_idx[p.item_base + n]];
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_reduce(const double* seq_out, int out_stride, int n_seq, int n_theta,
                                                      double* partial) {
   const int ncol = 4 + 2 * n_theta + 4;
@@ -596,6 +607,11 @@ hipError_t launch_mask(const BatchArrays& b, const SeqPlan* plans, int n_seq, in
 hipError_t launch_plan_cells(const PlanKernelArgs& a, int32_t* n_items_out, hipStream_t st) {
   if (a.count <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_plan_cells, dim3(a.count), dim3(kThreads), 0, st, a, n_items_out);
+  return hipGetLastError();
+}
+hipError_t launch_permute_items(const PlanKernelArgs& a, hipStream_t st) {
+  if (a.count <= 0 || !a.p.items_inner) return hipSuccess;
+  hipLaunchKernelGGL(k_permute_items, dim3(a.count), dim3(kThreads), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {

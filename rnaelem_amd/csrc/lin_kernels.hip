@@ -22,6 +22,12 @@
 #ifndef ELEMDP_KCO
 #define ELEMDP_KCO 2
 #endif
+#ifndef ELEMDP_LB_IN
+#define ELEMDP_LB_IN 5
+#endif
+#ifndef ELEMDP_LB_OUT
+#define ELEMDP_LB_OUT 4
+#endif
 #ifndef ELEMDP_KIB
 #define ELEMDP_KIB 4
 #endif
@@ -105,6 +111,8 @@ __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) 
   q.e_close = a.p.e_close + p.cell_base; q.e_hp = a.p.e_hp + p.cell_base;
   q.xwc = a.xwc + p.cell_base; q.xwc_stride = a.xwc_stride;
   q.xwi = a.xwi + p.item_base; q.xwi_stride = a.xwi_stride;
+  q.items_inner = a.p.items_inner + p.item_base; q.items_left = a.p.items_left + p.item_base;
+  q.items_right = a.p.items_right + p.item_base;
   q.items = a.p.items + p.item_base; q.item_in = a.p.item_in + p.item_base;
   q.by_outer_off = a.p.by_outer_off + p.off_base;
   q.by_inner_off = a.p.by_inner_off + p.off_base; q.by_inner_idx = a.p.by_inner_idx + p.item_base;
@@ -143,6 +151,12 @@ __global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
     const double t = a.items[n].tsc;
     a.xwi[n] = lin_weight(l0, t);
     a.xwi[a.n_items + n] = lin_weight(l1, t);
+    if (a.items_inner) {   // the same weights in the three secondary orders
+      const double t1 = a.items_inner[n].tsc, t2 = a.items_left[n].tsc, t3 = a.items_right[n].tsc;
+      a.xwi[2 * a.n_items + n] = lin_weight(l0, t1); a.xwi[3 * a.n_items + n] = lin_weight(l1, t1);
+      a.xwi[4 * a.n_items + n] = lin_weight(l0, t2); a.xwi[5 * a.n_items + n] = lin_weight(l1, t2);
+      a.xwi[6 * a.n_items + n] = lin_weight(l0, t3); a.xwi[7 * a.n_items + n] = lin_weight(l1, t3);
+    }
   }
 }
 
@@ -282,7 +296,7 @@ __device__ __forceinline__ void for_block_items(int nv, int nq, int tid, int* cn
 }
 
 template <bool BIG>
-__global__ __launch_bounds__(kThreads) void k4_in(LinArgs a) {
+__global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
   __shared__ AutomatonLayout s_lay;
   PhaseClock pc;
@@ -520,7 +534,7 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
 
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
 template <int MODE, bool BIG>
-__global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
+__global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   extern __shared__ double lds[];
   __shared__ AutomatonLayout s_lay;
   PhaseClock pc;
@@ -649,13 +663,12 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
         if (v.q.pair_ok(i, d)) { const int cell = v.q.cell(i, d); n0 = v.q.by_inner_off[cell]; n1 = v.q.by_inner_off[cell + 1]; }
       },
       [&](ItemSlot& x) {
-        x.idx = v.q.by_inner_idx[x.n];
+        x.idx = x.n;   // position in the by_inner order
+        x.it = v.q.items_inner[x.n];
+        x.xw = v.q.xwi[(size_t)(2 + lamk(v.m, G[A.quad1_ent + 3 * x.t])) * v.q.xwi_stride + x.n];
         x.aux = IB[in.idx(ST_P, d, i0 + x.c, G[A.quad1_tgt + x.t])];   // inside P(i,j,tgt)
       },
-      [&](ItemSlot& x) {
-        x.it = v.q.items[x.idx];
-        x.xw = xw_item(v.q, lamk(v.m, G[A.quad1_ent + 3 * x.t]), x.idx);
-      },
+      [&](ItemSlot& x) {},
       [&](ItemSlot& x) {
         const int i = i0 + x.c, j = i + d;
         x.x0 = OB[out.idx(ST_E, x.it.j - x.it.i, x.it.i, G[A.quad1_ent + 3 * x.t])];
@@ -674,13 +687,12 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
       nc, nq, tid, cnts, pre, base,
       [&](int c, int& n0, int& n1) { const int cell = v.q.cell(i0 + c, d); n0 = v.q.by_left_off[cell]; n1 = v.q.by_left_off[cell + 1]; },
       [&](ItemSlot& x) {
-        x.idx = v.q.by_left_idx[x.n];
+        x.idx = x.n;   // position in the by_left order
+        x.it = v.q.items_left[x.n];
+        x.xw = v.q.xwi[(size_t)(4 + lamk(v.m, G[A.quad2_ent + 3 * x.t])) * v.q.xwi_stride + x.n];
         x.aux = IB[in.idx(ST_L, d, i0 + x.c, G[A.quad2_tgt + x.t])];   // inside L(i,j,tgt)
       },
-      [&](ItemSlot& x) {
-        x.it = v.q.items[x.idx];
-        x.xw = xw_item(v.q, lamk(v.m, G[A.quad2_ent + 3 * x.t]), x.idx);
-      },
+      [&](ItemSlot& x) {},
       [&](ItemSlot& x) {
         x.x0 = OB[out.idx(ST_E, x.it.j - x.it.i, x.it.i, G[A.quad2_ent + 3 * x.t])];
         x.x1 = IB[in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad2_ent + 3 * x.t + 1])];
@@ -696,13 +708,12 @@ __global__ __launch_bounds__(kThreads) void k4_out(LinArgs a) {
       nc, nq, tid, cnts, pre, base,
       [&](int c, int& n0, int& n1) { const int cell = v.q.cell(i0 + c, d); n0 = v.q.by_right_off[cell]; n1 = v.q.by_right_off[cell + 1]; },
       [&](ItemSlot& x) {
-        x.idx = v.q.by_right_idx[x.n];
+        x.idx = x.n;   // position in the by_right order
+        x.it = v.q.items_right[x.n];
+        x.xw = v.q.xwi[(size_t)(6 + lamk(v.m, G[A.quad3_ent + 3 * x.t])) * v.q.xwi_stride + x.n];
         x.aux = IB[in.idx(ST_L, d, i0 + x.c, G[A.quad3_tgt + x.t])];
       },
-      [&](ItemSlot& x) {
-        x.it = v.q.items[x.idx];
-        x.xw = xw_item(v.q, lamk(v.m, G[A.quad3_ent + 3 * x.t]), x.idx);
-      },
+      [&](ItemSlot& x) {},
       [&](ItemSlot& x) {
         x.x0 = OB[out.idx(ST_E, x.it.j - x.it.i, x.it.i, G[A.quad3_ent + 3 * x.t])];
         x.x1 = IB[in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad3_ent + 3 * x.t + 1])];
