@@ -4,7 +4,9 @@
 One "step" = one evaluation of (fn, gr) over the whole batch = per sequence K2 (inside) + 2 x K3
 (outside + expected counts), the cached K1 (BPP filter) excluded, then ONE RCCL all-reduce of the
 partial sums when N > 1.  The roofline "launch" is the whole diagonal pipeline of one evaluation (all
-k3_* launches, timed with HIP events on the engine's stream: elemdp_last_timing()[1]).  Workload = BASELINE config C/D: 10 000 synthetic RNAs of L = 200, pattern
+k4_* launches of the scaled-linear pipeline, timed with HIP events on the engine's stream:
+elemdp_last_timing()[1]); `traffic` is the HBM byte count of the same pipeline from the committed
+rocprofv3 --pmc passes (profiles/traffic.json), scaled to this launch.  Workload = BASELINE config C/D: 10 000 synthetic RNAs of L = 200, pattern
 '((.*.))', x0 with lambda = (1,1) so the energy terms are exercised; the 10 000 sequences are sharded
 over the N ranks (strong scaling, as the metric is quoted).
 
@@ -145,7 +147,8 @@ def main():
             "bpp_filter": "cached (computed once at load_batch, %.1f s incl. plan)" % t_load, "fn": fn, "n_skipped": nsk},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "k3_* diagonal pipeline of one evaluation (sum of all launches; dominant %s)" % eng.kernel_name(),
+                     "kernel": "k4_* diagonal pipeline of one evaluation (sum of all launches; dominant %s)" % eng.kernel_name(),
+                     "log_space_fallback_sequences": int(eng.last_timing()[2]),
                      "kernel_ms": k_s * 1e3, "algorithmic_bytes_per_launch": alg},
     }
     if world == 1 and not args.no_cpu_baseline:

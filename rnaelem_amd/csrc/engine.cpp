@@ -1189,6 +1189,6 @@ int elemdp_debug_profile(elemdp_handle* h, double* cycles, int32_t n) {
   for (int k = 0; k < n && k < 16; ++k) cycles[k] = k < (int)h->e->last_prof.size() ? (double)h->e->last_prof[k] : 0.;
   return ELEMDP_OK;
 }
-const char* elemdp_kernel_name(void) { return "k3_out_heavy"; }
+const char* elemdp_kernel_name(void) { return "k4_out"; }
 
 }  // extern "C"

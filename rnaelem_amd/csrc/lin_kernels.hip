@@ -28,6 +28,9 @@
 #ifndef ELEMDP_LB_OUT
 #define ELEMDP_LB_OUT 4
 #endif
+#ifndef ELEMDP_CPB_MAX
+#define ELEMDP_CPB_MAX 64
+#endif
 #ifndef ELEMDP_KIB
 #define ELEMDP_KIB 4
 #endif
@@ -125,6 +128,18 @@ __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) 
   v.in.L = v.out.L = p.L; v.in.W = v.out.W = p.W; v.in.S = v.out.S = a.lay.S;
   v.row = a.seq_out + (size_t)n * a.out_stride;
   v.zs = a.zs + (size_t)g * 4;
+}
+
+// XCD-aware block swizzle (speed only): blocks are dealt round-robin over the 8 XCDs, each with a private L2.  The
+// remap gives every XCD a contiguous range of virtual block ids, so the workgroups of one sequence -- which re-read each
+// other's rows (out B segments of H1 / H2, neighbouring cells of the unary phase) -- share an L2.  Bijective for any grid.
+__device__ __forceinline__ void swizzled_block(unsigned& bx, unsigned& by) {
+  const unsigned nbx = gridDim.x, total = gridDim.x * gridDim.y;
+  const unsigned orig = blockIdx.y * nbx + blockIdx.x;
+  const unsigned q = total / 8, r = total % 8, xcd = orig % 8;
+  const unsigned vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  bx = vb % nbx;
+  by = vb / nbx;
 }
 
 // copies the automaton layout record into LDS (all threads; caller synchronises before the first use)
@@ -302,12 +317,14 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   PhaseClock pc;
   pc.start(a.prof);
   stage_layout(a, &s_lay, kThreads);
+  unsigned bx, by;
+  swizzled_block(bx, by);
   LViews v(s_lay);
-  make_lviews(a, blockIdx.y, v);
+  make_lviews(a, by, v);
   const AutomatonLayout& A = s_lay;   // (valid after the first barrier below)
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x;
   if (d > v.q.W) return;
-  const int ncell = v.q.L - d + 1, i0 = blockIdx.x * cpb;
+  const int ncell = v.q.L - d + 1, i0 = bx * cpb;
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
   const int CS = cpb * S, ncS = nc * S;
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     const Cell7 r = lin_inside_target_u(v.m, v.q, v.in, d, i, s, hb[c * S + s], he[c * S + s]);
     if (a.band_in0 != nullptr && s == A.s00) {   // compact copy of state (0,0) for the no-motif pass
       TableView t0;
-      t0.band = a.band_in0 + (size_t)blockIdx.y * a.band0_stride;
+      t0.band = a.band_in0 + (size_t)by * a.band0_stride;
       t0.ext = nullptr; t0.L = v.in.L; t0.W = v.in.W; t0.S = 1;
       t0.at(ST_P, d, i, 0) = r.vP; t0.at(ST_E, d, i, 0) = r.vE; t0.at(ST_M, d, i, 0) = r.vM; t0.at(ST_B, d, i, 0) = r.vB;
       t0.at(ST_1, d, i, 0) = r.v1; t0.at(ST_2, d, i, 0) = r.v2; t0.at(ST_L, d, i, 0) = r.vL;
@@ -540,14 +557,16 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   PhaseClock pc;
   pc.start(a.prof);
   stage_layout(a, &s_lay, kThreads);
+  unsigned bx, by;
+  swizzled_block(bx, by);
   LViews v(s_lay);
-  make_lviews(a, blockIdx.y, v);
+  make_lviews(a, by, v);
   const LPass pi = lpass(a, v);
   const AutomatonLayout& A = s_lay;   // (valid after the first barrier below)
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = a.lay.n_theta;
   if (pi.skip || d > v.q.W) return;
   const int L = v.q.L, W = v.q.W;
-  const int ncell = L - d + 1, i0 = blockIdx.x * cpb;
+  const int ncell = L - d + 1, i0 = bx * cpb;
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
   const int CS = cpb * S, ncS = nc * S;
@@ -774,6 +793,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   LinArgs a = full;
   const int S = a.lay.S, nt = a.lay.n_theta;
   a.cpb = kThreads / S;
+  if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
   const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
   const bool big = a.n_stage >= a.lay.n_ints;
@@ -792,6 +812,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
     LinArgs b = (a.schedule == 1 && pass == 1) ? compact : a;
     b.pass = pass;
     b.cpb = kThreads / b.lay.S;
+    if (b.cpb > ELEMDP_CPB_MAX) b.cpb = ELEMDP_CPB_MAX;
     b.wmax = Wmax;
     const size_t lds_b = block_lds((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, b.n_stage).total;
     const bool big_b = b.n_stage >= b.lay.n_ints;

@@ -260,6 +260,44 @@ def test_ragged_batch_and_batch_linearity():
     np.testing.assert_allclose(gr, go, rtol=1e-7, atol=1e-7)
 
 
+def test_pipelines_agree_and_linear_pipeline_is_the_one_measured():
+    """The scaled-linear pipeline (default, what bench.py times) against the log-space batch pipeline and the fused kernel
+    on a ragged batch: same fn / gr, and no sequence needed the log-space fallback."""
+    m = io.read_model(gpath("syn_b.model"))
+    recs = io.read_fastq(gpath("syn_L40_n3.fq")) + io.read_fastq(gpath("syn_L100_n3.fq")) + io.read_fastq(gpath("syn_L150_n8.fq"))
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    res = {}
+    for pipe in (4, 3, 2):
+        eng = io.engine_from_model(m)
+        eng.set_option("pipeline", pipe)
+        eng.load_batch(seqs, quals)
+        res[pipe] = eng.train_eval(m["x"])
+        if pipe == 4:
+            assert eng.last_timing()[2] == 0
+    for pipe in (3, 2):
+        assert res[pipe][0] == pytest.approx(res[4][0], rel=1e-11)
+        np.testing.assert_allclose(res[pipe][1], res[4][1], rtol=1e-9, atol=1e-10)
+        assert res[pipe][2:] == res[4][2:]
+
+
+def test_linear_pipeline_hands_out_of_range_sequences_to_the_log_pipeline():
+    """lambda = 40 puts the partition functions (~e^1000 and beyond) outside the double range of the scaled-linear tables:
+    those sequences are flagged and re-evaluated in log space, the result still matches the oracle."""
+    eng = api.Engine("((.*.))", PAR, 50, 30, 1e-4, 0.1)
+    o = po.make_oracle("((.*.))", 50, 30, min_bpp=1e-4, tau=0.1)
+    recs = io.read_fastq(gpath("syn_L150_n8.fq"))
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    x = eng.initial_params(40.0)
+    o.set_params(x)
+    eng.load_batch(seqs, quals)
+    fn, gr, eff, nsk = eng.train_eval(x)
+    assert eng.last_timing()[2] > 0          # some sequences took the fallback
+    fo, go, eo, no = o.train_eval(x, seqs, quals)
+    assert nsk == no
+    assert fn == pytest.approx(fo, rel=1e-8, abs=1e-9)
+    np.testing.assert_allclose(gr, go, rtol=1e-6, atol=1e-7)
+
+
 def test_error_behaviour():
     with pytest.raises(api.ElemdpError):
         api.Engine("(.")
@@ -282,6 +320,7 @@ def test_baseline_config_full_size():
     fn, gr, eff, nsk = eng.train_eval(x)
     stats = eng.seq_stats()
     assert nsk == 0 and np.all(np.isfinite(stats[:, :4]))
+    assert eng.last_timing()[2] == 0                 # the scaled-linear pipeline handled every sequence
     assert fn == pytest.approx(stats[:, 3].sum(), rel=1e-11)
     assert np.all(stats[:, 3] >= -1e-9)              # f_n = -log P(label | seq) >= 0
     assert np.all(stats[:, 1] <= stats[:, 0] + 1e-9) and np.all(stats[:, 2] <= stats[:, 0] + 1e-9)
