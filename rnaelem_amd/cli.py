@@ -1,0 +1,120 @@
+"""Command line of the path: the option names of the reference binary's `train` / `scan` sub-commands
+(RNAelem/application.hpp option table; what `script/elem` spawns), driving libelemdp instead of the CPU DP.
+
+    python -m rnaelem_amd.cli train --fastq pos.fq --motif-pattern '((.*.))' --out1 model.txt --no-shuffle [-i 300]
+    python -m rnaelem_amd.cli scan  --fastq seqs.fq --motif-model model.txt --out1 scan.raw
+    torchrun --nproc-per-node 8 -m rnaelem_amd.cli train ...      # one rank per GPU, one RCCL all-reduce per evaluation
+
+Implemented: the `--no-shuffle` full-batch training path named by BASELINE.json (L-BFGS-B) and `scan`.
+Not implemented (explicit error): shuffled negatives / mini-batches (`--kmer-shuf`, `--batch-size > 0`), `--lik-ratio`,
+`--param-set`, array jobs -- SURVEY.md §8(f) ranks 3-4.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from . import api, io, train as trainer
+from .distributed import ShardedTrainer
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="rnaelem_amd.cli", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = p.add_subparsers(dest="cmd", required=True)
+    for name in ("train", "scan"):
+        s = sub.add_parser(name)
+        s.add_argument("-f", "--fastq", required=True, help="input FASTQ with pseudo-qualities (L+1 quality characters)")
+        s.add_argument("--out1", required=True, help="train: model file; scan: raw records")
+        s.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK or 0)")
+    t = sub.choices["train"]
+    t.add_argument("-m", "--motif-pattern", required=True)
+    t.add_argument("-i", "--max-iter", type=int, default=300)
+    t.add_argument("--energy-param", default="~T2004~")
+    t.add_argument("-w", "--max-span", type=int, default=50)
+    t.add_argument("-c", "--max-internal-loop", type=int, default=30)
+    t.add_argument("--epsilon", type=float, default=1e-3)
+    t.add_argument("--rho-s", type=float, default=0.1)
+    t.add_argument("--rho-theta", type=float, default=0.1)
+    t.add_argument("--rho-lambda", type=float, default=0.1)
+    t.add_argument("--tau", type=float, default=0.1)
+    t.add_argument("--lambda-init", type=float, default=0.0)
+    t.add_argument("--lambda-prior", type=float, default=0.0)
+    t.add_argument("-p", "--min-bpp", type=float, default=1e-4)
+    t.add_argument("--no-rss", action="store_true")
+    t.add_argument("--no-profile", action="store_true")
+    t.add_argument("--no-energy", action="store_true")
+    t.add_argument("--no-shuffle", action="store_true")
+    t.add_argument("--theta-softmax", action="store_true")
+    t.add_argument("--batch-size", type=int, default=-1)
+    t.add_argument("--optimizer", choices=["lbfgsb", "adam"], default="lbfgsb")
+    sub.choices["scan"].add_argument("-q", "--motif-model", required=True)
+    return p
+
+
+def _rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def cmd_train(a):
+    if not a.no_shuffle or a.batch_size > 0:
+        raise SystemExit("only the --no-shuffle full-batch mode is implemented (shuffled negatives: SURVEY.md §8f rank 3)")
+    rank, local_rank, world = _rank_world()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    flags = (api.NO_RSS if a.no_rss else 0) | (api.NO_PROFILE if a.no_profile else 0) | (api.NO_ENERGY if a.no_energy else 0) | \
+        (api.THETA_SOFTMAX if a.theta_softmax else 0)
+    pattern = a.motif_pattern.replace("_", ".") if a.no_rss else a.motif_pattern
+    par = a.energy_param if a.energy_param in ("~T2004~", "~A2007~") else open(a.energy_param).read()
+    device = a.device if a.device is not None else local_rank
+    eng = api.Engine(pattern, par, a.max_span, a.max_internal_loop, a.min_bpp, a.tau, flags, device)
+    recs = io.read_fastq(a.fastq)
+    ev = ShardedTrainer(eng, [s for _, s, _ in recs], [q for _, _, q in recs], rank, world)
+    x0 = eng.initial_params(a.lambda_init)
+    log = (lambda msg: print(msg, file=sys.stderr, flush=True)) if rank == 0 else None
+    res = trainer.train(ev, x0, a.rho_s if a.theta_softmax else a.rho_theta, a.rho_lambda, a.max_iter, a.epsilon, a.optimizer, log)
+    if rank == 0:
+        d = eng.describe()
+        rows, k = [], 0
+        for w in d["theta_sizes"]:
+            rows.append([0.0] * w)
+            k += w
+        m = dict(pattern=pattern, rows=rows, lam=[0.0, 0.0], softmax=a.theta_softmax, ene_param=a.energy_param, max_span=a.max_span,
+                 max_iloop=a.max_internal_loop, min_bpp=a.min_bpp, tau=a.tau, rho_theta=a.rho_theta, rho_s=a.rho_s,
+                 rho_lambda=a.rho_lambda, lambda_prior=a.lambda_prior, no_rss=a.no_rss, no_prf=a.no_profile, no_ene=a.no_energy)
+        io.write_model(a.out1, m, res["x"])
+        print("%s after %d iterations (%d evaluations); final value: %.6g" % (res["message"], res["n_iter"], res["n_eval"], res["f"]),
+              file=sys.stderr)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cmd_scan(a):
+    rank, local_rank, world = _rank_world()
+    m = io.read_model(a.motif_model)
+    eng = io.engine_from_model(m, a.device if a.device is not None else local_rank)
+    recs = io.read_fastq(a.fastq)
+    from .distributed import assigned_range
+    lo, hi = assigned_range(len(recs), world, rank)     # scan needs no collective: every rank writes its own range
+    mine = recs[lo:hi]
+    out = a.out1 if world == 1 else "%s.%d" % (a.out1, rank)
+    with open(out, "w") as f:
+        if mine:
+            eng.load_batch([s for _, s, _ in mine], [q for _, _, q in mine])
+            res, en = eng.scan(m["x"])
+            nodes = eng.describe()["node"]
+            for (rid, codes, _), r in zip(mine, res):
+                f.write(io.scan_record(rid, codes, r, nodes) + "\n")
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
+    (cmd_train if a.cmd == "train" else cmd_scan)(a)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""Host optimizer loop around the evaluation path.
+
+Mirrors how `elem train` drives `RNAelemTrainer::operator()`:
+
+* objective handed to the optimizer = fn + sum_i rho_i x_i^2 / 2, gradient + rho_i x_i (L2 regulariser added by the
+  optimizer, `Lbfgsb::before_update` / `Adam::before_update`, RNAelem/optimizer.hpp:246-260, 107-122);
+  rho = rho_theta (or rho_s with --theta-softmax) for the theta entries, rho_lambda for lambda
+  (`set_regularization`, RNAelem/motif_trainer.hpp:527-540);
+* bounds: theta unbounded below (lower bound log 0), lambda >= 0 (`set_bounds`, :508-526);
+* `--no-shuffle` mode: L-BFGS-B with m = 5, factr = 1e7, pgtol = --epsilon, at most --max-iter iterations, the best
+  point seen at any evaluation is the result (`Lbfgsb::minimize`, optimizer.hpp:262-334).  The reference embeds the
+  L-BFGS-B 2.1 routine `setulb`; here the same algorithm family comes from SciPy (L-BFGS-B 3.0), so iterates agree with
+  the reference's trace to optimizer tolerance, not bitwise (tests/test_train_loop.py);
+* otherwise Adam with alpha = 0.1, beta = (0.9, 0.999), eps = 1e-8, moments initialised to 0, bias correction with
+  beta^(t+1), convergence `|g|^2 < (y + 1) * 1e-8`, projection onto the bounds after every step
+  (`Adam::minimize`, optimizer.hpp:127-160) -- mirrored operation by operation.
+
+`evaluate(x) -> (fn, gr, sum_eff, n_skipped)` is an `api.Engine.train_eval`, a `distributed.ShardedTrainer`, or any
+callable with that signature (tests pass the oracle).
+"""
+import math
+
+import numpy as np
+
+
+def regularisation(n_param, rho_theta, rho_lambda):
+    """rho vector in pack_params order: theta rows flattened, then lambda_0, lambda_1."""
+    return np.r_[np.full(n_param - 2, float(rho_theta)), np.full(2, float(rho_lambda))]
+
+
+def bounds(n_param):
+    """(lower, upper) of every parameter: theta free, lambda >= 0."""
+    return [(None, None)] * (n_param - 2) + [(0.0, None)] * 2
+
+
+class Objective:
+    """fn + L2 term as the reference's optimizers see it; keeps the trace and the best point."""
+
+    def __init__(self, evaluate, rho, log=None):
+        self.evaluate, self.rho, self.log = evaluate, np.asarray(rho, dtype=np.float64), log
+        self.n_eval = 0
+        self.best_f, self.best_x = math.inf, None
+        self.trace = []          # (n_eval, regularised f, |gr|^2 of the unregularised gradient, sum_eff)
+
+    def __call__(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        fn, gr, eff, nsk = self.evaluate(x)
+        y = fn + float(np.sum(self.rho * x * x) / 2.0)
+        g = np.asarray(gr, dtype=np.float64) + self.rho * x
+        self.n_eval += 1
+        self.trace.append((self.n_eval, y, float(np.dot(gr, gr)), eff))
+        if y < self.best_f:
+            self.best_f, self.best_x = y, x.copy()
+        if self.log:
+            self.log("eval %d: f %.6g (fn %.6g), |gr|^2 %.6g, considered BP %.6g, skipped %d" % (self.n_eval, y, fn, np.dot(gr, gr), eff, nsk))
+        return y, g
+
+
+def minimize_lbfgsb(evaluate, x0, rho, max_iter=300, epsilon=1e-3, log=None):
+    """`elem train --no-shuffle`: returns dict(x, f, n_iter, n_eval, trace, iter_f, message)."""
+    from scipy.optimize import fmin_l_bfgs_b
+    obj = Objective(evaluate, rho, log)
+    iter_f = []
+
+    def on_iter(xk):
+        iter_f.append(obj.trace[-1][1])
+
+    x, f, info = fmin_l_bfgs_b(obj, np.asarray(x0, dtype=np.float64), bounds=bounds(len(x0)), m=5, factr=1e7, pgtol=epsilon,
+                               maxiter=max_iter, maxfun=20 * max_iter + 20, callback=on_iter)
+    return dict(x=obj.best_x, f=obj.best_f, n_iter=info["nit"], n_eval=obj.n_eval, trace=obj.trace, iter_f=iter_f,
+                message=info["task"] if isinstance(info["task"], str) else info["task"].decode())
+
+
+def minimize_adam(evaluate, x0, rho, max_iter=100, alpha=0.1, beta1=0.9, beta2=0.999, eps=1e-8, log=None):
+    """`elem train` with shuffled negatives / mini-batches (optimizer.hpp:127-160), operation by operation."""
+    obj = Objective(evaluate, rho, log)
+    x = np.asarray(x0, dtype=np.float64).copy()
+    n = len(x)
+    lower = np.r_[np.full(n - 2, -np.inf), 0.0, 0.0]
+    m, v = np.zeros(n), np.zeros(n)
+    b1t, b2t = beta1, beta2
+    t = 0
+    while True:
+        t += 1
+        y, g = obj(x)
+        b1t *= beta1
+        b2t *= beta2
+        m += (1.0 - beta1) * (g - m)
+        v += (1.0 - beta2) * (g * g - v)
+        x = x - alpha * (m / (1.0 - b1t)) / (np.sqrt(v / (1.0 - b2t)) + eps)
+        x = np.maximum(x, lower)
+        if float(np.dot(g, g)) < (y + 1.0) * 1e-8 or t >= max_iter:
+            break
+    return dict(x=x, f=obj.trace[-1][1], n_iter=t - 1, n_eval=obj.n_eval, trace=obj.trace, message="adam")
+
+
+def train(evaluate, x0, rho_theta=0.1, rho_lambda=0.1, max_iter=300, epsilon=1e-3, optimizer="lbfgsb", log=None):
+    rho = regularisation(len(x0), rho_theta, rho_lambda)
+    if optimizer == "lbfgsb":
+        return minimize_lbfgsb(evaluate, x0, rho, max_iter, epsilon, log)
+    if optimizer == "adam":
+        return minimize_adam(evaluate, x0, rho, max_iter, log=log)
+    raise ValueError("optimizer must be 'lbfgsb' or 'adam'")

@@ -214,6 +214,17 @@ def main():
         sc.append({"model": mdl, "fq": fq, "records": parse_scan(open(out).read())})
     dump("scan.json", sc)
 
+    # ---- optimizer-loop traces of `RNAelem train --no-shuffle` (regularised objective after every L-BFGS-B iteration)
+    tt = []
+    for fq, pattern, iters in (("positive.fq", "(.....)", 12), ("positive_head6.fq", "(.....)", 10)):
+        r = subprocess.run([os.path.join(RB, "RNAelem"), "train", "--fastq", os.path.join(G, fq), "--motif-pattern", pattern,
+                            "--out1", "/tmp/tt.model", "--max-iter", str(iters), "--no-shuffle", "--batch-size", "-1", "-t", "8",
+                            "--lambda-init", "0", "--epsilon", "1e-5"], capture_output=True, text=True)
+        f = [float(m.group(2)) for m in re.finditer(r"^iter: (\d+) , f: ([-0-9.e+]+)", r.stdout + r.stderr, re.M)]
+        tt.append({"fq": fq, "pattern": pattern, "max_iter": iters, "epsilon": 1e-5, "lambda_init": 0, "rho_theta": 0.1,
+                   "rho_lambda": 0.1, "tau": 0.1, "iter_f": f})
+    dump("train_trace.json", tt)
+
     # ---- the reference's known-answer cases re-run through its debug configuration
     pc = []
     kat = [(".", "A", "."), (".", "AA", ".."), (".", "CAAAG", "(...)"), (".", "ACAAAGA", ".(...)."),
