@@ -163,6 +163,7 @@ class Engine {
   void run_train(bool first_pass_only);
   void run_train_batch();
   void run_lin_batch();
+  int balanced_group(size_t per_slot_bytes);
   TrArgs log_pipeline_args();
   void init_device();
   void require_device() const;
@@ -431,8 +432,8 @@ void Engine::ensure_slots(int S, bool scan, int n_want) {
   d_band_in_.reset(); d_band_out_.reset(); d_ext_in_.reset(); d_ext_out_.reset(); d_tr_band_.reset(); d_tr_ext_.reset(); d_tmp_.reset();
   d_tr_stack_.reset();
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
-  const size_t budget = free_b / 2;
-  while (want > 1 && per_slot * want > budget) want /= 2;
+  const size_t budget = (size_t)((double)free_b * 0.6);
+  if (per_slot * (size_t)want > budget) want = (int)std::max<size_t>(1, budget / per_slot);
   if (per_slot * want > free_b) throw HipError("not enough device memory for one table slot");
   n_slots_ = want; slots_S_ = S; slots_scan_ = scan;
   band_stride_ = band; ext_stride_ = ext;
@@ -684,6 +685,21 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   HIP_OK(hipStreamSynchronize(st_));
 }
 
+// Sequences swept in lockstep: as many as fit in ~55 % of the free device memory (at most 8192), then balanced so that all
+// groups of the batch have the same size (a small last group runs at lower efficiency).
+int Engine::balanced_group(size_t per_slot_bytes) {
+  if (opt_group_ > 0) return opt_group_;
+  size_t free_b = 0, total_b = 0;
+  HIP_OK(hipMemGetInfo(&free_b, &total_b));
+  const size_t held = d_band_in_.bytes() + d_band_out_.bytes() + d_ext_in_.bytes() + d_ext_out_.bytes() + d_band_in0_.bytes() +
+                      d_band_out0_.bytes();
+  const size_t budget = (size_t)((double)(free_b + held) * 0.55);
+  long cap = (long)(budget / std::max<size_t>(per_slot_bytes, 1));
+  cap = std::max(1L, std::min(cap, 8192L));
+  const long n_groups = (n_seq_ + cap - 1) / cap;
+  return (int)((n_seq_ + n_groups - 1) / n_groups);
+}
+
 TrArgs Engine::log_pipeline_args() {
   const int S = au_.S();
   TrArgs a;
@@ -735,10 +751,16 @@ void Engine::run_train_batch() {
 // The scaled-linear pipeline (lin_kernels.hip); sequences it flags (partition function outside the double range, or a
 // structurally empty component) are re-evaluated by the log-space pipeline, which applies the reference's skip rule.
 void Engine::run_lin_batch() {
-  slot_override_ = opt_group_ > 0 ? opt_group_ : 4096;
-  ensure_slots(au_.S(), false, n_seq_);
-  slot_override_ = 0;
   const int S = au_.S();
+  {
+    const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext = (size_t)(Lmax_ + 1);
+    slot_override_ = balanced_group((band + ext) * (S + 1) * 2 * sizeof(double) + ext * S * 3 * sizeof(double));
+  }
+  ensure_slots(S, false, n_seq_);
+  slot_override_ = 0;
+  // (if the allocation had to shrink, rebalance for the slots we got)
+  const int n_groups = (n_seq_ + n_slots_ - 1) / n_slots_;
+  const int gsz = (n_seq_ + n_groups - 1) / n_groups;
   const bool sched1 = opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_ && lay_.s00 == 0;
   const size_t band0 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext0 = (size_t)(Lmax_ + 1);
   if (lin_slots_ != n_slots_) {
@@ -807,8 +829,8 @@ void Engine::run_lin_batch() {
   w.params = d_params_.as<double>();
   w.xwc = d_xwc_.as<double>(); w.xwi = d_xwi_.as<double>();
   HIP_OK(launch_lin_weights(w, st_));
-  for (int g0 = 0; g0 < n_seq_; g0 += n_slots_) {
-    const int G = std::min(n_slots_, n_seq_ - g0);
+  for (int g0 = 0; g0 < n_seq_; g0 += gsz) {
+    const int G = std::min(gsz, n_seq_ - g0);
     a.grp = c.grp = d_order_.as<int32_t>() + g0;
     const int Lg = h_plans_[h_order_[g0]].L;
     HIP_OK(launch_lin_group(a, c, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, st_));
