@@ -89,6 +89,8 @@ struct SeqPlan {
   int32_t n_items;      // outside set; members of the inside set are flagged
   int32_t n_canonical;  // base pairs possible by sequence alone (denominator of bpp_eff)
   double bpp_eff;       // kept / possible pairs (energy_model.hpp:265)
+  int32_t index;        // position of the sequence in the batch (copies of the plan array kept in processing order)
+  int32_t pad_;
 };
 
 // interior-loop item: outer cell E(i,j), inner pair P(k,l), tsc = loop_energy(i-1,j,k,l-1)

@@ -212,9 +212,12 @@ class Engine {
   int64_t n_cells_total_ = 0;
   bool tables_linear_ = false;           // the resident tables hold scaled linear values (debug_tables converts)
   int n_flagged_last_ = 0;
+  DevBuf d_part_in_, d_part_h1_, d_part_h2_;   // tile partial sums of the split rules, per slot [4][Lmax+1][S]
+  DevBuf d_plans_sorted_;   // plan records in processing (h_order_) order
   DevBuf d_ews_, d_xwc_, d_xwi_, d_lin_, d_layc_, d_zs_, d_flagged_, d_band_in0_, d_band_out0_, d_ext_in0_, d_ext_out0_;
   int lin_slots_ = 0;
   int opt_schedule_ = 1;   // 1 = linear (ari pass + one-state nasi pass), 0 = the reference's two full passes
+  int opt_tile_ = 0;       // 1: split sums tiled over 4 diagonals (2.5x less table traffic, same speed: see DESIGN.md)
   int opt_dbg_ = 0;        // timing experiments (LinArgs::dbg); results are wrong when set
   int opt_group_ = 0;      // sequences swept in lockstep by the batch pipeline (0 = auto)
   DevBuf d_prof_;
@@ -313,6 +316,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "group") opt_group_ = (int)v;
   else if (key == "schedule") opt_schedule_ = (int)v;
   else if (key == "dbg") opt_dbg_ = (int)v;
+  else if (key == "tile") opt_tile_ = (int)v;
   else throw ArgError("unknown option: " + key);
 }
 
@@ -673,6 +677,12 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   plan_.d_plans.upload(plan_.h, st_);
   for (int k = 0; k < n; ++k) h_plans_[k] = plan_.h[k];
   d_order_.upload(h_order_, st_);
+  {
+    std::vector<SeqPlan> sorted(n);
+    for (int k = 0; k < n; ++k) { sorted[k] = h_plans_[h_order_[k]]; sorted[k].index = h_order_[k]; }
+    d_plans_sorted_.upload(sorted, st_);
+    HIP_OK(hipStreamSynchronize(st_));
+  }
   n_cells_total_ = 0;
   for (auto const& pl : h_plans_) n_cells_total_ += (int64_t)(pl.L + 1) * (pl.W + 1);
   d_xwc_.alloc(sizeof(double) * 10 * (size_t)n_cells_total_);
@@ -765,6 +775,9 @@ void Engine::run_lin_batch() {
   const size_t band0 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext0 = (size_t)(Lmax_ + 1);
   if (lin_slots_ != n_slots_) {
     d_zs_.alloc(sizeof(double) * 4 * n_slots_);
+    d_part_in_.alloc(sizeof(double) * 4 * (size_t)(Lmax_ + 1) * S * n_slots_);
+    d_part_h1_.alloc(sizeof(double) * 4 * (size_t)(Lmax_ + 1) * S * n_slots_);
+    d_part_h2_.alloc(sizeof(double) * 4 * (size_t)(Lmax_ + 1) * S * n_slots_);
     d_band_in0_.alloc(sizeof(double) * band0 * n_slots_);
     d_band_out0_.alloc(sizeof(double) * band0 * n_slots_);
     d_ext_in0_.alloc(sizeof(double) * ext0 * n_slots_);
@@ -796,6 +809,11 @@ void Engine::run_lin_batch() {
   a.ext_in0 = sched1 ? d_ext_in0_.as<double>() : nullptr;
   a.band0_stride = band0; a.ext0_stride = ext0;
   a.zs = d_zs_.as<double>();
+  a.part_in = d_part_in_.as<double>(); a.part_h1 = d_part_h1_.as<double>(); a.part_h2 = d_part_h2_.as<double>();
+  a.part_stride = 4 * (size_t)(Lmax_ + 1) * S;
+  a.tile_d0 = -1;
+  a.tile = opt_tile_;
+  a.tile_has_old = 0;
   a.seq_out = d_seq_out_.as<double>();
   a.out_stride = out_stride_;
   a.schedule = sched1 ? 1 : 0;
@@ -816,6 +834,7 @@ void Engine::run_lin_batch() {
   c.ext_in = d_ext_in0_.as<double>(); c.ext_out = d_ext_out0_.as<double>();
   c.band_stride = band0; c.ext_stride = ext0;
   c.band_in0 = nullptr; c.ext_in0 = nullptr;
+  c.part_in = c.part_h1 = c.part_h2 = nullptr;   // the one-state pass sums directly
   c.n_stage = (layc_.n_ints <= 4096) ? layc_.n_ints : layc_.n_small;
   HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n_seq_, st_));
   HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
@@ -832,6 +851,7 @@ void Engine::run_lin_batch() {
   for (int g0 = 0; g0 < n_seq_; g0 += gsz) {
     const int G = std::min(gsz, n_seq_ - g0);
     a.grp = c.grp = d_order_.as<int32_t>() + g0;
+    a.plans_slot = c.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
     const int Lg = h_plans_[h_order_[g0]].L;
     HIP_OK(launch_lin_group(a, c, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, st_));
   }

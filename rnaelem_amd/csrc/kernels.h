@@ -121,6 +121,7 @@ struct LinArgs {
   int32_t no_prf, m_min, no_rss;
   const SeqPlan* plans;
   const int32_t* grp;             // grp[g] = batch index of the sequence in table slot g
+  const SeqPlan* plans_slot;      // the plans of this group in slot order (saves the grp -> plans dependent load), or null
   BatchArrays b;
   const double* ews;              // exp of the position weights
   const uint32_t* okbits;
@@ -137,6 +138,12 @@ struct LinArgs {
   int32_t cpb;                    // cells per workgroup = kThreads / S
   int32_t* flagged;               // [0] = number of flagged sequences, [1..] = their batch indices
   long long* prof;                // optional [16] shader-clock sums per phase (thread 0 of every workgroup), or null
+  // tiling of the split sums over kTile diagonals: pairs whose operands were both final before the tile started are
+  // summed by k4_in_old / k4_out_old into part_* (per slot [level][i][s]); the per-diagonal kernels add the rest
+  double* part_in; double* part_h1; double* part_h2; size_t part_stride;   // (part_stride = doubles per slot and array)
+  int32_t tile_d0;                // first diagonal of the running tile, or -1: this launch sums all split points itself
+  int32_t tile;                   // 1: tile the split sums (k4_in_old / k4_out_old); 0 (default): every diagonal sums its own
+  int32_t tile_has_old;           // part_* of the running tile are valid (0: the tile has no old pairs, e.g. the outside tile at W)
   int32_t wmax;                   // largest span of the launch (sizes the position window staged in LDS)
   int32_t n_stage;                // ints of the automaton blob staged in LDS: n_ints (whole blob) or n_small
   int32_t dbg;                    // timing experiments only: bit 0 skip split sums, 1 skip item sums, 2 skip the unary phase

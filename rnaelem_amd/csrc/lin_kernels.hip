@@ -31,6 +31,9 @@
 #ifndef ELEMDP_CPB_MAX
 #define ELEMDP_CPB_MAX 64
 #endif
+#ifndef ELEMDP_TILE
+#define ELEMDP_TILE 4
+#endif
 #ifndef ELEMDP_KIB
 #define ELEMDP_KIB 4
 #endif
@@ -83,14 +86,16 @@ struct LViews {
   SeqView q;
   TableView in, out;
   int n;
+  bool positive;
   double* row;
   double* zs;
 };
 
 __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) {
-  const int n = a.grp[g];
+  const SeqPlan p = a.plans_slot ? a.plans_slot[g] : a.plans[a.grp[g]];
+  const int n = a.plans_slot ? p.index : a.grp[g];
   v.n = n;
-  const SeqPlan p = a.plans[n];
+  v.positive = p.positive != 0;
   const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
   v.m.ints = a.ints;
   v.m.big = a.ints;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
 // window of positions the workgroup touches, small int arrays, the automaton blob, and the dmin / base / unpaired
 // windows.  With the context in LDS the unary phase has a single level of global loads (the tables themselves).
 struct BlockLds {
-  int lin, ews, ints, dm, cnts, pre, base, blob, dmin16, seq8, unp8, total;   // byte offsets
+  int lin, ews, ints, dm, cnts, pre, base, blob, bits, dmin16, seq8, unp8, total;   // byte offsets
 };
 __host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int win, int n_stage) {
   BlockLds b;
@@ -193,6 +198,7 @@ __host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int wi
   b.pre = o; o += (cpb + 1) * 4;
   b.base = o; o += cpb * 4;
   b.blob = o; o += n_stage * 4;
+  b.bits = o; o += (((cpb + 2) * (win - cpb) + 31) / 32 + 2) * 4;   // pair-mask words of cells (i0-1 .. i0+cpb) x (0 .. W)
   b.dmin16 = o; o += ((win + 1) / 2) * 4;
   b.seq8 = o; o += ((win + 3) / 4) * 4;
   b.unp8 = o; o += ((win + 3) / 4) * 4;
@@ -219,6 +225,13 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   const int n_lin = kLinEth + a.lay.n_theta;
   for (int t = tid; t < a.n_stage; t += kThreads) blob[t] = a.ints[t];
   for (int t = tid; t < n_lin; t += kThreads) llin[t] = a.lin[t];
+  // pair mask: bits of the cells (i0-1, .) .. (i0+nc-1, .)  (bit index = i * (W+1) + d)
+  uint32_t* lbits = reinterpret_cast<uint32_t*>(raw + B.bits);
+  const int W1 = v.q.W + 1;
+  const int bit0 = ((i0 > 0) ? i0 - 1 : 0) * W1, bit1 = (i0 + nc) * W1;   // [bit0, bit1)
+  const int w0 = bit0 >> 5, w1 = (bit1 + 31) >> 5;
+  const int wend = (int)((((long long)(L + 1) * W1) + 31) >> 5);
+  for (int t = tid; t < w1 - w0; t += kThreads) lbits[t] = (w0 + t < wend) ? v.q.okbits[w0 + t] : 0u;
   for (int t = tid; t < len; t += kThreads) {
     const int p = p0 + t;
     lews[t] = v.q.ews[p];
@@ -239,6 +252,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   v.q.dmin = ldmin - p0;
   v.q.unp = lunp - p0;
   v.q.seq = lseq - p0;
+  v.q.okbits = lbits - w0;
   return c;
 }
 
@@ -310,6 +324,142 @@ __device__ __forceinline__ void for_block_items(int nv, int nq, int tid, int* cn
   __syncthreads();
 }
 
+// ---- inside, "old" split sums of a whole tile of kTile diagonals d0 .. d0+kTile-1 (launched before k4_in(d0)):
+//   part_in[t][i][s] = sum_{t < a < d0} sum_tuples 1(i, i+a, s1) * 2(i+a, i+d0+t, s2)
+// i.e. all pairs of split operands that were final before the tile started.  The point of doing them together: a row
+// 1(i,a,.) serves every level t, and a row 2(k,b,.) serves the kTile targets (k-a, d0+t) with a + b = d0 + t, so a chunk
+// of kOldA split points needs kOldA + (kOldA+kTile-1) staged segments for kOldA*kTile (a, t) products instead of two
+// segments per product: ~2.5x less table traffic than summing diagonal by diagonal.
+constexpr int kTile = ELEMDP_TILE;
+constexpr int kOldA = 4;
+constexpr int kOldB = kOldA + kTile - 1;
+constexpr int kTileStart = 8;   // diagonals below are summed directly (few split points)
+constexpr int kOldOwn = 8;      // (level, cell, tuple) products per lane held in registers
+template <bool BIG>
+__global__ __launch_bounds__(kThreads) void k4_in_old(LinArgs a) {
+  extern __shared__ double lds[];
+  __shared__ AutomatonLayout s_lay;
+  stage_layout(a, &s_lay, kThreads);
+  unsigned bx, by;
+  swizzled_block(bx, by);
+  LViews v(s_lay);
+  make_lviews(a, by, v);
+  const AutomatonLayout& A = s_lay;
+  const int S = a.lay.S, d0 = a.tile_d0, cpb = a.cpb, tid = threadIdx.x;
+  const int L = v.q.L, W = v.q.W;
+  if (d0 > W) return;                       // (k4_in returns for such diagonals, too: the partials are never read)
+  const int ncell = L - d0 + 1, i0 = bx * cpb;
+  if (i0 >= ncell) return;
+  const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
+  const int CS = cpb * S, CS2 = (cpb + kOldA - 1) * S;
+  double* acc = lds;                       // [kTile][CS]
+  double* st1 = acc + kTile * CS;          // [kOldA][CS]   rows 1(i0+c, a0+u, .)
+  double* st2 = st1 + kOldA * CS;          // [kOldB][CS2]  rows 2(i0+a0+c', b_lo+v, .)
+  int* blob = reinterpret_cast<int*>(st2 + kOldB * CS2);
+  int* dm = blob + a.n_stage;
+  for (int t = tid; t < a.n_stage; t += kThreads) blob[t] = a.ints[t];
+  for (int t = tid; t < kTile * CS; t += kThreads) acc[t] = 0.;
+  if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
+  const int32_t* G = BIG ? blob : a.ints;
+  __syncthreads();
+  int a_lo = d0;
+  for (int c = 0; c < nc; ++c) { const int x = dm[c]; if (x > 0 && x < a_lo) a_lo = x; }
+  if (a_lo < 1) a_lo = 1;
+  const int nsp = A.n_split;
+  const double* B = v.in.band;
+  // products owned by this lane: w = (t * nc + c) * nsp + tuple
+  int o1[kOldOwn], o2[kOldOwn], otg[kOldOwn], olv[kOldOwn];
+  double pacc[kOldOwn];
+  const int nwork = kTile * nc * nsp;
+#pragma unroll
+  for (int r = 0; r < kOldOwn; ++r) {
+    const int w = tid + r * kThreads;
+    o1[r] = -1; o2[r] = 0; otg[r] = 0; olv[r] = 0; pacc[r] = 0.;
+    if (w < nwork) {
+      const int tc = w / nsp, tu = w - tc * nsp;
+      const int t = tc / nc, c = tc - t * nc;
+      const int x = dm[c];
+      if (x > 0 && x <= d0 + t && d0 + t <= W && i0 + c + d0 + t <= L) {   // left_ok(i, d0+t) and the target exists
+        o1[r] = c * S + G[A.split_ent + 2 * tu];
+        o2[r] = c * S + G[A.split_ent + 2 * tu + 1];
+        otg[r] = t * CS + c * S + G[A.split_tgt + tu];
+        olv[r] = t;
+      }
+    }
+  }
+  for (int a0 = a_lo; a0 < d0; a0 += kOldA) {
+    const int b_lo = d0 - a0 - kOldA + 1;   // staged diagonals of plane 2: b_lo .. b_lo + kOldB - 1
+    // one element per lane and segment, all loads of the chunk issued before the first use (clamped addresses, masked values)
+    const int n1e = nc * S, n2e = (nc + kOldA - 1) * S;
+    {
+      const int r = (tid < n1e) ? tid : 0;
+      double x[kOldA];
+#pragma unroll
+      for (int u = 0; u < kOldA; ++u) {
+        const int aa = (a0 + u < d0) ? a0 + u : d0 - 1;
+        x[u] = B[v.in.idx(ST_1, aa, i0, 0) + r];
+      }
+      double y[kOldB][2];
+#pragma unroll
+      for (int vv = 0; vv < kOldB; ++vv) {
+        const int b = b_lo + vv;
+        const int bc = (b >= 1 && b < d0) ? b : 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = tid + h * kThreads;
+          const int k = i0 + a0 + e / S;
+          const bool ok = e < n2e && b >= 1 && b < d0 && k + b <= L;
+          y[vv][h] = B[v.in.idx(ST_2, bc, ok ? i0 + a0 : 0, 0) + (ok ? e : 0)];
+          if (!ok) y[vv][h] = 0.;
+        }
+      }
+      if (tid < n1e) {
+#pragma unroll
+        for (int u = 0; u < kOldA; ++u) st1[u * CS + tid] = (a0 + u < d0) ? x[u] : 0.;
+      }
+#pragma unroll
+      for (int vv = 0; vv < kOldB; ++vv) {
+        if (tid < n2e) st2[vv * CS2 + tid] = y[vv][0];
+        if (tid + kThreads < n2e) st2[vv * CS2 + tid + kThreads] = y[vv][1];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kOldOwn; ++r)
+      if (o1[r] >= 0) {
+        const int t = olv[r];
+#pragma unroll
+        for (int u = 0; u < kOldA; ++u) {
+          const int aa = a0 + u;
+          if (aa > t && aa < d0)   // (a <= t: the partner 2(i+a, d0+t-a) is not final yet -- k4_in adds that term)
+            pacc[r] = fma(st1[u * CS + o1[r]], st2[(t - u + kOldA - 1) * CS2 + u * S + o2[r]], pacc[r]);
+        }
+      }
+    for (int w = tid + kOldOwn * kThreads; w < nwork; w += kThreads) {   // (patterns with more tuples than lanes)
+      const int tc = w / nsp, tu = w - tc * nsp;
+      const int t = tc / nc, c = tc - t * nc;
+      const int x = dm[c];
+      if (!(x > 0 && x <= d0 + t && d0 + t <= W && i0 + c + d0 + t <= L)) continue;
+      const int p1 = c * S + G[A.split_ent + 2 * tu], p2 = c * S + G[A.split_ent + 2 * tu + 1];
+      double sum = 0.;
+      for (int u = 0; u < kOldA; ++u) {
+        const int aa = a0 + u;
+        if (aa > t && aa < d0) sum = fma(st1[u * CS + p1], st2[(t - u + kOldA - 1) * CS2 + u * S + p2], sum);
+      }
+      if (sum != 0.) atomicAdd(&acc[t * CS + c * S + G[A.split_tgt + tu]], sum);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < kOldOwn; ++r) if (o1[r] >= 0 && pacc[r] != 0.) atomicAdd(&acc[otg[r]], pacc[r]);
+  __syncthreads();
+  double* part = a.part_in + (size_t)by * a.part_stride;
+  for (int e = tid; e < kTile * nc * S; e += kThreads) {
+    const int t = e / (nc * S), r = e - t * (nc * S);
+    part[((size_t)t * (L + 1) + i0) * S + r] = acc[t * CS + r];
+  }
+}
+
 template <bool BIG>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
@@ -361,12 +511,21 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
       }
     }
   }
-  for (int a0 = a_lo; a0 < d; a0 += kChunkIn) {
-    const int kc = (kChunkIn < d - a0) ? kChunkIn : d - a0;
+  // split points handled here: all of [a_lo, d) -- or, inside a tile that started at d0 (level t = d - d0), only those
+  // with an operand of span >= d0: a in [a_lo, t] (2(i+a, d-a) is new) and a in [d0, d) (1(i, i+a) is new); k4_in_old
+  // summed the others into part_in.  The list is walked as q = 0 .. n1+n2: a = a_lo + q  |  d0 + (q - n1).
+  const int d0 = (a.tile_d0 >= 0) ? a.tile_d0 : d;
+  const int tl = d - d0;
+  const int n1 = (a.tile_d0 >= 0) ? ((tl >= a_lo) ? tl - a_lo + 1 : 0) : ((d > a_lo) ? d - a_lo : 0);
+  const int n2 = (a.tile_d0 >= 0 && !(a.dbg & 1)) ? tl : 0;
+  const int nf = (a.dbg & 1) ? 0 : n1 + n2;
+  for (int q0 = 0; q0 < nf; q0 += kChunkIn) {
+    const int kc = (kChunkIn < nf - q0) ? kChunkIn : nf - q0;
     if (tid < ncS) {
 #pragma unroll
       for (int u = 0; u < kChunkIn; ++u) {
-        const int aa = a0 + ((u < kc) ? u : 0);
+        const int q = q0 + ((u < kc) ? u : 0);
+        const int aa = (q < n1) ? a_lo + q : d0 + (q - n1);
         const double x1 = B[v.in.idx(ST_1, aa, i0, 0) + tid];
         const double x2 = B[v.in.idx(ST_2, d - aa, i0 + aa, 0) + tid];
         st1[u * CS + tid] = (u < kc) ? x1 : 0.;
@@ -423,7 +582,9 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   if (tid < nc * NA && !(a.dbg & 4)) {
     const int c = tid / NA, s = tid - c * NA;
     const int i = i0 + c;
-    const Cell7 r = lin_inside_target_u(v.m, v.q, v.in, d, i, s, hb[c * S + s], he[c * S + s]);
+    double HB = hb[c * S + s];
+    if (a.tile_d0 >= 0) HB += a.part_in[(size_t)by * a.part_stride + ((size_t)tl * (v.in.L + 1) + i) * S + s];
+    const Cell7 r = lin_inside_target_u(v.m, v.q, v.in, d, i, s, HB, he[c * S + s]);
     if (a.band_in0 != nullptr && s == A.s00) {   // compact copy of state (0,0) for the no-motif pass
       TableView t0;
       t0.band = a.band_in0 + (size_t)by * a.band0_stride;
@@ -485,7 +646,7 @@ struct LPass { double invZ; bool ari, nasi, skip; int en_off, eh_off; };
 __device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
   LPass pi;
   const int nt = a.lay.n_theta;
-  const bool positive = a.plans[v.n].positive != 0;
+  const bool positive = v.positive;
   pi.skip = v.row[4] != 0.;
   double Z;
   if (a.schedule == 0) {
@@ -549,6 +710,145 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   if (MODE == OUT_TRAIN) lflush(a, v, pi, sink, l_en, l_eh, 128);
 }
 
+// ---- outside, "old" split sums of a tile d0, d0-1, .., d0-kTile+1 (level t: d = d0 - t), launched before k4_out(d0):
+//   WHICH = 1:  part_h1[t][i][s] = sum_{b > t} sum_tuples out B(i, d+b, par) * in 2(i+d, b, s2)        (parents jj = j + b)
+//   WHICH = 2:  part_h2[t][i][s] = sum_{b > t} sum_tuples out B(i-b, d+b, par) * in 1(i-b, b, s1)      (parents ii = i - b)
+// i.e. the parents B of span D = d + b > d0, final before the tile started.  Chunks of kOldA parent spans D: the out-B
+// rows of one D serve all kTile levels and an inside row (., b) serves the kTile pairs (D, t) with D - d0 + t = b.
+template <int WHICH, bool BIG>
+__global__ __launch_bounds__(kThreads) void k4_out_old(LinArgs a) {
+  extern __shared__ double lds[];
+  __shared__ AutomatonLayout s_lay;
+  stage_layout(a, &s_lay, kThreads);
+  unsigned bx, by;
+  swizzled_block(bx, by);
+  LViews v(s_lay);
+  make_lviews(a, by, v);
+  const LPass pi = lpass(a, v);
+  const AutomatonLayout& A = s_lay;
+  const int S = a.lay.S, d0 = a.tile_d0, cpb = a.cpb, tid = threadIdx.x;
+  const int L = v.q.L, W = v.q.W;
+  if (pi.skip) return;
+  // (a sequence whose own W is <= d0 has no parents beyond the tile: the loop over D is empty and zeros are written)
+  const int dlow = (d0 - kTile + 1 > 0) ? d0 - kTile + 1 : 0;     // lowest diagonal of the tile: it has the most cells
+  const int ncell = L - dlow + 1, i0 = bx * cpb;
+  if (i0 >= ncell) return;
+  const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
+  const int CS = cpb * S, CS2 = (cpb + kTile - 1) * S;
+  // WHICH 1: sO = out B(i0+c, D) [kOldA][CS],  sI = in 2(jb+c', b) [kOldB][CS2], jb = i0 + d0 - (kTile-1)
+  // WHICH 2: sO = out B(kb_u+c', D) [kOldA][CS2], kb_u = i0 - (D-d0) - (kTile-1),  sI = in 1(i0+c-b, b) [kOldB][CS]
+  const int CSO = (WHICH == 1) ? CS : CS2, CSI = (WHICH == 1) ? CS2 : CS;
+  double* acc = lds;                    // [kTile][CS]
+  double* sO = acc + kTile * CS;        // [kOldA][CSO]
+  double* sI = sO + kOldA * CSO;        // [kOldB][CSI]
+  int* blob = reinterpret_cast<int*>(sI + kOldB * CSI);
+  int* dm = blob + a.n_stage;
+  for (int t = tid; t < a.n_stage; t += kThreads) blob[t] = a.ints[t];
+  for (int t = tid; t < kTile * CS; t += kThreads) acc[t] = 0.;
+  if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
+  const int32_t* G = BIG ? blob : a.ints;
+  __syncthreads();
+  const int nsp = A.n_split;
+  const int ent = (WHICH == 1) ? A.split1_ent : A.split2_ent, tgl = (WHICH == 1) ? A.split1_tgt : A.split2_tgt;
+  const double* IB = v.in.band;
+  const double* OB = v.out.band;
+  int o1[kOldOwn], o2[kOldOwn], otg[kOldOwn], olv[kOldOwn];
+  double pacc[kOldOwn];
+  const int nwork = kTile * nc * nsp;
+  auto target_ok = [&](int t, int c) {   // left_ok(i, d) for the level's diagonal d = d0 - t, and the cell exists
+    const int d = d0 - t, x = dm[c];
+    return d >= 0 && x > 0 && x <= d && i0 + c + d <= L;
+  };
+#pragma unroll
+  for (int r = 0; r < kOldOwn; ++r) {
+    const int w = tid + r * kThreads;
+    o1[r] = -1; o2[r] = 0; otg[r] = 0; olv[r] = 0; pacc[r] = 0.;
+    if (w < nwork) {
+      const int tc = w / nsp, tu = w - tc * nsp;
+      const int t = tc / nc, c = tc - t * nc;
+      if (target_ok(t, c)) {
+        const int par = G[ent + 2 * tu], sib = G[ent + 2 * tu + 1];
+        // WHICH 1: out row index c, inside row index c + kTile-1-t ; WHICH 2: the other way round
+        o1[r] = ((WHICH == 1) ? c : c + kTile - 1 - t) * S + par;
+        o2[r] = ((WHICH == 1) ? c + kTile - 1 - t : c) * S + sib;
+        otg[r] = t * CS + c * S + G[tgl + tu];
+        olv[r] = t;
+      }
+    }
+  }
+  for (int D0 = d0 + 1; D0 <= W; D0 += kOldA) {
+    const int b_lo = D0 - d0;   // staged inside diagonals b_lo .. b_lo + kOldB - 1
+    {
+      double x[kOldA][2], y[kOldB][2];
+#pragma unroll
+      for (int u = 0; u < kOldA; ++u) {
+        const int D = D0 + u;
+        const int Dc = (D <= W) ? D : W;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = tid + h * kThreads;
+          const int cell = ((WHICH == 1) ? i0 : i0 - (D - d0) - (kTile - 1)) + e / S;
+          const bool ok = e < ((WHICH == 1) ? nc * S : (nc + kTile - 1) * S) && D <= W && cell >= 0 && cell + D <= L;
+          const int base = (WHICH == 1) ? i0 : i0 - (D - d0) - (kTile - 1);
+          x[u][h] = OB[v.out.idx(ST_B, Dc, ok ? base : 0, 0) + (ok ? e : 0)];
+          if (!ok) x[u][h] = 0.;
+        }
+      }
+#pragma unroll
+      for (int vv = 0; vv < kOldB; ++vv) {
+        const int b = b_lo + vv;
+        const int bc = (b <= W) ? b : W;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = tid + h * kThreads;
+          const int base = (WHICH == 1) ? i0 + d0 - (kTile - 1) : i0 - b;
+          const int cell = base + e / S;
+          const bool ok = e < ((WHICH == 1) ? (nc + kTile - 1) * S : nc * S) && b <= W && cell >= 0 && cell + b <= L;
+          y[vv][h] = IB[v.in.idx((WHICH == 1) ? ST_2 : ST_1, bc, ok ? base : 0, 0) + (ok ? e : 0)];
+          if (!ok) y[vv][h] = 0.;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kOldA; ++u) {
+        if (tid < CSO) sO[u * CSO + tid] = x[u][0];
+        if (tid + kThreads < CSO) sO[u * CSO + tid + kThreads] = x[u][1];
+      }
+#pragma unroll
+      for (int vv = 0; vv < kOldB; ++vv) {
+        if (tid < CSI) sI[vv * CSI + tid] = y[vv][0];
+        if (tid + kThreads < CSI) sI[vv * CSI + tid + kThreads] = y[vv][1];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kOldOwn; ++r)
+      if (o1[r] >= 0) {
+        const int t = olv[r];
+#pragma unroll
+        for (int u = 0; u < kOldA; ++u) pacc[r] = fma(sO[u * CSO + o1[r]], sI[(u + t) * CSI + o2[r]], pacc[r]);
+      }
+    for (int w = tid + kOldOwn * kThreads; w < nwork; w += kThreads) {   // (patterns with more tuples than lanes)
+      const int tc = w / nsp, tu = w - tc * nsp;
+      const int t = tc / nc, c = tc - t * nc;
+      if (!target_ok(t, c)) continue;
+      const int p1 = ((WHICH == 1) ? c : c + kTile - 1 - t) * S + G[ent + 2 * tu];
+      const int p2 = ((WHICH == 1) ? c + kTile - 1 - t : c) * S + G[ent + 2 * tu + 1];
+      double sum = 0.;
+      for (int u = 0; u < kOldA; ++u) sum = fma(sO[u * CSO + p1], sI[(u + t) * CSI + p2], sum);
+      if (sum != 0.) atomicAdd(&acc[t * CS + c * S + G[tgl + tu]], sum);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < kOldOwn; ++r) if (o1[r] >= 0 && pacc[r] != 0.) atomicAdd(&acc[otg[r]], pacc[r]);
+  __syncthreads();
+  double* part = ((WHICH == 1) ? a.part_h1 : a.part_h2) + (size_t)by * a.part_stride;
+  for (int e = tid; e < kTile * nc * S; e += kThreads) {
+    const int t = e / (nc * S), r = e - t * (nc * S);
+    part[((size_t)t * (L + 1) + i0) * S + r] = acc[t * CS + r];
+  }
+}
+
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
 template <int MODE, bool BIG>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
@@ -597,7 +897,10 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   // B(i-b,j,par), sibling 1(i-b,i,s1);  b = 1 .. W-d.  Cells whose parent would leave [0,L] are masked.
   bool any_lok = false;
   for (int c = 0; c < nc; ++c) { const int x = dm[c]; any_lok = any_lok || (x > 0 && x <= d); }
-  const int bmax = (any_lok && !(a.dbg & 1)) ? W - d : 0;
+  // inside a tile (top diagonal d0, level t = d0 - d) only the parents computed in the tile are summed here: b <= t
+  const int tl = (a.tile_d0 >= 0) ? a.tile_d0 - d : 0;
+  const int bfull = (a.tile_d0 >= 0) ? ((tl < W - d) ? tl : W - d) : W - d;
+  const int bmax = (any_lok && !(a.dbg & 1)) ? bfull : 0;
   constexpr int kOwn = 2;
   int qa1[kOwn], qa2[kOwn], qat[kOwn], qb1[kOwn], qb2[kOwn], qbt[kOwn];
   double acc1[kOwn], acc2[kOwn];
@@ -748,6 +1051,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink};
     HeavyOut H;
     H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
+    if (a.tile_d0 >= 0 && a.tile_has_old) {
+      const size_t po = (size_t)by * a.part_stride + ((size_t)tl * (L + 1) + (i0 + c)) * S + s;
+      H.H1 += a.part_h1[po];
+      H.H2 += a.part_h2[po];
+    }
     lin_outside_target_u<MODE>(x, d, i0 + c, s, H);
   }
   pc.mark<11>();
@@ -798,14 +1106,24 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const size_t lds_stat = sizeof(double) * (nt + 2);
+  a.tile_d0 = -1;
+  const size_t lds_old = sizeof(double) * ((size_t)(kTile + kOldA) * a.cpb * S + (size_t)kOldB * (a.cpb + kOldA - 1) * S) +
+                         sizeof(int32_t) * ((size_t)a.n_stage + a.cpb + 2);
+  const bool tiled = a.part_in != nullptr && a.tile;
   if (!a.no_rss)
     for (int d = 0; d <= Wmax; ++d) {
       const int ncell = Lmax - d + 1;
       if (ncell <= 0) break;
       a.d = d;
+      if (tiled && d >= kTileStart && (d - kTileStart) % kTile == 0) {   // a new tile starts: sum its old pairs first
+        a.tile_d0 = d;
+        if (big) hipLaunchKernelGGL(k4_in_old<true>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_old, st, a);
+        else hipLaunchKernelGGL(k4_in_old<false>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_old, st, a);
+      }
       if (big) hipLaunchKernelGGL(k4_in<true>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
       else hipLaunchKernelGGL(k4_in<false>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
     }
+  a.tile_d0 = -1;
   hipLaunchKernelGGL(k4_in_ext, dim3(G), dim3(128), 0, st, a);
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1 && first_pass_only) break;
@@ -817,11 +1135,31 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
     const size_t lds_b = block_lds((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, b.n_stage).total;
     const bool big_b = b.n_stage >= b.lay.n_ints;
     hipLaunchKernelGGL(k4_out_ext<OUT_TRAIN>, dim3(G), dim3(128), lds_stat, st, b);
+    const bool tiled_b = b.part_h1 != nullptr && a.tile;
+    const size_t lds_oold = sizeof(double) * ((size_t)(kTile + kOldA + kOldB) * (b.cpb + kTile - 1) * b.lay.S) +
+                            sizeof(int32_t) * ((size_t)b.n_stage + b.cpb + 2);
+    b.tile_d0 = -1;
+    b.tile_has_old = 0;
     if (!b.no_rss)
       for (int d = Wmax; d >= 0; --d) {
         const int ncell = Lmax - d + 1;
         if (ncell <= 0) continue;
         b.d = d;
+        if (tiled_b && (Wmax - d) % kTile == 0) {   // a new tile starts at d: sum the parents beyond it first
+          b.tile_d0 = d;
+          b.tile_has_old = d < Wmax ? 1 : 0;
+          if (b.tile_has_old) {
+            const int dlow = (d - kTile + 1 > 0) ? d - kTile + 1 : 0;
+            const dim3 grid((Lmax - dlow + 1 + b.cpb - 1) / b.cpb, G);
+            if (big_b) {
+              hipLaunchKernelGGL((k4_out_old<1, true>), grid, dim3(kThreads), lds_oold, st, b);
+              hipLaunchKernelGGL((k4_out_old<2, true>), grid, dim3(kThreads), lds_oold, st, b);
+            } else {
+              hipLaunchKernelGGL((k4_out_old<1, false>), grid, dim3(kThreads), lds_oold, st, b);
+              hipLaunchKernelGGL((k4_out_old<2, false>), grid, dim3(kThreads), lds_oold, st, b);
+            }
+          }
+        }
         if (big_b) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
       }
