@@ -813,6 +813,8 @@ void Engine::run_lin_batch() {
   a.part_stride = 4 * (size_t)(Lmax_ + 1) * S;
   a.tile_d0 = -1;
   a.tile = opt_tile_;
+  a.lmax = Lmax_;
+  a.nword_max = nword_max_;
   a.tile_has_old = 0;
   a.seq_out = d_seq_out_.as<double>();
   a.out_stride = out_stride_;

@@ -144,6 +144,7 @@ struct LinArgs {
   int32_t tile_d0;                // first diagonal of the running tile, or -1: this launch sums all split points itself
   int32_t tile;                   // 1: tile the split sums (k4_in_old / k4_out_old); 0 (default): every diagonal sums its own
   int32_t tile_has_old;           // part_* of the running tile are valid (0: the tile has no old pairs, e.g. the outside tile at W)
+  int32_t lmax, nword_max;        // longest sequence of the launch / most pair-mask words of a sequence (LDS sizing)
   int32_t wmax;                   // largest span of the launch (sizes the position window staged in LDS)
   int32_t n_stage;                // ints of the automaton blob staged in LDS: n_ints (whole blob) or n_small
   int32_t dbg;                    // timing experiments only: bit 0 skip split sums, 1 skip item sums, 2 skip the unary phase

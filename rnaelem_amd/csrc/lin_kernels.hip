@@ -597,14 +597,63 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   pc.finish();
 }
 
+// Exterior-chain kernels (one workgroup of 128 per sequence, L sequential steps): the per-sequence context of the whole
+// sequence is staged in LDS when it fits (STAGE): pair mask, base codes, unpaired flags, position weights, automaton
+// blob and linear parameters -- a step is then a handful of LDS reads plus the table rows of the few pairs at that
+// position, instead of ~W dependent global loads for the pair tests alone.
+struct ExtLds { int lin, ews, blob, bits, seq8, unp8, total; };
+__host__ __device__ inline ExtLds ext_lds(int nd, int n_lin, int Lmax, int nword, int n_stage) {
+  ExtLds b;
+  int o = nd * 8;
+  b.lin = o; o += n_lin * 8;
+  b.ews = o; o += (Lmax + 1) * 8;
+  b.blob = o; o += n_stage * 4;
+  b.bits = o; o += (nword + 1) * 4;
+  b.seq8 = o; o += ((Lmax + 4) / 4) * 4;
+  b.unp8 = o; o += ((Lmax + 4) / 4) * 4;
+  b.total = o + 8;
+  return b;
+}
+template <bool STAGE>
+__device__ __forceinline__ void stage_ext_context(const LinArgs& a, LViews& v, unsigned char* raw, int nd) {
+  if (!STAGE) return;
+  const int tid = threadIdx.x, L = v.q.L;
+  const int nword = (int)((((long long)(L + 1) * (v.q.W + 1)) + 31) >> 5);
+  const ExtLds B = ext_lds(nd, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage);
+  double* llin = reinterpret_cast<double*>(raw + B.lin);
+  double* lews = reinterpret_cast<double*>(raw + B.ews);
+  int* blob = reinterpret_cast<int*>(raw + B.blob);
+  uint32_t* lbits = reinterpret_cast<uint32_t*>(raw + B.bits);
+  uint8_t* lseq = raw + B.seq8;
+  uint8_t* lunp = raw + B.unp8;
+  for (int t = tid; t < a.n_stage; t += 128) blob[t] = a.ints[t];
+  for (int t = tid; t < kLinEth + a.lay.n_theta; t += 128) llin[t] = a.lin[t];
+  for (int t = tid; t < nword; t += 128) lbits[t] = v.q.okbits[t];
+  for (int t = tid; t <= L; t += 128) {
+    lews[t] = v.q.ews[t];
+    lunp[t] = v.q.unp[t];
+    lseq[t] = (t < L) ? v.q.seq[t] : (uint8_t)0;
+  }
+  v.m.ints = blob;
+  if (a.n_stage >= a.lay.n_ints) v.m.big = blob;
+  v.m.lin = llin;
+  v.q.ews = lews;
+  v.q.unp = lunp;
+  v.q.seq = lseq;
+  v.q.okbits = lbits;
+}
+
 __device__ __forceinline__ bool out_of_range(double z) { return !(z > 0.) || !(z < HUGE_VAL); }
 
 // ---- exterior chain of the inside pass, partition functions, objective (one workgroup of 128 per sequence)
+template <bool STAGE>
 __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
+  extern __shared__ double l_ext[];
   __shared__ AutomatonLayout s_lay;
   stage_layout(a, &s_lay, 128);
   LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
+  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_ext), 0);
   const int S = a.lay.n_active, tid = threadIdx.x, L = v.q.L;
   double* ext0 = a.ext_in0 ? a.ext_in0 + (size_t)blockIdx.x * a.ext0_stride : nullptr;
   for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00) ? 1. : 0.;
@@ -679,15 +728,16 @@ __device__ __forceinline__ void lflush(const LinArgs& a, const LViews& v, const 
 }
 
 // ---- exterior chain of an outside pass
-template <int MODE>
+template <int MODE, bool STAGE>
 __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
-  extern __shared__ double l_stat[];   // n_theta + 2
+  extern __shared__ double l_stat[];   // n_theta + 2, then the staged context
   __shared__ AutomatonLayout s_lay;
   stage_layout(a, &s_lay, 128);
   LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
   const LPass pi = lpass(a, v);
   if (pi.skip) return;
+  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), a.lay.n_theta + 2);
   const int S = a.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
   double* l_en = l_stat;
   double* l_eh = l_stat + nt;
@@ -1124,7 +1174,11 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
       else hipLaunchKernelGGL(k4_in<false>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
     }
   a.tile_d0 = -1;
-  hipLaunchKernelGGL(k4_in_ext, dim3(G), dim3(128), 0, st, a);
+  a.lmax = Lmax;
+  const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
+  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
+  if (stage_ext) hipLaunchKernelGGL(k4_in_ext<true>, dim3(G), dim3(128), lds_ext_in, st, a);
+  else hipLaunchKernelGGL(k4_in_ext<false>, dim3(G), dim3(128), 0, st, a);
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1 && first_pass_only) break;
     LinArgs b = (a.schedule == 1 && pass == 1) ? compact : a;
@@ -1134,7 +1188,9 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
     b.wmax = Wmax;
     const size_t lds_b = block_lds((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, b.n_stage).total;
     const bool big_b = b.n_stage >= b.lay.n_ints;
-    hipLaunchKernelGGL(k4_out_ext<OUT_TRAIN>, dim3(G), dim3(128), lds_stat, st, b);
+    b.lmax = Lmax;
+    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(nt + 2, kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
+    else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), lds_stat, st, b);
     const bool tiled_b = b.part_h1 != nullptr && a.tile;
     const size_t lds_oold = sizeof(double) * ((size_t)(kTile + kOldA + kOldB) * (b.cpb + kTile - 1) * b.lay.S) +
                             sizeof(int32_t) * ((size_t)b.n_stage + b.cpb + 2);
