@@ -313,6 +313,26 @@ def test_linear_pipeline_hands_out_of_range_sequences_to_the_log_pipeline():
     np.testing.assert_allclose(gr, go, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("pattern", ["(((((.*.)))))(((.*.)))", ".", "(.)*(.)"])
+def test_other_automaton_sizes(pattern):
+    """S = 59 (automaton blob larger than the LDS staging limit: tuple lists stay in global memory, 4 cells per workgroup),
+    S = 6 and a pattern with two stems -- fn / gr of a ragged batch against the oracle."""
+    eng = api.Engine(pattern, PAR, 50, 30, 1e-4, 0.1)
+    o = po.make_oracle(pattern, 50, 30, min_bpp=1e-4, tau=0.1)
+    recs = io.read_fastq(gpath("syn_L40_n3.fq")) + io.read_fastq(gpath("syn_L100_n3.fq"))
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    rng = np.random.RandomState(11)
+    x = eng.initial_params(0.7)
+    x[:-2] += 0.3 * rng.randn(len(x) - 2)
+    o.set_params(x)
+    eng.load_batch(seqs, quals)
+    fn, gr, eff, nsk = eng.train_eval(x)
+    fo, go, eo, no = o.train_eval(x, seqs, quals)
+    assert nsk == no
+    assert fn == pytest.approx(fo, rel=1e-9, abs=1e-10)
+    np.testing.assert_allclose(gr, go, rtol=1e-7, atol=1e-7)
+
+
 def test_error_behaviour():
     with pytest.raises(api.ElemdpError):
         api.Engine("(.")
