@@ -163,6 +163,8 @@ class Engine {
   void run_train(bool first_pass_only);
   void run_train_batch();
   void run_lin_batch();
+  int prepare_lin(LinArgs& a, bool sched1);
+  void lin_weights();
   int balanced_group(size_t per_slot_bytes);
   TrArgs log_pipeline_args();
   void init_device();
@@ -760,7 +762,20 @@ void Engine::run_train_batch() {
 
 // The scaled-linear pipeline (lin_kernels.hip); sequences it flags (partition function outside the double range, or a
 // structurally empty component) are re-evaluated by the log-space pipeline, which applies the reference's skip rule.
-void Engine::run_lin_batch() {
+// slots, side buffers and the argument record of the scaled-linear pipeline; returns the balanced group size
+void Engine::lin_weights() {
+  LinWeightArgs w;
+  const PlanArrays pa = plan_.arrays();
+  w.e_stack = pa.e_stack; w.e_ext = pa.e_ext; w.e_ml = pa.e_ml; w.e_close = pa.e_close; w.e_hp = pa.e_hp;
+  w.items = pa.items;
+  w.items_inner = pa.items_inner; w.items_left = pa.items_left; w.items_right = pa.items_right;
+  w.n_cells = (size_t)n_cells_total_; w.n_items = (size_t)plan_.n_items;
+  w.params = d_params_.as<double>();
+  w.xwc = d_xwc_.as<double>(); w.xwi = d_xwi_.as<double>();
+  HIP_OK(launch_lin_weights(w, st_));
+}
+
+int Engine::prepare_lin(LinArgs& a, bool sched1) {
   const int S = au_.S();
   {
     const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext = (size_t)(Lmax_ + 1);
@@ -771,7 +786,6 @@ void Engine::run_lin_batch() {
   // (if the allocation had to shrink, rebalance for the slots we got)
   const int n_groups = (n_seq_ + n_slots_ - 1) / n_slots_;
   const int gsz = (n_seq_ + n_groups - 1) / n_groups;
-  const bool sched1 = opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_ && lay_.s00 == 0;
   const size_t band0 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext0 = (size_t)(Lmax_ + 1);
   if (lin_slots_ != n_slots_) {
     d_zs_.alloc(sizeof(double) * 4 * n_slots_);
@@ -784,7 +798,6 @@ void Engine::run_lin_batch() {
     d_ext_out0_.alloc(sizeof(double) * ext0 * n_slots_);
     lin_slots_ = n_slots_;
   }
-  LinArgs a;
   std::memset(&a, 0, sizeof(a));
   a.lay = lay_;
   a.layp = d_lay_.as<AutomatonLayout>();
@@ -828,6 +841,16 @@ void Engine::run_lin_batch() {
     a.prof = d_prof_.as<long long>();
   }
   a.n_stage = (lay_.n_ints <= 4096 && !(opt_dbg_ & 8)) ? lay_.n_ints : lay_.n_small;
+  return gsz;
+}
+
+void Engine::run_lin_batch() {
+  const int S = au_.S();
+  const bool sched1 = opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_ && lay_.s00 == 0;
+  const size_t band0 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext0 = (size_t)(Lmax_ + 1);
+  LinArgs a;
+  const int gsz = prepare_lin(a, sched1);
+  (void)S;
   LinArgs c = a;   // the no-motif pass: one-state automaton, compact tables
   c.lay = layc_;
   c.layp = d_layc_.as<AutomatonLayout>();
@@ -841,15 +864,7 @@ void Engine::run_lin_batch() {
   HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n_seq_, st_));
   HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
   HIP_OK(hipEventRecord(ev_[1], st_));
-  LinWeightArgs w;
-  const PlanArrays pa = plan_.arrays();
-  w.e_stack = pa.e_stack; w.e_ext = pa.e_ext; w.e_ml = pa.e_ml; w.e_close = pa.e_close; w.e_hp = pa.e_hp;
-  w.items = pa.items;
-  w.items_inner = pa.items_inner; w.items_left = pa.items_left; w.items_right = pa.items_right;
-  w.n_cells = (size_t)n_cells_total_; w.n_items = (size_t)plan_.n_items;
-  w.params = d_params_.as<double>();
-  w.xwc = d_xwc_.as<double>(); w.xwi = d_xwi_.as<double>();
-  HIP_OK(launch_lin_weights(w, st_));
+  lin_weights();
   for (int g0 = 0; g0 < n_seq_; g0 += gsz) {
     const int G = std::min(gsz, n_seq_ - g0);
     a.grp = c.grp = d_order_.as<int32_t>() + g0;
@@ -1030,31 +1045,90 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   if (flags_ & ELEMDP_NO_RSS) throw ArgError("scan is not available in --no-rss mode");
   if (!out) throw ArgError("scan: null output");
   upload_params(x, lay_, false);
-  ensure_slots(au_.S(), true, n_seq_);
-  const int nt = au_.n_theta(), n = n_seq_;
+  const int nt = au_.n_theta(), n = n_seq_, S = au_.S();
   const size_t n_seqpos = (size_t)h_seq_off_[n], n_pos = n_seqpos + n;
   DevBuf d_start, d_end, d_inner, d_psi, d_rss, d_ys, d_ye, d_exist, d_en;
   d_start.alloc(8 * n_seqpos); d_inner.alloc(8 * n_seqpos); d_end.alloc(8 * n_pos);
   d_psi.alloc(4 * n_seqpos); d_rss.alloc(n_seqpos);
   d_ys.alloc(4 * n); d_ye.alloc(4 * n); d_exist.alloc(8 * n); d_en.alloc(8 * (size_t)n * (nt + 1));
-  DpArgs a = base_args(lay_, d_ints_.as<int32_t>(), d_params_.as<double>(), plan_, d_okbits1_.as<uint32_t>(), au_.S());
-  a.order = d_order_.as<int32_t>();
-  a.tr_band = d_tr_band_.as<TraceRec>();
-  a.tr_ext = d_tr_ext_.as<TraceRec>();
-  a.trace_stack = d_tr_stack_.as<int32_t>();
-  a.trace_stack_stride = 4 * (4 * (Lmax_ + 2));
-  a.sc_start = d_start.as<double>(); a.sc_end = d_end.as<double>(); a.sc_inner = d_inner.as<double>();
-  a.sc_psihat = d_psi.as<int32_t>(); a.sc_rss = d_rss.as<char>();
-  a.sc_ys = d_ys.as<int32_t>(); a.sc_ye = d_ye.as<int32_t>(); a.sc_exist = d_exist.as<double>(); a.sc_en = d_en.as<double>();
-  a.lds = lds_layout(lay_, Lmax_, nword_max_, true);
-  HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
   HIP_OK(hipEventRecord(ev_[1], st_));
-  HIP_OK(launch_dp(DP_SCAN, a, std::min(n_slots_, n), st_));
+  // ---- K4 / K5 (the four sum passes, motif_scanner.hpp:186-202) on the scaled-linear batch pipeline
+  std::vector<int32_t> flagged;
+  const bool sums_on_batch = opt_pipeline_ == 4;
+  if (sums_on_batch) {
+    LinArgs a;
+    const int gsz = prepare_lin(a, false);
+    a.scan = 1;
+    a.ys = d_ys.as<int32_t>(); a.ye = d_ye.as<int32_t>();
+    a.pos_start = d_start.as<double>(); a.pos_inner = d_inner.as<double>(); a.pos_end = d_end.as<double>();
+    a.exist = d_exist.as<double>();
+    HIP_OK(hipMemsetAsync(d_start.as<void>(), 0, 8 * n_seqpos, st_));
+    HIP_OK(hipMemsetAsync(d_inner.as<void>(), 0, 8 * n_seqpos, st_));
+    HIP_OK(hipMemsetAsync(d_end.as<void>(), 0, 8 * n_pos, st_));
+    HIP_OK(hipMemsetAsync(d_ys.as<void>(), 0, 4 * n, st_));
+    HIP_OK(hipMemsetAsync(d_ye.as<void>(), 0, 4 * n, st_));
+    HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n, st_));
+    HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
+    lin_weights();
+    for (int g0 = 0; g0 < n; g0 += gsz) {
+      const int G = std::min(gsz, n - g0);
+      a.grp = d_order_.as<int32_t>() + g0;
+      a.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
+      const int Lg = h_plans_[h_order_[g0]].L;
+      HIP_OK(launch_lin_scan_group(a, G, Lg, std::min(Lg, max_span_), 0, st_));
+      HIP_OK(launch_lin_scan_group(a, G, Lg, std::min(Lg, max_span_), 1, st_));
+    }
+    int32_t n_flagged = 0;
+    HIP_OK(hipMemcpyAsync(&n_flagged, d_flagged_.as<void>(), sizeof(int32_t), hipMemcpyDeviceToHost, st_));
+    HIP_OK(hipStreamSynchronize(st_));
+    flagged.resize(n_flagged);
+    if (n_flagged) HIP_OK(hipMemcpy(flagged.data(), d_flagged_.as<int32_t>() + 1, sizeof(int32_t) * n_flagged, hipMemcpyDeviceToHost));
+    n_flagged_last_ = n_flagged;
+    tables_linear_ = false;
+  }
+  // ---- K6 (Viterbi parse + traceback) on the fused kernel; it also runs the whole schedule for the sequences the
+  // linear passes flagged (range check) and for pipeline != 4
+  int n_blocks;
+  if (sums_on_batch) {   // reuse the table slots of the batch pipeline; only the trace tables are extra
+    n_blocks = std::min(std::min(n_slots_, 2 * n_cu_), n);
+    const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S, ext = (size_t)(Lmax_ + 1) * S;
+    if (d_tr_band_.bytes() < band * n_blocks * sizeof(TraceRec)) {
+      d_tr_band_.alloc(band * n_blocks * sizeof(TraceRec));
+      d_tr_ext_.alloc(ext * n_blocks * sizeof(TraceRec));
+      d_tr_stack_.alloc((size_t)n_blocks * 4 * (4 * (Lmax_ + 2)) * sizeof(int32_t));
+    }
+  } else {
+    ensure_slots(S, true, n);
+    lin_slots_ = 0;   // (the table slots were re-allocated with trace tables)
+    n_blocks = std::min(n_slots_, n);
+  }
+  DpArgs d = base_args(lay_, d_ints_.as<int32_t>(), d_params_.as<double>(), plan_, d_okbits1_.as<uint32_t>(), S);
+  d.order = d_order_.as<int32_t>();
+  d.tr_band = d_tr_band_.as<TraceRec>();
+  d.tr_ext = d_tr_ext_.as<TraceRec>();
+  d.trace_stack = d_tr_stack_.as<int32_t>();
+  d.trace_stack_stride = 4 * (4 * (Lmax_ + 2));
+  d.sc_start = d_start.as<double>(); d.sc_end = d_end.as<double>(); d.sc_inner = d_inner.as<double>();
+  d.sc_psihat = d_psi.as<int32_t>(); d.sc_rss = d_rss.as<char>();
+  d.sc_ys = d_ys.as<int32_t>(); d.sc_ye = d_ye.as<int32_t>(); d.sc_exist = d_exist.as<double>(); d.sc_en = d_en.as<double>();
+  d.lds = lds_layout(lay_, Lmax_, nword_max_, true);
+  d.cyk_only = sums_on_batch ? 1 : 0;
+  HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
+  HIP_OK(launch_dp(DP_SCAN, d, n_blocks, st_));
+  if (!flagged.empty()) {
+    d.cyk_only = 0;
+    d.order = d_flagged_.as<int32_t>() + 1;
+    d.n_seq = (int32_t)flagged.size();
+    HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
+    HIP_OK(launch_dp(DP_SCAN, d, std::min(n_blocks, (int)flagged.size()), st_));
+  }
+  if (!sums_on_batch) n_slots_ = 0;   // scan slots are not reused by the train pipelines
   HIP_OK(hipEventRecord(ev_[2], st_));
   HIP_OK(hipStreamSynchronize(st_));
   float ms = 0;
   HIP_OK(hipEventElapsedTime(&ms, ev_[1], ev_[2]));
   last_ms[0] = last_ms[1] = ms;
+  last_ms[2] = (double)flagged.size();
   auto get = [&](void* dst, const DevBuf& src, size_t bytes) { if (dst) HIP_OK(hipMemcpy(dst, src.as<void>(), bytes, hipMemcpyDeviceToHost)); };
   get(out->start, d_start, 8 * n_seqpos);
   get(out->inner, d_inner, 8 * n_seqpos);
@@ -1065,10 +1139,18 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   get(out->ye, d_ye, 4 * n);
   get(out->exist_prob, d_exist, 8 * n);
   if (out->en) {  // E[N] summed over the batch in input order (motif_scanner.hpp:253-259)
-    std::vector<double> h((size_t)n * nt);
-    HIP_OK(hipMemcpy(h.data(), d_en.as<void>(), 8 * h.size(), hipMemcpyDeviceToHost));
     for (int t = 0; t < nt; ++t) out->en[t] = 0.;
-    for (int k = 0; k < n; ++k) for (int t = 0; t < nt; ++t) out->en[t] += h[(size_t)k * nt + t];
+    std::vector<char> is_flagged(n, 0);
+    for (int k : flagged) is_flagged[k] = 1;
+    std::vector<double> h((size_t)n * nt), rows;
+    if (!sums_on_batch || !flagged.empty()) HIP_OK(hipMemcpy(h.data(), d_en.as<void>(), 8 * h.size(), hipMemcpyDeviceToHost));
+    if (sums_on_batch) {
+      rows.resize((size_t)out_stride_ * n);
+      HIP_OK(hipMemcpy(rows.data(), d_seq_out_.as<void>(), sizeof(double) * rows.size(), hipMemcpyDeviceToHost));
+    }
+    for (int k = 0; k < n; ++k)
+      for (int t = 0; t < nt; ++t)
+        out->en[t] += (sums_on_batch && !is_flagged[k]) ? rows[(size_t)k * out_stride_ + 6 + t] : h[(size_t)k * nt + t];
   }
 }
 

@@ -57,6 +57,7 @@ struct DpArgs {
   const double* params;    // ParamBlock followed by theta[n_theta]
   int32_t no_prf, m_min, no_rss;
   int32_t first_pass_only;  // debug: TRAIN stops after the full-terminal outside pass
+  int32_t cyk_only;         // SCAN: Ys / Ye are given in sc_ys / sc_ye (batch pipeline); run the Viterbi pass and traceback only
   const SeqPlan* plans;
   const int32_t* order;    // processing order (longest first)
   int32_t n_seq;
@@ -137,6 +138,10 @@ struct LinArgs {
   int32_t schedule, pass, d;
   int32_t cpb;                    // cells per workgroup = kThreads / S
   int32_t* flagged;               // [0] = number of flagged sequences, [1..] = their batch indices
+  // scan (sum passes K4 / K5 on this pipeline): start constraint and position-posterior accumulators (batch offsets)
+  int32_t scan;                   // 1: only Z(ari,nasi) decides the range check
+  int32_t* ys; int32_t* ye;       // per batch index: argmax start / end
+  double* pos_start; double* pos_inner; double* pos_end; double* exist;
   long long* prof;                // optional [16] shader-clock sums per phase (thread 0 of every workgroup), or null
   // tiling of the split sums over kTile diagonals: pairs whose operands were both final before the tile started are
   // summed by k4_in_old / k4_out_old into part_* (per slot [level][i][s]); the per-diagonal kernels add the rest
@@ -160,6 +165,9 @@ struct LinWeightArgs {
 hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st);
 // one whole train evaluation of a group; `full` sweeps the pattern automaton, `compact` (schedule 1) the one-state
 // automaton of the no-motif pass over the compact tables
+// scan: phase 0 = inside + outside with start / inner posteriors and argmax start; phase 1 = the same constrained to that
+// start with end posteriors and argmax end (RNAelemScanDP::operator(), motif_scanner.hpp:186-202)
+hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax, int phase, hipStream_t st);
 hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, int Lmax, int Wmax, bool first_pass_only,
                             hipStream_t st);
 hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax, int Wmax, hipStream_t st);

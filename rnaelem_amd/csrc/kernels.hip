@@ -511,34 +511,39 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
       }
     } else {
       // ---- schedule of RNAelemScanDP::operator() (motif_scanner.hpp:204-252)
-      double* Pys = l_post; double* Pyi = l_post + (L + 1); double* Pye = l_post + 2 * (L + 1);
-      sweep_inside<false>(m, q, Tin, c0, no_rss, sc, pf);
-      if (tid == 0) { l_zs[0] = part_func(m, Tin, true, true); l_zs[1] = Tin.o(L, m.lay.s00); }
-      __syncthreads();
-      const double ZL = l_zs[0];
-      sink.post_[0] = Pys; sink.post_[1] = Pyi;
-      sweep_outside<OUT_SCAN>(m, q, Tin, Tout, ZL, c0, true, true, sink, l_eh, no_rss, sc, pf);
-      if (tid == 0) l_zs[4] = (double)last_argmax(Pys, L);
-      __syncthreads();
-      const int Ys = (int)l_zs[4];
-      for (int t = tid; t < L; t += kThreads) { a.sc_start[p.seq_base + t] = Pys[t]; a.sc_inner[p.seq_base + t] = Pyi[t]; }
-      if (a.sc_en) for (int t = tid; t < nt; t += kThreads) a.sc_en[(size_t)n * nt + t] = l_en_o[t];
-      const Constraint c1{Ys, -1, 0};
-      sweep_inside<true>(m, q, Tin, c1, no_rss, sc, pf);
-      if (tid == 0) l_zs[2] = part_func(m, Tin, true, true);
-      __syncthreads();
-      sink.post_[0] = sink.post_[1] = nullptr; sink.post_[2] = Pye;
-      sink.en_ = l_en_x;
-      sweep_outside<OUT_END>(m, q, Tin, Tout, l_zs[2], c1, true, true, sink, l_eh, no_rss, sc, pf);
-      if (tid == 0) {
-        l_zs[5] = (double)last_argmax(Pye, L + 1);
-        double tot = ELEMDP_NEG_INF;
-        for (int t = 0; t < L; ++t) tot = lse2(tot, Pys[t]);
-        a.sc_exist[n] = exp(tot);
+      int Ys, Ye;
+      if (a.cyk_only) {   // the sum passes ran on the batch pipeline (lin_kernels.hip)
+        Ys = a.sc_ys[n]; Ye = a.sc_ye[n];
+      } else {
+        double* Pys = l_post; double* Pyi = l_post + (L + 1); double* Pye = l_post + 2 * (L + 1);
+        sweep_inside<false>(m, q, Tin, c0, no_rss, sc, pf);
+        if (tid == 0) { l_zs[0] = part_func(m, Tin, true, true); l_zs[1] = Tin.o(L, m.lay.s00); }
+        __syncthreads();
+        const double ZL = l_zs[0];
+        sink.post_[0] = Pys; sink.post_[1] = Pyi;
+        sweep_outside<OUT_SCAN>(m, q, Tin, Tout, ZL, c0, true, true, sink, l_eh, no_rss, sc, pf);
+        if (tid == 0) l_zs[4] = (double)last_argmax(Pys, L);
+        __syncthreads();
+        Ys = (int)l_zs[4];
+        for (int t = tid; t < L; t += kThreads) { a.sc_start[p.seq_base + t] = Pys[t]; a.sc_inner[p.seq_base + t] = Pyi[t]; }
+        if (a.sc_en) for (int t = tid; t < nt; t += kThreads) a.sc_en[(size_t)n * nt + t] = l_en_o[t];
+        const Constraint c1{Ys, -1, 0};
+        sweep_inside<true>(m, q, Tin, c1, no_rss, sc, pf);
+        if (tid == 0) l_zs[2] = part_func(m, Tin, true, true);
+        __syncthreads();
+        sink.post_[0] = sink.post_[1] = nullptr; sink.post_[2] = Pye;
+        sink.en_ = l_en_x;
+        sweep_outside<OUT_END>(m, q, Tin, Tout, l_zs[2], c1, true, true, sink, l_eh, no_rss, sc, pf);
+        if (tid == 0) {
+          l_zs[5] = (double)last_argmax(Pye, L + 1);
+          double tot = ELEMDP_NEG_INF;
+          for (int t = 0; t < L; ++t) tot = lse2(tot, Pys[t]);
+          a.sc_exist[n] = exp(tot);
+        }
+        __syncthreads();
+        Ye = (int)l_zs[5];
+        for (int t = tid; t <= L; t += kThreads) a.sc_end[p.pos_base + t] = Pye[t];
       }
-      __syncthreads();
-      const int Ye = (int)l_zs[5];
-      for (int t = tid; t <= L; t += kThreads) a.sc_end[p.pos_base + t] = Pye[t];
       // Viterbi parse (calc_viterbi_alignment :172-184)
       TraceView R;
       R.band = a.tr_band + blockIdx.x * a.band_stride;

@@ -48,8 +48,15 @@ namespace {
 struct LinSink {
   double* en_;
   double eh0, eh1;
+  double* pos0 = nullptr;   // scan: per-sequence position posteriors (global memory, linear): start, inner, end
+  double* pos1 = nullptr;
+  double* pos2 = nullptr;
   __device__ __forceinline__ void en(int idx, double w) { atomicAdd(&en_[idx], w); }
   __device__ __forceinline__ void eh(int k, double w) { if (k) eh1 += w; else eh0 += w; }
+  __device__ __forceinline__ void pos(int which, int p, double w) {
+    double* a = (which == 0) ? pos0 : (which == 1) ? pos1 : pos2;
+    if (a) atomicAdd(&a[p], w);
+  }
 };
 
 // phase timer (option "profile"): thread 0 of a workgroup sums the shader clocks between marks per slot and adds
@@ -87,6 +94,7 @@ struct LViews {
   TableView in, out;
   int n;
   bool positive;
+  long long seq_base, pos_base;
   double* row;
   double* zs;
 };
@@ -96,6 +104,8 @@ __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) 
   const int n = a.plans_slot ? p.index : a.grp[g];
   v.n = n;
   v.positive = p.positive != 0;
+  v.seq_base = p.seq_base;
+  v.pos_base = p.pos_base;
   const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
   v.m.ints = a.ints;
   v.m.big = a.ints;
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(kThreads) void k4_in_old(LinArgs a) {
   }
 }
 
-template <bool BIG>
+template <bool BIG, bool CON>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
   __shared__ AutomatonLayout s_lay;
@@ -584,7 +594,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     const int i = i0 + c;
     double HB = hb[c * S + s];
     if (a.tile_d0 >= 0) HB += a.part_in[(size_t)by * a.part_stride + ((size_t)tl * (v.in.L + 1) + i) * S + s];
-    const Cell7 r = lin_inside_target_u(v.m, v.q, v.in, d, i, s, HB, he[c * S + s]);
+    const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
+    const Cell7 r = lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, HB, he[c * S + s], con);
     if (a.band_in0 != nullptr && s == A.s00) {   // compact copy of state (0,0) for the no-motif pass
       TableView t0;
       t0.band = a.band_in0 + (size_t)by * a.band0_stride;
@@ -646,7 +657,7 @@ __device__ __forceinline__ void stage_ext_context(const LinArgs& a, LViews& v, u
 __device__ __forceinline__ bool out_of_range(double z) { return !(z > 0.) || !(z < HUGE_VAL); }
 
 // ---- exterior chain of the inside pass, partition functions, objective (one workgroup of 128 per sequence)
-template <bool STAGE>
+template <bool STAGE, bool CON>
 __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   extern __shared__ double l_ext[];
   __shared__ AutomatonLayout s_lay;
@@ -661,7 +672,7 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   __syncthreads();
   for (int j = 1; j <= L; ++j) {
     for (int s = tid; s < S; s += 128) {
-      lin_inside_ext_target(v.m, v.q, v.in, j, s);
+      lin_inside_ext_target<CON>(v.m, v.q, v.in, j, s, Constraint{CON ? a.ys[v.n] : -1, -1, 0});
       if (ext0 && s == a.lay.s00) ext0[j] = v.in.o(j, s);
     }
     __syncthreads();
@@ -676,7 +687,9 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
     v.row[0] = (Zo > 0.) ? log(Zo) - sl * ln2 : ELEMDP_NEG_INF;
     v.row[1] = (Za > 0.) ? log(Za) - sl * ln2 : ELEMDP_NEG_INF;
     v.row[2] = (Zn > 0.) ? log(Zn) - sl * ln2 : ELEMDP_NEG_INF;
-    if (out_of_range(Zo) || out_of_range(Za) || out_of_range(Zn)) {
+    if (CON && v.row[4] != 0.) {
+      // (second scan pass of a sequence the first one already flagged: nothing to add)
+    } else if (out_of_range(Zo) || (!a.scan && (out_of_range(Za) || out_of_range(Zn)))) {
       // outside the double range (or a structurally empty component): the log-space pipeline re-evaluates the
       // sequence and applies the reference's skip rule (motif_trainer.hpp:211-215)
       v.row[3] = 0.; v.row[4] = 2.; v.row[5] = 0.;
@@ -727,6 +740,42 @@ __device__ __forceinline__ void lflush(const LinArgs& a, const LViews& v, const 
   if (threadIdx.x < 2 && l_eh[threadIdx.x] != 0.) atomicAdd(&v.row[pi.eh_off + threadIdx.x], l_eh[threadIdx.x]);
 }
 
+// position-posterior accumulators of the scan passes (linear, global memory, batch offsets)
+template <int MODE>
+__device__ __forceinline__ void scan_sink(const LinArgs& a, const LViews& v, LinSink& sink) {
+  if (MODE == OUT_SCAN) { sink.pos0 = a.pos_start + v.seq_base; sink.pos1 = a.pos_inner + v.seq_base; }
+  if (MODE == OUT_END) sink.pos2 = a.pos_end + v.pos_base;
+}
+
+// argmax with the reference's tie rule (the LAST maximum, util.hpp:232-241) over the linear posteriors of one sequence,
+// then the logarithms the scan record prints.  WHICH 0: start (+ inner, exist prob); 1: end.
+template <int WHICH>
+__global__ __launch_bounds__(64) void k5_pick(LinArgs a, int G) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= G) return;
+  const SeqPlan p = a.plans_slot ? a.plans_slot[g] : a.plans[a.grp[g]];
+  const int n = a.plans_slot ? p.index : a.grp[g];
+  const int L = p.L;
+  double* arr = (WHICH == 0) ? a.pos_start + p.seq_base : a.pos_end + p.pos_base;
+  const int cnt = (WHICH == 0) ? L : L + 1;
+  double best = -1., tot = 0.;
+  int idx = 0;
+  for (int t = 0; t < cnt; ++t) {
+    const double x = arr[t];
+    if (best <= x) { best = x; idx = t; }
+    tot += x;
+    arr[t] = (x > 0.) ? log(x) : ELEMDP_NEG_INF;
+  }
+  if (WHICH == 0) {
+    a.ys[n] = idx;
+    a.exist[n] = tot;
+    double* inn = a.pos_inner + p.seq_base;
+    for (int t = 0; t < L; ++t) { const double x = inn[t]; inn[t] = (x > 0.) ? log(x) : ELEMDP_NEG_INF; }
+  } else {
+    a.ye[n] = idx;
+  }
+}
+
 // ---- exterior chain of an outside pass
 template <int MODE, bool STAGE>
 __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
@@ -745,7 +794,8 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   LinSink sink;
   sink.en_ = l_en;
   sink.eh0 = sink.eh1 = 0.;
-  LinOutCtx<LinSink> x{v.m, v.q, v.in, v.out, pi.invZ, sink};
+  scan_sink<MODE>(a, v, sink);
+  LinOutCtx<LinSink> x{v.m, v.q, v.in, v.out, pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
   for (int s = tid; s < S; s += 128) {
     double t = 0.;
     if (pi.nasi && s == a.lay.s00) t = 1.;
@@ -757,7 +807,7 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
     for (int s = tid; s < S; s += 128) lin_outside_ext_target<MODE>(x, i, s);
     __syncthreads();
   }
-  if (MODE == OUT_TRAIN) lflush(a, v, pi, sink, l_en, l_eh, 128);
+  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, 128);
 }
 
 // ---- outside, "old" split sums of a tile d0, d0-1, .., d0-kTile+1 (level t: d = d0 - t), launched before k4_out(d0):
@@ -940,6 +990,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   LinSink sink;
   sink.en_ = l_en;
   sink.eh0 = sink.eh1 = 0.;
+  scan_sink<MODE>(a, v, sink);
   const TableView& in = v.in;
   const TableView& out = v.out;
   const int nsp = A.n_split, nq = (a.dbg & 2) ? 0 : A.n_quad;
@@ -1098,7 +1149,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   pc.mark<10>();
   if (tid < nc * NA && !(a.dbg & 4)) {
     const int c = tid / NA, s = tid - c * NA;
-    LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink};
+    LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
     HeavyOut H;
     H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
     if (a.tile_d0 >= 0 && a.tile_has_old) {
@@ -1109,7 +1160,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     lin_outside_target_u<MODE>(x, d, i0 + c, s, H);
   }
   pc.mark<11>();
-  if (MODE == OUT_TRAIN) lflush(a, v, pi, sink, l_en, l_eh, kThreads);
+  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, kThreads);
   pc.mark<12>();
   pc.finish();
 }
@@ -1145,6 +1196,58 @@ hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax, int phase, hipStream_t st) {
+  if (G <= 0) return hipSuccess;
+  LinArgs a = full;
+  const int S = a.lay.S, nt = a.lay.n_theta;
+  a.cpb = kThreads / S;
+  if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
+  a.wmax = Wmax;
+  a.lmax = Lmax;
+  a.tile_d0 = -1;
+  a.schedule = 0;   // terminals (ari, nasi), Z = Z(ari,nasi): pass 0 of the reference schedule
+  a.pass = 0;
+  a.scan = 1;
+  const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
+  const size_t lds_out = block_lds((4 + 4 * kChunkOut) * a.cpb * S + nt + 2, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
+  const bool big = a.n_stage >= a.lay.n_ints;
+  const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
+  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
+  const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(nt + 2, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (nt + 2);
+#define ELEMDP_SCAN_PASS(CON, MODE)                                                                                              \
+  do {                                                                                                                           \
+    for (int d = 0; d <= Wmax; ++d) {                                                                                            \
+      const int ncell = Lmax - d + 1;                                                                                            \
+      if (ncell <= 0) break;                                                                                                     \
+      a.d = d;                                                                                                                   \
+      const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
+      if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kThreads), lds_in, st, a);                                      \
+      else hipLaunchKernelGGL((k4_in<false, CON>), grid, dim3(kThreads), lds_in, st, a);                                         \
+    }                                                                                                                            \
+    if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, CON>), dim3(G), dim3(128), lds_ext_in, st, a);                            \
+    else hipLaunchKernelGGL((k4_in_ext<false, CON>), dim3(G), dim3(128), 0, st, a);                                              \
+    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<MODE, true>), dim3(G), dim3(128), lds_ext_out, st, a);                         \
+    else hipLaunchKernelGGL((k4_out_ext<MODE, false>), dim3(G), dim3(128), lds_ext_out, st, a);                                  \
+    for (int d = Wmax; d >= 0; --d) {                                                                                            \
+      const int ncell = Lmax - d + 1;                                                                                            \
+      if (ncell <= 0) continue;                                                                                                  \
+      a.d = d;                                                                                                                   \
+      const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
+      if (big) hipLaunchKernelGGL((k4_out<MODE, true>), grid, dim3(kThreads), lds_out, st, a);                                   \
+      else hipLaunchKernelGGL((k4_out<MODE, false>), grid, dim3(kThreads), lds_out, st, a);                                      \
+    }                                                                                                                            \
+  } while (0)
+  if (phase == 0) {
+    ELEMDP_SCAN_PASS(false, OUT_SCAN);
+    hipLaunchKernelGGL(k5_pick<0>, dim3((G + 63) / 64), dim3(64), 0, st, a, G);
+  } else {
+    ELEMDP_SCAN_PASS(true, OUT_END);
+    hipLaunchKernelGGL(k5_pick<1>, dim3((G + 63) / 64), dim3(64), 0, st, a, G);
+  }
+#undef ELEMDP_SCAN_PASS
+  return hipGetLastError();
+}
+
 hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, int Lmax, int Wmax, bool first_pass_only,
                             hipStream_t st) {
   if (G <= 0) return hipSuccess;
@@ -1170,15 +1273,15 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
         if (big) hipLaunchKernelGGL(k4_in_old<true>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_old, st, a);
         else hipLaunchKernelGGL(k4_in_old<false>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_old, st, a);
       }
-      if (big) hipLaunchKernelGGL(k4_in<true>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
-      else hipLaunchKernelGGL(k4_in<false>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
+      if (big) hipLaunchKernelGGL((k4_in<true, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
+      else hipLaunchKernelGGL((k4_in<false, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
     }
   a.tile_d0 = -1;
   a.lmax = Lmax;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
-  if (stage_ext) hipLaunchKernelGGL(k4_in_ext<true>, dim3(G), dim3(128), lds_ext_in, st, a);
-  else hipLaunchKernelGGL(k4_in_ext<false>, dim3(G), dim3(128), 0, st, a);
+  if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, false>), dim3(G), dim3(128), lds_ext_in, st, a);
+  else hipLaunchKernelGGL((k4_in_ext<false, false>), dim3(G), dim3(128), 0, st, a);
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == 1 && first_pass_only) break;
     LinArgs b = (a.schedule == 1 && pass == 1) ? compact : a;

@@ -99,8 +99,10 @@ ELEMDP_HD double lheavy_loop(const ModelView& m, const SeqView& q, const TableVi
 struct Cell7 { double vP, vE, vM, vB, v1, v2, vL; };
 
 // P,E,M,B,1,2,L of target (i,d,s) from the heavy sums HB (rule 2) and HE (rule 6c); stores and returns them.
+// CON: the start constraint of the scan's second pass (c.ys) is applied to the emitting rules (motif_scanner.hpp:594-622)
+template <bool CON = false>
 ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s, double HB,
-                                    double HE) {
+                                    double HE, const Constraint& con = Constraint{-1, -1, 0}) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
   const int j = i + d;
@@ -136,16 +138,20 @@ ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const 
     const double tL = T.at(ST_L, d1, i, s1), t2 = T.at(ST_2, d1, i, s1);
     const double tE = T.at(ST_E, d2, i1, sp), tP = T.at(ST_P, d2, i1, sp);
     const double tM = T.at(ST_M, d1, i1, sl);
-    const double wr = (vr && d > 0) ? lw_right(m, q, s, tfr, pr) : 0.;
-    const double wp = (vp && pok) ? lw_pair(m, q, s, sp, tfp, i, pr) : 0.;
-    const double wl = (vl && doM) ? lw_left(m, q, sl, tfl, i) : 0.;
-    sL += (doL && vr) ? tL * wr : 0.;
-    s2 += (do2 && vr) ? t2 * wr : 0.;
-    sP += (pok && vp) ? wp * fma(tP, xst, tE) : 0.;
-    sM += (doM && vl) ? tM * wl : 0.;
+    const bool okr = vr && (!CON || allow_right(m, con, q.L, j, s, s1));
+    const bool okp = vp && pok && (!CON || allow_pair(m, con, q.L, i, j, s, sp));
+    const bool okl = vl && doM && (!CON || allow_left(m, con, i, s, sl));
+    const double wr = (okr && d > 0) ? lw_right(m, q, s, tfr, pr) : 0.;
+    const double wp = okp ? lw_pair(m, q, s, sp, tfp, i, pr) : 0.;
+    const double wl = okl ? lw_left(m, q, sl, tfl, i) : 0.;
+    sL += (doL && okr) ? tL * wr : 0.;
+    s2 += (do2 && okr) ? t2 * wr : 0.;
+    sP += okp ? wp * fma(tP, xst, tE) : 0.;
+    sM += okl ? tM * wl : 0.;
   }
   for (int u = kUnary; u < nR; ++u) {
     const int s1 = I[A.right_ent + 2 * (r0 + u)], tf = I[A.right_ent + 2 * (r0 + u) + 1];
+    if (CON && !allow_right(m, con, q.L, j, s, s1)) continue;
     const double wr = lw_right(m, q, s, tf, pr);
     if (doL) sL += T.at(ST_L, d - 1, i, s1) * wr;
     if (do2) s2 += T.at(ST_2, d - 1, i, s1) * wr;
@@ -153,11 +159,13 @@ ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const 
   for (int u = kUnary; u < nP; ++u) {
     if (!pok) break;
     const int s1 = I[A.pair_ent + 2 * (p0 + u)], tf = I[A.pair_ent + 2 * (p0 + u) + 1];
+    if (CON && !allow_pair(m, con, q.L, i, j, s, s1)) continue;
     sP += lw_pair(m, q, s, s1, tf, i, j - 1) * fma(T.at(ST_P, d - 2, i + 1, s1), xst, T.at(ST_E, d - 2, i + 1, s1));
   }
   for (int u = kUnary; u < nL; ++u) {
     if (!doM) break;
     const int s1 = I[A.left_ent + 2 * (l0 + u)], tf = I[A.left_ent + 2 * (l0 + u) + 1];
+    if (CON && !allow_left(m, con, i, s, s1)) continue;
     sM += T.at(ST_M, d - 1, i + 1, s1) * lw_left(m, q, s1, tf, i);
   }
   Cell7 c;
@@ -177,14 +185,18 @@ ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const 
   T.at(ST_E, d, i, s) = c.vE;
   return c;
 }
-ELEMDP_HD Cell7 lin_inside_target(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
+template <bool CON = false>
+ELEMDP_HD Cell7 lin_inside_target(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s,
+                                  const Constraint& c = Constraint{-1, -1, 0}) {
   const double HB = q.left_ok(i, d) ? lheavy_bif(m, q, T, d, i, s) : 0.;
   const double HE = q.e_ok(i, d) ? lheavy_loop(m, q, T, d, i, s) : 0.;
-  return lin_inside_target_u(m, q, T, d, i, s, HB, HE);
+  return lin_inside_target_u<CON>(m, q, T, d, i, s, HB, HE, c);
 }
 
 // exterior chain, one step (rules 7, 8), j >= 1
-ELEMDP_HD void lin_inside_ext_target(const ModelView& m, const SeqView& q, const TableView& T, int j, int s) {
+template <bool CON = false>
+ELEMDP_HD void lin_inside_ext_target(const ModelView& m, const SeqView& q, const TableView& T, int j, int s,
+                                     const Constraint& c = Constraint{-1, -1, 0}) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
   const int32_t* G = m.big;
@@ -202,8 +214,10 @@ ELEMDP_HD void lin_inside_ext_target(const ModelView& m, const SeqView& q, const
     a = fma(b, xe, a);
   }
   if (q.unp[j - 1])
-    for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t)
+    for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+      if (CON && !allow_right(m, c, q.L, j, s, I[A.right_ent + 2 * t])) continue;
       a = fma(T.o(j - 1, I[A.right_ent + 2 * t]), lw_right(m, q, s, I[A.right_ent + 2 * t + 1], j - 1), a);
+    }
   T.o(j, s) = a;
 }
 ELEMDP_HD double lin_part(const ModelView& m, const TableView& T, bool ari, bool nasi) {
@@ -218,13 +232,39 @@ template <class Sink> struct LinOutCtx {
   const TableView& out;
   double invZ;
   Sink& sink;
+  Constraint c = Constraint{-1, -1, 0};   // OUT_END: the motif starts at c.ys
 };
 
-// expected emission counts (motif_trainer.hpp:384-388 / profile_hmm.hpp:144-179); z = linear posterior
-template <int MODE, class Sink> ELEMDP_HD void lstat_pair(LinOutCtx<Sink>& x, int i, int j, int par, int ch, double z) {
-  if (MODE != OUT_TRAIN || x.m.no_prf || z == 0.) return;
+// Statistics of one emitting transition; z = linear posterior.  OUT_TRAIN / OUT_SCAN: expected emission counts
+// (motif_trainer.hpp:384-388 / profile_hmm.hpp:144-179); OUT_SCAN: + start / inner position posteriors
+// (motif_scanner.hpp:546-573); OUT_END: end posteriors given the start (:715-747) -- returns false when the start
+// constraint excludes the transition (the caller then drops the term from the outside sums as well).
+// Sink: en(idx, w), eh(k, w), pos(which, p, w) with which 0 = start, 1 = inner, 2 = end (linear accumulators).
+template <int MODE, class Sink> ELEMDP_HD bool lstat_pair(LinOutCtx<Sink>& x, int i, int j, int par, int ch, double z) {
+  if (MODE == OUT_NONE) return true;
   const ModelView& m = x.m;
-  const int bi = x.q.seq[i - 1], bj = x.q.seq[j];
+  const int k = i - 1;
+  if (MODE == OUT_SCAN || MODE == OUT_END) {
+    const int pl = m.st_l(par), pr = m.st_r(par), cl = m.st_l(ch), cr = m.st_r(ch), M = m.lay.M;
+    if (MODE == OUT_END) {
+      if (x.c.ys == k && !(pl == 0 && cl == 1)) return false;
+      if (x.c.ys == j && !(cr == 0 && pr == 1)) return false;
+      if (z != 0.) {
+        if (pl == M - 2 && cl == M - 1) x.sink.pos(2, k, z);
+        if (cr == M - 2 && pr == M - 1) x.sink.pos(2, j, z);
+        if (pr == M - 2 && x.q.L == j + 1) x.sink.pos(2, x.q.L, z);
+      }
+      return true;
+    }
+    if (z != 0.) {
+      if (pl == 0 && cl == 1) x.sink.pos(0, k, z);
+      if (cr == 0 && pr == 1) x.sink.pos(0, j, z);
+      if (cl != 0 && cl != M - 1) x.sink.pos(1, k, z);
+      if (pr != 0 && pr != M - 1) x.sink.pos(1, j, z);
+    }
+  }
+  if (m.no_prf || z == 0.) return true;
+  const int bi = x.q.seq[k], bj = x.q.seq[j];
   if (m.ints[m.lay.st_pair_r + par]) {
     const int t = bp_type(bi, bj);
     if (t) x.sink.en(m.param_index(m.ints[m.lay.st_row_r + par], t - 1), z);
@@ -232,16 +272,53 @@ template <int MODE, class Sink> ELEMDP_HD void lstat_pair(LinOutCtx<Sink>& x, in
     if (bi) x.sink.en(m.param_index(m.ints[m.lay.st_row_l + ch], bi - 1), z);
     if (bj) x.sink.en(m.param_index(m.ints[m.lay.st_row_r + par], bj - 1), z);
   }
+  return true;
 }
-template <int MODE, class Sink> ELEMDP_HD void lstat_right(LinOutCtx<Sink>& x, int j, int par, double z) {
-  if (MODE != OUT_TRAIN || x.m.no_prf || z == 0.) return;
+// right emission: parent (., j+1, par), child (., j, ch): position j
+template <int MODE, class Sink> ELEMDP_HD bool lstat_right(LinOutCtx<Sink>& x, int j, int par, int ch, double z) {
+  if (MODE == OUT_NONE) return true;
+  const ModelView& m = x.m;
+  if (MODE == OUT_SCAN || MODE == OUT_END) {
+    const int pr = m.st_r(par), cr = m.st_r(ch), M = m.lay.M;
+    if (MODE == OUT_END) {
+      if (x.c.ys == j && !(cr == 0 && pr == 1)) return false;
+      if (z != 0.) {
+        if (cr == M - 2 && pr == M - 1) x.sink.pos(2, j, z);
+        if (pr == M - 2 && x.q.L == j + 1) x.sink.pos(2, x.q.L, z);
+      }
+      return true;
+    }
+    if (z != 0.) {
+      if (cr == 0 && pr == 1) x.sink.pos(0, j, z);
+      if (pr != 0 && pr != M - 1) x.sink.pos(1, j, z);
+    }
+  }
+  if (m.no_prf || z == 0.) return true;
   const int b = x.q.seq[j];
-  if (b) x.sink.en(x.m.param_index(x.m.ints[x.m.lay.st_row_r + par], b - 1), z);
+  if (b) x.sink.en(m.param_index(m.ints[m.lay.st_row_r + par], b - 1), z);
+  return true;
 }
-template <int MODE, class Sink> ELEMDP_HD void lstat_left(LinOutCtx<Sink>& x, int i, int ch, double z) {
-  if (MODE != OUT_TRAIN || x.m.no_prf || z == 0.) return;
-  const int b = x.q.seq[i - 1];
-  if (b) x.sink.en(x.m.param_index(x.m.ints[x.m.lay.st_row_l + ch], b - 1), z);
+// left emission: parent M(i-1, j, par), child M(i, j, ch): position i-1
+template <int MODE, class Sink> ELEMDP_HD bool lstat_left(LinOutCtx<Sink>& x, int i, int par, int ch, double z) {
+  if (MODE == OUT_NONE) return true;
+  const ModelView& m = x.m;
+  const int k = i - 1;
+  if (MODE == OUT_SCAN || MODE == OUT_END) {
+    const int pl = m.st_l(par), cl = m.st_l(ch), M = m.lay.M;
+    if (MODE == OUT_END) {
+      if (x.c.ys == k && !(pl == 0 && cl == 1)) return false;
+      if (z != 0. && pl == M - 2 && cl == M - 1) x.sink.pos(2, k, z);
+      return true;
+    }
+    if (z != 0.) {
+      if (pl == 0 && cl == 1) x.sink.pos(0, k, z);
+      if (cl != 0 && cl != M - 1) x.sink.pos(1, k, z);
+    }
+  }
+  if (m.no_prf || z == 0.) return true;
+  const int b = x.q.seq[k];
+  if (b) x.sink.en(m.param_index(m.ints[m.lay.st_row_l + ch], b - 1), z);
+  return true;
 }
 // EH[idx(parent)] += tsc * posterior (motif_trainer.hpp:380-381); tsc may be log 0 where the posterior is 0
 template <int MODE, class Sink> ELEMDP_HD void lstat_energy(LinOutCtx<Sink>& x, int par, double tsc, double z) {
@@ -263,7 +340,7 @@ template <int MODE, class Sink> ELEMDP_HD void lin_outside_ext_target(LinOutCtx<
     for (int t = I[A.rright_off + s]; t < I[A.rright_off + s + 1]; ++t) {
       const int par = I[A.rright_ent + 2 * t], tf = I[A.rright_ent + 2 * t + 1];
       const double term = x.out.o(i + 1, par) * lw_right(m, q, par, tf, i);
-      lstat_right<MODE>(x, i, par, term * inz);
+      if (!lstat_right<MODE>(x, i, par, s, term * inz)) continue;
       a += term;
     }
   const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
@@ -422,21 +499,21 @@ ELEMDP_HD void lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, con
     const double w = lw_pair(m, q, par, s, tf, im1, jr);
     const double tE = aE ? op * w : 0.;
     const double tP = aP ? op * (w * (lamk(m, par) ? xsu1 : xsu0)) : 0.;
-    lstat_pair<MODE>(x, i, j, par, s, fma(tE, inEz, tP * inPz));
+    if (!lstat_pair<MODE>(x, i, j, par, s, fma(tE, inEz, tP * inPz))) return;
     lstat_energy<MODE>(x, par, e_su, tP * inPz);
     oE += tE;
     oP1b += tP;
   };
   auto step_left = [&](int par, int tf, double op) {
     const double term = op * lw_left(m, q, s, tf, im1);
-    lstat_left<MODE>(x, i, s, term * inMz);
+    if (!lstat_left<MODE>(x, i, par, s, term * inMz)) return;
     sM += term;
   };
   auto step_right = [&](int par, int tf, double op2, double opL) {
     const double w = lw_right(m, q, par, tf, jr);
     const double t2 = a2 ? op2 * w : 0.;
     const double tL = (aL && I[A.st_is_loop + par]) ? opL * w : 0.;
-    lstat_right<MODE>(x, j, par, fma(t2, in2z, tL * inLz));
+    if (!lstat_right<MODE>(x, j, par, s, fma(t2, in2z, tL * inLz))) return;
     s2 += t2;
     sL += tL;
   };

@@ -543,4 +543,120 @@ int emu_scan_seq(void* h, const double* x, const uint8_t* seq, int L, const uint
   } catch (std::exception& e) { g_err = e.what(); return 1; }
 }
 
+
+// ---- scan of one sequence with the sum passes (K4, K5) in the scaled-linear semiring (lin_rules.h) and the CYK pass
+// in log space, as elemdp_scan runs them on the GPU.  Same outputs as emu_scan_seq.
+struct CpuLinSink {
+  double* EN; double* EH; double* post[3];
+  void en(int idx, double w) { EN[idx] += w; }
+  void eh(int k, double w) { EH[k] += w; }
+  void pos(int which, int p, double w) { if (post[which]) post[which][p] += w; }
+};
+int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const uint8_t* qual, double* out6, double* start,
+                     double* end, double* inner, int32_t* psihat, char* rss, double* EN) {
+  try {
+    Emu& E = *(Emu*)h;
+    const int nt = E.au->n_theta();
+    std::vector<double> theta(x, x + nt);
+    if (E.flags & F_SOFTMAX)
+      for (int r = 0; r < E.au->n_rows(); ++r) {
+        double tot = NEG;
+        for (int c = 0; c < E.au->row_width(r); ++c) tot = lse2(tot, x[E.au->row_offset(r) + c]);
+        for (int c = 0; c < E.au->row_width(r); ++c) theta[E.au->row_offset(r) + c] = x[E.au->row_offset(r) + c] - tot;
+      }
+    const bool no_prf = E.flags & F_NO_PRF;
+    std::vector<double> lin;
+    make_lin_params(E.lay, E.ints.data(), theta.data(), E.tau, no_prf, &lin);
+    ModelView m = make_view(E.lay, E.ints, theta.data(), x[nt], x[nt + 1], std::log(E.tau), no_prf, E.flags & F_NO_TURN);
+    m.lin = lin.data();
+    HostPlan P;
+    prepare(E, P, seq, L, qual, nullptr);
+    SeqView q = P.view();
+    const int S = m.lay.S;
+    const size_t nc = (size_t)(L + 1) * (P.W + 1), ni = P.items.size();
+    std::vector<double> ews(L + 1), xwc(10 * nc), xwi(2 * ni + 1);
+    for (int p = 0; p <= L; ++p) ews[p] = std::exp(P.ws[p]);
+    const double* terms[5] = {P.e_stack.data(), P.e_ext.data(), P.e_ml.data(), P.e_close.data(), P.e_hp.data()};
+    for (int k = 0; k < 2; ++k) {
+      for (int t = 0; t < 5; ++t)
+        for (size_t c = 0; c < nc; ++c) xwc[(size_t)(k * 5 + t) * nc + c] = lin_weight(m.lambda[k], terms[t][c]);
+      for (size_t n = 0; n < ni; ++n) xwi[(size_t)k * ni + n] = lin_weight(m.lambda[k], P.items[n].tsc);
+    }
+    q.ews = ews.data(); q.xwc = xwc.data(); q.xwc_stride = nc; q.xwi = xwi.data(); q.xwi_stride = ni;
+    Tab in(L, P.W, S), out(L, P.W, S);
+    auto zero = [](Tab& T) { std::fill(T.band.begin(), T.band.end(), 0.); std::fill(T.ext.begin(), T.ext.end(), 0.); };
+    auto run_in = [&](const Constraint& c, bool con) {
+      zero(in);
+      for (int d = 0; d <= q.W; ++d)
+        for (int i = 0; i + d <= q.L; ++i)
+          for (int s = 0; s < S; ++s) { if (con) lin_inside_target<true>(m, q, in.v, d, i, s, c); else lin_inside_target<false>(m, q, in.v, d, i, s, c); }
+      for (int s = 0; s < S; ++s) in.v.o(0, s) = (s == m.lay.s00) ? 1. : 0.;
+      for (int j = 1; j <= L; ++j)
+        for (int s = 0; s < S; ++s) { if (con) lin_inside_ext_target<true>(m, q, in.v, j, s, c); else lin_inside_ext_target<false>(m, q, in.v, j, s, c); }
+    };
+    std::vector<double> Pys(L, 0.), Pyi(L, 0.), Pye(L + 1, 0.), en(nt + 1, 0.);
+    double eh[2] = {0, 0};
+    // K4: start / inner posteriors
+    Constraint c0{-1, -1, 0};
+    run_in(c0, false);
+    const double ZLm = lin_part(m, in.v, true, true);
+    const double PyNL = std::log(in.v.o(L, m.lay.s00) / ZLm);
+    double sl = 0.;
+    for (int p = 0; p < L; ++p) sl += lin[kLinPl2 + seq[p]];
+    const double ln2 = 0.69314718055994530942;
+    {
+      zero(out);
+      CpuLinSink s1{en.data(), eh, {Pys.data(), Pyi.data(), nullptr}};
+      LinOutCtx<CpuLinSink> xo{m, q, in.v, out.v, 1. / ZLm, s1, c0};
+      out.v.o(L, m.lay.s00) = 1.; out.v.o(L, m.lay.s0m1) = 1.; out.v.o(L, m.lay.s0m2) = 1.;
+      for (int i = L - 1; i >= 0; --i) for (int s = 0; s < S; ++s) lin_outside_ext_target<OUT_SCAN>(xo, i, s);
+      for (int d = q.W; d >= 0; --d) for (int i = 0; i + d <= L; ++i) for (int s = 0; s < S; ++s) lin_outside_target<OUT_SCAN>(xo, d, i, s);
+    }
+    auto tolog = [](double v) { return v > 0. ? std::log(v) : NEG; };
+    std::vector<double> lPys(L), lPyi(L), lPye(L + 1);
+    for (int p = 0; p < L; ++p) { lPys[p] = tolog(Pys[p]); lPyi[p] = tolog(Pyi[p]); }
+    const int Ys = last_argmax(lPys.data(), L);
+    // K5: end posterior given the start
+    Constraint c1{Ys, -1, 0};
+    run_in(c1, true);
+    const double ZeLm = lin_part(m, in.v, true, true);
+    {
+      zero(out);
+      CpuLinSink s2{en.data(), eh, {nullptr, nullptr, Pye.data()}};
+      LinOutCtx<CpuLinSink> xo{m, q, in.v, out.v, 1. / ZeLm, s2, c1};
+      out.v.o(L, m.lay.s00) = 1.; out.v.o(L, m.lay.s0m1) = 1.; out.v.o(L, m.lay.s0m2) = 1.;
+      for (int i = L - 1; i >= 0; --i) for (int s = 0; s < S; ++s) lin_outside_ext_target<OUT_END>(xo, i, s);
+      for (int d = q.W; d >= 0; --d) for (int i = 0; i + d <= L; ++i) for (int s = 0; s < S; ++s) lin_outside_target<OUT_END>(xo, d, i, s);
+    }
+    for (int p = 0; p <= L; ++p) lPye[p] = tolog(Pye[p]);
+    const int Ye = last_argmax(lPye.data(), L + 1);
+    // K6: Viterbi parse in log space (scan_rules.h)
+    Tab cyk(L, P.W, S);
+    std::vector<TraceRec> tr((size_t)7 * (P.W + 1) * (L + 1) * S), tro((size_t)(L + 1) * S);
+    TraceView tv{tr.data(), tro.data()};
+    Constraint c2{Ys, Ye, 1};
+    for (int d = 0; d <= q.W; ++d)
+      for (int i = 0; i + d <= q.L; ++i)
+        for (int s = 0; s < S; ++s) cyk_target(m, q, cyk.v, tv, c2, d, i, s);
+    for (int s = 0; s < S; ++s) { cyk.v.o(0, s) = (s == m.lay.s00) ? 0. : NEG; tro[s] = TraceRec{-1, -1, -1, -1, -1}; }
+    for (int j = 1; j <= L; ++j)
+      for (int s = 0; s < S; ++s) cyk_ext_target(m, q, cyk.v, tv, c2, j, s);
+    std::vector<int32_t> path(L, 0);
+    std::string r(L, ' ');
+    std::vector<TraceFrame> stack((size_t)4 * (L + 2));
+    int s0 = cyk.v.o(L, m.lay.s0m2) < cyk.v.o(L, m.lay.s0m1) ? m.lay.s0m1 : m.lay.s0m2;
+    trace_back(m, cyk.v, tv, L, s0, path.data(), &r[0], stack.data(), (int)stack.size());
+    double tot = 0.;
+    for (double v : Pys) tot += v;
+    out6[0] = Ys; out6[1] = Ye; out6[2] = tot; out6[3] = tolog(ZLm) - sl * ln2; out6[4] = tolog(ZeLm) - sl * ln2; out6[5] = PyNL;
+    if (start) std::copy(lPys.begin(), lPys.end(), start);
+    if (end) std::copy(lPye.begin(), lPye.end(), end);
+    if (inner) std::copy(lPyi.begin(), lPyi.end(), inner);
+    if (psihat) std::copy(path.begin(), path.end(), psihat);
+    if (rss) memcpy(rss, r.data(), L);
+    if (EN) for (int k = 0; k < nt; ++k) EN[k] += en[k];
+    return 0;
+  } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
 }  // extern "C"

@@ -32,6 +32,7 @@ def lib():
         L.emu_train_seq.argtypes = [C.c_void_p, dp, u8, C.c_int, u8, C.c_char_p] + [dp] * 9
         L.emu_train_seq_lin.argtypes = [C.c_void_p, dp, u8, C.c_int, u8, C.c_char_p, C.c_int] + [dp] * 9
         L.emu_scan_seq.argtypes = [C.c_void_p, dp, u8, C.c_int, u8, dp, dp, dp, dp, i32, C.c_char_p, dp]
+        L.emu_scan_seq_lin.argtypes = L.emu_scan_seq.argtypes
         _lib = L
     return _lib
 
@@ -120,7 +121,7 @@ class Emul:
             r["outside"] = outs.reshape(L + 1, W + 1, 7, self.S)
         return r
 
-    def scan_seq(self, x, seq, qual):
+    def scan_seq(self, x, seq, qual, linear=False):
         L = len(seq)
         x = np.ascontiguousarray(x, dtype=np.float64)
         out6 = np.zeros(6)
@@ -128,7 +129,7 @@ class Emul:
         psi = np.zeros(L, dtype=np.int32)
         rss = C.create_string_buffer(L + 1)
         EN = np.zeros(self.n_param - 2)
-        rc = lib().emu_scan_seq(self.h, _dp(x), _u8(seq), L, _u8(qual), _dp(out6), _dp(start), _dp(end), _dp(inner),
+        rc = (lib().emu_scan_seq_lin if linear else lib().emu_scan_seq)(self.h, _dp(x), _u8(seq), L, _u8(qual), _dp(out6), _dp(start), _dp(end), _dp(inner),
                                 psi.ctypes.data_as(C.POINTER(C.c_int32)), rss, _dp(EN))
         if rc:
             raise RuntimeError(lib().emu_last_error().decode())

@@ -237,3 +237,22 @@ def test_scan_sequence_matches_oracle(model, fq):
         assert list(a["psihat"]) == list(b["psihat"])
         assert a["rss"] == b["rss"]
         np.testing.assert_allclose(b["EN"], a["EN"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("model,fq", SCAN)
+def test_scan_with_linear_sum_passes_matches_oracle(model, fq):
+    """K4 / K5 of the scan in the scaled-linear semiring (lin_rules.h with the start constraint and the SCAN / END
+    statistics), K6 in log space: what elemdp_scan's batch pipeline runs."""
+    o, e, x = model_pair(model)
+    for rid, seq, qual in po.read_fastq(gpath(fq)):
+        a = o.scan_seq(seq, qual)
+        b = e.scan_seq(x, seq, qual, linear=True)
+        assert (a["Ys"], a["Ye"]) == (b["Ys"], b["Ye"])
+        for k in ("ZL", "ZeL", "PyNL"):
+            assert_log_close(b[k], a[k], rtol=1e-10, atol=1e-10, what=k)
+        for k in ("start", "end", "inner"):
+            assert_log_close(b[k], a[k], rtol=1e-9, atol=1e-9, what=k)
+        assert b["exist_prob"] == pytest.approx(a["exist_prob"], rel=1e-10)
+        assert list(a["psihat"]) == list(b["psihat"])
+        assert a["rss"] == b["rss"]
+        np.testing.assert_allclose(b["EN"], a["EN"], rtol=1e-9, atol=1e-11)
