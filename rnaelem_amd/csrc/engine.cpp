@@ -1054,6 +1054,7 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   HIP_OK(hipEventRecord(ev_[1], st_));
   // ---- K4 / K5 (the four sum passes, motif_scanner.hpp:186-202) on the scaled-linear batch pipeline
   std::vector<int32_t> flagged;
+  bool cyk_done = false;
   const bool sums_on_batch = opt_pipeline_ == 4;
   if (sums_on_batch) {
     LinArgs a;
@@ -1070,6 +1071,28 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
     HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n, st_));
     HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
     lin_weights();
+    // trace tables of the Viterbi pass: one per slot of a CYK sub-batch (as large as one band table each)
+    const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S, ext = (size_t)(Lmax_ + 1) * S;
+    const int stack_stride = 4 * (4 * (Lmax_ + 2));
+    int tr_slots;
+    {
+      size_t free_b = 0, total_b = 0;
+      HIP_OK(hipMemGetInfo(&free_b, &total_b));
+      const size_t per = (band + ext) * sizeof(TraceRec) + (size_t)stack_stride * sizeof(int32_t);
+      const size_t have = d_tr_band_.bytes() / std::max<size_t>(band * sizeof(TraceRec), 1);
+      size_t want = std::min<size_t>((size_t)gsz, std::max<size_t>(have, (size_t)((double)free_b * 0.5) / per));
+      want = std::max<size_t>(want, std::min<size_t>((size_t)gsz, 2 * (size_t)n_cu_));
+      if (have < want) {
+        d_tr_band_.alloc(band * want * sizeof(TraceRec));
+        d_tr_ext_.alloc(ext * want * sizeof(TraceRec));
+        d_tr_stack_.alloc(want * stack_stride * sizeof(int32_t));
+      }
+      tr_slots = (int)std::max<size_t>(have, want);
+    }
+    a.tr_band = d_tr_band_.as<TraceRec>(); a.tr_ext = d_tr_ext_.as<TraceRec>();
+    a.trace_stack = d_tr_stack_.as<int32_t>(); a.trace_stack_stride = stack_stride;
+    a.sc_psihat = d_psi.as<int32_t>(); a.sc_rss = d_rss.as<char>();
+    const bool cyk_on_batch = !(opt_dbg_ & 64);
     for (int g0 = 0; g0 < n; g0 += gsz) {
       const int G = std::min(gsz, n - g0);
       a.grp = d_order_.as<int32_t>() + g0;
@@ -1077,7 +1100,19 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
       const int Lg = h_plans_[h_order_[g0]].L;
       HIP_OK(launch_lin_scan_group(a, G, Lg, std::min(Lg, max_span_), 0, st_));
       HIP_OK(launch_lin_scan_group(a, G, Lg, std::min(Lg, max_span_), 1, st_));
+      if (cyk_on_batch)
+        for (int r0 = 0; r0 < G; r0 += tr_slots) {   // K6 on the tables of slots [r0, r0 + R)
+          const int R = std::min(tr_slots, G - r0);
+          LinArgs c = a;
+          c.grp = a.grp + r0;
+          c.plans_slot = a.plans_slot + r0;
+          c.band_in = a.band_in + (size_t)r0 * a.band_stride;
+          c.ext_in = a.ext_in + (size_t)r0 * a.ext_stride;
+          const int Lr = h_plans_[h_order_[g0 + r0]].L;
+          HIP_OK(launch_cyk_group(c, R, Lr, std::min(Lr, max_span_), st_));
+        }
     }
+    cyk_done = cyk_on_batch;
     int32_t n_flagged = 0;
     HIP_OK(hipMemcpyAsync(&n_flagged, d_flagged_.as<void>(), sizeof(int32_t), hipMemcpyDeviceToHost, st_));
     HIP_OK(hipStreamSynchronize(st_));
@@ -1113,8 +1148,10 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   d.sc_ys = d_ys.as<int32_t>(); d.sc_ye = d_ye.as<int32_t>(); d.sc_exist = d_exist.as<double>(); d.sc_en = d_en.as<double>();
   d.lds = lds_layout(lay_, Lmax_, nword_max_, true);
   d.cyk_only = sums_on_batch ? 1 : 0;
-  HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
-  HIP_OK(launch_dp(DP_SCAN, d, n_blocks, st_));
+  if (!cyk_done) {
+    HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
+    HIP_OK(launch_dp(DP_SCAN, d, n_blocks, st_));
+  }
   if (!flagged.empty()) {
     d.cyk_only = 0;
     d.order = d_flagged_.as<int32_t>() + 1;

@@ -142,6 +142,8 @@ struct LinArgs {
   int32_t scan;                   // 1: only Z(ari,nasi) decides the range check
   int32_t* ys; int32_t* ye;       // per batch index: argmax start / end
   double* pos_start; double* pos_inner; double* pos_end; double* exist;
+  // scan, Viterbi pass on the batch pipeline: trace tables per slot (same indexing as the band / ext tables), outputs
+  TraceRec* tr_band; TraceRec* tr_ext; int32_t* sc_psihat; char* sc_rss; int32_t* trace_stack; int32_t trace_stack_stride;
   long long* prof;                // optional [16] shader-clock sums per phase (thread 0 of every workgroup), or null
   // tiling of the split sums over kTile diagonals: pairs whose operands were both final before the tile started are
   // summed by k4_in_old / k4_out_old into part_* (per slot [level][i][s]); the per-diagonal kernels add the rest
@@ -168,6 +170,8 @@ hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st);
 // scan: phase 0 = inside + outside with start / inner posteriors and argmax start; phase 1 = the same constrained to that
 // start with end posteriors and argmax end (RNAelemScanDP::operator(), motif_scanner.hpp:186-202)
 hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax, int phase, hipStream_t st);
+// scan: Viterbi parse (max-plus CYK with trace records, then traceback) of a group; uses band_in / ext_in as the CYK table
+hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipStream_t st);
 hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, int Lmax, int Wmax, bool first_pass_only,
                             hipStream_t st);
 hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax, int Wmax, hipStream_t st);

@@ -39,6 +39,7 @@
 #endif
 #include "kernels.h"
 #include "lin_rules.h"
+#include "scan_rules.h"
 #include "wave_gather.h"
 
 namespace elemdp {
@@ -1185,6 +1186,64 @@ __global__ __launch_bounds__(kThreads) void k4_combine(LinArgs a, int G) {
   }
 }
 
+
+// ---- Viterbi pass of the scan on the batch pipeline (log space, max-plus; rules: scan_rules.h, reference
+// RNAelemScanDP::CYKFun motif_scanner.hpp:802-913).  One lane per (cell, state) evaluates the whole target in the
+// reference's candidate order (ties are broken by the first strictly greater candidate, :821), so no cross-lane
+// reduction can reorder candidates.  No exp / log here: a candidate is a few adds and a compare.
+__global__ __launch_bounds__(kThreads) void k5_cyk(LinArgs a) {
+  __shared__ AutomatonLayout s_lay;
+  stage_layout(a, &s_lay, kThreads);
+  unsigned bx, by;
+  swizzled_block(bx, by);
+  LViews v(s_lay);
+  make_lviews(a, by, v);
+  __syncthreads();
+  const int S = a.lay.S, d = a.d;
+  if (d > v.q.W) return;
+  const int t = bx * kThreads + threadIdx.x;
+  if (t >= (v.q.L - d + 1) * S) return;
+  const int i = t / S, s = t - i * S;
+  TraceView R;
+  R.band = a.tr_band + (size_t)by * a.band_stride;
+  R.ext = a.tr_ext + (size_t)by * a.ext_stride;
+  const Constraint c{a.ys[v.n], a.ye[v.n], 1};
+  cyk_target(v.m, v.q, v.in, R, c, d, i, s);
+}
+
+// exterior chain of the Viterbi pass and the traceback (one workgroup of 64 per sequence; lane 0 walks the trace)
+__global__ __launch_bounds__(64) void k5_cyk_ext(LinArgs a) {
+  __shared__ AutomatonLayout s_lay;
+  stage_layout(a, &s_lay, 64);
+  LViews v(s_lay);
+  make_lviews(a, blockIdx.x, v);
+  __syncthreads();
+  const int S = a.lay.S, tid = threadIdx.x, L = v.q.L;
+  TraceView R;
+  R.band = a.tr_band + (size_t)blockIdx.x * a.band_stride;
+  R.ext = a.tr_ext + (size_t)blockIdx.x * a.ext_stride;
+  const Constraint c{a.ys[v.n], a.ye[v.n], 1};
+  for (int s = tid; s < S; s += 64) {
+    v.in.o(0, s) = (s == a.lay.s00) ? 0. : ELEMDP_NEG_INF;
+    TraceRec z; z.k = z.l = -1; z.t = -1; z.e1 = -1; z.s1 = -1;
+    R.ext[s] = z;
+  }
+  __syncthreads();
+  for (int j = 1; j <= L; ++j) {
+    for (int s = tid; s < S; s += 64) cyk_ext_target(v.m, v.q, v.in, R, c, j, s);
+    __syncthreads();
+  }
+  int32_t* path = a.sc_psihat + v.seq_base;
+  char* rss = a.sc_rss + v.seq_base;
+  for (int p = tid; p < L; p += 64) { path[p] = 0; rss[p] = ' '; }
+  __syncthreads();
+  if (tid == 0) {
+    const int s0 = v.in.o(L, a.lay.s0m2) < v.in.o(L, a.lay.s0m1) ? a.lay.s0m1 : a.lay.s0m2;
+    TraceFrame* stack = reinterpret_cast<TraceFrame*>(a.trace_stack + (size_t)blockIdx.x * a.trace_stack_stride);
+    trace_back(v.m, v.in, R, L, s0, path, rss, stack, (int)(a.trace_stack_stride * sizeof(int32_t) / sizeof(TraceFrame)));
+  }
+}
+
 }  // namespace
 
 hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st) {
@@ -1193,6 +1252,20 @@ hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st) {
   size_t blocks = (work + kThreads - 1) / kThreads;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(k4_weights, dim3((unsigned)blocks), dim3(kThreads), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipStream_t st) {
+  if (G <= 0) return hipSuccess;
+  LinArgs a = full;
+  const int S = a.lay.S;
+  for (int d = 0; d <= Wmax; ++d) {
+    const int ncell = Lmax - d + 1;
+    if (ncell <= 0) break;
+    a.d = d;
+    hipLaunchKernelGGL(k5_cyk, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+  }
+  hipLaunchKernelGGL(k5_cyk_ext, dim3(G), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 
