@@ -260,6 +260,43 @@ def test_ragged_batch_and_batch_linearity():
     np.testing.assert_allclose(gr, go, rtol=1e-7, atol=1e-7)
 
 
+def test_scan_config_b_size_properties_and_spot_checks():
+    """BASELINE config B: 1 000 synthetic RNAs of L=150, pattern '((.*.))' -- scan on the batch pipeline.
+    Size-independent properties of every record + the oracle on sampled sequences; the fused log-space kernel
+    (pipeline 2) must give the same records."""
+    m = io.read_model(gpath("syn_l1.model"))
+    seqs, quals = synth.synth_batch(1000, 150)
+    eng = io.engine_from_model(m)
+    eng.load_batch(seqs, quals)
+    recs, en = eng.scan(m["x"])
+    assert eng.last_timing()[2] == 0                       # no sequence needed the log-space fallback
+    M = len(eng.describe()["node"])
+    for r in recs:
+        assert 0.0 <= r["exist_prob"] <= 1.0 + 1e-12
+        assert np.logaddexp.reduce(r["start"]) == pytest.approx(np.log(r["exist_prob"]), abs=1e-9)
+        assert r["Ys"] == len(r["start"]) - 1 - int(np.argmax(r["start"][::-1]))     # last maximum
+        assert r["Ye"] == len(r["end"]) - 1 - int(np.argmax(r["end"][::-1]))
+        assert np.all(r["inner"] <= 1e-9) and np.all(r["start"] <= 1e-9)
+        assert set(r["rss"]) <= set("OLRHBIM ") and np.all((0 <= r["psihat"]) & (r["psihat"] < M))
+        assert r["rss"].count("L") == r["rss"].count("R")
+    assert np.all(en >= 0) and np.all(np.isfinite(en))
+    o, xo = oracle_for("syn_l1.model")
+    for k in (0, 333, 999):
+        a = o.scan_seq(seqs[k], quals[k])
+        b = recs[k]
+        assert (a["Ys"], a["Ye"]) == (b["Ys"], b["Ye"])
+        for key in ("start", "end", "inner"):
+            assert_log_close(b[key], a[key], rtol=1e-8, atol=1e-6, what=key)
+        assert list(a["psihat"]) == list(b["psihat"]) and a["rss"] == b["rss"]
+    eng2 = io.engine_from_model(m)
+    eng2.set_option("pipeline", 2)
+    eng2.load_batch(seqs[:64], quals[:64])
+    recs2, en2 = eng2.scan(m["x"])
+    for a, b in zip(recs2, recs[:64]):
+        assert (a["Ys"], a["Ye"], a["rss"]) == (b["Ys"], b["Ye"], b["rss"]) and list(a["psihat"]) == list(b["psihat"])
+        assert_log_close(b["start"], a["start"], rtol=1e-8, atol=1e-6, what="start")
+
+
 def test_pipelines_agree_and_linear_pipeline_is_the_one_measured():
     """The scaled-linear pipeline (default, what bench.py times) against the log-space batch pipeline and the fused kernel
     on a ragged batch: same fn / gr, and no sequence needed the log-space fallback."""
