@@ -7,7 +7,7 @@
 
 Implemented: the `--no-shuffle` full-batch training path named by BASELINE.json (L-BFGS-B) and `scan`.
 Not implemented (explicit error): shuffled negatives / mini-batches (`--kmer-shuf`, `--batch-size > 0`), `--lik-ratio`,
-`--param-set`, array jobs -- SURVEY.md §8(f) ranks 3-4.
+array jobs -- SURVEY.md §8(f) ranks 3-4.  `--param-set` (mask trainer) is supported.
 """
 import argparse
 import os
@@ -47,6 +47,7 @@ def build_parser():
     t.add_argument("--no-shuffle", action="store_true")
     t.add_argument("--theta-softmax", action="store_true")
     t.add_argument("--batch-size", type=int, default=-1)
+    t.add_argument("--param-set", default=None, help="comma separated indexes of the parameters to fit (the others stay fixed)")
     t.add_argument("--optimizer", choices=["lbfgsb", "adam"], default="lbfgsb")
     sub.choices["scan"].add_argument("-q", "--motif-model", required=True)
     return p
@@ -76,7 +77,8 @@ def cmd_train(a):
     ev = ShardedTrainer(eng, [s for _, s, _ in recs], [q for _, _, q in recs], rank, world)
     x0 = eng.initial_params(a.lambda_init)
     log = (lambda msg: print(msg, file=sys.stderr, flush=True)) if rank == 0 else None
-    res = trainer.train(ev, x0, a.rho_s if a.theta_softmax else a.rho_theta, a.rho_lambda, a.max_iter, a.epsilon, a.optimizer, log)
+    vary = [int(v) for v in a.param_set.split(",")] if a.param_set else None
+    res = trainer.train(ev, x0, a.rho_s if a.theta_softmax else a.rho_theta, a.rho_lambda, a.max_iter, a.epsilon, a.optimizer, log, vary)
     if rank == 0:
         d = eng.describe()
         rows, k = [], 0

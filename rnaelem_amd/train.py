@@ -28,9 +28,14 @@ def regularisation(n_param, rho_theta, rho_lambda):
     return np.r_[np.full(n_param - 2, float(rho_theta)), np.full(2, float(rho_lambda))]
 
 
-def bounds(n_param):
-    """(lower, upper) of every parameter: theta free, lambda >= 0."""
-    return [(None, None)] * (n_param - 2) + [(0.0, None)] * 2
+def bounds(n_param, x0=None, vary=None):
+    """(lower, upper) of every parameter: theta free, lambda >= 0.  `vary` (--param-set, motif_mask_trainer.hpp:66-103):
+    indices of the parameters to fit; the others are fixed at x0 by equal bounds."""
+    b = [(None, None)] * (n_param - 2) + [(0.0, None)] * 2
+    if vary is not None:
+        keep = set(int(i) for i in vary)
+        b = [b[i] if i in keep else (float(x0[i]), float(x0[i])) for i in range(n_param)]
+    return b
 
 
 class Objective:
@@ -56,7 +61,7 @@ class Objective:
         return y, g
 
 
-def minimize_lbfgsb(evaluate, x0, rho, max_iter=300, epsilon=1e-3, log=None):
+def minimize_lbfgsb(evaluate, x0, rho, max_iter=300, epsilon=1e-3, log=None, vary=None):
     """`elem train --no-shuffle`: returns dict(x, f, n_iter, n_eval, trace, iter_f, message)."""
     from scipy.optimize import fmin_l_bfgs_b
     obj = Objective(evaluate, rho, log)
@@ -65,7 +70,7 @@ def minimize_lbfgsb(evaluate, x0, rho, max_iter=300, epsilon=1e-3, log=None):
     def on_iter(xk):
         iter_f.append(obj.trace[-1][1])
 
-    x, f, info = fmin_l_bfgs_b(obj, np.asarray(x0, dtype=np.float64), bounds=bounds(len(x0)), m=5, factr=1e7, pgtol=epsilon,
+    x, f, info = fmin_l_bfgs_b(obj, np.asarray(x0, dtype=np.float64), bounds=bounds(len(x0), x0, vary), m=5, factr=1e7, pgtol=epsilon,
                                maxiter=max_iter, maxfun=20 * max_iter + 20, callback=on_iter)
     return dict(x=obj.best_x, f=obj.best_f, n_iter=info["nit"], n_eval=obj.n_eval, trace=obj.trace, iter_f=iter_f,
                 message=info["task"] if isinstance(info["task"], str) else info["task"].decode())
@@ -94,10 +99,14 @@ def minimize_adam(evaluate, x0, rho, max_iter=100, alpha=0.1, beta1=0.9, beta2=0
     return dict(x=x, f=obj.trace[-1][1], n_iter=t - 1, n_eval=obj.n_eval, trace=obj.trace, message="adam")
 
 
-def train(evaluate, x0, rho_theta=0.1, rho_lambda=0.1, max_iter=300, epsilon=1e-3, optimizer="lbfgsb", log=None):
+def train(evaluate, x0, rho_theta=0.1, rho_lambda=0.1, max_iter=300, epsilon=1e-3, optimizer="lbfgsb", log=None, vary=None):
     rho = regularisation(len(x0), rho_theta, rho_lambda)
+    if vary is not None:   # only the fitted parameters are regularised (set_mask_regularization, motif_mask_trainer.hpp:36-64)
+        mask = np.zeros(len(x0))
+        mask[[int(i) for i in vary]] = 1.0
+        rho = rho * mask
     if optimizer == "lbfgsb":
-        return minimize_lbfgsb(evaluate, x0, rho, max_iter, epsilon, log)
+        return minimize_lbfgsb(evaluate, x0, rho, max_iter, epsilon, log, vary)
     if optimizer == "adam":
         return minimize_adam(evaluate, x0, rho, max_iter, log=log)
     raise ValueError("optimizer must be 'lbfgsb' or 'adam'")
