@@ -37,6 +37,8 @@ enum { /* elemdp_model_desc.flags */
   ELEMDP_NO_PROFILE = 1 << 1,    /* --no-profile   RNAelem/application.hpp:265 */
   ELEMDP_NO_ENERGY = 1 << 2,     /* --no-energy    RNAelem/application.hpp:271 */
   ELEMDP_THETA_SOFTMAX = 1 << 3, /* --theta-softmax RNAelem/application.hpp:289 */
+  ELEMDP_LIK_RATIO = 1 << 4,     /* --lik-ratio: a sequence without motif contributes Z(ari) - Z(ari,nasi) and the statistics of
+                                    those two terminal sets (RNAelem/motif_trainer.hpp:156-202, --no-shuffle branch) */
   /* runtime forms of the reference's compile-time test switches (RNAelem/const_options.hpp:12-24) */
   ELEMDP_DBG_FIX_RSS = 1 << 9,   /* structure fixed per sequence (elemdp_load_batch `fix_rss`) */
   ELEMDP_DBG_NO_TURN = 1 << 10,  /* hairpins of any size */

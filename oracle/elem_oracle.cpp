@@ -486,6 +486,7 @@ struct Model {
   bool no_prf() const { return flags & ORC_NO_PRF; }
   bool no_ene() const { return flags & ORC_NO_ENE; }
   bool softmax() const { return flags & ORC_THETA_SOFTMAX; }
+  bool lik_ratio() const { return flags & ORC_LIK_RATIO; }
   bool no_theta() const { return flags & ORC_DBG_NO_THETA; }
   bool fix_rss() const { return flags & ORC_DBG_FIX_RSS; }
   bool no_turn() const { return flags & ORC_DBG_NO_TURN; }
@@ -1448,13 +1449,26 @@ static int train_seq_impl(Model& m, const vector<int>& seq, const vector<int>& q
   if (inside_o) std::copy(d.in_o.begin(), d.in_o.end(), inside_o);
   if (inside) std::copy(d.in_.begin(), d.in_.end(), inside);
   if (!(std::isfinite(Zo) && std::isfinite(Za))) { res->skipped = 1; return 0; }
+  if (m.lik_ratio() && NINF < q.ws.back()) {
+    /* --lik-ratio, sequence without motif (motif_trainer.hpp:163-171): the roles are swapped,
+       "x" = Z(ari,nasi) with the full terminals, "o" = Z(ari only) */
+    TrainOut fx{d, Zo, EHx, ENx};
+    run_outside(d, fx);
+    if (outside) std::copy(d.out_.begin(), d.out_.end(), outside);
+    if (outside_o) std::copy(d.out_o.begin(), d.out_o.end(), outside_o);
+    d.init_outside(true, false);
+    TrainOut fo{d, Za, EHo, ENo};
+    run_outside(d, fo);
+    res->f = Za - Zo;
+    return 0;
+  }
   TrainOut fo{d, Zo, EHo, ENo};
   run_outside(d, fo);
   if (outside) std::copy(d.out_.begin(), d.out_.end(), outside);
   if (outside_o) std::copy(d.out_o.begin(), d.out_o.end(), outside_o);
   double Zx;
   if (NINF < q.ws.back()) { d.init_outside(false, true); Zx = Zn; }
-  else { d.init_outside(true, false); Zx = Za; }
+  else { d.init_outside(true, false); Zx = Za; }   /* (the same with --lik-ratio, motif_trainer.hpp:172-180) */
   TrainOut fx{d, Zx, EHx, ENx};
   run_outside(d, fx);
   res->f = Zo - Zx;

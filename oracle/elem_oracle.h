@@ -22,6 +22,7 @@ enum {
   ORC_NO_PRF = 1 << 1,        /* --no-profile  (motif_model.hpp:44)  */
   ORC_NO_ENE = 1 << 2,        /* --no-energy   (energy_model.hpp:28) */
   ORC_THETA_SOFTMAX = 1 << 3, /* --theta-softmax */
+  ORC_LIK_RATIO = 1 << 4,     /* --lik-ratio   (motif_trainer.hpp:156-202) */
   /* the reference's compile-time debug switches (const_options.hpp:12-24), runtime here */
   ORC_DBG_NO_THETA = 1 << 8,
   ORC_DBG_FIX_RSS = 1 << 9,

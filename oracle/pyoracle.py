@@ -15,7 +15,7 @@ REPO = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "liboracle.so")
 DEFAULT_PAR = os.path.join(REPO, "rnaelem_amd", "data", "turner2004.elempar")
 
-NO_RSS, NO_PRF, NO_ENE, THETA_SOFTMAX = 1, 2, 4, 8
+NO_RSS, NO_PRF, NO_ENE, THETA_SOFTMAX, LIK_RATIO = 1, 2, 4, 8, 16
 DBG_NO_THETA, DBG_FIX_RSS, DBG_NO_TURN = 1 << 8, 1 << 9, 1 << 10
 
 _CODE = np.zeros(256, dtype=np.uint8)
@@ -257,10 +257,10 @@ def read_model(path):
     return out
 
 
-def oracle_from_model(path):
+def oracle_from_model(path, extra_flags=0):
     md = read_model(path)
     flags = (NO_RSS if md["no_rss"] else 0) | (NO_PRF if md["no_prf"] else 0) | (NO_ENE if md["no_ene"] else 0) | \
-        (THETA_SOFTMAX if md["softmax"] else 0)
+        (THETA_SOFTMAX if md["softmax"] else 0) | extra_flags
     o = make_oracle(md["pattern"], md["max_span"], md["max_iloop"], min_bpp=md["min_bpp"], tau=md["tau"], flags=flags)
     x = np.array([v for row in md["w"] for v in row] + list(md["lam"]), dtype=np.float64)
     o.set_params(x)

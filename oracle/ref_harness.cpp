@@ -253,7 +253,7 @@ static int cmd_bpp(string fq, int W, int C, double min_bpp) {
 static int cmd_eval(string fq, Opts const& o) {
   RNAelem model;
   build_model(model, o);
-  RNAelemTrainer t(TR_NORMAL | TR_NO_SHUFFLE, o.geti("threads", 1));
+  RNAelemTrainer t(TR_NORMAL | TR_NO_SHUFFLE | (o.geti("lik", 0) ? TR_LIK_RATIO : 0), o.geti("threads", 1));   // lik=1: --lik-ratio
   t.set_fq_name(fq);
   t.set_conditions(1, 1e-5, 0, 2, -1, "~NULL~");
   V x; model.pack_params(x);

@@ -16,7 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libelemdp.so")
 
-NO_RSS, NO_PROFILE, NO_ENERGY, THETA_SOFTMAX = 1, 2, 4, 8
+NO_RSS, NO_PROFILE, NO_ENERGY, THETA_SOFTMAX, LIK_RATIO = 1, 2, 4, 8, 16
 DBG_FIX_RSS, DBG_NO_TURN = 1 << 9, 1 << 10
 
 # every symbol include/elemdp.h declares

@@ -6,8 +6,8 @@
     torchrun --nproc-per-node 8 -m rnaelem_amd.cli train ...      # one rank per GPU, one RCCL all-reduce per evaluation
 
 Implemented: the `--no-shuffle` full-batch training path named by BASELINE.json (L-BFGS-B) and `scan`.
-Not implemented (explicit error): shuffled negatives / mini-batches (`--kmer-shuf`, `--batch-size > 0`), `--lik-ratio`,
-array jobs -- SURVEY.md §8(f) ranks 3-4.  `--param-set` (mask trainer) is supported.
+Not implemented (explicit error): shuffled negatives / mini-batches (`--kmer-shuf`, `--batch-size > 0`) and array jobs
+(SURVEY.md §8f rank 3).  `--lik-ratio`, `--param-set` (mask trainer) and `--theta-softmax` are supported.
 """
 import argparse
 import os
@@ -46,6 +46,7 @@ def build_parser():
     t.add_argument("--no-energy", action="store_true")
     t.add_argument("--no-shuffle", action="store_true")
     t.add_argument("--theta-softmax", action="store_true")
+    t.add_argument("--lik-ratio", action="store_true")
     t.add_argument("--batch-size", type=int, default=-1)
     t.add_argument("--param-set", default=None, help="comma separated indexes of the parameters to fit (the others stay fixed)")
     t.add_argument("--optimizer", choices=["lbfgsb", "adam"], default="lbfgsb")
@@ -68,7 +69,7 @@ def cmd_train(a):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     flags = (api.NO_RSS if a.no_rss else 0) | (api.NO_PROFILE if a.no_profile else 0) | (api.NO_ENERGY if a.no_energy else 0) | \
-        (api.THETA_SOFTMAX if a.theta_softmax else 0)
+        (api.THETA_SOFTMAX if a.theta_softmax else 0) | (api.LIK_RATIO if a.lik_ratio else 0)
     pattern = a.motif_pattern.replace("_", ".") if a.no_rss else a.motif_pattern
     par = a.energy_param if a.energy_param in ("~T2004~", "~A2007~") else open(a.energy_param).read()
     device = a.device if a.device is not None else local_rank

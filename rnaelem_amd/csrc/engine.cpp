@@ -724,6 +724,7 @@ TrArgs Engine::log_pipeline_args() {
   a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
   a.no_rss = (flags_ & ELEMDP_NO_RSS) ? 1 : 0;
   a.first_pass_only = opt_first_pass_only_ ? 1 : 0;
+  a.lik_ratio = (flags_ & ELEMDP_LIK_RATIO) ? 1 : 0;
   a.schedule = (opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_) ? 1 : 0;
   a.layp_r = d_layr_.as<AutomatonLayout>();
   a.ints_r = d_intsr_.as<int32_t>();
@@ -807,6 +808,7 @@ int Engine::prepare_lin(LinArgs& a, bool sched1) {
   a.no_prf = (flags_ & ELEMDP_NO_PROFILE) ? 1 : 0;
   a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
   a.no_rss = (flags_ & ELEMDP_NO_RSS) ? 1 : 0;
+  a.lik_ratio = (flags_ & ELEMDP_LIK_RATIO) ? 1 : 0;
   a.plans = plan_.d_plans.as<SeqPlan>();
   a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>(); a.b.ndot = nullptr;
   a.ews = d_ews_.as<double>();
@@ -896,6 +898,7 @@ void Engine::run_lin_batch() {
 }
 
 void Engine::run_train(bool) {
+  if ((flags_ & ELEMDP_LIK_RATIO) && opt_pipeline_ == 2) throw ArgError("--lik-ratio is not available on the fused kernel (pipeline 2)");
   if (opt_pipeline_ == 4) { run_lin_batch(); return; }
   if (opt_pipeline_ == 3) { run_train_batch(); return; }
   tables_linear_ = false;

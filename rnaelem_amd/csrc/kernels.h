@@ -92,6 +92,7 @@ struct TrArgs {
   const int32_t* ints;
   const double* params;
   int32_t no_prf, m_min, no_rss, first_pass_only;
+  int32_t lik_ratio;    // --lik-ratio objective (ELEMDP_LIK_RATIO)
   int32_t schedule;     // 0 = the reference's two outside passes, 1 = ari-only + restricted nasi-only (linear)
   int32_t restricted;   // set per launch: this pass sweeps the one-state automaton
   const AutomatonLayout* layp_r; const int32_t* ints_r;
@@ -139,6 +140,7 @@ struct LinArgs {
   int32_t cpb;                    // cells per workgroup = kThreads / S
   int32_t* flagged;               // [0] = number of flagged sequences, [1..] = their batch indices
   // scan (sum passes K4 / K5 on this pipeline): start constraint and position-posterior accumulators (batch offsets)
+  int32_t lik_ratio;              // --lik-ratio objective (ELEMDP_LIK_RATIO)
   int32_t scan;                   // 1: only Z(ari,nasi) decides the range check
   int32_t* ys; int32_t* ye;       // per batch index: argmax start / end
   double* pos_start; double* pos_inner; double* pos_end; double* exist;

@@ -697,7 +697,8 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
       const int k = atomicAdd(&a.flagged[0], 1);
       a.flagged[1 + k] = v.n;
     } else {
-      v.row[3] = p.positive ? log1p(Zn / Za) : log1p(Za / Zn);   // Z(ari,nasi) - Z(label)
+      // Z(ari,nasi) - Z(label); with --lik-ratio a sequence without motif contributes Z(ari) - Z(ari,nasi)
+      v.row[3] = p.positive ? log1p(Zn / Za) : (a.lik_ratio ? -log1p(Zn / Za) : log1p(Za / Zn));
       v.row[4] = 0.;
       v.row[5] = p.bpp_eff;
     }
@@ -714,7 +715,10 @@ __device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
   double Z;
   if (a.schedule == 0) {
     if (a.pass == 0) { Z = v.zs[0]; pi.ari = true; pi.nasi = true; }
-    else { Z = positive ? v.zs[1] : v.zs[2]; pi.ari = positive; pi.nasi = !positive; }
+    else {   // (--lik-ratio: the "has motif" terminals for both labels, roles swapped in k4_combine)
+      const bool use_ari = positive || a.lik_ratio;
+      Z = use_ari ? v.zs[1] : v.zs[2]; pi.ari = use_ari; pi.nasi = !use_ari;
+    }
   } else {
     if (a.pass == 0) { Z = v.zs[1]; pi.ari = true; pi.nasi = false; }
     else { Z = v.zs[2]; pi.ari = false; pi.nasi = true; }
@@ -1166,7 +1170,9 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   pc.finish();
 }
 
-// schedule 1: statistics of the reference's two passes from those of the ari-only (A) and nasi-only (B) passes
+// Final statistics of a sequence from those of its two outside passes (see k3_combine in train_kernels.hip):
+// schedule 1: A = ari-only, B = nasi-only, F = p_a A + p_n B; (o, x) = (F, A) with motif, (F, B) without, (A, F) without
+// under --lik-ratio.  schedule 0 + --lik-ratio: swap (o, x) of the sequences without motif.
 __global__ __launch_bounds__(kThreads) void k4_combine(LinArgs a, int G) {
   const int g = blockIdx.x;
   if (g >= G) return;
@@ -1181,11 +1187,15 @@ __global__ __launch_bounds__(kThreads) void k4_combine(LinArgs a, int G) {
     double* A = (t < nt) ? &row[6 + t] : &row[6 + 2 * nt + (t - nt)];
     double* B = (t < nt) ? &row[6 + nt + t] : &row[6 + 2 * nt + 2 + (t - nt)];
     const double va = *A, vb = *B;
-    *A = pa * va + pn * vb;
-    *B = positive ? va : vb;
+    if (a.schedule == 1) {
+      const double full = pa * va + pn * vb;
+      if (a.lik_ratio && !positive) { *A = va; *B = full; }
+      else { *A = full; *B = positive ? va : vb; }
+    } else if (a.lik_ratio && !positive) {
+      *A = vb; *B = va;
+    }
   }
 }
-
 
 // ---- Viterbi pass of the scan on the batch pipeline (log space, max-plus; rules: scan_rules.h, reference
 // RNAelemScanDP::CYKFun motif_scanner.hpp:802-913).  One lane per (cell, state) evaluates the whole target in the
@@ -1396,7 +1406,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
         else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
       }
   }
-  if (a.schedule == 1 && !first_pass_only) hipLaunchKernelGGL(k4_combine, dim3(G), dim3(kThreads), 0, st, a, G);
+  if ((a.schedule == 1 || a.lik_ratio) && !first_pass_only) hipLaunchKernelGGL(k4_combine, dim3(G), dim3(kThreads), 0, st, a, G);
   return hipGetLastError();
 }
 

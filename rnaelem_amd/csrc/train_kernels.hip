@@ -123,7 +123,8 @@ __global__ __launch_bounds__(128) void k3_in_ext(TrArgs a) {
     const bool skip = !(isfinite(Zo) && isfinite(Za));   // motif_trainer.hpp:211-215
     const SeqPlan p = a.plans[v.n];
     v.row[0] = Zo; v.row[1] = Za; v.row[2] = Zn;
-    v.row[3] = skip ? 0. : Zo - (p.positive ? Za : Zn);
+    // f_n = Z(ari,nasi) - Z(label); with --lik-ratio a sequence without motif contributes Z(ari) - Z(ari,nasi)
+    v.row[3] = skip ? 0. : (p.positive ? Zo - Za : (a.lik_ratio ? Za - Zo : Zo - Zn));
     v.row[4] = skip ? 1. : 0.;
     v.row[5] = skip ? 0. : p.bpp_eff;
   }
@@ -141,7 +142,10 @@ __device__ __forceinline__ PassInfo pass_info(const TrArgs& a, const Views& v) {
   pi.skip = v.row[4] != 0.;
   if (a.schedule == 0) {
     if (a.pass == 0) { pi.Z = v.row[0]; pi.ari = true; pi.nasi = true; }
-    else { pi.Z = positive ? v.row[1] : v.row[2]; pi.ari = positive; pi.nasi = !positive; }
+    else {   // the label's mask; --lik-ratio uses the "has motif" terminals for both labels (the roles are swapped in k3_combine)
+      const bool use_ari = positive || a.lik_ratio;
+      pi.Z = use_ari ? v.row[1] : v.row[2]; pi.ari = use_ari; pi.nasi = !use_ari;
+    }
   } else {
     if (a.pass == 0) { pi.Z = v.row[1]; pi.ari = true; pi.nasi = false; }
     else { pi.Z = v.row[2]; pi.ari = false; pi.nasi = true; }
@@ -263,9 +267,12 @@ __global__ __launch_bounds__(kThreads) void k3_out_u(TrArgs a) {
   if (MODE == OUT_TRAIN) flush_stats(a, v, pi, sink, l_en, l_eh);
 }
 
-// schedule 1: statistics of the reference's two passes from those of the ari-only (A) and nasi-only (B) passes.
-// Outside values are linear in the terminal vector, so with p_a = Z(ari)/Z, p_n = Z(nasi)/Z the full-terminal
-// statistics are p_a * A + p_n * B, and the masked pass is A (label "has motif") or B.
+// Final statistics of a sequence from those of the two outside passes (A in the "o" slot, B in the "x" slot).
+// schedule 1: A = ari-only, B = nasi-only.  Outside values are linear in the terminal vector, so with p_a = Z(ari)/Z,
+//   p_n = Z(nasi)/Z the full-terminal statistics are F = p_a A + p_n B; the reference's pair (o, x) is (F, A) for a
+//   sequence with motif, (F, B) without -- and (A, F) without motif under --lik-ratio (motif_trainer.hpp:163-171).
+// schedule 0 (the reference's own two passes): only --lik-ratio needs work here: (o, x) were computed as (F, A) and are
+//   swapped for a sequence without motif.
 __global__ __launch_bounds__(kThreads) void k3_combine(TrArgs a, int G) {
   const int g = blockIdx.x;
   if (g >= G) return;
@@ -280,8 +287,13 @@ __global__ __launch_bounds__(kThreads) void k3_combine(TrArgs a, int G) {
     double* A = (t < nt) ? &row[6 + t] : &row[6 + 2 * nt + (t - nt)];
     double* B = (t < nt) ? &row[6 + nt + t] : &row[6 + 2 * nt + 2 + (t - nt)];
     const double va = *A, vb = *B;
-    *A = pa * va + pn * vb;
-    *B = positive ? va : vb;
+    if (a.schedule == 1) {
+      const double full = pa * va + pn * vb;
+      if (a.lik_ratio && !positive) { *A = va; *B = full; }
+      else { *A = full; *B = positive ? va : vb; }
+    } else if (a.lik_ratio && !positive) {
+      *A = vb; *B = va;
+    }
   }
 }
 
@@ -388,7 +400,7 @@ hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hip
       }
     }
   }
-  if (a.schedule == 1 && !a.first_pass_only) hipLaunchKernelGGL(k3_combine, dim3(G), dim3(kThreads), 0, st, a, G);
+  if ((a.schedule == 1 || a.lik_ratio) && !a.first_pass_only) hipLaunchKernelGGL(k3_combine, dim3(G), dim3(kThreads), 0, st, a, G);
   return hipGetLastError();
 }
 

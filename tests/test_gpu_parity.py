@@ -370,6 +370,31 @@ def test_other_automaton_sizes(pattern):
     np.testing.assert_allclose(gr, go, rtol=1e-7, atol=1e-7)
 
 
+EVAL_LIK = gload("eval_lik.json")
+
+
+@pytest.mark.parametrize("case", EVAL_LIK, ids=["%s-%s" % (c["model"], c["fq"]) for c in EVAL_LIK])
+def test_lik_ratio_objective_against_reference_golden(case):
+    """ELEMDP_LIK_RATIO (--lik-ratio, motif_trainer.hpp:156-202) vs fn / gr of the compiled reference, on batches with
+    both labels; every pipeline / schedule gives the same numbers."""
+    m = io.read_model(gpath(case["model"]))
+    recs = io.read_fastq(gpath(case["fq"]))
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    for pipe, sched in ((4, 1), (4, 0), (3, 1), (3, 0)):
+        par = m["ene_param"] if m["ene_param"] in ("~T2004~", "~A2007~") else open(m["ene_param"]).read()
+        eng = api.Engine(m["pattern"], par, m["max_span"], m["max_iloop"], m["min_bpp"], m["tau"], m["flags"] | api.LIK_RATIO)
+        eng.set_option("pipeline", pipe)
+        eng.set_option("schedule", sched)
+        eng.load_batch(seqs, quals)
+        fn, gr, eff, nsk = eng.train_eval(m["x"])
+        assert fn == pytest.approx(case["fn"], rel=1e-9, abs=1e-12), (pipe, sched)
+        np.testing.assert_allclose(gr, arr(case["gr"]), rtol=1e-7, atol=1e-9, err_msg=str((pipe, sched)))
+        assert nsk == 0
+    eng.set_option("pipeline", 2)
+    with pytest.raises(api.ElemdpError):
+        eng.train_eval(m["x"])
+
+
 def test_error_behaviour():
     with pytest.raises(api.ElemdpError):
         api.Engine("(.")

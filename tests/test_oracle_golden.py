@@ -181,6 +181,20 @@ def test_fn_gr_against_reference(case):
     assert eff == pytest.approx(case["sum_eff"], rel=1e-14)
 
 
+EVAL_LIK = gload("eval_lik.json")
+
+
+@pytest.mark.parametrize("case", EVAL_LIK, ids=["%s-%s" % (c["model"], c["fq"]) for c in EVAL_LIK])
+def test_fn_gr_lik_ratio_against_reference(case):
+    """--lik-ratio objective (motif_trainer.hpp:156-202): sequences without motif contribute Z(ari) - Z(ari,nasi)."""
+    o, x = po.oracle_from_model(gpath(case["model"]), extra_flags=po.LIK_RATIO)
+    assert np.array_equal(x, arr(case["x"]))
+    recs = po.read_fastq(gpath(case["fq"]))
+    fn, gr, eff, nsk = o.train_eval(x, [s for _, s, _ in recs], [q for _, _, q in recs])
+    assert fn == pytest.approx(case["fn"], rel=1e-12, abs=1e-14)
+    np.testing.assert_allclose(gr, arr(case["gr"]), rtol=1e-9, atol=1e-12)
+
+
 def test_fn_gr_config_a():
     """BASELINE config A: material/positive.fa x '(.....)' (76 tRNA), x0 and a perturbed point."""
     recs = po.read_fastq(gpath("positive.fq"))

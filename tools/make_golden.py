@@ -193,6 +193,13 @@ def main():
         print(mdl, fq, r["fn"])
     dump("eval.json", ev)
 
+    # ---- --lik-ratio objective (motif_trainer.hpp:156-202) on batches with both labels
+    evl = []
+    for mdl, fq in (("0.model", "0.fq"), ("syn_b.model", "syn_L100_n3.fq"), ("tiny_a.model", "tiny.fq"), ("1.model", "0.fq")):
+        r = jload(run([os.path.join(RB, "ref_dump"), "eval", os.path.join(G, mdl), os.path.join(G, fq), "lik=1"]))
+        evl.append({"model": mdl, "fq": fq, "n_seq": r["n_seq"], "x": r["x"], "fn": r["fn"], "gr": r["gr"][:-1], "sum_eff": r["sum_eff"]})
+    dump("eval_lik.json", evl)
+
     # ---- per-sequence DP details
     dps = []
     for mdl, fq, full in (("0.model", "0.fq", 0), ("1.model", "0.fq", 0), ("2.model", "0.fq", 0), ("3.model", "0.fq", 0),
