@@ -156,6 +156,11 @@ int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n);
  * pipeline 4 (16 values): k4_in [setup, stage split operands, split products, item sums, unary phase],
  * k4_out [setup, stage, products, items inner, items left, items right, unary phase, statistics flush] */
 int elemdp_debug_profile(elemdp_handle* h, double* cycles, int32_t n);
+/* Host only: the shuffled negative of one sequence as `elem train` (without --no-shuffle) generates it per iteration:
+ * k-let preserving Euler-tour shuffle (uShuffle, Jiang et al. 2007; RNAelem/ushuffle/ushuffle.c:139-290) driven by the C
+ * library's srand(seed) / rand() exactly as RNAelem/motif_trainer.hpp:145-152 does (seed = occurrences of the first base
+ * + iteration count).  codes / out: L base codes.  Not thread safe (rand() is process global). */
+int elemdp_kmer_shuffle(const uint8_t* codes, int32_t L, int32_t k, int32_t iter_cnt, uint8_t* out);
 /* name of the dominant kernel (for matching rocprofv3 rows) */
 const char* elemdp_kernel_name(void);
 

@@ -412,6 +412,15 @@ int main(int argc, char** argv) {
       return cmd_eval(argv[2], o);
     }
     if (c == "dp" && argc >= 4) return cmd_dp(argv[2], parse_opts(argc, argv, 3));
+    if (c == "shuffle" && argc >= 5) {   // shuffle <seq> <k> <iter_cnt>: the negative of motif_trainer.hpp:145-152
+      string sq(argv[2]);
+      srand((int)std::count(sq.begin(), sq.end(), sq[0]) + atoi(argv[4]));
+      ushuffle::set_randfunc(long_rand);
+      std::vector<char> neg(sq.size() + 1, 0);
+      ushuffle::shuffle(sq.c_str(), neg.data(), (int)sq.size(), atoi(argv[3]));
+      printf("%s\n", neg.data());
+      return 0;
+    }
     if (c == "time" && argc >= 6) return cmd_time(argv[2], atoi(argv[3]), atoi(argv[4]), parse_opts(argc, argv, 5));
 #else
     if (c == "pathcount" && argc >= 5) return cmd_pathcount(argv[2], argv[3], argv[4]);

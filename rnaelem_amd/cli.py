@@ -5,9 +5,9 @@
     python -m rnaelem_amd.cli scan  --fastq seqs.fq --motif-model model.txt --out1 scan.raw
     torchrun --nproc-per-node 8 -m rnaelem_amd.cli train ...      # one rank per GPU, one RCCL all-reduce per evaluation
 
-Implemented: the `--no-shuffle` full-batch training path named by BASELINE.json (L-BFGS-B) and `scan`.
-Not implemented (explicit error): shuffled negatives / mini-batches (`--kmer-shuf`, `--batch-size > 0`) and array jobs
-(SURVEY.md §8f rank 3).  `--lik-ratio`, `--param-set` (mask trainer) and `--theta-softmax` are supported.
+Implemented: full-batch training -- `--no-shuffle` (L-BFGS-B, the path named by BASELINE.json) and the default mode with
+per-iteration shuffled negatives (Adam, `--kmer-shuf`) --, `--lik-ratio`, `--param-set`, `--theta-softmax`, and `scan`.
+Not implemented (explicit error): mini-batches (`--batch-size > 0`) and array jobs.
 """
 import argparse
 import os
@@ -48,6 +48,7 @@ def build_parser():
     t.add_argument("--theta-softmax", action="store_true")
     t.add_argument("--lik-ratio", action="store_true")
     t.add_argument("--batch-size", type=int, default=-1)
+    t.add_argument("--kmer-shuf", type=int, default=2)
     t.add_argument("--param-set", default=None, help="comma separated indexes of the parameters to fit (the others stay fixed)")
     t.add_argument("--optimizer", choices=["lbfgsb", "adam"], default="lbfgsb")
     sub.choices["scan"].add_argument("-q", "--motif-model", required=True)
@@ -59,9 +60,11 @@ def _rank_world():
 
 
 def cmd_train(a):
-    if not a.no_shuffle or a.batch_size > 0:
-        raise SystemExit("only the --no-shuffle full-batch mode is implemented (shuffled negatives: SURVEY.md §8f rank 3)")
+    if a.batch_size > 0:
+        raise SystemExit("mini-batches (--batch-size > 0) are not implemented: use --batch-size -1 (SURVEY.md §8f rank 3)")
     rank, local_rank, world = _rank_world()
+    if not a.no_shuffle and world > 1:
+        raise SystemExit("shuffled negatives are implemented for one GPU; use --no-shuffle with torchrun")
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -75,11 +78,22 @@ def cmd_train(a):
     device = a.device if a.device is not None else local_rank
     eng = api.Engine(pattern, par, a.max_span, a.max_internal_loop, a.min_bpp, a.tau, flags, device)
     recs = io.read_fastq(a.fastq)
-    ev = ShardedTrainer(eng, [s for _, s, _ in recs], [q for _, _, q in recs], rank, world)
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    ev = ShardedTrainer(eng, seqs, quals, rank, world)
     x0 = eng.initial_params(a.lambda_init)
     log = (lambda msg: print(msg, file=sys.stderr, flush=True)) if rank == 0 else None
     vary = [int(v) for v in a.param_set.split(",")] if a.param_set else None
-    res = trainer.train(ev, x0, a.rho_s if a.theta_softmax else a.rho_theta, a.rho_lambda, a.max_iter, a.epsilon, a.optimizer, log, vary)
+    optimizer = a.optimizer
+    if not a.no_shuffle:   # default `elem train`: Adam over positives + per-iteration shuffled negatives (main.cpp:132-152)
+        neg = api.Engine(pattern, par, a.max_span, a.max_internal_loop, a.min_bpp, a.tau, flags, device)
+
+        def eval_neg(s2, q2, x):
+            neg.load_batch(s2, q2)
+            return neg.train_eval(x)
+
+        ev = trainer.ShuffledNegatives(seqs, eng.train_eval, lambda: eng.seq_stats()[:, 4] != 0, eval_neg, a.kmer_shuf)
+        optimizer = "adam"
+    res = trainer.train(ev, x0, a.rho_s if a.theta_softmax else a.rho_theta, a.rho_lambda, a.max_iter, a.epsilon, optimizer, log, vary)
     if rank == 0:
         d = eng.describe()
         rows, k = [], 0

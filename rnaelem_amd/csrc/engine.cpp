@@ -1194,6 +1194,61 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   }
 }
 
+
+// ---- shuffled negatives (host) ------------------------------------------------------------------------------------
+// k-let preserving shuffle by a random Euler tour (uShuffle): vertices = distinct (k-1)-lets in order of first
+// appearance, edges = consecutive lets; a random arborescence towards the last let (Wilson), the remaining out-edges of
+// every vertex permuted, then the walk from the first let.  The calls of rand() -- `rand() % n` in exactly this order --
+// are what makes the result identical to the reference's for the same srand() seed.
+namespace {
+void kmer_shuffle(const uint8_t* s, int l, int k, uint8_t* t) {
+  auto rnd = [](int n) { return (int)(static_cast<long>(std::rand()) % n); };
+  if (k >= l) { std::copy(s, s + l, t); return; }
+  if (k <= 1) {
+    std::copy(s, s + l, t);
+    for (int i = l - 1; i > 0; --i) std::swap(t[i], t[rnd(i + 1)]);
+    return;
+  }
+  const int n_lets = l - k + 2;
+  std::vector<int> let_vertex(n_lets), first_pos;   // vertex id of every let; first position of every vertex
+  for (int i = 0; i < n_lets; ++i) {
+    int v = -1;
+    for (size_t u = 0; u < first_pos.size() && v < 0; ++u)
+      if (std::equal(s + first_pos[u], s + first_pos[u] + (k - 1), s + i)) v = (int)u;
+    if (v < 0) { v = (int)first_pos.size(); first_pos.push_back(i); }
+    let_vertex[i] = v;
+  }
+  const int nv = (int)first_pos.size(), root = let_vertex[n_lets - 1];
+  std::vector<std::vector<int>> succ(nv);
+  for (int i = 0; i + 1 < n_lets; ++i) succ[let_vertex[i]].push_back(let_vertex[i + 1]);
+  std::vector<char> intree(nv, 0);
+  std::vector<int> next(nv, 0);
+  intree[root] = 1;
+  for (int i = 0; i < nv; ++i) {
+    int u = i;
+    while (!intree[u]) { next[u] = rnd((int)succ[u].size()); u = succ[u][next[u]]; }
+    u = i;
+    while (!intree[u]) { intree[u] = 1; u = succ[u][next[u]]; }
+  }
+  auto permute = [&](std::vector<int>& a, int n) { for (int i = n - 1; i > 0; --i) std::swap(a[i], a[rnd(i + 1)]); };
+  for (int i = 0; i < nv; ++i) {
+    std::vector<int>& a = succ[i];
+    const int n = (int)a.size();
+    if (i != root) { std::swap(a[n - 1], a[next[i]]); permute(a, n - 1); }
+    else permute(a, n);
+  }
+  std::copy(s, s + (k - 1), t);
+  std::vector<int> walked(nv, 0);
+  int u = 0, pos = k - 1;
+  while (walked[u] < (int)succ[u].size()) {
+    const int v = succ[u][walked[u]];
+    t[pos++] = s[first_pos[v] + k - 2];
+    ++walked[u];
+    u = v;
+  }
+}
+}  // namespace
+
 }  // namespace elemdp
 
 // =================================================================================================
@@ -1353,6 +1408,14 @@ int elemdp_last_timing(elemdp_handle* h, double* ms, int32_t n) {
 int elemdp_debug_profile(elemdp_handle* h, double* cycles, int32_t n) {
   if (!h || !cycles) return ELEMDP_EINVAL;
   for (int k = 0; k < n && k < 16; ++k) cycles[k] = k < (int)h->e->last_prof.size() ? (double)h->e->last_prof[k] : 0.;
+  return ELEMDP_OK;
+}
+int elemdp_kmer_shuffle(const uint8_t* codes, int32_t L, int32_t k, int32_t iter_cnt, uint8_t* out) {
+  if (!codes || !out || L <= 0) return ELEMDP_EINVAL;
+  int cnt = 0;
+  for (int i = 0; i < L; ++i) cnt += codes[i] == codes[0];
+  std::srand((unsigned)(cnt + iter_cnt));   // motif_trainer.hpp:147
+  elemdp::kmer_shuffle(codes, L, k, out);
   return ELEMDP_OK;
 }
 const char* elemdp_kernel_name(void) { return "k4_out"; }

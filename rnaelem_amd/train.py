@@ -45,7 +45,7 @@ class Objective:
         self.evaluate, self.rho, self.log = evaluate, np.asarray(rho, dtype=np.float64), log
         self.n_eval = 0
         self.best_f, self.best_x = math.inf, None
-        self.trace = []          # (n_eval, regularised f, |gr|^2 of the unregularised gradient, sum_eff)
+        self.trace = []          # (n_eval, regularised f, |gr|^2 of the unregularised gradient, sum_eff, fn)
 
     def __call__(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
@@ -53,7 +53,7 @@ class Objective:
         y = fn + float(np.sum(self.rho * x * x) / 2.0)
         g = np.asarray(gr, dtype=np.float64) + self.rho * x
         self.n_eval += 1
-        self.trace.append((self.n_eval, y, float(np.dot(gr, gr)), eff))
+        self.trace.append((self.n_eval, y, float(np.dot(gr, gr)), eff, fn))
         if y < self.best_f:
             self.best_f, self.best_x = y, x.copy()
         if self.log:
@@ -97,6 +97,32 @@ def minimize_adam(evaluate, x0, rho, max_iter=100, alpha=0.1, beta1=0.9, beta2=0
         if float(np.dot(g, g)) < (y + 1.0) * 1e-8 or t >= max_iter:
             break
     return dict(x=x, f=obj.trace[-1][1], n_iter=t - 1, n_eval=obj.n_eval, trace=obj.trace, message="adam")
+
+
+class ShuffledNegatives:
+    """`elem train` without --no-shuffle (motif_trainer.hpp:145-152, 228-245): every evaluation pairs each sequence with a
+    k-let shuffled copy of itself (uShuffle seeded by srand(#occurrences of the first base + evaluation count)) that is
+    treated as "no motif" with all position weights 0; a negative is dropped when its positive was skipped.
+
+    evaluate_pos(x) evaluates the resident positives; evaluate_batch(seqs, quals, x) loads and evaluates another batch
+    (a second engine on the GPU, or the oracle in tests); skipped_pos() -> bool array after evaluate_pos."""
+
+    def __init__(self, seqs, evaluate_pos, skipped_pos, evaluate_batch, k=2):
+        from .api import kmer_shuffle
+        self._shuffle = kmer_shuffle
+        self.seqs, self.k, self.count = seqs, k, 0
+        self.evaluate_pos, self.skipped_pos, self.evaluate_batch = evaluate_pos, skipped_pos, evaluate_batch
+
+    def __call__(self, x):
+        fn, gr, eff, nsk = self.evaluate_pos(x)
+        skipped = self.skipped_pos()
+        negs = [self._shuffle(s, self.k, self.count) for s, sk in zip(self.seqs, skipped) if not sk]
+        self.count += 1
+        if negs:
+            quals = [np.r_[np.zeros(len(s), dtype=np.uint8), np.uint8(1)] for s in negs]   # ws = 0, label "no motif"
+            fn2, gr2, _, nsk2 = self.evaluate_batch(negs, quals, x)
+            fn, gr, nsk = fn + fn2, np.asarray(gr) + np.asarray(gr2), nsk + nsk2
+        return fn, gr, eff, nsk
 
 
 def train(evaluate, x0, rho_theta=0.1, rho_lambda=0.1, max_iter=300, epsilon=1e-3, optimizer="lbfgsb", log=None, vary=None):

@@ -232,6 +232,23 @@ def main():
                    "rho_lambda": 0.1, "tau": 0.1, "iter_f": f})
     dump("train_trace.json", tt)
 
+    # ---- shuffled negatives: uShuffle driven as motif_trainer.hpp:145-152, and the Adam trace of the default train mode
+    from rnaelem_amd import io as _io, synth as _synth
+    sh = []
+    for k in (1, 2, 3, 4):
+        for it in (0, 1, 7):
+            for sq in _synth.synth_batch(5, 60)[0][:3]:
+                st = _io.decode_seq(sq)
+                sh.append({"seq": st, "k": k, "iter": it,
+                           "shuffled": run([os.path.join(RB, "ref_dump"), "shuffle", st, str(k), str(it)]).strip()})
+    dump("shuffle.json", sh)
+    r = subprocess.run([os.path.join(RB, "RNAelem"), "train", "--fastq", os.path.join(G, "positive_head6.fq"), "--motif-pattern", "(.....)",
+                        "--out1", "/tmp/ts.model", "--max-iter", "6", "--batch-size", "-1", "-t", "1", "--lambda-init", "0"],
+                       capture_output=True, text=True)
+    ys = [float(m.group(2)) for m in re.finditer(r"^iter: (\d+) , y: ([-0-9.e+]+)", r.stdout + r.stderr, re.M)]
+    dump("train_trace_shuffle.json", {"fq": "positive_head6.fq", "pattern": "(.....)", "max_iter": 6, "kmer_shuf": 2, "rho_theta": 0.1,
+                                      "rho_lambda": 0.1, "tau": 0.1, "lambda_init": 0, "iter_fn": ys})
+
     # ---- the reference's known-answer cases re-run through its debug configuration
     pc = []
     kat = [(".", "A", "."), (".", "AA", ".."), (".", "CAAAG", "(...)"), (".", "ACAAAGA", ".(...)."),
