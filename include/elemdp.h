@@ -161,6 +161,12 @@ int elemdp_debug_profile(elemdp_handle* h, double* cycles, int32_t n);
  * library's srand(seed) / rand() exactly as RNAelem/motif_trainer.hpp:145-152 does (seed = occurrences of the first base
  * + iteration count).  codes / out: L base codes.  Not thread safe (rand() is process global). */
 int elemdp_kmer_shuffle(const uint8_t* codes, int32_t L, int32_t k, int32_t iter_cnt, uint8_t* out);
+/* Host only: the order in which `elem train --batch-size N` reads the records in epoch `seed`+1: the permutation that
+ * std::shuffle(first, last, std::mt19937(seed)) applies to an array of n elements (FastqReader::shuffle,
+ * RNAelem/fastq_io.hpp:115-124).  perm[i] = index (before the shuffle) of the element that ends at position i.  The
+ * permutation is whatever the C++ standard library this library is built with produces -- the same one a reference
+ * binary built with the same toolchain uses. */
+int elemdp_epoch_permutation(int32_t n, int32_t seed, int32_t* perm);
 /* name of the dominant kernel (for matching rocprofv3 rows) */
 const char* elemdp_kernel_name(void);
 

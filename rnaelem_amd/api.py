@@ -24,7 +24,7 @@ SYMBOLS = ["elemdp_last_error", "elemdp_abi_version", "elemdp_set_data_dir", "el
            "elemdp_n_param", "elemdp_n_state", "elemdp_n_node", "elemdp_initial_params", "elemdp_describe",
            "elemdp_set_option", "elemdp_load_batch", "elemdp_batch_bpp_eff", "elemdp_batch_pairs", "elemdp_train_eval",
            "elemdp_partial_len", "elemdp_train_partial", "elemdp_train_finish", "elemdp_set_finish_params", "elemdp_train_seq_stats",
-           "elemdp_debug_tables", "elemdp_scan", "elemdp_last_timing", "elemdp_debug_profile", "elemdp_kernel_name", "elemdp_kmer_shuffle"]
+           "elemdp_debug_tables", "elemdp_scan", "elemdp_last_timing", "elemdp_debug_profile", "elemdp_kernel_name", "elemdp_kmer_shuffle", "elemdp_epoch_permutation"]
 
 
 class ModelDesc(C.Structure):
@@ -77,6 +77,7 @@ def load_library():
         L.elemdp_debug_tables.argtypes = [hp] + [dp] * 7
         L.elemdp_scan.argtypes = [hp, dp, C.c_int32, C.POINTER(ScanOut)]
         L.elemdp_last_timing.argtypes = [hp, dp, C.c_int32]
+        L.elemdp_epoch_permutation.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
         L.elemdp_kmer_shuffle.argtypes = [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
         L.elemdp_debug_profile.argtypes = [hp, dp, C.c_int32]
         _lib = L
@@ -93,6 +94,15 @@ def _u8(a):
 
 def _i32(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def epoch_permutation(n, seed):
+    """perm of std::shuffle(.., std::mt19937(seed)) on n elements (host; elemdp_epoch_permutation)."""
+    perm = np.zeros(n, dtype=np.int32)
+    rc = load_library().elemdp_epoch_permutation(int(n), int(seed), _i32(perm))
+    if rc:
+        raise ElemdpError(rc, "epoch_permutation")
+    return perm
 
 
 def kmer_shuffle(codes, k, iter_cnt):

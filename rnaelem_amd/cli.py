@@ -6,8 +6,8 @@
     torchrun --nproc-per-node 8 -m rnaelem_amd.cli train ...      # one rank per GPU, one RCCL all-reduce per evaluation
 
 Implemented: full-batch training -- `--no-shuffle` (L-BFGS-B, the path named by BASELINE.json) and the default mode with
-per-iteration shuffled negatives (Adam, `--kmer-shuf`) --, `--lik-ratio`, `--param-set`, `--theta-softmax`, and `scan`.
-Not implemented (explicit error): mini-batches (`--batch-size > 0`) and array jobs.
+per-iteration shuffled negatives (Adam, `--kmer-shuf`) --, mini-batches (`--batch-size N`, one GPU), `--lik-ratio`,
+`--param-set`, `--theta-softmax`, and `scan`.  Not implemented: grid-engine array jobs (out of scope).
 """
 import argparse
 import os
@@ -60,11 +60,9 @@ def _rank_world():
 
 
 def cmd_train(a):
-    if a.batch_size > 0:
-        raise SystemExit("mini-batches (--batch-size > 0) are not implemented: use --batch-size -1 (SURVEY.md §8f rank 3)")
     rank, local_rank, world = _rank_world()
-    if not a.no_shuffle and world > 1:
-        raise SystemExit("shuffled negatives are implemented for one GPU; use --no-shuffle with torchrun")
+    if (not a.no_shuffle or a.batch_size > 0) and world > 1:
+        raise SystemExit("shuffled negatives and mini-batches are implemented for one GPU; use --no-shuffle --batch-size -1 with torchrun")
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -79,12 +77,19 @@ def cmd_train(a):
     eng = api.Engine(pattern, par, a.max_span, a.max_internal_loop, a.min_bpp, a.tau, flags, device)
     recs = io.read_fastq(a.fastq)
     seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
-    ev = ShardedTrainer(eng, seqs, quals, rank, world)
+    ev = None if a.batch_size > 0 else ShardedTrainer(eng, seqs, quals, rank, world)
     x0 = eng.initial_params(a.lambda_init)
     log = (lambda msg: print(msg, file=sys.stderr, flush=True)) if rank == 0 else None
     vary = [int(v) for v in a.param_set.split(",")] if a.param_set else None
     optimizer = a.optimizer
-    if not a.no_shuffle:   # default `elem train`: Adam over positives + per-iteration shuffled negatives (main.cpp:132-152)
+    if a.batch_size > 0:   # mini-batches: every evaluation loads the next records of the epoch order (motif_trainer.hpp:595-632)
+        def eval_batch(s2, q2, x):
+            eng.load_batch(s2, q2)
+            return eng.train_eval(x) + (eng.seq_stats()[:, 4] != 0,)
+
+        ev = trainer.MiniBatches(seqs, quals, a.batch_size, eval_batch, None if a.no_shuffle else a.kmer_shuf)
+        optimizer = "lbfgsb" if a.no_shuffle else "adam"
+    elif not a.no_shuffle:   # default `elem train`: Adam over positives + per-iteration shuffled negatives (main.cpp:132-152)
         neg = api.Engine(pattern, par, a.max_span, a.max_internal_loop, a.min_bpp, a.tau, flags, device)
 
         def eval_neg(s2, q2, x):

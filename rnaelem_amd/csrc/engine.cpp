@@ -17,6 +17,7 @@
 #include <limits>
 #include <memory>
 #include <numeric>
+#include <random>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -1416,6 +1417,16 @@ int elemdp_kmer_shuffle(const uint8_t* codes, int32_t L, int32_t k, int32_t iter
   for (int i = 0; i < L; ++i) cnt += codes[i] == codes[0];
   std::srand((unsigned)(cnt + iter_cnt));   // motif_trainer.hpp:147
   elemdp::kmer_shuffle(codes, L, k, out);
+  return ELEMDP_OK;
+}
+int elemdp_epoch_permutation(int32_t n, int32_t seed, int32_t* perm) {
+  if (n < 0 || (n > 0 && !perm)) return ELEMDP_EINVAL;
+  std::vector<int32_t> v(n);
+  std::iota(v.begin(), v.end(), 0);
+  std::mt19937 m;
+  m.seed((unsigned)seed);
+  std::shuffle(v.begin(), v.end(), m);   // fastq_io.hpp:117
+  std::copy(v.begin(), v.end(), perm);
   return ELEMDP_OK;
 }
 const char* elemdp_kernel_name(void) { return "k4_out"; }

@@ -125,6 +125,44 @@ class ShuffledNegatives:
         return fn, gr, eff, nsk
 
 
+class MiniBatches:
+    """`elem train --batch-size N` (FastqBatchReader, fastq_io.hpp:132-167; RNAelemTrainer::operator(), motif_trainer.hpp:595-632):
+    every evaluation reads the next N records of the current epoch order; a rest of fewer than N records is dropped; at
+    the end of an epoch the order is shuffled with std::shuffle(mt19937(epoch)) on top of the previous order.  With
+    `kmer_shuf` every record also gets its shuffled negative (seed = evaluation count, as in ShuffledNegatives).
+
+    evaluate_batch(seqs, quals, x) -> (fn, gr, sum_eff, n_skipped, skipped flags per sequence)."""
+
+    def __init__(self, seqs, quals, batch, evaluate_batch, kmer_shuf=None):
+        from .api import epoch_permutation, kmer_shuffle
+        self._perm, self._shuffle = epoch_permutation, kmer_shuffle
+        self.seqs, self.quals, self.batch = seqs, quals, batch if batch > 0 else len(seqs)
+        self.evaluate_batch, self.k = evaluate_batch, kmer_shuf
+        self.order, self.pos, self.n_shuffles, self.count = list(range(len(seqs))), 0, 0, 0
+
+    def __call__(self, x):
+        n = len(self.seqs)
+        if n - self.pos < self.batch:
+            self.pos = n                                   # the partial last batch is skipped
+        if self.pos == n:                                  # end of the epoch: reshuffle, rewind
+            perm = self._perm(n, self.n_shuffles)
+            self.order = [self.order[p] for p in perm]
+            self.n_shuffles += 1
+            self.pos = 0
+        idx = self.order[self.pos:self.pos + self.batch]
+        self.pos += self.batch
+        s1, q1 = [self.seqs[i] for i in idx], [self.quals[i] for i in idx]
+        fn, gr, eff, nsk, skipped = self.evaluate_batch(s1, q1, x)
+        if self.k is not None:
+            negs = [self._shuffle(s, self.k, self.count) for s, sk in zip(s1, skipped) if not sk]
+            if negs:
+                quals = [np.r_[np.zeros(len(s), dtype=np.uint8), np.uint8(1)] for s in negs]
+                fn2, gr2, _, nsk2, _ = self.evaluate_batch(negs, quals, x)
+                fn, gr, nsk = fn + fn2, np.asarray(gr) + np.asarray(gr2), nsk + nsk2
+        self.count += 1
+        return fn, gr, eff, nsk
+
+
 def train(evaluate, x0, rho_theta=0.1, rho_lambda=0.1, max_iter=300, epsilon=1e-3, optimizer="lbfgsb", log=None, vary=None):
     rho = regularisation(len(x0), rho_theta, rho_lambda)
     if vary is not None:   # only the fitted parameters are regularised (set_mask_regularization, motif_mask_trainer.hpp:36-64)

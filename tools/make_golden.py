@@ -249,6 +249,14 @@ def main():
     dump("train_trace_shuffle.json", {"fq": "positive_head6.fq", "pattern": "(.....)", "max_iter": 6, "kmer_shuf": 2, "rho_theta": 0.1,
                                       "rho_lambda": 0.1, "tau": 0.1, "lambda_init": 0, "iter_fn": ys})
 
+    # ---- mini-batches: `--batch-size 2` over the 6 records, 8 evaluations (3 per epoch; epochs reshuffled by mt19937(epoch))
+    r = subprocess.run([os.path.join(RB, "RNAelem"), "train", "--fastq", os.path.join(G, "positive_head6.fq"), "--motif-pattern", "(.....)",
+                        "--out1", "/tmp/tb.model", "--max-iter", "8", "--batch-size", "2", "-t", "1", "--lambda-init", "0"],
+                       capture_output=True, text=True)
+    ys = [float(m.group(2)) for m in re.finditer(r"^iter: (\d+) , y: ([-0-9.e+]+)", r.stdout + r.stderr, re.M)]
+    dump("train_trace_minibatch.json", {"fq": "positive_head6.fq", "pattern": "(.....)", "max_iter": 8, "batch_size": 2, "kmer_shuf": 2,
+                                        "rho_theta": 0.1, "rho_lambda": 0.1, "tau": 0.1, "lambda_init": 0, "iter_fn": ys})
+
     # ---- the reference's known-answer cases re-run through its debug configuration
     pc = []
     kat = [(".", "A", "."), (".", "AA", ".."), (".", "CAAAG", "(...)"), (".", "ACAAAGA", ".(...)."),
