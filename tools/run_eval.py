@@ -1,4 +1,4 @@
-"""One load + a few train evaluations (target for rocprofv3).  args: n L reps pipeline group"""
+"""One load + a few train evaluations (target for rocprofv3).  args: n L reps pipeline group [option=value ...]"""
 import sys, time
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -12,6 +12,9 @@ eng = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
 eng.set_option("pipeline", pipeline)
 if group:
     eng.set_option("group", group)
+for kv in sys.argv[6:]:
+    k, val = kv.split("=")
+    eng.set_option(k, int(val))
 seqs, quals = synth.synth_batch(n, L)
 t0 = time.time()
 eng.load_batch(seqs, quals)
