@@ -1198,10 +1198,23 @@ __global__ __launch_bounds__(kThreads) void k4_combine(LinArgs a, int G) {
 }
 
 // ---- Viterbi pass of the scan on the batch pipeline (log space, max-plus; rules: scan_rules.h, reference
-// RNAelemScanDP::CYKFun motif_scanner.hpp:802-913).  One lane per (cell, state) evaluates the whole target in the
-// reference's candidate order (ties are broken by the first strictly greater candidate, :821), so no cross-lane
-// reduction can reorder candidates.  No exp / log here: a candidate is a few adds and a compare.
-__global__ __launch_bounds__(kThreads) void k5_cyk(LinArgs a) {
+// RNAelemScanDP::CYKFun motif_scanner.hpp:802-913).  Ties are broken by the first strictly greater candidate (:821), and
+// with uniform theta ties are frequent -- so a parallel maximum has to reproduce the reference's candidate ORDER.  Every
+// candidate of the two heavy lists gets its ordinal in that order (rule 2: split point, then tuple; rule 6c: item, then
+// tuple); the workgroup reduces (value, ordinal) pairs: an LDS atomic max over order-preserving integer keys of the
+// values, then an atomic min of the ordinals among the candidates that reached the maximum.  Values are single sums in
+// the reference's association, so they are bitwise those of the serial evaluation.  No exp / log here.
+__device__ __forceinline__ unsigned long long cyk_key(double v) {
+  const long long b = __double_as_longlong(v + 0.);   // (-0 -> +0: equal values must have equal keys)
+  return (unsigned long long)(b >= 0 ? b : (b ^ 0x7fffffffffffffffLL)) ^ 0x8000000000000000ULL;
+}
+__device__ __forceinline__ double cyk_unkey(unsigned long long k) {
+  const long long b = (long long)(k ^ 0x8000000000000000ULL);
+  return __longlong_as_double(b >= 0 ? b : (b ^ 0x7fffffffffffffffLL));
+}
+
+// lane-per-target form (any automaton size): one lane evaluates the whole target serially
+__global__ __launch_bounds__(kThreads) void k5_cyk_serial(LinArgs a) {
   __shared__ AutomatonLayout s_lay;
   stage_layout(a, &s_lay, kThreads);
   unsigned bx, by;
@@ -1219,6 +1232,151 @@ __global__ __launch_bounds__(kThreads) void k5_cyk(LinArgs a) {
   R.ext = a.tr_ext + (size_t)by * a.ext_stride;
   const Constraint c{a.ys[v.n], a.ye[v.n], 1};
   cyk_target(v.m, v.q, v.in, R, c, d, i, s);
+}
+
+// staged form: same workgroup shape, context and operand staging as k4_in; KOWN (cell, tuple) products per lane
+template <bool BIG, int KOWN>
+__global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
+  extern __shared__ double lds[];
+  __shared__ AutomatonLayout s_lay;
+  stage_layout(a, &s_lay, kThreads);
+  unsigned bx, by;
+  swizzled_block(bx, by);
+  LViews v(s_lay);
+  make_lviews(a, by, v);
+  const AutomatonLayout& A = s_lay;   // (valid after the first barrier below)
+  const int S = a.lay.S, d = a.d, cpb = a.cpb, tid = threadIdx.x;
+  if (d > v.q.W) return;
+  const int ncell = v.q.L - d + 1, i0 = bx * cpb;
+  if (i0 >= ncell) return;
+  const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
+  const int CS = cpb * S, ncS = nc * S;
+  const double NEG = ELEMDP_NEG_INF;
+  unsigned long long* kb = reinterpret_cast<unsigned long long*>(lds);   // [CS] best key, rule 2
+  unsigned long long* ke = kb + CS;                                      // [CS] best key, rule 6c
+  double* st1 = lds + 2 * CS;           // [kChunkIn][CS]  rows 1(i, i+a, .)
+  double* st2 = st1 + kChunkIn * CS;    // [kChunkIn][CS]  rows 2(i+a, j, .)
+  unsigned* ob = reinterpret_cast<unsigned*>(st2 + kChunkIn * CS);       // [CS] first ordinal reaching the best, rule 2
+  unsigned* oe = ob + CS;                                                //                                      rule 6c
+  const BlockLds BL = block_lds((3 + 2 * kChunkIn) * CS, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, a.n_stage);
+  const BlockCtx cx = stage_context<BIG>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
+  const int32_t* G = v.m.big;
+  const unsigned long long kneg = cyk_key(NEG);
+  for (int t = tid; t < CS; t += kThreads) { kb[t] = kneg; ke[t] = kneg; ob[t] = 0xffffffffu; oe[t] = 0xffffffffu; }
+  __syncthreads();
+  // rule 2: candidates 1(i,i+a,s1) + 2(i+a,j,s2), a ascending; a lane keeps the first best split point of its tuples
+  int a_lo = d;
+  for (int c = 0; c < nc; ++c) { const int x = dm[c]; if (x > 0 && x < a_lo) a_lo = x; }
+  const int nsp = A.n_split;
+  const double* B = v.in.band;
+  int po1[KOWN], po2[KOWN], pa[KOWN];
+  double pv[KOWN];
+#pragma unroll
+  for (int r = 0; r < KOWN; ++r) {
+    const int w = tid + r * kThreads;
+    po1[r] = -1; po2[r] = 0; pa[r] = 0; pv[r] = NEG;
+    if (w < nc * nsp) {
+      const int c = w / nsp, t = w - c * nsp;
+      const int x = dm[c];
+      if (x > 0 && x <= d) { po1[r] = c * S + G[A.split_ent + 2 * t]; po2[r] = c * S + G[A.split_ent + 2 * t + 1]; }   // left_ok(i, d)
+    }
+  }
+  for (int q0 = a_lo; q0 < d; q0 += kChunkIn) {
+    const int kc = (kChunkIn < d - q0) ? kChunkIn : d - q0;
+    if (tid < ncS) {
+#pragma unroll
+      for (int u = 0; u < kChunkIn; ++u) {
+        const int aa = q0 + ((u < kc) ? u : 0);
+        const double x1 = B[v.in.idx(ST_1, aa, i0, 0) + tid];
+        const double x2 = B[v.in.idx(ST_2, d - aa, i0 + aa, 0) + tid];
+        st1[u * CS + tid] = (u < kc) ? x1 : NEG;
+        st2[u * CS + tid] = (u < kc) ? x2 : NEG;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KOWN; ++r)
+      if (po1[r] >= 0) {
+#pragma unroll
+        for (int u = 0; u < kChunkIn; ++u) {
+          const double y = st1[u * CS + po1[r]] + st2[u * CS + po2[r]];
+          if (pv[r] < y) { pv[r] = y; pa[r] = q0 + u; }
+        }
+      }
+    __syncthreads();
+  }
+  unsigned long long pk[KOWN];
+#pragma unroll
+  for (int r = 0; r < KOWN; ++r) {
+    pk[r] = kneg;
+    if (po1[r] >= 0 && pv[r] != NEG) {
+      const int w = tid + r * kThreads;
+      const int c = w / nsp, t = w - c * nsp;
+      pk[r] = cyk_key(pv[r]);
+      atomicMax(&kb[c * S + G[A.split_tgt + t]], pk[r]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < KOWN; ++r)
+    if (pk[r] != kneg) {
+      const int w = tid + r * kThreads;
+      const int c = w / nsp, t = w - c * nsp;
+      const int tg = c * S + G[A.split_tgt + t];
+      if (kb[tg] == pk[r]) atomicMin(&ob[tg], (unsigned)(pa[r] * nsp + t));
+    }
+  // rule 6c: candidates P(k,l,s1) + (L(i,k,s2) + (L(l,j,s3) + lam * tsc)); items in by_outer order, then tuples.
+  // Two sweeps over the work items: the maximum of the keys, then the first ordinal that reaches it.
+  const int nq = A.n_quad;
+#pragma unroll 1
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    for_block_items(
+        nc, nq, tid, cnts, pre, base,
+        [&](int c, int& c0, int& c1) {
+          const int i = i0 + c;
+          if (v.q.e_ok(i, d)) { const int cell = v.q.cell(i, d); c0 = v.q.by_outer_off[cell]; c1 = v.q.by_outer_off[cell + 1]; }
+        },
+        [&](ItemSlot& x) { x.idx = x.n; },
+        [&](ItemSlot& x) {
+          x.it = v.q.items[x.idx];
+          x.aux = v.q.item_in[x.idx] ? 1. : 0.;
+        },
+        [&](ItemSlot& x) {
+          const int i = i0 + x.c, j = i + d;
+          x.x0 = B[v.in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad_ent + 3 * x.t])];
+          x.x1 = B[v.in.idx(ST_L, x.it.k - i, i, G[A.quad_ent + 3 * x.t + 1])];
+          x.x2 = B[v.in.idx(ST_L, j - x.it.l, x.it.l, G[A.quad_ent + 3 * x.t + 2])];
+        },
+        [&](ItemSlot& x) {
+          if (x.aux == 0.) return;
+          const int tgs = G[A.quad_tgt + x.t];
+          const double y = x.x0 + (x.x1 + (x.x2 + ELEMDP_MUL_RN(v.m.lam(tgs), x.it.tsc)));
+          if (y == NEG) return;
+          const unsigned long long k = cyk_key(y);
+          if (sweep == 0) atomicMax(&ke[x.c * S + tgs], k);
+          else if (ke[x.c * S + tgs] == k) atomicMin(&oe[x.c * S + tgs], (unsigned)((x.n - base[x.c]) * nq + x.t));
+        });
+  }
+  if (tid < ncS) {
+    const int c = tid / S, s = tid - c * S;
+    const int i = i0 + c;
+    MaxAcc hB, hE;
+    if (ob[tid] != 0xffffffffu) {
+      const int aa = (int)(ob[tid] / (unsigned)nsp), t = (int)(ob[tid] - (unsigned)aa * (unsigned)nsp);
+      hB.offer(cyk_unkey(kb[tid]), i, i + aa, TT_B_12, ST_1, G[A.split_ent + 2 * t]);
+    }
+    if (oe[tid] != 0xffffffffu) {
+      const int n = (int)(oe[tid] / (unsigned)nq), t = (int)(oe[tid] - (unsigned)n * (unsigned)nq);
+      const LoopItem it = v.q.items[v.q.by_outer_off[v.q.cell(i, d)] + n];
+      hE.offer(cyk_unkey(ke[tid]), it.k, it.l, TT_E_P, ST_P, G[A.quad_ent + 3 * t]);
+    }
+    TraceView R;
+    R.band = a.tr_band + (size_t)by * a.band_stride;
+    R.ext = a.tr_ext + (size_t)by * a.ext_stride;
+    const Constraint con{a.ys[v.n], a.ye[v.n], 1};
+    cyk_target_u(v.m, v.q, v.in, R, con, d, i, s, hB, hE);
+  }
 }
 
 // exterior chain of the Viterbi pass and the traceback (one workgroup of 64 per sequence; lane 0 walks the trace)
@@ -1268,12 +1426,26 @@ hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st) {
 hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipStream_t st) {
   if (G <= 0) return hipSuccess;
   LinArgs a = full;
-  const int S = a.lay.S;
+  const int S = a.lay.S, nt = a.lay.n_theta;
+  a.cpb = kThreads / S;
+  if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
+  a.wmax = Wmax;
+  a.lmax = Lmax;
+  a.tile_d0 = -1;
+  const size_t lds = block_lds((3 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
+  const bool big = a.n_stage >= a.lay.n_ints;
+  const long long products = (long long)a.cpb * a.lay.n_split;   // (cell, tuple) products of a workgroup
+  const int kown = products <= 2 * kThreads ? 2 : products <= 4 * kThreads ? 4 : products <= 8 * kThreads ? 8 : 0;
+  const bool staged = big && kown > 0 && !(a.dbg & 8) && lds <= 64 * 1024;
   for (int d = 0; d <= Wmax; ++d) {
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) break;
     a.d = d;
-    hipLaunchKernelGGL(k5_cyk, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+    const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);
+    if (!staged) hipLaunchKernelGGL(k5_cyk_serial, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+    else if (kown == 2) hipLaunchKernelGGL((k5_cyk<true, 2>), grid, dim3(kThreads), lds, st, a);
+    else if (kown == 4) hipLaunchKernelGGL((k5_cyk<true, 4>), grid, dim3(kThreads), lds, st, a);
+    else hipLaunchKernelGGL((k5_cyk<true, 8>), grid, dim3(kThreads), lds, st, a);
   }
   hipLaunchKernelGGL(k5_cyk_ext, dim3(G), dim3(64), 0, st, a);
   return hipGetLastError();

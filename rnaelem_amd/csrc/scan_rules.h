@@ -9,6 +9,14 @@
 
 namespace elemdp {
 
+// products that enter a candidate are rounded before the sum, as in the reference's CPU code (no fma contraction):
+// equal candidates must compare equal whatever form the sum has
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ELEMDP_MUL_RN(a, b) __dmul_rn((a), (b))
+#else
+#define ELEMDP_MUL_RN(a, b) ((a) * (b))
+#endif
+
 struct TraceView {
   TraceRec* band;  // same indexing as TableView::band
   TraceRec* ext;   // [j][s]
@@ -35,11 +43,50 @@ ELEMDP_HD int last_argmax(const double* v, int n) {
   return s;
 }
 
-ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
-                          const Constraint& c, int d, int i, int s) {
+// The two candidate lists of a target that grow with the span (the "heavy" part): kept apart so that the batch kernel
+// (k5_cyk in lin_kernels.hip) can evaluate them with lanes over (split point | item, state tuple) and hand the winner to
+// cyk_target_u.  Candidate order = reference order: rule 2 by split point, then by tuple of s; rule 6c by item (by_outer
+// order), then by tuple of s.
+ELEMDP_HD MaxAcc cyk_split_best(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const int j = i + d;
+  MaxAcc aB;
+  for (int k = i + q.dmin[i]; k < j; ++k) {
+    const int dk = q.dmin[k];
+    if (dk == 0 || j - k < dk) continue;
+    for (int t = G[A.split_off + s]; t < G[A.split_off + s + 1]; ++t) {
+      const int s1 = G[A.split_ent + 2 * t], s2 = G[A.split_ent + 2 * t + 1];
+      aB.offer(T.at(ST_1, k - i, i, s1) + T.at(ST_2, j - k, k, s2), i, k, TT_B_12, ST_1, s1);
+    }
+  }
+  return aB;
+}
+ELEMDP_HD MaxAcc cyk_item_best(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const int j = i + d;
+  const double lam = m.lam(s);
+  MaxAcc aE;
+  const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
+  for (int it = c0; it < c1; ++it) {
+    if (!q.item_in[it]) continue;
+    const LoopItem x = q.items[it];
+    const double lt = ELEMDP_MUL_RN(lam, x.tsc);
+    for (int t = G[A.quad_off + s]; t < G[A.quad_off + s + 1]; ++t) {
+      const int s1 = G[A.quad_ent + 3 * t], s2 = G[A.quad_ent + 3 * t + 1], s3 = G[A.quad_ent + 3 * t + 2];
+      aE.offer(T.at(ST_P, x.l - x.k, x.k, s1) + (T.at(ST_L, x.k - i, i, s2) + (T.at(ST_L, j - x.l, x.l, s3) + lt)), x.k,
+               x.l, TT_E_P, ST_P, s1);
+    }
+  }
+  return aE;
+}
+
+// everything else of the target; hB = winner of rule 2 (used when left_ok), hE = winner of rule 6c (used when e_ok)
+ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
+                            const Constraint& c, int d, int i, int s, const MaxAcc& hB, const MaxAcc& hE) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
-  const int32_t* G = m.big;
   const int j = i + d;
   const double NEG = ELEMDP_NEG_INF;
   const double lam = m.lam(s);
@@ -71,7 +118,7 @@ ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView&
       for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {  // ... then 1b
         const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
         if (!allow_pair(m, c, q.L, i, j, s, s1)) continue;
-        aP.offer(T.at(ST_P, d - 2, i + 1, s1) + (w_pair(m, q, s, s1, tf, i, j - 1) + lam * est), i + 1, j - 1, TT_P_P,
+        aP.offer(T.at(ST_P, d - 2, i + 1, s1) + (w_pair(m, q, s, s1, tf, i, j - 1) + ELEMDP_MUL_RN(lam, est)), i + 1, j - 1, TT_P_P,
                  ST_P, s1);
       }
   }
@@ -80,16 +127,7 @@ ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView&
 
   const bool lok = q.left_ok(i, d);
   MaxAcc aB;
-  if (lok) {
-    for (int k = i + q.dmin[i]; k < j; ++k) {
-      const int dk = q.dmin[k];
-      if (dk == 0 || j - k < dk) continue;
-      for (int t = G[A.split_off + s]; t < G[A.split_off + s + 1]; ++t) {
-        const int s1 = G[A.split_ent + 2 * t], s2 = G[A.split_ent + 2 * t + 1];
-        aB.offer(T.at(ST_1, k - i, i, s1) + T.at(ST_2, j - k, k, s2), i, k, TT_B_12, ST_1, s1);
-      }
-    }
-  }
+  if (lok) aB = hB;
   T.at(ST_B, d, i, s) = aB.best;
   R.band[T.idx(ST_B, d, i, s)] = aB.tr;
 
@@ -103,7 +141,7 @@ ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView&
       }
     if (pok) {
       const double eml = q.e_ml[q.cell(i, d)];
-      if (eml != NEG) a2.offer(aP.best + lam * eml, i, j, TT_2_P, ST_P, s);
+      if (eml != NEG) a2.offer(aP.best + ELEMDP_MUL_RN(lam, eml), i, j, TT_2_P, ST_P, s);
     }
     a1.offer(a2.best, i, j, TT_1_2, ST_2, s);
     a1.offer(aB.best, i, j, TT_1_B, ST_B, s);
@@ -130,22 +168,19 @@ ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView&
   MaxAcc aE;
   if (q.e_ok(i, d)) {
     const int pc = q.cell(i - 1, d + 2);
-    if (mok) { const double t = q.e_close[pc]; if (t != NEG) aE.offer(aM.best + lam * t, i, j, TT_E_M, ST_M, s); }
-    if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) aE.offer(aL.best + lam * t, i, j, TT_E_H, ST_L, s); }
-    const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
-    for (int it = c0; it < c1; ++it) {
-      if (!q.item_in[it]) continue;
-      const LoopItem x = q.items[it];
-      const double lt = lam * x.tsc;
-      for (int t = G[A.quad_off + s]; t < G[A.quad_off + s + 1]; ++t) {
-        const int s1 = G[A.quad_ent + 3 * t], s2 = G[A.quad_ent + 3 * t + 1], s3 = G[A.quad_ent + 3 * t + 2];
-        aE.offer(T.at(ST_P, x.l - x.k, x.k, s1) + (T.at(ST_L, x.k - i, i, s2) + (T.at(ST_L, j - x.l, x.l, s3) + lt)), x.k,
-                 x.l, TT_E_P, ST_P, s1);
-      }
-    }
+    if (mok) { const double t = q.e_close[pc]; if (t != NEG) aE.offer(aM.best + ELEMDP_MUL_RN(lam, t), i, j, TT_E_M, ST_M, s); }
+    if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) aE.offer(aL.best + ELEMDP_MUL_RN(lam, t), i, j, TT_E_H, ST_L, s); }
+    if (aE.best < hE.best) aE = hE;   // (the item candidates come last; the first strictly greatest one wins)
   }
   T.at(ST_E, d, i, s) = aE.best;
   R.band[T.idx(ST_E, d, i, s)] = aE.tr;
+}
+
+ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
+                          const Constraint& c, int d, int i, int s) {
+  const MaxAcc hB = q.left_ok(i, d) ? cyk_split_best(m, q, T, d, i, s) : MaxAcc();
+  const MaxAcc hE = q.e_ok(i, d) ? cyk_item_best(m, q, T, d, i, s) : MaxAcc();
+  cyk_target_u(m, q, T, R, c, d, i, s, hB, hE);
 }
 
 ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
@@ -162,7 +197,7 @@ ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableV
     if (!q.pair_ok(i, d)) continue;
     const double t = q.e_ext[q.cell(i, d)];
     if (t == NEG) continue;
-    const double lt = lam * t;
+    const double lt = ELEMDP_MUL_RN(lam, t);
     for (int u = G[A.split_off + s]; u < G[A.split_off + s + 1]; ++u) {
       const int s2 = G[A.split_ent + 2 * u], s1 = G[A.split_ent + 2 * u + 1];
       a.offer(T.o(i, s2) + (T.at(ST_P, d, i, s1) + lt), i, j, TT_O_OP, ST_P, s1);

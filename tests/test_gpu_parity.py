@@ -297,6 +297,33 @@ def test_scan_config_b_size_properties_and_spot_checks():
         assert_log_close(b["start"], a["start"], rtol=1e-8, atol=1e-6, what="start")
 
 
+@pytest.mark.parametrize("pattern", ["((.*.))", "(.....)", "((((...))))", ".(.*.).(.*.)."])
+def test_staged_cyk_keeps_the_reference_tie_order(pattern):
+    """k5_cyk reduces (value, ordinal) pairs across lanes; with uniform theta (x0) ties are everywhere, so the parse must
+    be the one of the serial lane-per-target evaluation in the reference's candidate order (option dbg = 8) -- on a
+    ragged batch, for automata that take 2, 4 and 8 products per lane."""
+    seqs, quals = [], []
+    for n, L in ((40, 37), (40, 90), (24, 160)):
+        a, b = synth.synth_batch(n, L)
+        seqs += a
+        quals += b
+    eng = api.Engine(pattern)
+    eng.load_batch(seqs, quals)
+    x = eng.initial_params(1.0)
+    recs, en = eng.scan(x)
+    eng.set_option("dbg", 8)
+    recs2, en2 = eng.scan(x)
+    for a, b in zip(recs, recs2):
+        assert (a["Ys"], a["Ye"], a["rss"]) == (b["Ys"], b["Ye"], b["rss"])
+        assert list(a["psihat"]) == list(b["psihat"])
+    np.testing.assert_allclose(en, en2, rtol=1e-12)       # (the sum passes accumulate with atomics)
+    o = po.make_oracle(pattern, 50, 30, min_bpp=1e-4, tau=0.1)
+    o.set_params(x)
+    for k in (0, 41, 103):
+        r = o.scan_seq(seqs[k], quals[k])
+        assert r["rss"] == recs[k]["rss"] and list(r["psihat"]) == list(recs[k]["psihat"])
+
+
 def test_pipelines_agree_and_linear_pipeline_is_the_one_measured():
     """The scaled-linear pipeline (default, what bench.py times) against the log-space batch pipeline and the fused kernel
     on a ragged batch: same fn / gr, and no sequence needed the log-space fallback."""
