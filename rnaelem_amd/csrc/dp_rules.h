@@ -970,7 +970,8 @@ template <int MODE, class Sink> ELEMDP_HD void outside_target(OutCtx<Sink>& x, i
   H.H1 = (lok && x.in.at(ST_1, d, i, s) != ELEMDP_NEG_INF) ? heavy_o1(x, d, i, s) : ELEMDP_NEG_INF;
   H.H2 = (lok && x.in.at(ST_2, d, i, s) != ELEMDP_NEG_INF) ? heavy_o2(x, d, i, s) : ELEMDP_NEG_INF;
   H.HP = q.pair_ok(i, d) ? heavy_oP<MODE>(x, d, i, s) : ELEMDP_NEG_INF;
-  H.HL = (x.m.ints[x.m.lay.st_is_loop + s] && x.in.at(ST_L, d, i, s) != ELEMDP_NEG_INF) ? heavy_oL(x, d, i, s) : ELEMDP_NEG_INF;
+  // (OUT_NONE = BPP filter: nothing reads the outside value of a loop cell, and its plan has no by_left / by_right order)
+  H.HL = (MODE != OUT_NONE && x.m.ints[x.m.lay.st_is_loop + s] && x.in.at(ST_L, d, i, s) != ELEMDP_NEG_INF) ? heavy_oL(x, d, i, s) : ELEMDP_NEG_INF;
   outside_target_u<MODE>(x, d, i, s, H);
 }
 

@@ -108,6 +108,7 @@ struct PlanSet {
   DevBuf d_plans, dmin, e_stack, e_ext, e_ml, e_close, e_hp, off_outer, off_inner, off_left, off_right, cursor, items,
       item_in, idx_inner, idx_left, idx_right, items_inner, items_left, items_right;
   bool permuted = false;   // keep item copies in the secondary orders (resident plan of the train pipeline)
+  bool inner_only = false; // build only the by_inner order (the BPP filter needs no outside values of loop cells)
   int64_t n_items = 0;
   PlanArrays arrays() const {
     PlanArrays a;
@@ -384,12 +385,18 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   ps.first = first;
   ps.count = count;
   ps.h.assign(h_plans_.begin() + first, h_plans_.begin() + first + count);
-  int64_t dmin_b = 0, cell_b = 0, off_b = 0;
+  int64_t dmin_b = 0, cell_b = 0, off_b = 0, bits_end = 0, ncell_max = 0;
+  int lmax = 0;
   for (auto& p : ps.h) {
     const int64_t nc = (int64_t)(p.L + 1) * (p.W + 1);
     p.dmin_base = dmin_b; p.cell_base = cell_b; p.off_base = off_b; p.item_base = 0; p.n_items = 0;
     dmin_b += p.L + 1; cell_b += nc; off_b += nc + 1;
+    bits_end = std::max<int64_t>(bits_end, p.bits_base + (nc + 31) / 32);
+    ncell_max = std::max(ncell_max, nc);
+    lmax = std::max(lmax, (int)p.L);
   }
+  DevBuf d_okbits_end;   // the pair mask by (end, span): scratch of the item enumeration
+  d_okbits_end.alloc(sizeof(uint32_t) * (size_t)bits_end);
   ps.d_plans.upload(ps.h, st_);
   ps.dmin.alloc(sizeof(int16_t) * dmin_b);
   for (DevBuf* b : {&ps.e_stack, &ps.e_ext, &ps.e_ml, &ps.e_close, &ps.e_hp}) b->alloc(sizeof(double) * cell_b);
@@ -401,6 +408,11 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>();
   a.b.ndot = (flags_ & ELEMDP_DBG_FIX_RSS) ? d_ndot_.as<int32_t>() : nullptr;
   a.okbits = d_okbits;
+  a.okbits_end = d_okbits_end.as<uint32_t>();
+  a.ncell_max = (int32_t)ncell_max;
+  a.n_roles = ps.inner_only ? 1 : 3;
+  a.lmax = lmax;
+  a.nword_max = (int32_t)((ncell_max + 31) / 32);
   a.plans = ps.d_plans.as<SeqPlan>();
   a.first = 0; a.count = count;
   a.p = ps.arrays();
@@ -412,8 +424,12 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   HIP_OK(hipMemcpyAsync(n_items.data(), d_nitems.as<void>(), sizeof(int32_t) * count, hipMemcpyDeviceToHost, st_));
   HIP_OK(hipStreamSynchronize(st_));
   int64_t ib = 0;
-  for (int k = 0; k < count; ++k) { ps.h[k].n_items = n_items[k]; ps.h[k].item_base = ib; ib += n_items[k]; }
+  for (int k = 0; k < count; ++k) {
+    ps.h[k].n_items = n_items[k]; ps.h[k].item_base = ib; ib += n_items[k];
+    a.nitems_max = std::max(a.nitems_max, n_items[k]);
+  }
   ps.n_items = ib;
+  if (getenv("ELEMDP_PLAN_DEBUG")) fprintf(stderr, "planset: %d sequences, %lld items, largest %d, cells %lld\n", count, (long long)ib, a.nitems_max, (long long)ncell_max);
   ps.d_plans.upload(ps.h, st_);
   ps.items.alloc(sizeof(LoopItem) * ib);
   ps.item_in.alloc(ib);
@@ -610,6 +626,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         ++count;
       }
       PlanSet tmp;
+      tmp.inner_only = true;
       build_planset(tmp, first, count, d_okbits0_.as<uint32_t>());
       // table slots for S = 1, one per sequence of the chunk
       slot_override_ = count;

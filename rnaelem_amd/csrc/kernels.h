@@ -37,10 +37,13 @@ struct PlanKernelArgs {
   const EnergyTables* et;
   BatchArrays b;
   const uint32_t* okbits;
+  uint32_t* okbits_end = nullptr;   // the same mask indexed by (end, span): scratch of the plan builder
   SeqPlan* plans;       // plans[first .. first+count)
   int32_t first, count;
   PlanArrays p;
   int32_t no_ene, min_span, fix_rss;
+  int32_t ncell_max = 0, nword_max = 0, nitems_max = 0, lmax = 0;   // largest sequence of the set (grid sizes)
+  int32_t n_roles = 3;   // 1: only the by_inner order (plan of the BPP filter)
 };
 
 // byte offsets of the dynamic LDS regions of the DP kernels

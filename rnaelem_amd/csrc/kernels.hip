@@ -98,49 +98,74 @@ __global__ __launch_bounds__(kThreads) void k_mask(BatchArrays b, const SeqPlan*
 }
 
 // ---------------------------------------------------------------------------------------------
-// K-plan 1: dmin, structural terms of every kept pair, interior-loop counts per E cell
+// Plan builder.  All kernels: grid (chunks of 256 cells / words / items, sequences of the plan set), so that a set of a
+// few hundred long sequences still fills the GPU; per-sequence prefix sums are one workgroup per sequence.
 // ---------------------------------------------------------------------------------------------
+// the pair mask indexed by (end l, span d): bit l * (W+1) + d <=> pair cell (l - d, d)   (see enum_interior_by_end)
+__global__ __launch_bounds__(kThreads) void k_mask_by_end(PlanKernelArgs a) {
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
+  const int L = p.L, W = p.W;
+  const int ncell = (L + 1) * (W + 1), nword = (ncell + 31) / 32;
+  const int w = blockIdx.x * kThreads + threadIdx.x;
+  if (w >= nword) return;
+  const OkBits ok{a.okbits + p.bits_base, L, W};
+  uint32_t bits = 0;
+  for (int b = 0; b < 32; ++b) {
+    const int c = w * 32 + b;
+    if (c >= ncell) break;
+    const int l = c / (W + 1), d = c - l * (W + 1);
+    if (l - d >= 0 && ok(l - d, d)) bits |= 1u << b;
+  }
+  a.okbits_end[p.bits_base + w] = bits;
+}
+
+struct EndWords {
+  const uint32_t* bits; int nword;
+  __device__ __forceinline__ uint32_t operator()(int n) const { return n < nword ? bits[n] : 0u; }
+};
+
+// K-plan 1: dmin, structural terms of every kept pair, interior-loop counts per E cell
 __global__ __launch_bounds__(kThreads) void k_plan_cells(PlanKernelArgs a, int32_t* n_items_out) {
   __shared__ int tmp[kThreads / 64];
-  SeqPlan& pl = a.plans[a.first + blockIdx.x];
-  const SeqPlan p = pl;
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
   const int L = p.L, W = p.W;
+  const int ncell = (L + 1) * (W + 1);
+  if ((int)(blockIdx.x * kThreads) >= ncell) return;
   const uint8_t* seq = a.b.seq + p.seq_base;
   const int32_t* ndot = a.fix_rss ? a.b.ndot + p.pos_base : nullptr;
   const OkBits ok{a.okbits + p.bits_base, L, W};
+  const EndWords words{a.okbits_end + p.bits_base, (ncell + 31) / 32};
   const PlanCfg cfg{a.no_ene, a.min_span, a.fix_rss};
-  int16_t* dmin = a.p.dmin + p.dmin_base;
-  for (int i = threadIdx.x; i <= L; i += kThreads) {
-    int dm = 0;
-    for (int d = 1; d <= W && i + d <= L; ++d)
-      if (ok(i, d)) { dm = d; break; }
-    dmin[i] = (int16_t)dm;
+  if (blockIdx.x == 0) {
+    int16_t* dmin = a.p.dmin + p.dmin_base;
+    for (int i = threadIdx.x; i <= L; i += kThreads) {
+      int dm = 0;
+      for (int d = 1; d <= W && i + d <= L; ++d)
+        if (ok(i, d)) { dm = d; break; }
+      dmin[i] = (int16_t)dm;
+    }
   }
-  const int ncell = (L + 1) * (W + 1);
   int32_t* cnt = a.p.by_outer_off + p.off_base;
-  int total = 0;
-  for (int c = threadIdx.x; c < ncell; c += kThreads) {
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  int n = 0;
+  if (c < ncell) {
     const int i = c / (W + 1), d = c - i * (W + 1);
     if (ok(i, d)) {
       const PairTerms t = pair_terms(*a.et, cfg, seq, L, ndot, i, d, ok(i + 1, d - 2));
       const size_t g = p.cell_base + c;
       a.p.e_stack[g] = t.stack; a.p.e_ext[g] = t.ext; a.p.e_ml[g] = t.ml; a.p.e_close[g] = t.close; a.p.e_hp[g] = t.hp;
     }
-    int n = 0;
     if (i + d <= L && i > 0 && d + 2 <= W && ok(i - 1, d + 2))
-      enum_interior(*a.et, cfg, seq, L, W, p.C, ndot, ok, i, d, [&](int, int, double, bool) { ++n; });
+      enum_interior_by_end(*a.et, cfg, seq, L, W, p.C, ndot, words, i, d, [&](int, int, double, bool) { ++n; });
     cnt[c] = n;
-    total += n;
   }
-  const int tot = block_sum_int(total, tmp);
-  if (threadIdx.x == 0) { n_items_out[blockIdx.x] = tot; pl.n_items = tot; }
+  const int tot = block_sum_int(n, tmp);
+  if (threadIdx.x == 0 && tot) atomicAdd(&n_items_out[blockIdx.y], tot);
 }
 
-// ---------------------------------------------------------------------------------------------
-// K-plan 2: item lists.  CSR by outer cell (deterministic enumeration), then three index lists
-// (by inner pair, by left loop, by right loop) via counting sort; segments are sorted by item
-// index so that the summation order of the gathers is reproducible.
-// ---------------------------------------------------------------------------------------------
+// K-plan 2: item lists.  CSR by outer cell (deterministic enumeration: the reference's order), then three index lists
+// (by inner pair, by left loop, by right loop) via counting sort; segments are sorted by item index so that the
+// summation order of the gathers is reproducible.
 __device__ __forceinline__ int role_key(const LoopItem& it, int role, int W) {
   switch (role) {
     case 0: return it.k * (W + 1) + (it.l - it.k);  // inner pair cell (k, l)
@@ -148,62 +173,139 @@ __device__ __forceinline__ int role_key(const LoopItem& it, int role, int W) {
     default: return it.l * (W + 1) + (it.j - it.l); // right loop cell (l, j)
   }
 }
+__device__ __forceinline__ int32_t* role_off(const PlanArrays& p, int role) {
+  return role < 0 ? p.by_outer_off : role == 0 ? p.by_inner_off : role == 1 ? p.by_left_off : p.by_right_off;
+}
+__device__ __forceinline__ int32_t* role_idx(const PlanArrays& p, int role) {
+  return role == 0 ? p.by_inner_idx : role == 1 ? p.by_left_idx : p.by_right_idx;
+}
 
-__global__ __launch_bounds__(kThreads) void k_plan_items(PlanKernelArgs a) {
+// counts -> offsets of one CSR array per sequence (role -1: by_outer)
+__global__ __launch_bounds__(kThreads) void k_plan_scan(PlanKernelArgs a, int role) {
   __shared__ int tmp[kThreads + 1];
   const SeqPlan p = a.plans[a.first + blockIdx.x];
+  block_exclusive_scan(role_off(a.p, role) + p.off_base, (p.L + 1) * (p.W + 1), tmp);
+}
+
+__global__ __launch_bounds__(kThreads) void k_plan_fill(PlanKernelArgs a) {
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
   const int L = p.L, W = p.W;
+  const int ncell = (L + 1) * (W + 1);
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= ncell) return;
+  const int i = c / (W + 1), d = c - i * (W + 1);
+  const OkBits ok{a.okbits + p.bits_base, L, W};
+  if (!(i + d <= L && i > 0 && d + 2 <= W && ok(i - 1, d + 2))) return;
   const uint8_t* seq = a.b.seq + p.seq_base;
   const int32_t* ndot = a.fix_rss ? a.b.ndot + p.pos_base : nullptr;
-  const OkBits ok{a.okbits + p.bits_base, L, W};
+  const EndWords words{a.okbits_end + p.bits_base, (ncell + 31) / 32};
   const PlanCfg cfg{a.no_ene, a.min_span, a.fix_rss};
-  const int ncell = (L + 1) * (W + 1);
-  int32_t* off = a.p.by_outer_off + p.off_base;
-  block_exclusive_scan(off, ncell, tmp);
   LoopItem* items = a.p.items + p.item_base;
   uint8_t* item_in = a.p.item_in + p.item_base;
-  for (int c = threadIdx.x; c < ncell; c += kThreads) {
-    const int i = c / (W + 1), d = c - i * (W + 1);
-    if (!(i + d <= L && i > 0 && d + 2 <= W && ok(i - 1, d + 2))) continue;
-    int pos = off[c];
-    enum_interior(*a.et, cfg, seq, L, W, p.C, ndot, ok, i, d, [&](int k, int l, double tsc, bool in) {
-      LoopItem it;
-      it.tsc = tsc; it.i = (int16_t)i; it.j = (int16_t)(i + d); it.k = (int16_t)k; it.l = (int16_t)l;
-      items[pos] = it;
-      item_in[pos] = in ? 1 : 0;
-      ++pos;
-    });
-  }
-  __syncthreads();
-  const int n_items = p.n_items;
-  int32_t* cursor = a.p.cursor + p.off_base;
-  for (int role = 0; role < 3; ++role) {
-    int32_t* roff = (role == 0 ? a.p.by_inner_off : role == 1 ? a.p.by_left_off : a.p.by_right_off) + p.off_base;
-    int32_t* ridx = (role == 0 ? a.p.by_inner_idx : role == 1 ? a.p.by_left_idx : a.p.by_right_idx) + p.item_base;
-    for (int c = threadIdx.x; c <= ncell; c += kThreads) roff[c] = 0;
-    __syncthreads();
-    for (int t = threadIdx.x; t < n_items; t += kThreads) atomicAdd(&roff[role_key(items[t], role, W)], 1);
-    __syncthreads();
-    block_exclusive_scan(roff, ncell, tmp);
-    for (int c = threadIdx.x; c < ncell; c += kThreads) cursor[c] = 0;
-    __syncthreads();
-    for (int t = threadIdx.x; t < n_items; t += kThreads) {
-      const int key = role_key(items[t], role, W);
-      const int pos = atomicAdd(&cursor[key], 1);
-      ridx[roff[key] + pos] = t;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < ncell; c += kThreads) {  // insertion sort of each (short) segment
-      const int s0 = roff[c], s1 = roff[c + 1];
-      for (int x = s0 + 1; x < s1; ++x) {
-        const int v = ridx[x];
-        int y = x - 1;
-        while (y >= s0 && ridx[y] > v) { ridx[y + 1] = ridx[y]; --y; }
-        ridx[y + 1] = v;
+  int pos = a.p.by_outer_off[p.off_base + c];
+  enum_interior_by_end(*a.et, cfg, seq, L, W, p.C, ndot, words, i, d, [&](int k, int l, double tsc, bool in) {
+    LoopItem it;
+    it.tsc = tsc; it.i = (int16_t)i; it.j = (int16_t)(i + d); it.k = (int16_t)k; it.l = (int16_t)l;
+    items[pos] = it;
+    item_in[pos] = in ? 1 : 0;
+    ++pos;
+  });
+}
+
+// one role: zero the counters | count the keys | (k_plan_scan) | scatter the item indices | sort every segment
+__global__ __launch_bounds__(kThreads) void k_role_zero(PlanKernelArgs a, int role) {
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c > (p.L + 1) * (p.W + 1)) return;
+  role_off(a.p, role)[p.off_base + c] = 0;
+  a.p.cursor[p.off_base + c] = 0;
+}
+__global__ __launch_bounds__(kThreads) void k_role_count(PlanKernelArgs a, int role) {
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= p.n_items) return;
+  atomicAdd(&role_off(a.p, role)[p.off_base + role_key(a.p.items[p.item_base + t], role, p.W)], 1);
+}
+__global__ __launch_bounds__(kThreads) void k_role_scatter(PlanKernelArgs a, int role) {
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= p.n_items) return;
+  const int key = role_key(a.p.items[p.item_base + t], role, p.W);
+  const int pos = atomicAdd(&a.p.cursor[p.off_base + key], 1);
+  role_idx(a.p, role)[p.item_base + role_off(a.p, role)[p.off_base + key] + pos] = t;
+}
+// Sorts every segment of one role by item index (the scatter above leaves them in arbitrary order).  The segments of the
+// cells (i, 0..W) of one row are contiguous in the CSR array: a workgroup takes a row, builds the composite values
+// (cell << 32 | item index) in LDS, bitonic-sorts the whole row -- the cells are already grouped, so this sorts inside every
+// segment, and the hundreds of items that share an empty loop cell (i, 0) are sorted by all lanes instead of one --
+// and writes the indices back.  CAP = LDS capacity in elements; a launch handles the rows with CAP_LO < n <= CAP, longer
+// rows (only with the BPP filter off on long sequences) fall back to a heapsort per segment in global memory.
+template <int CAP, int CAP_LO>
+__global__ __launch_bounds__(kThreads) void k_role_sort(PlanKernelArgs a, int role) {
+  __shared__ unsigned long long sv[CAP];
+  __shared__ int srow[1024 + 2];
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
+  const int i = blockIdx.x, W1 = p.W + 1;
+  if (i > p.L) return;
+  const int32_t* roff = role_off(a.p, role) + p.off_base + (size_t)i * W1;
+  int32_t* ridx = role_idx(a.p, role) + p.item_base;
+  const int row0 = roff[0], n = roff[W1] - row0;
+  if (n <= CAP_LO || n <= 1) return;
+  const int tid = threadIdx.x;
+  if (n > CAP || W1 > 1024) {
+    if (CAP < 8192) return;   // (the launch with the largest capacity takes the oversized rows)
+    for (int c = tid; c < W1; c += kThreads) {
+      int32_t* v = ridx + roff[c];
+      const int m = roff[c + 1] - roff[c];
+      auto sift = [&](int root, int end) {
+        const int e = v[root];
+        for (;;) {
+          int ch = 2 * root + 1;
+          if (ch >= end) break;
+          if (ch + 1 < end && v[ch + 1] > v[ch]) ++ch;
+          if (v[ch] <= e) break;
+          v[root] = v[ch];
+          root = ch;
+        }
+        v[root] = e;
+      };
+      for (int r = m / 2 - 1; r >= 0; --r) sift(r, m);
+      for (int end = m - 1; end > 0; --end) {
+        const int t = v[0]; v[0] = v[end]; v[end] = t;
+        sift(0, end);
       }
     }
-    __syncthreads();
+    return;
   }
+  for (int c = tid; c <= W1; c += kThreads) srow[c] = roff[c] - row0;
+  int np = 2;
+  while (np < n) np <<= 1;
+  __syncthreads();
+  for (int x = tid; x < np; x += kThreads) {
+    unsigned long long e = ~0ull;
+    if (x < n) {
+      int lo = 0, hi = W1 - 1;   // the cell whose segment holds position x: largest c with srow[c] <= x
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (srow[mid] <= x) lo = mid; else hi = mid - 1;
+      }
+      e = ((unsigned long long)lo << 32) | (unsigned)ridx[row0 + x];
+    }
+    sv[x] = e;
+  }
+  __syncthreads();
+  for (int k = 2; k <= np; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int x = tid; x < np; x += kThreads) {
+        const int y = x ^ j;
+        if (y > x) {
+          const unsigned long long u = sv[x], w = sv[y];
+          if ((u > w) == ((x & k) == 0)) { sv[x] = w; sv[y] = u; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int x = tid; x < n; x += kThreads) ridx[row0 + x] = (int32_t)(unsigned)sv[x];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -570,13 +672,13 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
 // ---------------------------------------------------------------------------------------------
 // copies of the items of one sequence in the by_inner / by_left / by_right orders
 __global__ __launch_bounds__(kThreads) void k_permute_items(PlanKernelArgs a) {
-  const SeqPlan p = a.plans[a.first + blockIdx.x];
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
   const LoopItem* src = a.p.items + p.item_base;
-  for (int n = threadIdx.x; n < p.n_items; n += kThreads) {
-    a.p.items_inner[p.item_base + n] = src[a.p.by_inner_idx[p.item_base + n]];
-    a.p.items_left[p.item_base + n] = src[a.p.by_left_idx[p.item_base + n]];
-    a.p.items_right[p.item_base + n] = src[a.p.by_right_idx[p.item_base + n]];
-  }
+  const int n = blockIdx.x * kThreads + threadIdx.x;
+  if (n >= p.n_items) return;
+  a.p.items_inner[p.item_base + n] = src[a.p.by_inner_idx[p.item_base + n]];
+  a.p.items_left[p.item_base + n] = src[a.p.by_left_idx[p.item_base + n]];
+  a.p.items_right[p.item_base + n] = src[a.p.by_right_idx[p.item_base + n]];
 }
 
 __global__ __launch_bounds__(kThreads) void k_reduce(const double* seq_out, int out_stride, int n_seq, int n_theta,
@@ -611,17 +713,32 @@ hipError_t launch_mask(const BatchArrays& b, const SeqPlan* plans, int n_seq, in
 }
 hipError_t launch_plan_cells(const PlanKernelArgs& a, int32_t* n_items_out, hipStream_t st) {
   if (a.count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_plan_cells, dim3(a.count), dim3(kThreads), 0, st, a, n_items_out);
+  hipError_t e = hipMemsetAsync(n_items_out, 0, sizeof(int32_t) * a.count, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_mask_by_end, dim3((a.nword_max + kThreads - 1) / kThreads, a.count), dim3(kThreads), 0, st, a);
+  hipLaunchKernelGGL(k_plan_cells, dim3((a.ncell_max + kThreads - 1) / kThreads, a.count), dim3(kThreads), 0, st, a, n_items_out);
   return hipGetLastError();
 }
 hipError_t launch_permute_items(const PlanKernelArgs& a, hipStream_t st) {
-  if (a.count <= 0 || !a.p.items_inner) return hipSuccess;
-  hipLaunchKernelGGL(k_permute_items, dim3(a.count), dim3(kThreads), 0, st, a);
+  if (a.count <= 0 || !a.p.items_inner || a.nitems_max <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_permute_items, dim3((a.nitems_max + kThreads - 1) / kThreads, a.count), dim3(kThreads), 0, st, a);
   return hipGetLastError();
 }
 hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
   if (a.count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_plan_items, dim3(a.count), dim3(kThreads), 0, st, a);
+  const dim3 cells((a.ncell_max + 1 + kThreads - 1) / kThreads, a.count), items((a.nitems_max + kThreads - 1) / kThreads, a.count);
+  const dim3 rows(a.lmax + 1, a.count);
+  hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, -1);
+  hipLaunchKernelGGL(k_plan_fill, cells, dim3(kThreads), 0, st, a);
+  for (int role = 0; role < a.n_roles; ++role) {
+    hipLaunchKernelGGL(k_role_zero, cells, dim3(kThreads), 0, st, a, role);
+    if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_count, items, dim3(kThreads), 0, st, a, role);
+    hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, role);
+    if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_scatter, items, dim3(kThreads), 0, st, a, role);
+    hipLaunchKernelGGL((k_role_sort<512, 0>), rows, dim3(kThreads), 0, st, a, role);
+    hipLaunchKernelGGL((k_role_sort<2048, 512>), rows, dim3(kThreads), 0, st, a, role);
+    hipLaunchKernelGGL((k_role_sort<8192, 2048>), rows, dim3(kThreads), 0, st, a, role);
+  }
   return hipGetLastError();
 }
 hipError_t launch_dp(int kind, const DpArgs& a, int n_blocks, hipStream_t st) {

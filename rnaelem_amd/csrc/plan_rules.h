@@ -64,4 +64,37 @@ ELEMDP_HD void enum_interior(const EnergyTables& e, const PlanCfg& cfg, const ui
   }
 }
 
+// The same enumeration, in the same order, from the END-major pair mask (bit l * (W+1) + (l - k) <=> pair cell (k, l-k)):
+// for a fixed end l the candidates k = i .. kmax are one run of bits (k ascending = span descending), so only kept pairs
+// are visited -- ~(d-1) short bit runs per E cell instead of up to C * d single tests.  `word(n)` returns the n-th 32-bit
+// word of the mask (0 past the end).
+template <class WordFn, class F>
+ELEMDP_HD void enum_interior_by_end(const EnergyTables& e, const PlanCfg& cfg, const uint8_t* seq, int L, int W, int C,
+                                    const int32_t* ndot, const WordFn& word, int i, int d, F&& f) {
+  const int j = i + d;
+  for (int l = j; l >= i + 2; --l) {
+    const int kmax = (l - 2 < i + C) ? l - 2 : i + C;
+    const int dhi = (l - i < W) ? l - i : W, dlo = l - kmax;   // spans l - k of the candidates k = i .. kmax
+    for (int top = dhi; top >= dlo; top -= 32) {
+      const int lo = (top - 31 > dlo) ? top - 31 : dlo;
+      const int len = top - lo + 1;
+      const long long b0 = (long long)l * (W + 1) + lo;
+      const int w = (int)(b0 >> 5), sh = (int)(b0 & 31);
+      const unsigned long long two = ((unsigned long long)word(w + 1) << 32) | (unsigned long long)word(w);
+      uint32_t m = (uint32_t)(two >> sh);
+      if (len < 32) m &= (1u << len) - 1u;
+      while (m) {
+        const int b = 31 - __builtin_clz(m);
+        m &= ~(1u << b);
+        const int k = l - (lo + b);
+        if (k == i && l == j) continue;
+        const double tsc = cfg.no_ene ? 0. : loop_energy(e, seq, i - 1, j, k, l - 1);
+        if (tsc == ELEMDP_NEG_INF) continue;
+        if (!all_dots(ndot, i, k) || !all_dots(ndot, l, j)) continue;
+        f(k, l, tsc, (k - i) + (j - l) <= C);
+      }
+    }
+  }
+}
+
 }  // namespace elemdp

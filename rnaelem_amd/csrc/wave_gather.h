@@ -274,8 +274,9 @@ __device__ void heavy_outside_cell(OutCtx<GpuSink>& x, const WaveCtx& w, int d, 
   {
     // HL: left loop (cell = (it.i, it.k)) and right loop (cell = (it.l, it.j)) of interior loops
     LseAcc st[kStateChunks];
-    const int l0 = q.by_left_off[cellid], l1 = q.by_left_off[cellid + 1];
-    const int r0 = q.by_right_off[cellid], r1 = q.by_right_off[cellid + 1];
+    // (OUT_NONE = BPP filter: the outside value of a loop cell is never read, its plan has no by_left / by_right order)
+    const int l0 = (MODE == OUT_NONE) ? 0 : q.by_left_off[cellid], l1 = (MODE == OUT_NONE) ? 0 : q.by_left_off[cellid + 1];
+    const int r0 = (MODE == OUT_NONE) ? 0 : q.by_right_off[cellid], r1 = (MODE == OUT_NONE) ? 0 : q.by_right_off[cellid + 1];
     if (l1 > l0) {
       for (int t0 = 0; t0 < A.n_quad; t0 += 64) {
         const int t = t0 + lane;

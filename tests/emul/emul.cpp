@@ -23,6 +23,7 @@
 #include "../../rnaelem_amd/csrc/scan_rules.h"
 
 using namespace elemdp;
+static long g_enum_checked = 0, g_enum_mismatch = 0;
 
 namespace {
 
@@ -149,6 +150,26 @@ void plan_finish(const Emu& E, HostPlan& P) {
       });
     }
   P.by_outer_off[nc] = (int32_t)P.items.size();
+  {  // the product's plan builder enumerates from the END-major mask (enum_interior_by_end): same items, same order
+    std::vector<uint32_t> endbits((nc + 31) / 32 + 2, 0u);
+    for (int l = 0; l <= L; ++l)
+      for (int d = 0; d <= W && d <= l; ++d)
+        if (P.ok(l - d, d)) { size_t c = (size_t)l * (W + 1) + d; endbits[c >> 5] |= 1u << (c & 31); }
+    auto word = [&](int n) { return (size_t)n < endbits.size() ? endbits[n] : 0u; };
+    size_t n = 0;
+    for (int i = 0; i <= L; ++i)
+      for (int d = 0; d <= W && i + d <= L; ++d) {
+        if (!(i > 0 && d + 2 <= W && P.ok(i - 1, d + 2))) continue;
+        enum_interior_by_end(E.et, cfg, P.seq.data(), L, W, P.C, ndot, word, i, d, [&](int k, int l, double tsc, bool in) {
+          if (n >= P.items.size()) { ++g_enum_mismatch; return; }
+          const LoopItem& it = P.items[n];
+          if (it.i != i || it.j != i + d || it.k != k || it.l != l || it.tsc != tsc || (P.item_in[n] != 0) != in) ++g_enum_mismatch;
+          ++n;
+        });
+      }
+    if (n != P.items.size()) ++g_enum_mismatch;
+    ++g_enum_checked;
+  }
   // secondary orderings (ascending item index inside a key)
   auto build = [&](std::vector<int32_t>& off, std::vector<int32_t>& idx, auto key) {
     off.assign(nc + 1, 0);
@@ -265,6 +286,10 @@ thread_local std::string g_err;
 }  // namespace
 
 extern "C" {
+// plans built so far / differences between the two interior-loop enumerators (must stay 0)
+long emu_enum_checked() { return g_enum_checked; }
+long emu_enum_mismatches() { return g_enum_mismatch; }
+
 
 const char* emu_last_error() { return g_err.c_str(); }
 

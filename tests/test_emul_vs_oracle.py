@@ -256,3 +256,24 @@ def test_scan_with_linear_sum_passes_matches_oracle(model, fq):
         assert list(a["psihat"]) == list(b["psihat"])
         assert a["rss"] == b["rss"]
         np.testing.assert_allclose(b["EN"], a["EN"], rtol=1e-9, atol=1e-11)
+
+
+def test_plan_enumeration_from_the_end_major_mask_is_identical():
+    """The plan builder (k_plan_cells / k_plan_fill) enumerates the interior-loop items with enum_interior_by_end (bit runs
+    of the pair mask indexed by end position) instead of the reference-shaped double loop enum_interior: every plan the
+    emulation builds is enumerated both ways; items, order, tsc and inside-set flags must be identical -- with and without
+    the BPP filter, with a small C, and with C larger than a mask word."""
+    import ctypes
+    from rnaelem_amd import api, synth
+    from tests.emul import pyemul
+    L = pyemul.lib()
+    L.emu_enum_checked.restype = L.emu_enum_mismatches.restype = ctypes.c_long
+    before = L.emu_enum_checked()
+    seqs, quals = synth.synth_batch(3, 120)
+    x = api.Engine("((.*.))").initial_params(1.0)
+    for kw in (dict(), dict(min_bpp=0.0), dict(max_iloop=7), dict(max_span=45, max_iloop=40)):
+        e = Emul("((.*.))", PAR, **kw)
+        for s, q in zip(seqs, quals):
+            e.train_seq(x, s, q)
+    assert L.emu_enum_checked() >= before + 12
+    assert L.emu_enum_mismatches() == 0
