@@ -70,6 +70,26 @@ def cpu_baseline(seqs, quals, x, n_theta):
             "sample": "%d of the %d sequences, 1 eval, %d threads (oracle port, BPP filter included)" % (sample, len(seqs), cores)}
 
 
+def scan_secondary(api, synth, device, n=2000, L=300, pattern="(.....)"):
+    """BASELINE's secondary metric on a bounded sample of the config-E shape: `elem scan` sequences / second (K4 + K5 sum
+    passes and the K6 Viterbi parse per sequence), steady state, plus the one-off load (BPP filter + plan) time."""
+    import gc
+    gc.collect()
+    eng = api.Engine(pattern, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
+    seqs, quals = synth.synth_batch(n, L)
+    t0 = time.perf_counter()
+    eng.load_batch(seqs, quals)
+    t_load = time.perf_counter() - t0
+    x = eng.initial_params(1.0)
+    eng.scan(x)                      # allocates the table and trace slots
+    t0 = time.perf_counter()
+    eng.scan(x)
+    dt = time.perf_counter() - t0
+    return {"metric": "scan seqs/sec", "value": n / dt, "unit": "seq/s", "load_s": t_load,
+            "with_load": n / (dt + t_load), "log_space_fallback_sequences": int(eng.last_timing()[2]),
+            "workload": "%d synthetic RNAs L=%d, pattern %s (S=%d), W=%d C=%d" % (n, L, pattern, eng.n_state, MAX_SPAN, MAX_ILOOP)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +98,7 @@ def main():
     ap.add_argument("--n-seq", type=int, default=N_SEQ)
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the scan measurement (BASELINE's secondary metric)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,6 +174,9 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(seqs, quals, x, eng.n_param - 2)
+    if world == 1 and not args.no_secondary:
+        del trainer, eng
+        line["secondary"] = scan_secondary(api, synth, local_rank)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -379,6 +380,16 @@ LdsLayout Engine::lds_layout(const AutomatonLayout& lay, int Lmax, int nword_max
   l.total = o;
   if (l.total > 160 * 1024) throw ArgError("sequence / pattern too large for the LDS staging of this build");
   return l;
+}
+
+// wall-clock laps on stderr when ELEMDP_TIME is set (where does a first call spend its time?)
+static void dbg_lap(const char* what) {
+  static const bool on = getenv("ELEMDP_TIME") != nullptr;
+  static auto t0 = std::chrono::steady_clock::now();
+  if (!on) return;
+  const auto t1 = std::chrono::steady_clock::now();
+  fprintf(stderr, "[elemdp %8.1f ms] %s\n", std::chrono::duration<double, std::milli>(t1 - t0).count(), what);
+  t0 = t1;
 }
 
 void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_okbits) {
@@ -1079,7 +1090,9 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   const bool sums_on_batch = opt_pipeline_ == 4;
   if (sums_on_batch) {
     LinArgs a;
+    dbg_lap("scan: start");
     const int gsz = prepare_lin(a, false);
+    dbg_lap("scan: prepare_lin (table slots)");
     a.scan = 1;
     a.ys = d_ys.as<int32_t>(); a.ye = d_ye.as<int32_t>();
     a.pos_start = d_start.as<double>(); a.pos_inner = d_inner.as<double>(); a.pos_end = d_end.as<double>();
@@ -1110,6 +1123,7 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
       }
       tr_slots = (int)std::max<size_t>(have, want);
     }
+    dbg_lap("scan: weights + trace slots");
     a.tr_band = d_tr_band_.as<TraceRec>(); a.tr_ext = d_tr_ext_.as<TraceRec>();
     a.trace_stack = d_tr_stack_.as<int32_t>(); a.trace_stack_stride = stack_stride;
     a.sc_psihat = d_psi.as<int32_t>(); a.sc_rss = d_rss.as<char>();
@@ -1134,9 +1148,11 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
         }
     }
     cyk_done = cyk_on_batch;
+    dbg_lap("scan: launches queued");
     int32_t n_flagged = 0;
     HIP_OK(hipMemcpyAsync(&n_flagged, d_flagged_.as<void>(), sizeof(int32_t), hipMemcpyDeviceToHost, st_));
     HIP_OK(hipStreamSynchronize(st_));
+    dbg_lap("scan: device done");
     flagged.resize(n_flagged);
     if (n_flagged) HIP_OK(hipMemcpy(flagged.data(), d_flagged_.as<int32_t>() + 1, sizeof(int32_t) * n_flagged, hipMemcpyDeviceToHost));
     n_flagged_last_ = n_flagged;

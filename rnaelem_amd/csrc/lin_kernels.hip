@@ -198,16 +198,17 @@ __global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
 struct BlockLds {
   int lin, ews, ints, dm, cnts, pre, base, blob, bits, dmin16, seq8, unp8, total;   // byte offsets
 };
-__host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int win, int n_stage) {
+__host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int win, int n_stage, int nv = 0) {
   BlockLds b;
+  if (nv < cpb) nv = cpb;   // CSR ranges of the item sums: one per cell, or one per (role, cell) in k4_out
   int o = nd * 8;
   b.lin = o; o += n_lin * 8;
   b.ews = o; o += win * 8;
   b.ints = o;
   b.dm = o; o += cpb * 4;
-  b.cnts = o; o += cpb * 4;
-  b.pre = o; o += (cpb + 1) * 4;
-  b.base = o; o += cpb * 4;
+  b.cnts = o; o += nv * 4;
+  b.pre = o; o += (nv + 1) * 4;
+  b.base = o; o += nv * 4;
   b.blob = o; o += n_stage * 4;
   b.bits = o; o += (((cpb + 2) * (win - cpb) + 31) / 32 + 2) * 4;   // pair-mask words of cells (i0-1 .. i0+cpb) x (0 .. W)
   b.dmin16 = o; o += ((win + 1) / 2) * 4;
@@ -985,7 +986,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* sI2 = sOB1 + kChunkOut * CS;   //                 in  2(j, j+b, .)
   double* sOB2 = sI2 + kChunkOut * CS;   //                 out B(i-b, j, .)        (H2)
   double* sI1 = sOB2 + kChunkOut * CS;   //                 in  1(i-b, i, .)
-  const BlockLds BL = block_lds((4 + 4 * kChunkOut) * CS + nt + 2, cpb, kLinEth + nt, cpb + a.wmax + 3, a.n_stage);
+  const BlockLds BL = block_lds((4 + 4 * kChunkOut) * CS + nt + 2, cpb, kLinEth + nt, cpb + a.wmax + 3, a.n_stage, 3 * cpb);
   const BlockCtx cx = stage_context<BIG>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
@@ -1080,77 +1081,99 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       if (acc1[r] != 0.) atomicAdd(&h1[qat[r]], acc1[r]);
       if (acc2[r] != 0.) atomicAdd(&h2[qbt[r]], acc2[r]);
     }
-  // HP / HL: the three roles of a cell in the interior loops around it (rule 6c)
+  // HP / HL: the three roles of a cell in the interior loops around it (rule 6c) -- inner pair P(i,j,tgt) of E(it.i,it.j,par)
+  // (with the energy statistic of the rule), left loop L(i,j,tgt) = L(it.i,it.k), right loop L(i,j,tgt) = L(it.l,it.j) --
+  // as ONE flat list of work items (role, item, tuple): CSR range per (role, cell) -> LDS prefix; the item records and
+  // their weights are staged into the (now free) operand staging area by all lanes with one round of loads; a work item
+  // then needs a single round of table loads, selected by role without branches.
   const double* IB = in.band;
   const double* OB = out.band;
-  // inner pair P(i,j,tgt) of E(it.i,it.j,par), with the energy statistic of the rule
-  for_block_items(
-      nc, nq, tid, cnts, pre, base,
-      [&](int c, int& n0, int& n1) {
-        const int i = i0 + c;
-        if (v.q.pair_ok(i, d)) { const int cell = v.q.cell(i, d); n0 = v.q.by_inner_off[cell]; n1 = v.q.by_inner_off[cell + 1]; }
-      },
-      [&](ItemSlot& x) {
-        x.idx = x.n;   // position in the by_inner order
-        x.it = v.q.items_inner[x.n];
-        x.xw = v.q.xwi[(size_t)(2 + lamk(v.m, G[A.quad1_ent + 3 * x.t])) * v.q.xwi_stride + x.n];
-        x.aux = IB[in.idx(ST_P, d, i0 + x.c, G[A.quad1_tgt + x.t])];   // inside P(i,j,tgt)
-      },
-      [&](ItemSlot& x) {},
-      [&](ItemSlot& x) {
-        const int i = i0 + x.c, j = i + d;
-        x.x0 = OB[out.idx(ST_E, x.it.j - x.it.i, x.it.i, G[A.quad1_ent + 3 * x.t])];
-        x.x1 = IB[in.idx(ST_L, i - x.it.i, x.it.i, G[A.quad1_ent + 3 * x.t + 1])];
-        x.x2 = IB[in.idx(ST_L, x.it.j - j, j, G[A.quad1_ent + 3 * x.t + 2])];
-      },
-      [&](ItemSlot& x) {
-        const double term = x.x0 * (x.x1 * x.x2) * x.xw;
-        if (x.aux == 0. || term == 0.) return;
-        atomicAdd(&hp[x.c * S + G[A.quad1_tgt + x.t]], term);
-        if (MODE == OUT_TRAIN) sink.eh(v.m.eh_index(G[A.quad1_ent + 3 * x.t]), x.it.tsc * term * (x.aux * pi.invZ));
-      });
-  pc.mark<8>();
-  // left loop L(i,j,tgt) = L(it.i,it.k)
-  for_block_items(
-      nc, nq, tid, cnts, pre, base,
-      [&](int c, int& n0, int& n1) { const int cell = v.q.cell(i0 + c, d); n0 = v.q.by_left_off[cell]; n1 = v.q.by_left_off[cell + 1]; },
-      [&](ItemSlot& x) {
-        x.idx = x.n;   // position in the by_left order
-        x.it = v.q.items_left[x.n];
-        x.xw = v.q.xwi[(size_t)(4 + lamk(v.m, G[A.quad2_ent + 3 * x.t])) * v.q.xwi_stride + x.n];
-        x.aux = IB[in.idx(ST_L, d, i0 + x.c, G[A.quad2_tgt + x.t])];   // inside L(i,j,tgt)
-      },
-      [&](ItemSlot& x) {},
-      [&](ItemSlot& x) {
-        x.x0 = OB[out.idx(ST_E, x.it.j - x.it.i, x.it.i, G[A.quad2_ent + 3 * x.t])];
-        x.x1 = IB[in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad2_ent + 3 * x.t + 1])];
-        x.x2 = IB[in.idx(ST_L, x.it.j - x.it.l, x.it.l, G[A.quad2_ent + 3 * x.t + 2])];
-      },
-      [&](ItemSlot& x) {
-        const double term = x.x0 * (x.x1 * x.x2) * x.xw;
-        if (x.aux != 0. && term != 0.) atomicAdd(&hl[x.c * S + G[A.quad2_tgt + x.t]], term);
-      });
-  pc.mark<9>();
-  // right loop L(i,j,tgt) = L(it.l,it.j)
-  for_block_items(
-      nc, nq, tid, cnts, pre, base,
-      [&](int c, int& n0, int& n1) { const int cell = v.q.cell(i0 + c, d); n0 = v.q.by_right_off[cell]; n1 = v.q.by_right_off[cell + 1]; },
-      [&](ItemSlot& x) {
-        x.idx = x.n;   // position in the by_right order
-        x.it = v.q.items_right[x.n];
-        x.xw = v.q.xwi[(size_t)(6 + lamk(v.m, G[A.quad3_ent + 3 * x.t])) * v.q.xwi_stride + x.n];
-        x.aux = IB[in.idx(ST_L, d, i0 + x.c, G[A.quad3_tgt + x.t])];
-      },
-      [&](ItemSlot& x) {},
-      [&](ItemSlot& x) {
-        x.x0 = OB[out.idx(ST_E, x.it.j - x.it.i, x.it.i, G[A.quad3_ent + 3 * x.t])];
-        x.x1 = IB[in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad3_ent + 3 * x.t + 1])];
-        x.x2 = IB[in.idx(ST_L, x.it.k - x.it.i, x.it.i, G[A.quad3_ent + 3 * x.t + 2])];
-      },
-      [&](ItemSlot& x) {
-        const double term = x.x0 * (x.x1 * x.x2) * x.xw;
-        if (x.aux != 0. && term != 0.) atomicAdd(&hl[x.c * S + G[A.quad3_tgt + x.t]], term);
-      });
+  {
+    const int nv = 3 * nc;
+    for (int vc = tid; vc < nv; vc += kThreads) {
+      const int role = vc / nc, c = vc - role * nc;
+      const int i = i0 + c;
+      const int cell = v.q.cell(i, d);
+      const int32_t* off = role == 0 ? v.q.by_inner_off : role == 1 ? v.q.by_left_off : v.q.by_right_off;
+      int n0 = 0, n1 = 0;
+      if (nq > 0 && (role != 0 || v.q.pair_ok(i, d))) { n0 = off[cell]; n1 = off[cell + 1]; }
+      base[vc] = n0;
+      cnts[vc] = (n1 > n0) ? n1 - n0 : 0;
+    }
+    __syncthreads();
+    for (int vc = tid; vc <= nv; vc += kThreads) {
+      int p = 0;
+      for (int c = 0; c < vc; ++c) p += cnts[c];
+      pre[vc] = p;
+    }
+    __syncthreads();
+    const int n_rec = pre[nv];
+    // record area: LoopItem it[cap], double xw[2][cap], int meta[cap] (role << 16 | cell)
+    const int cap = (4 * kChunkOut * CS * 8) / 40;
+    LoopItem* r_it = reinterpret_cast<LoopItem*>(sOB1);
+    double* r_xw = reinterpret_cast<double*>(r_it + cap);
+    int* r_meta = reinterpret_cast<int*>(r_xw + 2 * cap);
+    for (int p0 = 0; p0 < n_rec; p0 += cap) {
+      const int np = (cap < n_rec - p0) ? cap : n_rec - p0;
+      for (int x = tid; x < np; x += kThreads) {
+        const int p = p0 + x;
+        int lo = 0, hi = nv - 1;   // the (role, cell) owning record p: largest vc with pre[vc] <= p
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (pre[mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        const int role = lo / nc, c = lo - role * nc;
+        const int n = base[lo] + (p - pre[lo]);
+        const LoopItem* src = role == 0 ? v.q.items_inner : role == 1 ? v.q.items_left : v.q.items_right;
+        r_it[x] = src[n];
+        r_xw[x] = v.q.xwi[(size_t)(2 + 2 * role) * v.q.xwi_stride + n];
+        r_xw[cap + x] = v.q.xwi[(size_t)(3 + 2 * role) * v.q.xwi_stride + n];
+        r_meta[x] = (role << 16) | c;
+      }
+      __syncthreads();
+      pc.mark<8>();
+      const int total = np * nq;
+      for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
+        LoopItem it[kItemBatch];
+        double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], xw[kItemBatch], aux[kItemBatch];
+        int hidx[kItemBatch], par[kItemBatch];
+        bool ok[kItemBatch];
+#pragma unroll
+        for (int u = 0; u < kItemBatch; ++u) {
+          const int w = w0 + u * kThreads;
+          ok[u] = w < total;
+          const int wc = ok[u] ? w : total - 1;
+          const int x = wc / nq, t = wc - x * nq;
+          const int role = r_meta[x] >> 16, c = r_meta[x] & 0xffff;
+          it[u] = r_it[x];
+          const int ent = (role == 0 ? A.quad1_ent : role == 1 ? A.quad2_ent : A.quad3_ent) + 3 * t;
+          const int tgt = G[(role == 0 ? A.quad1_tgt : role == 1 ? A.quad2_tgt : A.quad3_tgt) + t];
+          const int q0 = G[ent], q1 = G[ent + 1], q2 = G[ent + 2];
+          const int i = i0 + c, j = i + d;
+          const int e1 = role == 0 ? ST_L : ST_P;
+          const int d1 = role == 0 ? i - it[u].i : it[u].l - it[u].k, p1 = role == 0 ? it[u].i : it[u].k;
+          const int d2 = role == 0 ? it[u].j - j : role == 1 ? it[u].j - it[u].l : it[u].k - it[u].i;
+          const int p2 = role == 0 ? j : role == 1 ? it[u].l : it[u].i;
+          x0[u] = OB[out.idx(ST_E, it[u].j - it[u].i, it[u].i, q0)];
+          x1[u] = IB[in.idx(e1, d1, p1, q1)];
+          x2[u] = IB[in.idx(ST_L, d2, p2, q2)];
+          aux[u] = IB[in.idx(role == 0 ? ST_P : ST_L, d, i, tgt)];
+          xw[u] = r_xw[lamk(v.m, q0) * cap + x];
+          hidx[u] = (role == 0 ? 0 : CS) + c * S + tgt;   // hp, or hl = hp + CS
+          par[u] = role == 0 ? q0 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kItemBatch; ++u) {
+          const double term = x0[u] * (x1[u] * x2[u]) * xw[u];
+          if (!ok[u] || aux[u] == 0. || term == 0.) continue;
+          atomicAdd(&hp[hidx[u]], term);
+          if (MODE == OUT_TRAIN && par[u] >= 0) sink.eh(v.m.eh_index(par[u]), it[u].tsc * term * (aux[u] * pi.invZ));
+        }
+      }
+      __syncthreads();
+      pc.mark<9>();
+    }
+  }
   pc.mark<10>();
   if (tid < nc * NA && !(a.dbg & 4)) {
     const int c = tid / NA, s = tid - c * NA;
@@ -1464,7 +1487,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   a.pass = 0;
   a.scan = 1;
   const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
-  const size_t lds_out = block_lds((4 + 4 * kChunkOut) * a.cpb * S + nt + 2, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
+  const size_t lds_out = block_lds((4 + 4 * kChunkOut) * a.cpb * S + nt + 2, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage, 3 * a.cpb).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
@@ -1544,7 +1567,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
     b.cpb = kThreads / b.lay.S;
     if (b.cpb > ELEMDP_CPB_MAX) b.cpb = ELEMDP_CPB_MAX;
     b.wmax = Wmax;
-    const size_t lds_b = block_lds((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, b.n_stage).total;
+    const size_t lds_b = block_lds((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, b.n_stage, 3 * b.cpb).total;
     const bool big_b = b.n_stage >= b.lay.n_ints;
     b.lmax = Lmax;
     if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(nt + 2, kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
