@@ -367,12 +367,11 @@ __global__ __launch_bounds__(kThreads) void k4_in_old(LinArgs a) {
   double* acc = lds;                       // [kTile][CS]
   double* st1 = acc + kTile * CS;          // [kOldA][CS]   rows 1(i0+c, a0+u, .)
   double* st2 = st1 + kOldA * CS;          // [kOldB][CS2]  rows 2(i0+a0+c', b_lo+v, .)
-  int* blob = reinterpret_cast<int*>(st2 + kOldB * CS2);
-  int* dm = blob + a.n_stage;
-  for (int t = tid; t < a.n_stage; t += kThreads) blob[t] = a.ints[t];
+  // (the tuple lists are read once per lane, from global memory: no copy of the automaton blob, one more workgroup per CU)
+  int* dm = reinterpret_cast<int*>(st2 + kOldB * CS2);
   for (int t = tid; t < kTile * CS; t += kThreads) acc[t] = 0.;
   if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
-  const int32_t* G = BIG ? blob : a.ints;
+  const int32_t* G = a.ints;
   __syncthreads();
   int a_lo = d0;
   for (int c = 0; c < nc; ++c) { const int x = dm[c]; if (x > 0 && x < a_lo) a_lo = x; }
@@ -672,10 +671,26 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00) ? 1. : 0.;
   if (ext0 && tid == 0) ext0[0] = 1.;
   __syncthreads();
+  // lanes = (part, state): the pairs ending at j are dealt to nparts lanes per state, the partial sums meet in LDS
+  __shared__ double s_part[128];
+  const int nparts = (S <= 128) ? 128 / S : 1;
+  const int part = tid / S, ps = tid - part * S;
+  const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
   for (int j = 1; j <= L; ++j) {
-    for (int s = tid; s < S; s += 128) {
-      lin_inside_ext_target<CON>(v.m, v.q, v.in, j, s, Constraint{CON ? a.ys[v.n] : -1, -1, 0});
-      if (ext0 && s == a.lay.s00) ext0[j] = v.in.o(j, s);
+    if (S <= 128) {
+      if (part < nparts) s_part[tid] = lin_inside_ext_part<CON>(v.m, v.q, v.in, j, ps, con, part, nparts);
+      __syncthreads();
+      if (tid < S) {
+        double t = 0.;
+        for (int k = 0; k < nparts; ++k) t += s_part[k * S + tid];
+        v.in.o(j, tid) = t;
+        if (ext0 && tid == a.lay.s00) ext0[j] = t;
+      }
+    } else {
+      for (int s = tid; s < S; s += 128) {
+        lin_inside_ext_target<CON>(v.m, v.q, v.in, j, s, con);
+        if (ext0 && s == a.lay.s00) ext0[j] = v.in.o(j, s);
+      }
     }
     __syncthreads();
   }
@@ -809,8 +824,21 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
     v.out.o(v.q.L, s) = t;
   }
   __syncthreads();
+  __shared__ double s_part[128];
+  const int nparts = (S <= 128) ? 128 / S : 1;
+  const int part = tid / S, ps = tid - part * S;
   for (int i = v.q.L - 1; i >= 0; --i) {
-    for (int s = tid; s < S; s += 128) lin_outside_ext_target<MODE>(x, i, s);
+    if (S <= 128) {
+      if (part < nparts) s_part[tid] = lin_outside_ext_part<MODE>(x, i, ps, part, nparts);
+      __syncthreads();
+      if (tid < S) {
+        double t = 0.;
+        for (int k = 0; k < nparts; ++k) t += s_part[k * S + tid];
+        v.out.o(i, tid) = t;
+      }
+    } else {
+      for (int s = tid; s < S; s += 128) lin_outside_ext_target<MODE>(x, i, s);
+    }
     __syncthreads();
   }
   if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, 128);
@@ -847,12 +875,10 @@ __global__ __launch_bounds__(kThreads) void k4_out_old(LinArgs a) {
   double* acc = lds;                    // [kTile][CS]
   double* sO = acc + kTile * CS;        // [kOldA][CSO]
   double* sI = sO + kOldA * CSO;        // [kOldB][CSI]
-  int* blob = reinterpret_cast<int*>(sI + kOldB * CSI);
-  int* dm = blob + a.n_stage;
-  for (int t = tid; t < a.n_stage; t += kThreads) blob[t] = a.ints[t];
+  int* dm = reinterpret_cast<int*>(sI + kOldB * CSI);
   for (int t = tid; t < kTile * CS; t += kThreads) acc[t] = 0.;
   if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
-  const int32_t* G = BIG ? blob : a.ints;
+  const int32_t* G = a.ints;
   __syncthreads();
   const int nsp = A.n_split;
   const int ent = (WHICH == 1) ? A.split1_ent : A.split2_ent, tgl = (WHICH == 1) ? A.split1_tgt : A.split2_tgt;
@@ -1539,7 +1565,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   const size_t lds_stat = sizeof(double) * (nt + 2);
   a.tile_d0 = -1;
   const size_t lds_old = sizeof(double) * ((size_t)(kTile + kOldA) * a.cpb * S + (size_t)kOldB * (a.cpb + kOldA - 1) * S) +
-                         sizeof(int32_t) * ((size_t)a.n_stage + a.cpb + 2);
+                         sizeof(int32_t) * ((size_t)a.cpb + 2);
   const bool tiled = a.part_in != nullptr && a.tile;
   if (!a.no_rss)
     for (int d = 0; d <= Wmax; ++d) {
@@ -1574,7 +1600,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
     else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), lds_stat, st, b);
     const bool tiled_b = b.part_h1 != nullptr && a.tile;
     const size_t lds_oold = sizeof(double) * ((size_t)(kTile + kOldA + kOldB) * (b.cpb + kTile - 1) * b.lay.S) +
-                            sizeof(int32_t) * ((size_t)b.n_stage + b.cpb + 2);
+                            sizeof(int32_t) * ((size_t)b.cpb + 2);
     b.tile_d0 = -1;
     b.tile_has_old = 0;
     if (!b.no_rss)

@@ -193,17 +193,18 @@ ELEMDP_HD Cell7 lin_inside_target(const ModelView& m, const SeqView& q, const Ta
   return lin_inside_target_u<CON>(m, q, T, d, i, s, HB, HE, c);
 }
 
-// exterior chain, one step (rules 7, 8), j >= 1
+// exterior chain, one step (rules 7, 8), j >= 1.  `part` of `nparts`: the pairs (i, j) are dealt to nparts lanes (i = j-1-part,
+// j-1-part-nparts, ..); part 0 also takes rule 8.  The value of the step is the sum of the parts.
 template <bool CON = false>
-ELEMDP_HD void lin_inside_ext_target(const ModelView& m, const SeqView& q, const TableView& T, int j, int s,
-                                     const Constraint& c = Constraint{-1, -1, 0}) {
+ELEMDP_HD double lin_inside_ext_part(const ModelView& m, const SeqView& q, const TableView& T, int j, int s, const Constraint& c,
+                                    int part, int nparts) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
   const int32_t* G = m.big;
   const int kl = lamk(m, s);
   double a = 0.;
   const int i0 = (j - q.W > 0) ? j - q.W : 0;
-  for (int i = j - 1; i >= i0; --i) {
+  for (int i = j - 1 - part; i >= i0; i -= nparts) {
     const int d = j - i;
     if (!q.pair_ok(i, d)) continue;
     const double xe = xw_cell(q, kl, XT_EXT, q.cell(i, d));
@@ -213,12 +214,17 @@ ELEMDP_HD void lin_inside_ext_target(const ModelView& m, const SeqView& q, const
       b = fma(T.o(i, G[A.split_ent + 2 * u]), T.at(ST_P, d, i, G[A.split_ent + 2 * u + 1]), b);
     a = fma(b, xe, a);
   }
-  if (q.unp[j - 1])
+  if (part == 0 && q.unp[j - 1])
     for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
       if (CON && !allow_right(m, c, q.L, j, s, I[A.right_ent + 2 * t])) continue;
       a = fma(T.o(j - 1, I[A.right_ent + 2 * t]), lw_right(m, q, s, I[A.right_ent + 2 * t + 1], j - 1), a);
     }
-  T.o(j, s) = a;
+  return a;
+}
+template <bool CON = false>
+ELEMDP_HD void lin_inside_ext_target(const ModelView& m, const SeqView& q, const TableView& T, int j, int s,
+                                     const Constraint& c = Constraint{-1, -1, 0}) {
+  T.o(j, s) = lin_inside_ext_part<CON>(m, q, T, j, s, c, 0, 1);
 }
 ELEMDP_HD double lin_part(const ModelView& m, const TableView& T, bool ari, bool nasi) {
   return (nasi ? T.o(T.L, m.lay.s00) : 0.) + (ari ? T.o(T.L, m.lay.s0m2) + T.o(T.L, m.lay.s0m1) : 0.);
@@ -325,18 +331,19 @@ template <int MODE, class Sink> ELEMDP_HD void lstat_energy(LinOutCtx<Sink>& x, 
   if (MODE == OUT_TRAIN && z != 0.) x.sink.eh(x.m.eh_index(par), tsc * z);
 }
 
-// exterior chain backwards, one step (rules 8, 7 reversed) with the statistics of those transitions
-template <int MODE, class Sink> ELEMDP_HD void lin_outside_ext_target(LinOutCtx<Sink>& x, int i, int s) {
+// exterior chain backwards, one step (rules 8, 7 reversed) with the statistics of those transitions; `part` of `nparts`
+// as in lin_inside_ext_part (the parents (i, j) dealt by j; part 0 also takes rule 8)
+template <int MODE, class Sink> ELEMDP_HD double lin_outside_ext_part(LinOutCtx<Sink>& x, int i, int s, int part, int nparts) {
   const ModelView& m = x.m;
   const SeqView& q = x.q;
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
   const int32_t* G = m.big;
   const double in_c = x.in.o(i, s);
-  if (in_c == 0.) { x.out.o(i, s) = 0.; return; }
+  if (in_c == 0.) return 0.;
   const double inz = in_c * x.invZ;
   double a = 0.;
-  if (q.unp[i])
+  if (part == 0 && q.unp[i])
     for (int t = I[A.rright_off + s]; t < I[A.rright_off + s + 1]; ++t) {
       const int par = I[A.rright_ent + 2 * t], tf = I[A.rright_ent + 2 * t + 1];
       const double term = x.out.o(i + 1, par) * lw_right(m, q, par, tf, i);
@@ -344,7 +351,7 @@ template <int MODE, class Sink> ELEMDP_HD void lin_outside_ext_target(LinOutCtx<
       a += term;
     }
   const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
-  for (int j = i + 1; j <= jmax; ++j) {
+  for (int j = i + 1 + part; j <= jmax; j += nparts) {
     const int d = j - i;
     if (!q.pair_ok(i, d)) continue;
     const int c = q.cell(i, d);
@@ -358,7 +365,10 @@ template <int MODE, class Sink> ELEMDP_HD void lin_outside_ext_target(LinOutCtx<
       a += term;
     }
   }
-  x.out.o(i, s) = a;
+  return a;
+}
+template <int MODE, class Sink> ELEMDP_HD void lin_outside_ext_target(LinOutCtx<Sink>& x, int i, int s) {
+  x.out.o(i, s) = lin_outside_ext_part<MODE>(x, i, s, 0, 1);
 }
 
 // serial heavy sums of the outside pass
