@@ -69,7 +69,7 @@ class DevBuf {
     bytes_ = bytes ? bytes : 8;
     HIP_OK(hipMalloc(&p_, bytes_));
   }
-  void reset() { if (p_) { hipFree(p_); p_ = nullptr; bytes_ = 0; } }
+  void reset() { if (p_) { (void)hipFree(p_); p_ = nullptr; bytes_ = 0; } }
   template <class T> T* as() const { return static_cast<T*>(p_); }
   size_t bytes() const { return bytes_; }
   template <class T> void upload(const std::vector<T>& v, hipStream_t st) {
@@ -307,9 +307,9 @@ void Engine::init_device() {
 }
 
 Engine::~Engine() {
-  if (st_) hipStreamSynchronize(st_);
-  for (auto& e : ev_) if (e) hipEventDestroy(e);
-  if (st_) hipStreamDestroy(st_);
+  if (st_) (void)hipStreamSynchronize(st_);
+  for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+  if (st_) (void)hipStreamDestroy(st_);
 }
 
 void Engine::set_option(const std::string& key, double v) {

@@ -336,6 +336,60 @@ __device__ __forceinline__ void for_block_items(int nv, int nq, int tid, int* cn
   __syncthreads();
 }
 
+// Item records of the workgroup's cells in LDS (k4_in, k5_cyk: the by_outer order; k4_out stages its three roles the same
+// way inline): CSR range per cell -> prefix in LDS, then all lanes fetch the records of [p0, p0 + cap) with one round of
+// loads.  meta = cell << 16 | position of the item in its cell; xw = exp(lambda_k tsc) for k = 0, 1 (0 when the item is
+// not in the inside set).
+struct OuterRecs { LoopItem* it; double* xw; int* meta; int cap; };
+__device__ __forceinline__ OuterRecs outer_recs(double* area, int n_doubles) {
+  OuterRecs r;
+  r.cap = (n_doubles * 8) / 40;
+  r.it = reinterpret_cast<LoopItem*>(area);
+  r.xw = reinterpret_cast<double*>(r.it + r.cap);
+  r.meta = reinterpret_cast<int*>(r.xw + 2 * r.cap);
+  return r;
+}
+// ranges + prefix; returns the number of records of the workgroup
+__device__ __forceinline__ int outer_ranges(const LViews& v, int i0, int nc, int d, bool on, int tid, int* cnts, int* pre, int* base) {
+  for (int c = tid; c < nc; c += kThreads) {
+    const int i = i0 + c;
+    int n0 = 0, n1 = 0;
+    if (on && v.q.e_ok(i, d)) { const int cell = v.q.cell(i, d); n0 = v.q.by_outer_off[cell]; n1 = v.q.by_outer_off[cell + 1]; }
+    base[c] = n0;
+    cnts[c] = (n1 > n0) ? n1 - n0 : 0;
+  }
+  __syncthreads();
+  for (int c = tid; c <= nc; c += kThreads) {
+    int p = 0;
+    for (int k = 0; k < c; ++k) p += cnts[k];
+    pre[c] = p;
+  }
+  __syncthreads();
+  return pre[nc];
+}
+template <bool WEIGHTS>
+__device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r, int p0, int np, int nc, int tid, const int* pre,
+                                            const int* base) {
+  for (int x = tid; x < np; x += kThreads) {
+    const int p = p0 + x;
+    int lo = 0, hi = nc - 1;   // the cell owning record p: largest c with pre[c] <= p
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pre[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const int n = base[lo] + (p - pre[lo]);
+    const bool in = v.q.item_in[n] != 0;
+    r.it[x] = v.q.items[n];
+    if (WEIGHTS) {
+      const double w0 = v.q.xwi[n], w1 = v.q.xwi[v.q.xwi_stride + n];
+      r.xw[x] = in ? w0 : 0.;
+      r.xw[r.cap + x] = in ? w1 : 0.;
+    }
+    r.meta[x] = (in ? 0 : (int)0x80000000) | (lo << 16) | (p - pre[lo]);
+  }
+  __syncthreads();
+}
+
 // ---- inside, "old" split sums of a whole tile of kTile diagonals d0 .. d0+kTile-1 (launched before k4_in(d0)):
 //   part_in[t][i][s] = sum_{t < a < d0} sum_tuples 1(i, i+a, s1) * 2(i+a, i+d0+t, s2)
 // i.e. all pairs of split operands that were final before the tile started.  The point of doing them together: a row
@@ -565,30 +619,45 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   }
 #pragma unroll
   for (int r = 0; r < kOwn; ++r) if (po1[r] >= 0 && pacc[r] != 0.) atomicAdd(&hb[ptg[r]], pacc[r]);
-  // rule 6c: E(i,j,tgt) += sum_items P(k,l,s1) * L(i,k,s2) * L(l,j,s3) * exp(lambda * tsc)
+  // rule 6c: E(i,j,tgt) += sum_items P(k,l,s1) * L(i,k,s2) * L(l,j,s3) * exp(lambda * tsc): work item = (item, tuple), the
+  // item records staged in the (now free) operand staging area, one round of table loads per work item
   const int nq = (a.dbg & 2) ? 0 : A.n_quad;
-  for_block_items(
-      nc, nq, tid, cnts, pre, base,
-      [&](int c, int& c0, int& c1) {
-        const int i = i0 + c;
-        if (v.q.e_ok(i, d)) { const int cell = v.q.cell(i, d); c0 = v.q.by_outer_off[cell]; c1 = v.q.by_outer_off[cell + 1]; }
-      },
-      [&](ItemSlot& x) { x.idx = x.n; },
-      [&](ItemSlot& x) {
-        x.it = v.q.items[x.idx];
-        x.aux = v.q.item_in[x.idx] ? 1. : 0.;
-        x.xw = xw_item(v.q, lamk(v.m, G[A.quad_tgt + x.t]), x.idx);
-      },
-      [&](ItemSlot& x) {
-        const int i = i0 + x.c, j = i + d;
-        x.x0 = B[v.in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad_ent + 3 * x.t])];
-        x.x1 = B[v.in.idx(ST_L, x.it.k - i, i, G[A.quad_ent + 3 * x.t + 1])];
-        x.x2 = B[v.in.idx(ST_L, j - x.it.l, x.it.l, G[A.quad_ent + 3 * x.t + 2])];
-      },
-      [&](ItemSlot& x) {
-        const double term = x.x0 * (x.x1 * x.x2) * x.xw;
-        if (x.aux != 0. && term != 0.) atomicAdd(&he[x.c * S + G[A.quad_tgt + x.t]], term);
-      });
+  {
+    const int n_rec = outer_ranges(v, i0, nc, d, nq > 0, tid, cnts, pre, base);
+    const OuterRecs R = outer_recs(st1, 2 * kChunkIn * CS);
+    for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
+      const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
+      outer_stage<true>(v, R, p0, np, nc, tid, pre, base);
+      const int total = np * nq;
+      for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
+        double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], xw[kItemBatch];
+        int hidx[kItemBatch];
+        bool ok[kItemBatch];
+#pragma unroll
+        for (int u = 0; u < kItemBatch; ++u) {
+          const int w = w0 + u * kThreads;
+          ok[u] = w < total;
+          const int wc = ok[u] ? w : total - 1;
+          const int x = wc / nq, t = wc - x * nq;
+          const LoopItem it = R.it[x];
+          const int c = (R.meta[x] >> 16) & 0x7fff;
+          const int i = i0 + c, j = i + d;
+          const int tgt = G[A.quad_tgt + t];
+          x0[u] = B[v.in.idx(ST_P, it.l - it.k, it.k, G[A.quad_ent + 3 * t])];
+          x1[u] = B[v.in.idx(ST_L, it.k - i, i, G[A.quad_ent + 3 * t + 1])];
+          x2[u] = B[v.in.idx(ST_L, j - it.l, it.l, G[A.quad_ent + 3 * t + 2])];
+          xw[u] = R.xw[lamk(v.m, tgt) * R.cap + x];
+          hidx[u] = c * S + tgt;
+        }
+#pragma unroll
+        for (int u = 0; u < kItemBatch; ++u) {
+          const double term = x0[u] * (x1[u] * x2[u]) * xw[u];
+          if (ok[u] && term != 0.) atomicAdd(&he[hidx[u]], term);
+        }
+      }
+      __syncthreads();
+    }
+  }
   pc.mark<3>();
   if (tid < nc * NA && !(a.dbg & 4)) {
     const int c = tid / NA, s = tid - c * NA;
@@ -1376,36 +1445,54 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
       if (kb[tg] == pk[r]) atomicMin(&ob[tg], (unsigned)(pa[r] * nsp + t));
     }
   // rule 6c: candidates P(k,l,s1) + (L(i,k,s2) + (L(l,j,s3) + lam * tsc)); items in by_outer order, then tuples.
-  // Two sweeps over the work items: the maximum of the keys, then the first ordinal that reaches it.
+  // The item records are staged in LDS; two sweeps over the work items: the maximum of the keys, then the first ordinal
+  // that reaches it.  (The maximum runs over ALL records of the workgroup, so both sweeps cover every chunk.)
   const int nq = A.n_quad;
+  {
+    const int n_rec = outer_ranges(v, i0, nc, d, true, tid, cnts, pre, base);
+    const OuterRecs R = outer_recs(st1, 2 * kChunkIn * CS);
 #pragma unroll 1
-  for (int sweep = 0; sweep < 2; ++sweep) {
-    for_block_items(
-        nc, nq, tid, cnts, pre, base,
-        [&](int c, int& c0, int& c1) {
-          const int i = i0 + c;
-          if (v.q.e_ok(i, d)) { const int cell = v.q.cell(i, d); c0 = v.q.by_outer_off[cell]; c1 = v.q.by_outer_off[cell + 1]; }
-        },
-        [&](ItemSlot& x) { x.idx = x.n; },
-        [&](ItemSlot& x) {
-          x.it = v.q.items[x.idx];
-          x.aux = v.q.item_in[x.idx] ? 1. : 0.;
-        },
-        [&](ItemSlot& x) {
-          const int i = i0 + x.c, j = i + d;
-          x.x0 = B[v.in.idx(ST_P, x.it.l - x.it.k, x.it.k, G[A.quad_ent + 3 * x.t])];
-          x.x1 = B[v.in.idx(ST_L, x.it.k - i, i, G[A.quad_ent + 3 * x.t + 1])];
-          x.x2 = B[v.in.idx(ST_L, j - x.it.l, x.it.l, G[A.quad_ent + 3 * x.t + 2])];
-        },
-        [&](ItemSlot& x) {
-          if (x.aux == 0.) return;
-          const int tgs = G[A.quad_tgt + x.t];
-          const double y = x.x0 + (x.x1 + (x.x2 + ELEMDP_MUL_RN(v.m.lam(tgs), x.it.tsc)));
-          if (y == NEG) return;
-          const unsigned long long k = cyk_key(y);
-          if (sweep == 0) atomicMax(&ke[x.c * S + tgs], k);
-          else if (ke[x.c * S + tgs] == k) atomicMin(&oe[x.c * S + tgs], (unsigned)((x.n - base[x.c]) * nq + x.t));
-        });
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
+        const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
+        if (sweep == 0 || n_rec > R.cap) outer_stage<false>(v, R, p0, np, nc, tid, pre, base);
+        const int total = np * nq;
+        for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
+          double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], lt[kItemBatch];
+          int hidx[kItemBatch];
+          unsigned ord[kItemBatch];
+          bool ok[kItemBatch];
+#pragma unroll
+          for (int u = 0; u < kItemBatch; ++u) {
+            const int w = w0 + u * kThreads;
+            ok[u] = w < total;
+            const int wc = ok[u] ? w : total - 1;
+            const int x = wc / nq, t = wc - x * nq;
+            const LoopItem it = R.it[x];
+            const int meta = R.meta[x];
+            const int c = (meta >> 16) & 0x7fff;
+            const int i = i0 + c, j = i + d;
+            const int tgs = G[A.quad_tgt + t];
+            ok[u] = ok[u] && meta >= 0;   // (sign bit: not in the inside set)
+            x0[u] = B[v.in.idx(ST_P, it.l - it.k, it.k, G[A.quad_ent + 3 * t])];
+            x1[u] = B[v.in.idx(ST_L, it.k - i, i, G[A.quad_ent + 3 * t + 1])];
+            x2[u] = B[v.in.idx(ST_L, j - it.l, it.l, G[A.quad_ent + 3 * t + 2])];
+            lt[u] = ELEMDP_MUL_RN(v.m.lam(tgs), it.tsc);
+            hidx[u] = c * S + tgs;
+            ord[u] = (unsigned)((meta & 0xffff) * nq + t);
+          }
+#pragma unroll
+          for (int u = 0; u < kItemBatch; ++u) {
+            const double y = x0[u] + (x1[u] + (x2[u] + lt[u]));
+            if (!ok[u] || y == NEG) continue;
+            const unsigned long long k = cyk_key(y);
+            if (sweep == 0) atomicMax(&ke[hidx[u]], k);
+            else if (ke[hidx[u]] == k) atomicMin(&oe[hidx[u]], ord[u]);
+          }
+        }
+        __syncthreads();
+      }
+    }
   }
   if (tid < ncS) {
     const int c = tid / S, s = tid - c * S;
