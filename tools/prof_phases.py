@@ -14,8 +14,8 @@ eng.set_option("profile", 1)
 fn, gr, eff, nsk = eng.train_eval(x)
 ms = eng.last_timing()
 c = eng.profile()
-names = ["in setup", "in stage", "in products", "in items", "in unary", "out setup", "out stage", "out products", "out items-inner",
-         "out items-left", "out items-right", "out unary", "out flush"]
+names = ["in setup", "in stage", "in products", "in items", "in unary", "out setup", "out stage", "out products", "out item records",
+         "out item terms", "out (unused)", "out unary", "out flush"]
 tot = c[:13].sum()
 print("n=%d L=%d pipeline %.1f ms -> %.0f seq/s ; fn=%.6f" % (n, L, ms[1], n / ms[1] * 1e3, fn))
 for k, nm in enumerate(names):
