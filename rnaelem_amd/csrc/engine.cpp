@@ -169,6 +169,7 @@ class Engine {
   int prepare_lin(LinArgs& a, bool sched1);
   void lin_weights();
   int balanced_group(size_t per_slot_bytes);
+  int group_cap_ = 8192;   // most sequences swept in lockstep (a first scan uses fewer: fresh table memory costs ~20 ms / GB)
   TrArgs log_pipeline_args();
   void init_device();
   void require_device() const;
@@ -736,7 +737,7 @@ int Engine::balanced_group(size_t per_slot_bytes) {
                       d_band_out0_.bytes();
   const size_t budget = (size_t)((double)(free_b + held) * 0.55);
   long cap = (long)(budget / std::max<size_t>(per_slot_bytes, 1));
-  cap = std::max(1L, std::min(cap, 8192L));
+  cap = std::max(1L, std::min(cap, (long)group_cap_));
   const long n_groups = (n_seq_ + cap - 1) / cap;
   return (int)((n_seq_ + n_groups - 1) / n_groups);
 }
@@ -1091,7 +1092,11 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   if (sums_on_batch) {
     LinArgs a;
     dbg_lap("scan: start");
+    // a scan is one pass: 1 024 sequences per group run within 4 % of the largest groups and need a third of the table
+    // memory (an evaluation loop that already holds larger groups keeps them)
+    group_cap_ = (n_slots_ == 0) ? 1024 : 8192;
     const int gsz = prepare_lin(a, false);
+    group_cap_ = 8192;
     dbg_lap("scan: prepare_lin (table slots)");
     a.scan = 1;
     a.ys = d_ys.as<int32_t>(); a.ye = d_ye.as<int32_t>();
