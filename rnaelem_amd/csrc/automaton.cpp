@@ -299,18 +299,20 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   put(rleft, &A.rleft_off, &A.rleft_ent);
   put(rpair, &A.rpair_off, &A.rpair_ent);
   A.n_small = (int32_t)ints->size();
-  // big part: tuple lists of the bifurcation and interior-loop rules
+  // big part: tuple lists of the bifurcation and interior-loop rules -- first the ones the inside direction reads (by
+  // parent), then the ones of the outside direction (by child): a kernel stages the small part and its own run
   put(split, &A.split_off, &A.split_ent);
   put(quad, &A.quad_off, &A.quad_ent);
+  A.split_tgt = split.emit_targets(ints);
+  A.quad_tgt = quad.emit_targets(ints);
+  A.big_in_end = (int32_t)ints->size();
   put(split1, &A.split1_off, &A.split1_ent);
   put(split2, &A.split2_off, &A.split2_ent);
   put(quad1, &A.quad1_off, &A.quad1_ent);
   put(quad2, &A.quad2_off, &A.quad2_ent);
   put(quad3, &A.quad3_off, &A.quad3_ent);
-  A.split_tgt = split.emit_targets(ints);
   A.split1_tgt = split1.emit_targets(ints);
   A.split2_tgt = split2.emit_targets(ints);
-  A.quad_tgt = quad.emit_targets(ints);
   A.quad1_tgt = quad1.emit_targets(ints);
   A.quad2_tgt = quad2.emit_targets(ints);
   A.quad3_tgt = quad3.emit_targets(ints);
@@ -339,9 +341,11 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   csr(2, &A.rright_off, &A.rright_ent); csr(2, &A.rleft_off, &A.rleft_ent); csr(2, &A.rpair_off, &A.rpair_ent);
   A.n_small = (int32_t)ints->size();
   csr(2, &A.split_off, &A.split_ent); csr(3, &A.quad_off, &A.quad_ent);
+  A.split_tgt = A.quad_tgt = one(0);
+  A.big_in_end = (int32_t)ints->size();
   csr(2, &A.split1_off, &A.split1_ent); csr(2, &A.split2_off, &A.split2_ent);
   csr(3, &A.quad1_off, &A.quad1_ent); csr(3, &A.quad2_off, &A.quad2_ent); csr(3, &A.quad3_off, &A.quad3_ent);
-  A.split_tgt = A.split1_tgt = A.split2_tgt = A.quad_tgt = A.quad1_tgt = A.quad2_tgt = A.quad3_tgt = one(0);
+  A.split1_tgt = A.split2_tgt = A.quad1_tgt = A.quad2_tgt = A.quad3_tgt = one(0);
   A.n_split = 1; A.n_quad = 1;
   A.n_ints = (int32_t)ints->size();
 }

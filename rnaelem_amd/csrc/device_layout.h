@@ -61,6 +61,8 @@ struct AutomatonLayout {
   int32_t n_split, n_quad;  // entries per split* list / per quad* list
   int32_t n_small;  // the first n_small ints (per-state attributes, unary lists) are staged in LDS;
                     // the tuple lists behind them are read from global memory (ModelView::big)
+  int32_t big_in_end;  // the tuple lists behind n_small come in two runs: [n_small, big_in_end) = lists of the inside
+                       // direction (split, quad + targets), [big_in_end, n_ints) = lists of the outside direction
   int32_t n_ints;   // total length of the int blob
 };
 

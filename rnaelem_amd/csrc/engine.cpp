@@ -1094,7 +1094,7 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
     dbg_lap("scan: start");
     // a scan is one pass: 1 024 sequences per group run within 4 % of the largest groups and need a third of the table
     // memory (an evaluation loop that already holds larger groups keeps them)
-    group_cap_ = (n_slots_ == 0) ? 1024 : 8192;
+    group_cap_ = std::max(1024, n_slots_);
     const int gsz = prepare_lin(a, false);
     group_cap_ = 8192;
     dbg_lap("scan: prepare_lin (table slots)");

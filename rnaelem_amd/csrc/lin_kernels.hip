@@ -20,7 +20,7 @@
 #define ELEMDP_KCI 4
 #endif
 #ifndef ELEMDP_KCO
-#define ELEMDP_KCO 2
+#define ELEMDP_KCO 3
 #endif
 #ifndef ELEMDP_LB_IN
 #define ELEMDP_LB_IN 5
@@ -218,9 +218,15 @@ __host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int wi
   return b;
 }
 struct BlockCtx { int* dm; int* cnts; int* pre; int* base; };
+// ints of the automaton blob a band kernel stages: everything (n_stage = n_ints) means the small part plus the run of
+// tuple lists of its direction (PART 0: inside, 1: outside); otherwise only the small part
+__host__ __device__ inline int staged_ints(const AutomatonLayout& L, int n_stage, int part) {
+  if (n_stage < L.n_ints) return n_stage;
+  return L.n_small + (part == 0 ? L.big_in_end - L.n_small : L.n_ints - L.big_in_end);
+}
 
 // stages the context and redirects the views to it; positions [p0, p0+len) = [i0-1, i0+nc+d] clipped to [0, L]
-template <bool BIG>
+template <bool BIG, int PART>
 __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, unsigned char* raw, const BlockLds& B, int i0, int nc,
                                                   int d, int cpb) {
   const int tid = threadIdx.x;
@@ -235,7 +241,13 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   uint8_t* lseq = raw + B.seq8;
   uint8_t* lunp = raw + B.unp8;
   const int n_lin = kLinEth + a.lay.n_theta;
-  for (int t = tid; t < a.n_stage; t += kThreads) blob[t] = a.ints[t];
+  const int big_lo = (PART == 0) ? a.lay.n_small : a.lay.big_in_end, big_hi = (PART == 0) ? a.lay.big_in_end : a.lay.n_ints;
+  if (BIG) {
+    for (int t = tid; t < a.lay.n_small; t += kThreads) blob[t] = a.ints[t];
+    for (int t = big_lo + tid; t < big_hi; t += kThreads) blob[a.lay.n_small + (t - big_lo)] = a.ints[t];
+  } else {
+    for (int t = tid; t < a.n_stage; t += kThreads) blob[t] = a.ints[t];
+  }
   for (int t = tid; t < n_lin; t += kThreads) llin[t] = a.lin[t];
   // pair mask: bits of the cells (i0-1, .) .. (i0+nc-1, .)  (bit index = i * (W+1) + d)
   uint32_t* lbits = reinterpret_cast<uint32_t*>(raw + B.bits);
@@ -258,7 +270,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   c.base = reinterpret_cast<int*>(raw + B.base);
   if (tid < cpb) c.dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
   v.m.ints = blob;
-  if (BIG) v.m.big = blob;
+  if (BIG) v.m.big = blob + a.lay.n_small - big_lo;   // (indices of the staged run keep their global values)
   v.m.lin = llin;
   v.q.ews = lews - p0;
   v.q.dmin = ldmin - p0;
@@ -547,8 +559,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   double* he = hb + CS;
   double* st1 = he + CS;               // [kChunkIn][CS]  rows 1(i, i+a, .)
   double* st2 = st1 + kChunkIn * CS;   // [kChunkIn][CS]  rows 2(i+a, j, .)
-  const BlockLds BL = block_lds((2 + 2 * kChunkIn) * CS, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, a.n_stage);
-  const BlockCtx cx = stage_context<BIG>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  const BlockLds BL = block_lds((2 + 2 * kChunkIn) * CS, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
+  const BlockCtx cx = stage_context<BIG, 0>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   for (int t = tid; t < 2 * CS; t += kThreads) lds[t] = 0.;
@@ -1081,8 +1093,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* sI2 = sOB1 + kChunkOut * CS;   //                 in  2(j, j+b, .)
   double* sOB2 = sI2 + kChunkOut * CS;   //                 out B(i-b, j, .)        (H2)
   double* sI1 = sOB2 + kChunkOut * CS;   //                 in  1(i-b, i, .)
-  const BlockLds BL = block_lds((4 + 4 * kChunkOut) * CS + nt + 2, cpb, kLinEth + nt, cpb + a.wmax + 3, a.n_stage, 3 * cpb);
-  const BlockCtx cx = stage_context<BIG>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  const BlockLds BL = block_lds((4 + 4 * kChunkOut) * CS + nt + 2, cpb, kLinEth + nt, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb);
+  const BlockCtx cx = stage_context<BIG, 1>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   for (int t = tid; t < 4 * CS + nt + 2; t += kThreads) lds[t] = 0.;
@@ -1376,8 +1388,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   double* st2 = st1 + kChunkIn * CS;    // [kChunkIn][CS]  rows 2(i+a, j, .)
   unsigned* ob = reinterpret_cast<unsigned*>(st2 + kChunkIn * CS);       // [CS] first ordinal reaching the best, rule 2
   unsigned* oe = ob + CS;                                                //                                      rule 6c
-  const BlockLds BL = block_lds((3 + 2 * kChunkIn) * CS, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, a.n_stage);
-  const BlockCtx cx = stage_context<BIG>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  const BlockLds BL = block_lds((3 + 2 * kChunkIn) * CS, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
+  const BlockCtx cx = stage_context<BIG, 0>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   const unsigned long long kneg = cyk_key(NEG);
@@ -1568,7 +1580,7 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   a.wmax = Wmax;
   a.lmax = Lmax;
   a.tile_d0 = -1;
-  const size_t lds = block_lds((3 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
+  const size_t lds = block_lds((3 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const long long products = (long long)a.cpb * a.lay.n_split;   // (cell, tuple) products of a workgroup
   const int kown = products <= 2 * kThreads ? 2 : products <= 4 * kThreads ? 4 : products <= 8 * kThreads ? 8 : 0;
@@ -1599,8 +1611,8 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   a.schedule = 0;   // terminals (ari, nasi), Z = Z(ari,nasi): pass 0 of the reference schedule
   a.pass = 0;
   a.scan = 1;
-  const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
-  const size_t lds_out = block_lds((4 + 4 * kChunkOut) * a.cpb * S + nt + 2, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage, 3 * a.cpb).total;
+  const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
+  const size_t lds_out = block_lds((4 + 4 * kChunkOut) * a.cpb * S + nt + 2, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
@@ -1647,7 +1659,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   a.cpb = kThreads / S;
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
-  const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, a.n_stage).total;
+  const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const size_t lds_stat = sizeof(double) * (nt + 2);
   a.tile_d0 = -1;
@@ -1680,7 +1692,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
     b.cpb = kThreads / b.lay.S;
     if (b.cpb > ELEMDP_CPB_MAX) b.cpb = ELEMDP_CPB_MAX;
     b.wmax = Wmax;
-    const size_t lds_b = block_lds((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, b.n_stage, 3 * b.cpb).total;
+    const size_t lds_b = block_lds((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, staged_ints(b.lay, b.n_stage, 1), 3 * b.cpb).total;
     const bool big_b = b.n_stage >= b.lay.n_ints;
     b.lmax = Lmax;
     if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(nt + 2, kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
