@@ -52,6 +52,9 @@ def build_parser():
     t.add_argument("--param-set", default=None, help="comma separated indexes of the parameters to fit (the others stay fixed)")
     t.add_argument("--optimizer", choices=["lbfgsb", "adam"], default="lbfgsb")
     sub.choices["scan"].add_argument("-q", "--motif-model", required=True)
+    sub.choices["scan"].add_argument("--chunk", type=int, default=20000,
+                                     help="sequences resident on the GPU at a time (plan + tables; BASELINE config E = 100 k x L=300 "
+                                          "does not fit at once)")
     return p
 
 
@@ -124,12 +127,14 @@ def cmd_scan(a):
     lo, hi = assigned_range(len(recs), world, rank)     # scan needs no collective: every rank writes its own range
     mine = recs[lo:hi]
     out = a.out1 if world == 1 else "%s.%d" % (a.out1, rank)
+    nodes = eng.describe()["node"]
+    step = max(1, a.chunk)
     with open(out, "w") as f:
-        if mine:
-            eng.load_batch([s for _, s, _ in mine], [q for _, _, q in mine])
+        for c0 in range(0, len(mine), step):        # records are independent: chunks in input order
+            part = mine[c0:c0 + step]
+            eng.load_batch([s for _, s, _ in part], [q for _, _, q in part])
             res, en = eng.scan(m["x"])
-            nodes = eng.describe()["node"]
-            for (rid, codes, _), r in zip(mine, res):
+            for (rid, codes, _), r in zip(part, res):
                 f.write(io.scan_record(rid, codes, r, nodes) + "\n")
 
 
