@@ -397,6 +397,38 @@ def test_other_automaton_sizes(pattern):
     np.testing.assert_allclose(gr, go, rtol=1e-7, atol=1e-7)
 
 
+def test_long_sequences_take_the_unstaged_exterior_path():
+    """L = 2 300 > 2 048: the exterior-chain kernels cannot stage the per-sequence context in LDS (STAGE = false), the band
+    kernels run 2 300 cells per diagonal; train evaluation and scan of a ragged batch (2 300, 2 100, 60) against the oracle."""
+    pattern = "((.*.))"
+    seqs, quals = [], []
+    for L, seed in ((2300, 5), (2100, 6), (60, 7)):
+        a, b = synth.synth_batch(1, L, seed=seed)
+        seqs += a
+        quals += b
+    quals[1] = quals[1].copy()
+    quals[1][-1] = 5                                          # one sequence without motif
+    eng = api.Engine(pattern, PAR, 50, 30, 1e-4, 0.1)
+    o = po.make_oracle(pattern, 50, 30, min_bpp=1e-4, tau=0.1)
+    x = eng.initial_params(0.5)
+    x[:-2] += 0.2 * np.random.RandomState(3).randn(len(x) - 2)
+    o.set_params(x)
+    eng.load_batch(seqs, quals)
+    fn, gr, eff, nsk = eng.train_eval(x)
+    fo, go, eo, no = o.train_eval(x, seqs, quals, n_threads=3)
+    assert nsk == no
+    assert fn == pytest.approx(fo, rel=1e-9, abs=1e-10)
+    np.testing.assert_allclose(gr, go, rtol=1e-7, atol=1e-7)
+    assert eff == pytest.approx(eo, rel=1e-12)
+    recs, en = eng.scan(x)
+    for k in (0, 2):
+        a = o.scan_seq(seqs[k], quals[k])
+        assert (a["Ys"], a["Ye"]) == (recs[k]["Ys"], recs[k]["Ye"])
+        assert a["rss"] == recs[k]["rss"] and list(a["psihat"]) == list(recs[k]["psihat"])
+        assert_log_close(recs[k]["start"], a["start"], rtol=1e-8, atol=1e-6, what="start")
+        assert_log_close(recs[k]["end"], a["end"], rtol=1e-8, atol=1e-6, what="end")
+
+
 EVAL_LIK = gload("eval_lik.json")
 
 
