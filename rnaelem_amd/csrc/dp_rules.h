@@ -86,6 +86,27 @@ struct LseAcc {
   ELEMDP_HD double value() const { return (m == ELEMDP_NEG_INF) ? ELEMDP_NEG_INF : m + log(s); }
 };
 
+// Serial heavy sums with ONE state tuple (the BPP filter's one-state automaton: one lane per cell walks up to ~100 split
+// points / items): the terms of kRun consecutive steps are fetched together, then added in the original order -- the
+// chain of dependent loads per step (index -> item record -> table values) is paid once per kRun steps.
+constexpr int kRun = 8;
+template <class OkFn, class TermFn>
+ELEMDP_HD void lse_run4(LseAcc& a, int n, OkFn ok, TermFn term) {
+  for (int k0 = 0; k0 < n; k0 += kRun) {
+    double v[kRun];
+    bool g[kRun];
+#pragma unroll
+    for (int u = 0; u < kRun; ++u) {
+      const int k = (k0 + u < n) ? k0 + u : n - 1;
+      g[u] = k0 + u < n && ok(k);
+      v[u] = term(k);
+    }
+#pragma unroll
+    for (int u = 0; u < kRun; ++u)
+      if (g[u]) a.add(v[u]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // views
 // ---------------------------------------------------------------------------------------------
@@ -281,6 +302,12 @@ ELEMDP_HD double heavy_bif(const ModelView& m, const SeqView& q, const TableView
   const int32_t* G = m.big;
   const int j = i + d;
   LseAcc a;
+  const int t0 = G[A.split_off + s];
+  if (G[A.split_off + s + 1] - t0 == 1) {
+    const int s1 = G[A.split_ent + 2 * t0], s2 = G[A.split_ent + 2 * t0 + 1], k_lo = i + q.dmin[i];
+    lse_run4(a, j - k_lo, [&](int n) { return bif_valid(q, j, k_lo + n); }, [&](int n) { return bif_term(T, i, j, k_lo + n, s1, s2); });
+    return a.value();
+  }
   for (int k = i + q.dmin[i]; k < j; ++k) {
     if (!bif_valid(q, j, k)) continue;
     for (int t = G[A.split_off + s]; t < G[A.split_off + s + 1]; ++t)
@@ -296,6 +323,13 @@ ELEMDP_HD double heavy_loop(const ModelView& m, const SeqView& q, const TableVie
   const double lam = m.lam(s);
   LseAcc a;
   const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
+  const int t0 = G[A.quad_off + s];
+  if (G[A.quad_off + s + 1] - t0 == 1) {
+    const int s1 = G[A.quad_ent + 3 * t0], s2 = G[A.quad_ent + 3 * t0 + 1], s3 = G[A.quad_ent + 3 * t0 + 2];
+    lse_run4(a, c1 - c0, [&](int n) { return q.item_in[c0 + n] != 0; },
+             [&](int n) { const LoopItem x = q.items[c0 + n]; return loop_term(T, i, j, x, s1, s2, s3, lam * x.tsc); });
+    return a.value();
+  }
   for (int it = c0; it < c1; ++it) {
     if (!q.item_in[it]) continue;
     const LoopItem x = q.items[it];
@@ -700,6 +734,12 @@ template <class Sink> ELEMDP_HD double heavy_o1(OutCtx<Sink>& x, int d, int i, i
   const int dj = q.dmin[j];
   if (j < q.L && dj > 0) {
     const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+    const int u0 = G[A.split1_off + s];
+    if (G[A.split1_off + s + 1] - u0 == 1) {
+      const int par = G[A.split1_ent + 2 * u0], s2 = G[A.split1_ent + 2 * u0 + 1], j_lo = j + dj;
+      lse_run4(a, jmax - j_lo + 1, [&](int) { return true; }, [&](int n) { return o1_term(x.in, x.out, i, j, j_lo + n, par, s2); });
+      return a.value();
+    }
     for (int jj = j + dj; jj <= jmax; ++jj)
       for (int u = G[A.split1_off + s]; u < G[A.split1_off + s + 1]; ++u)
         a.add(o1_term(x.in, x.out, i, j, jj, G[A.split1_ent + 2 * u], G[A.split1_ent + 2 * u + 1]));
@@ -713,6 +753,13 @@ template <class Sink> ELEMDP_HD double heavy_o2(OutCtx<Sink>& x, int d, int i, i
   const int j = i + d;
   LseAcc a;
   const int imin = (j - q.W > 0) ? j - q.W : 0;
+  const int u0 = G[A.split2_off + s];
+  if (G[A.split2_off + s + 1] - u0 == 1) {
+    const int par = G[A.split2_ent + 2 * u0], s1 = G[A.split2_ent + 2 * u0 + 1];
+    lse_run4(a, i - imin, [&](int n) { return o2_valid(q, i, i - 1 - n); },
+             [&](int n) { return o2_term(x.in, x.out, i, j, i - 1 - n, par, s1); });
+    return a.value();
+  }
   for (int ii = i - 1; ii >= imin; --ii) {
     if (!o2_valid(q, i, ii)) continue;
     for (int u = G[A.split2_off + s]; u < G[A.split2_off + s + 1]; ++u)
@@ -729,6 +776,17 @@ template <int MODE, class Sink> ELEMDP_HD double heavy_oP(OutCtx<Sink>& x, int d
   LseAcc a;
   if (in_c == ELEMDP_NEG_INF) return ELEMDP_NEG_INF;
   const int pc = q.cell(i, d);
+  const int u0 = G[A.quad1_off + s];
+  if (MODE == OUT_NONE && G[A.quad1_off + s + 1] - u0 == 1) {   // (no statistics: the BPP filter)
+    const int par = G[A.quad1_ent + 3 * u0], s2 = G[A.quad1_ent + 3 * u0 + 1], s3 = G[A.quad1_ent + 3 * u0 + 2];
+    const int n0 = q.by_inner_off[pc];
+    const double lam = m.lam(par);
+    lse_run4(a, q.by_inner_off[pc + 1] - n0, [&](int) { return true; }, [&](int n) {
+      const LoopItem it = q.items[q.by_inner_idx[n0 + n]];
+      return oP_term(x.in, x.out, i, j, it, par, s2, s3, lam * it.tsc);
+    });
+    return a.value();
+  }
   for (int n = q.by_inner_off[pc]; n < q.by_inner_off[pc + 1]; ++n) {
     const LoopItem it = q.items[q.by_inner_idx[n]];
     for (int u = G[A.quad1_off + s]; u < G[A.quad1_off + s + 1]; ++u) {
