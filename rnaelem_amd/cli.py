@@ -6,7 +6,8 @@
     torchrun --nproc-per-node 8 -m rnaelem_amd.cli train ...      # one rank per GPU, one RCCL all-reduce per evaluation
 
 Implemented: full-batch training -- `--no-shuffle` (L-BFGS-B, the path named by BASELINE.json) and the default mode with
-per-iteration shuffled negatives (Adam, `--kmer-shuf`) --, mini-batches (`--batch-size N`, one GPU), `--lik-ratio`,
+per-iteration shuffled negatives (Adam, `--kmer-shuf`) --, mini-batches (`--batch-size N`), all of them on one or several
+GPUs (torchrun), `--lik-ratio`,
 `--param-set`, `--theta-softmax`, and `scan`.  Not implemented: grid-engine array jobs (out of scope).
 """
 import argparse
@@ -16,7 +17,7 @@ import sys
 import numpy as np
 
 from . import api, io, train as trainer
-from .distributed import ShardedTrainer
+from .distributed import ShardedPairs, ShardedShuffledNegatives, ShardedTrainer
 
 
 def build_parser():
@@ -64,8 +65,6 @@ def _rank_world():
 
 def cmd_train(a):
     rank, local_rank, world = _rank_world()
-    if (not a.no_shuffle or a.batch_size > 0) and world > 1:
-        raise SystemExit("shuffled negatives and mini-batches are implemented for one GPU; use --no-shuffle --batch-size -1 with torchrun")
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -80,12 +79,21 @@ def cmd_train(a):
     eng = api.Engine(pattern, par, a.max_span, a.max_internal_loop, a.min_bpp, a.tau, flags, device)
     recs = io.read_fastq(a.fastq)
     seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
-    ev = None if a.batch_size > 0 else ShardedTrainer(eng, seqs, quals, rank, world)
+    sharded_pairs = world > 1 and (not a.no_shuffle or a.batch_size > 0)
+    ev = None if (a.batch_size > 0 or sharded_pairs) else ShardedTrainer(eng, seqs, quals, rank, world)
     x0 = eng.initial_params(a.lambda_init)
     log = (lambda msg: print(msg, file=sys.stderr, flush=True)) if rank == 0 else None
     vary = [int(v) for v in a.param_set.split(",")] if a.param_set else None
     optimizer = a.optimizer
-    if a.batch_size > 0:   # mini-batches: every evaluation loads the next records of the epoch order (motif_trainer.hpp:595-632)
+    if sharded_pairs:      # several GPUs: records (and their negatives) sharded per evaluation, one all-reduce
+        neg = api.Engine(pattern, par, a.max_span, a.max_internal_loop, a.min_bpp, a.tau, flags, device)
+        pairs = ShardedPairs.on_engines(eng, neg, rank, world, None if a.no_shuffle else a.kmer_shuf)
+        if a.batch_size > 0:
+            ev = trainer.MiniBatches(seqs, quals, a.batch_size, None, pairs=pairs)
+        else:
+            ev = ShardedShuffledNegatives(pairs, seqs, quals)
+        optimizer = "lbfgsb" if a.no_shuffle else "adam"
+    elif a.batch_size > 0:   # mini-batches: every evaluation loads the next records of the epoch order (motif_trainer.hpp:595-632)
         def eval_batch(s2, q2, x):
             eng.load_batch(s2, q2)
             return eng.train_eval(x) + (eng.seq_stats()[:, 4] != 0,)

@@ -131,13 +131,14 @@ class MiniBatches:
     the end of an epoch the order is shuffled with std::shuffle(mt19937(epoch)) on top of the previous order.  With
     `kmer_shuf` every record also gets its shuffled negative (seed = evaluation count, as in ShuffledNegatives).
 
-    evaluate_batch(seqs, quals, x) -> (fn, gr, sum_eff, n_skipped, skipped flags per sequence)."""
+    evaluate_batch(seqs, quals, x) -> (fn, gr, sum_eff, n_skipped, skipped flags per sequence); or `pairs`: a
+    distributed.ShardedPairs that evaluates a batch and its negatives over several ranks (then evaluate_batch is unused)."""
 
-    def __init__(self, seqs, quals, batch, evaluate_batch, kmer_shuf=None):
+    def __init__(self, seqs, quals, batch, evaluate_batch, kmer_shuf=None, pairs=None):
         from .api import epoch_permutation, kmer_shuffle
         self._perm, self._shuffle = epoch_permutation, kmer_shuffle
         self.seqs, self.quals, self.batch = seqs, quals, batch if batch > 0 else len(seqs)
-        self.evaluate_batch, self.k = evaluate_batch, kmer_shuf
+        self.evaluate_batch, self.k, self.pairs = evaluate_batch, kmer_shuf, pairs
         self.order, self.pos, self.n_shuffles, self.count = list(range(len(seqs))), 0, 0, 0
 
     def __call__(self, x):
@@ -152,6 +153,11 @@ class MiniBatches:
         idx = self.order[self.pos:self.pos + self.batch]
         self.pos += self.batch
         s1, q1 = [self.seqs[i] for i in idx], [self.quals[i] for i in idx]
+        if self.pairs is not None:
+            self.pairs.load(s1, q1)
+            res = self.pairs(x, self.count)
+            self.count += 1
+            return res
         fn, gr, eff, nsk, skipped = self.evaluate_batch(s1, q1, x)
         if self.k is not None:
             negs = [self._shuffle(s, self.k, self.count) for s, sk in zip(s1, skipped) if not sk]

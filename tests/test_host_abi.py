@@ -176,3 +176,77 @@ def test_two_rank_gloo_all_reduce_path(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0]
+
+
+PAIRS_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch.distributed as dist
+from oracle import pyoracle as po
+from rnaelem_amd import api, io, train
+from rnaelem_amd.distributed import ShardedPairs, ShardedShuffledNegatives
+from tests.emul.pyemul import Emul
+from tests.util import gload, gpath
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+t = gload(sys.argv[2])
+recs = io.read_fastq(gpath(t["fq"]))
+seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+emu = Emul(t["pattern"], open(po.DEFAULT_PAR).read(), 50, 30, 1e-4, t["tau"], 0)
+eng = api.Engine(t["pattern"], "~T2004~", 50, 30, 1e-4, t["tau"])       # host-only handle: x0 and finish through the C ABI
+nt = emu.n_param - 2
+state = {}
+
+def partial_of(s2, q2, x):
+    """what elemdp_train_partial returns for a resident batch (here from the CPU emulation of the kernels' rule code)"""
+    part, skipped = np.zeros(4 + 2 * nt + 4), []
+    for s, q in zip(s2, q2):
+        r = emu.train_seq(x, s, q)
+        skipped.append(bool(r["skipped"]))
+        if r["skipped"]:
+            part[3] += 1
+            continue
+        part[0] += r["f"]; part[1] += r["bpp_eff"]; part[2] += 1
+        part[4:4 + nt] += r["ENo"]; part[4 + nt:4 + 2 * nt] += r["ENx"]
+        part[4 + 2 * nt:4 + 2 * nt + 2] += r["EHo"]; part[4 + 2 * nt + 2:] += r["EHx"]
+    return part, np.array(skipped, dtype=bool)
+
+def load(s2, q2):
+    state["batch"] = (s2, q2)
+
+def partial_pos(x):
+    part, state["skipped"] = partial_of(*state["batch"], x)
+    return part
+
+pairs = ShardedPairs(load, partial_pos, lambda: state["skipped"], lambda s2, q2, x: partial_of(s2, q2, x)[0],
+                     lambda total, x: eng.train_finish(total, x=x), 4 + 2 * nt + 4, rank, world, t["kmer_shuf"])
+if "batch_size" in t:
+    ev = train.MiniBatches(seqs, quals, t["batch_size"], None, pairs=pairs)
+else:
+    ev = ShardedShuffledNegatives(pairs, seqs, quals)
+x0 = eng.initial_params(t["lambda_init"])
+r = train.minimize_adam(ev, x0, train.regularisation(len(x0), t["rho_theta"], t["rho_lambda"]), max_iter=t["max_iter"])
+fn = [row[4] for row in r["trace"]]
+assert len(fn) == len(t["iter_fn"]), (fn, t["iter_fn"])
+for a, b in zip(fn, t["iter_fn"]):
+    assert abs(a - b) <= 2e-5 * abs(b), (fn, t["iter_fn"])
+print("OK rank", rank, fn[-1])
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("trace,port", [("train_trace_shuffle.json", "29573"), ("train_trace_minibatch.json", "29575")])
+def test_two_rank_default_training_modes_reproduce_the_reference_traces(tmp_path, trace, port):
+    """Shuffled negatives and mini-batches over two ranks (distributed.ShardedPairs, gloo): records and the negatives of a
+    rank's own records are evaluated per rank, one all-reduce per evaluation; the data term of every evaluation equals the
+    trace of the reference binary (one process), whatever the sharding."""
+    script = tmp_path / "worker.py"
+    script.write_text(PAIRS_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), REPO, trace], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("OK rank" in o for o in outs)
