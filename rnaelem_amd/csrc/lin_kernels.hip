@@ -540,15 +540,15 @@ __global__ __launch_bounds__(kThreads) void k4_in_old(LinArgs a) {
 template <bool BIG, bool CON>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
-  __shared__ AutomatonLayout s_lay;
+  // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
   PhaseClock pc;
   pc.start(a.prof);
-  stage_layout(a, &s_lay, kThreads);
+
   unsigned bx, by;
   swizzled_block(bx, by);
-  LViews v(s_lay);
+  LViews v(a.lay);
   make_lviews(a, by, v);
-  const AutomatonLayout& A = s_lay;   // (valid after the first barrier below)
+  const AutomatonLayout& A = a.lay;
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x;
   if (d > v.q.W) return;
   const int ncell = v.q.L - d + 1, i0 = bx * cpb;
@@ -1066,16 +1066,16 @@ __global__ __launch_bounds__(kThreads) void k4_out_old(LinArgs a) {
 template <int MODE, bool BIG>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   extern __shared__ double lds[];
-  __shared__ AutomatonLayout s_lay;
+  // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
   PhaseClock pc;
   pc.start(a.prof);
-  stage_layout(a, &s_lay, kThreads);
+
   unsigned bx, by;
   swizzled_block(bx, by);
-  LViews v(s_lay);
+  LViews v(a.lay);
   make_lviews(a, by, v);
   const LPass pi = lpass(a, v);
-  const AutomatonLayout& A = s_lay;   // (valid after the first barrier below)
+  const AutomatonLayout& A = a.lay;
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = a.lay.n_theta;
   if (pi.skip || d > v.q.W) return;
   const int L = v.q.L, W = v.q.W;
@@ -1368,13 +1368,13 @@ __global__ __launch_bounds__(kThreads) void k5_cyk_serial(LinArgs a) {
 template <bool BIG, int KOWN>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   extern __shared__ double lds[];
-  __shared__ AutomatonLayout s_lay;
-  stage_layout(a, &s_lay, kThreads);
+  // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
+
   unsigned bx, by;
   swizzled_block(bx, by);
-  LViews v(s_lay);
+  LViews v(a.lay);
   make_lviews(a, by, v);
-  const AutomatonLayout& A = s_lay;   // (valid after the first barrier below)
+  const AutomatonLayout& A = a.lay;
   const int S = a.lay.S, d = a.d, cpb = a.cpb, tid = threadIdx.x;
   if (d > v.q.W) return;
   const int ncell = v.q.L - d + 1, i0 = bx * cpb;
