@@ -101,8 +101,17 @@ struct LViews {
 };
 
 __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) {
-  const SeqPlan p = a.plans_slot ? a.plans_slot[g] : a.plans[a.grp[g]];
-  const int n = a.plans_slot ? p.index : a.grp[g];
+  // the plan of the slot: one uniform record (g is the same for the whole workgroup: scalar loads), no grp -> plans chain
+  // (read through the constant address space: the record is not written while kernels run, and a uniform address then
+  // becomes scalar loads -- one wait for the whole record)
+  g = __builtin_amdgcn_readfirstlane(g);
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const SeqPlan __attribute__((address_space(4))) * ConstPlan;
+  const SeqPlan p = *reinterpret_cast<ConstPlan>(reinterpret_cast<uintptr_t>(a.plans_slot + g));
+#else
+  const SeqPlan p = a.plans_slot[g];
+#endif
+  const int n = p.index;
   v.n = n;
   v.positive = p.positive != 0;
   v.seq_base = p.seq_base;
@@ -154,8 +163,8 @@ __device__ __forceinline__ void swizzled_block(unsigned& bx, unsigned& by) {
   const unsigned orig = blockIdx.y * nbx + blockIdx.x;
   const unsigned q = total / 8, r = total % 8, xcd = orig % 8;
   const unsigned vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-  bx = vb % nbx;
-  by = vb / nbx;
+  bx = __builtin_amdgcn_readfirstlane(vb % nbx);   // (uniform: keeps the block coordinates in scalar registers)
+  by = __builtin_amdgcn_readfirstlane(vb / nbx);
 }
 
 // copies the automaton layout record into LDS (all threads; caller synchronises before the first use)
@@ -242,21 +251,51 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   uint8_t* lunp = raw + B.unp8;
   const int n_lin = kLinEth + a.lay.n_theta;
   const int big_lo = (PART == 0) ? a.lay.n_small : a.lay.big_in_end, big_hi = (PART == 0) ? a.lay.big_in_end : a.lay.n_ints;
-  if (BIG) {
-    for (int t = tid; t < a.lay.n_small; t += kThreads) blob[t] = a.ints[t];
-    for (int t = big_lo + tid; t < big_hi; t += kThreads) blob[a.lay.n_small + (t - big_lo)] = a.ints[t];
-  } else {
-    for (int t = tid; t < a.n_stage; t += kThreads) blob[t] = a.ints[t];
-  }
-  for (int t = tid; t < n_lin; t += kThreads) llin[t] = a.lin[t];
-  // pair mask: bits of the cells (i0-1, .) .. (i0+nc-1, .)  (bit index = i * (W+1) + d)
   uint32_t* lbits = reinterpret_cast<uint32_t*>(raw + B.bits);
+  // pair mask: bits of the cells (i0-1, .) .. (i0+nc-1, .)  (bit index = i * (W+1) + d)
   const int W1 = v.q.W + 1;
   const int bit0 = ((i0 > 0) ? i0 - 1 : 0) * W1, bit1 = (i0 + nc) * W1;   // [bit0, bit1)
   const int w0 = bit0 >> 5, w1 = (bit1 + 31) >> 5;
   const int wend = (int)((((long long)(L + 1) * W1) + 31) >> 5);
-  for (int t = tid; t < w1 - w0; t += kThreads) lbits[t] = (w0 + t < wend) ? v.q.okbits[w0 + t] : 0u;
-  for (int t = tid; t < len; t += kThreads) {
+  // ALL loads of the context are issued before the first LDS store (clamped addresses, fixed unrolling): one round trip
+  // for the whole context instead of one per array (a plain copy loop waits for its loads before it stores)
+  constexpr int kU = 4;
+  const int n_sm = BIG ? a.lay.n_small : a.n_stage, n_bg = BIG ? big_hi - big_lo : 0;
+  int r_sm[kU], r_bg[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int t = tid + u * kThreads;
+    r_sm[u] = a.ints[t < n_sm ? t : 0];
+    r_bg[u] = a.ints[t < n_bg ? big_lo + t : 0];
+  }
+  const double r_lin = a.lin[tid < n_lin ? tid : 0];
+  const uint32_t r_bits = v.q.okbits[(tid < w1 - w0 && w0 + tid < wend) ? w0 + tid : 0];
+  const int pw = p0 + (tid < len ? tid : 0);
+  const double r_ews = v.q.ews[pw];
+  const int16_t r_dmin = v.q.dmin[pw];
+  const uint8_t r_unp = v.q.unp[pw];
+  const uint8_t r_seq = v.q.seq[pw < L ? pw : (L > 0 ? L - 1 : 0)];
+  const int16_t r_dm = v.q.dmin[i0 + (tid < nc ? tid : 0)];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int t = tid + u * kThreads;
+    if (t < n_sm) blob[t] = r_sm[u];
+    if (t < n_bg) blob[a.lay.n_small + t] = r_bg[u];
+  }
+  if (tid < n_lin) llin[tid] = r_lin;
+  if (tid < w1 - w0) lbits[tid] = (w0 + tid < wend) ? r_bits : 0u;
+  if (tid < len) {
+    lews[tid] = r_ews;
+    ldmin[tid] = r_dmin;
+    lunp[tid] = r_unp;
+    lseq[tid] = (pw < L) ? r_seq : (uint8_t)0;
+  }
+  // (larger automata / windows than the unrolled part covers)
+  for (int t = tid + kU * kThreads; t < n_sm; t += kThreads) blob[t] = a.ints[t];
+  for (int t = tid + kU * kThreads; t < n_bg; t += kThreads) blob[a.lay.n_small + t] = a.ints[big_lo + t];
+  for (int t = tid + kThreads; t < n_lin; t += kThreads) llin[t] = a.lin[t];
+  for (int t = tid + kThreads; t < w1 - w0; t += kThreads) lbits[t] = (w0 + t < wend) ? v.q.okbits[w0 + t] : 0u;
+  for (int t = tid + kThreads; t < len; t += kThreads) {
     const int p = p0 + t;
     lews[t] = v.q.ews[p];
     ldmin[t] = v.q.dmin[p];
@@ -268,7 +307,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   c.cnts = reinterpret_cast<int*>(raw + B.cnts);
   c.pre = reinterpret_cast<int*>(raw + B.pre);
   c.base = reinterpret_cast<int*>(raw + B.base);
-  if (tid < cpb) c.dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
+  if (tid < cpb) c.dm[tid] = (tid < nc) ? (int)r_dm : 0;
   v.m.ints = blob;
   if (BIG) v.m.big = blob + a.lay.n_small - big_lo;   // (indices of the staged run keep their global values)
   v.m.lin = llin;
