@@ -116,7 +116,13 @@ __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) 
   v.positive = p.positive != 0;
   v.seq_base = p.seq_base;
   v.pos_base = p.pos_base;
-  const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const ParamBlock __attribute__((address_space(4))) * ConstParams;   // (uniform, read-only: scalar loads)
+  const ParamBlock pbv = *reinterpret_cast<ConstParams>(reinterpret_cast<uintptr_t>(a.params));
+#else
+  const ParamBlock pbv = *reinterpret_cast<const ParamBlock*>(a.params);
+#endif
+  const ParamBlock* pb = &pbv;
   v.m.ints = a.ints;
   v.m.big = a.ints;
   v.m.theta = a.params + sizeof(ParamBlock) / sizeof(double);
@@ -1116,7 +1122,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   const LPass pi = lpass(a, v);
   const AutomatonLayout& A = a.lay;
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = a.lay.n_theta;
-  if (pi.skip || d > v.q.W) return;
+  if (d > v.q.W) return;
   const int L = v.q.L, W = v.q.W;
   const int ncell = L - d + 1, i0 = bx * cpb;
   if (i0 >= ncell) return;
@@ -1134,6 +1140,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* sI1 = sOB2 + kChunkOut * CS;   //                 in  1(i-b, i, .)
   const BlockLds BL = block_lds((4 + 4 * kChunkOut) * CS + nt + 2, cpb, kLinEth + nt, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb);
   const BlockCtx cx = stage_context<BIG, 1>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  if (pi.skip) return;   // (tested here: the loads behind `pi` travel with those of the context instead of before them)
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   for (int t = tid; t < 4 * CS + nt + 2; t += kThreads) lds[t] = 0.;
