@@ -393,6 +393,18 @@ __device__ __forceinline__ void for_block_items(int nv, int nq, int tid, int* cn
   __syncthreads();
 }
 
+// (record, tuple) of the work item w = x * nq + t without a division per work item: the kernels are bound by instruction
+// issue (SQ counters: the waves of a SIMD are active ~95 % of the time between them), and an integer division is ~25
+// instructions.  `step` advances by kThreads work items; q256 = kThreads / nq, r256 = kThreads % nq.
+struct WorkIdx {
+  int x, t;
+  __device__ __forceinline__ void step(int q256, int r256, int nq) {
+    x += q256;
+    t += r256;
+    if (t >= nq) { t -= nq; ++x; }
+  }
+};
+
 // Item records of the workgroup's cells in LDS (k4_in, k5_cyk: the by_outer order; k4_out stages its three roles the same
 // way inline): CSR range per cell -> prefix in LDS, then all lanes fetch the records of [p0, p0 + cap) with one round of
 // loads.  meta = cell << 16 | position of the item in its cell; xw = exp(lambda_k tsc) for k = 0, 1 (0 when the item is
@@ -686,6 +698,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
       const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
       outer_stage<true>(v, R, p0, np, nc, tid, pre, base);
       const int total = np * nq;
+      const int nqd = nq > 0 ? nq : 1, q256 = kThreads / nqd, r256 = kThreads % nqd;
+      WorkIdx wi{tid / nqd, tid % nqd};
       for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
         double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], xw[kItemBatch];
         int hidx[kItemBatch];
@@ -694,8 +708,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
         for (int u = 0; u < kItemBatch; ++u) {
           const int w = w0 + u * kThreads;
           ok[u] = w < total;
-          const int wc = ok[u] ? w : total - 1;
-          const int x = wc / nq, t = wc - x * nq;
+          const int x = ok[u] ? wi.x : np - 1, t = ok[u] ? wi.t : nq - 1;
+          wi.step(q256, r256, nqd);
           const LoopItem it = R.it[x];
           const int c = (R.meta[x] >> 16) & 0x7fff;
           const int i = i0 + c, j = i + d;
@@ -1286,6 +1300,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       __syncthreads();
       pc.mark<8>();
       const int total = np * nq;
+      const int nqd = nq > 0 ? nq : 1, q256 = kThreads / nqd, r256 = kThreads % nqd;
+      WorkIdx wi{tid / nqd, tid % nqd};
       for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
         LoopItem it[kItemBatch];
         double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], xw[kItemBatch], aux[kItemBatch];
@@ -1295,8 +1311,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         for (int u = 0; u < kItemBatch; ++u) {
           const int w = w0 + u * kThreads;
           ok[u] = w < total;
-          const int wc = ok[u] ? w : total - 1;
-          const int x = wc / nq, t = wc - x * nq;
+          const int x = ok[u] ? wi.x : np - 1, t = ok[u] ? wi.t : nq - 1;
+          wi.step(q256, r256, nqd);
           const int role = r_meta[x] >> 16, c = r_meta[x] & 0xffff;
           it[u] = r_it[x];
           const int ent = (role == 0 ? A.quad1_ent : role == 1 ? A.quad2_ent : A.quad3_ent) + 3 * t;
@@ -1515,6 +1531,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
         const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
         if (sweep == 0 || n_rec > R.cap) outer_stage<false>(v, R, p0, np, nc, tid, pre, base);
         const int total = np * nq;
+        const int nqd = nq > 0 ? nq : 1, q256 = kThreads / nqd, r256 = kThreads % nqd;
+        WorkIdx wi{tid / nqd, tid % nqd};
         for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
           double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], lt[kItemBatch];
           int hidx[kItemBatch];
@@ -1524,8 +1542,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
           for (int u = 0; u < kItemBatch; ++u) {
             const int w = w0 + u * kThreads;
             ok[u] = w < total;
-            const int wc = ok[u] ? w : total - 1;
-            const int x = wc / nq, t = wc - x * nq;
+            const int x = ok[u] ? wi.x : np - 1, t = ok[u] ? wi.t : nq - 1;
+            wi.step(q256, r256, nqd);
             const LoopItem it = R.it[x];
             const int meta = R.meta[x];
             const int c = (meta >> 16) & 0x7fff;
