@@ -1191,20 +1191,28 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       }
     }
   }
+  // Addresses of the staged rows as base + bb * stride (the kernels are bound by instruction issue: recomputing four table
+  // indices with their clamps per load was ~60 instructions per load).  Row of the parent span d + bb: one diagonal
+  // further per bb; the H2 rows start one cell earlier per bb.  A lane whose parent leaves [0, L] reads offset 0 of the
+  // same rows (inside the plane) and stores 0.
+  const uint32_t dstride = (uint32_t)(L + 1) * (uint32_t)S;
+  const int li = i0 + ((tid < ncS) ? tid / S : 0);
+  const int b1max = L - li - d, b2max = li;   // ok1 <=> bb <= b1max, ok2 <=> bb <= b2max
+  const double* pOB = out.band + out.idx(ST_B, d, i0, 0) + ((tid < ncS) ? tid : 0);
+  const double* pI2 = in.band + in.idx(ST_2, 0, i0 + d, 0) + ((tid < ncS) ? tid : 0);
+  const double* pI1 = in.band + in.idx(ST_1, 0, i0, 0) + ((tid < ncS) ? tid : 0);
   for (int b0 = 1; b0 <= bmax; b0 += kChunkOut) {
     const int kc = (kChunkOut < bmax - b0 + 1) ? kChunkOut : bmax - b0 + 1;
     if (tid < ncS) {
-      const int i = i0 + tid / S;
 #pragma unroll
       for (int u = 0; u < kChunkOut; ++u) {
-        const int bb = b0 + ((u < kc) ? u : 0);
-        const bool ok1 = u < kc && i + d + bb <= L, ok2 = u < kc && i - bb >= 0;
-        const int ia = ok1 ? i0 : 0, ib = ok2 ? i0 - bb : 0;   // (clamped: the load itself must stay inside the plane)
-        const int r1 = ok1 ? tid : 0, r2 = ok2 ? tid : 0;
-        const double x1 = out.band[out.idx(ST_B, d + bb, ia, 0) + r1];
-        const double x2 = in.band[in.idx(ST_2, bb, ok1 ? i0 + d : 0, 0) + r1];
-        const double x3 = out.band[out.idx(ST_B, d + bb, ib, 0) + r2];
-        const double x4 = in.band[in.idx(ST_1, bb, ib, 0) + r2];
+        const int bb = b0 + u;
+        const bool ok1 = u < kc && bb <= b1max, ok2 = u < kc && bb <= b2max;
+        const uint32_t o1 = ok1 ? (uint32_t)bb * dstride : 0u, o2 = ok2 ? (uint32_t)bb * (dstride - (uint32_t)S) : 0u;
+        const double x1 = pOB[o1];
+        const double x2 = pI2[o1];
+        const double x3 = pOB[o2];
+        const double x4 = pI1[o2];
         sOB1[u * CS + tid] = ok1 ? x1 : 0.;
         sI2[u * CS + tid] = ok1 ? x2 : 0.;
         sOB2[u * CS + tid] = ok2 ? x3 : 0.;
