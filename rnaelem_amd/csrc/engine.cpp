@@ -64,9 +64,13 @@ class DevBuf {
   ~DevBuf() { reset(); }
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
+  // (an allocation that is large enough and at most twice too large is kept: fresh device memory costs ~20 ms / GB, and
+  // the plan sets of a load are rebuilt chunk after chunk with similar sizes; bytes() is the capacity)
   void alloc(size_t bytes) {
+    bytes = bytes ? bytes : 8;
+    if (p_ && bytes <= bytes_ && bytes_ <= 2 * bytes + (size_t(1) << 20)) return;
     reset();
-    bytes_ = bytes ? bytes : 8;
+    bytes_ = bytes;
     HIP_OK(hipMalloc(&p_, bytes_));
   }
   void reset() { if (p_) { (void)hipFree(p_); p_ = nullptr; bytes_ = 0; } }
@@ -398,7 +402,7 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   ps.count = count;
   ps.h.assign(h_plans_.begin() + first, h_plans_.begin() + first + count);
   int64_t dmin_b = 0, cell_b = 0, off_b = 0, bits_end = 0, ncell_max = 0;
-  int lmax = 0;
+  int lmax = 0, wmax1 = 0;
   for (auto& p : ps.h) {
     const int64_t nc = (int64_t)(p.L + 1) * (p.W + 1);
     p.dmin_base = dmin_b; p.cell_base = cell_b; p.off_base = off_b; p.item_base = 0; p.n_items = 0;
@@ -406,6 +410,7 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
     bits_end = std::max<int64_t>(bits_end, p.bits_base + (nc + 31) / 32);
     ncell_max = std::max(ncell_max, nc);
     lmax = std::max(lmax, (int)p.L);
+    wmax1 = std::max(wmax1, (int)p.W + 1);
   }
   DevBuf d_okbits_end;   // the pair mask by (end, span): scratch of the item enumeration
   d_okbits_end.alloc(sizeof(uint32_t) * (size_t)bits_end);
@@ -424,6 +429,7 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   a.ncell_max = (int32_t)ncell_max;
   a.n_roles = ps.inner_only ? 1 : 3;
   a.lmax = lmax;
+  a.wmax1 = wmax1;
   a.nword_max = (int32_t)((ncell_max + 31) / 32);
   a.plans = ps.d_plans.as<SeqPlan>();
   a.first = 0; a.count = count;
@@ -630,6 +636,8 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
     if (opt_keep_lnbpp_) h_lnbpp_base_.assign(n + 1, 0);
     int64_t cells_cap = 24LL * 1000 * 1000;
     int first = 0;
+    PlanSet tmp;   // (one set of buffers for all chunks: DevBuf::alloc keeps an allocation that is large enough)
+    tmp.inner_only = true;
     while (first < n) {
       int count = 0;
       int64_t cells = 0;
@@ -637,8 +645,6 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         cells += (int64_t)(h_plans_[first + count].L + 1) * (h_plans_[first + count].W + 1);
         ++count;
       }
-      PlanSet tmp;
-      tmp.inner_only = true;
       build_planset(tmp, first, count, d_okbits0_.as<uint32_t>());
       // table slots for S = 1, one per sequence of the chunk
       slot_override_ = count;

@@ -43,6 +43,7 @@ struct PlanKernelArgs {
   PlanArrays p;
   int32_t no_ene, min_span, fix_rss;
   int32_t ncell_max = 0, nword_max = 0, nitems_max = 0, lmax = 0;   // largest sequence of the set (grid sizes)
+  int32_t wmax1 = 0;     // largest W + 1 of the set
   int32_t n_roles = 3;   // 1: only the by_inner order (plan of the BPP filter)
 };
 

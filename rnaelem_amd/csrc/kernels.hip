@@ -240,9 +240,12 @@ __global__ __launch_bounds__(kThreads) void k_role_scatter(PlanKernelArgs a, int
 // segment, and the hundreds of items that share an empty loop cell (i, 0) are sorted by all lanes instead of one --
 // and writes the indices back.  CAP = LDS capacity in elements; a launch handles the rows with CAP_LO < n <= CAP, longer
 // rows (only with the BPP filter off on long sequences) fall back to a heapsort per segment in global memory.
-template <int CAP, int CAP_LO>
+template <int CAP, int CAP_LO, class KEY>
 __global__ __launch_bounds__(kThreads) void k_role_sort(PlanKernelArgs a, int role) {
-  __shared__ unsigned long long sv[CAP];
+  // KEY = uint32_t: cell in the top 6 bits, item index below (W + 1 <= 64 and fewer than 2^26 items per sequence: half the
+  // LDS, twice the workgroups per CU); uint64_t otherwise
+  constexpr int kShift = sizeof(KEY) == 4 ? 26 : 32;
+  __shared__ KEY sv[CAP];
   __shared__ int srow[1024 + 2];
   const SeqPlan p = a.plans[a.first + blockIdx.y];
   const int i = blockIdx.x, W1 = p.W + 1;
@@ -282,14 +285,14 @@ __global__ __launch_bounds__(kThreads) void k_role_sort(PlanKernelArgs a, int ro
   while (np < n) np <<= 1;
   __syncthreads();
   for (int x = tid; x < np; x += kThreads) {
-    unsigned long long e = ~0ull;
+    KEY e = (KEY)~(KEY)0;
     if (x < n) {
       int lo = 0, hi = W1 - 1;   // the cell whose segment holds position x: largest c with srow[c] <= x
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (srow[mid] <= x) lo = mid; else hi = mid - 1;
       }
-      e = ((unsigned long long)lo << 32) | (unsigned)ridx[row0 + x];
+      e = ((KEY)lo << kShift) | (KEY)(unsigned)ridx[row0 + x];
     }
     sv[x] = e;
   }
@@ -299,13 +302,13 @@ __global__ __launch_bounds__(kThreads) void k_role_sort(PlanKernelArgs a, int ro
       for (int x = tid; x < np; x += kThreads) {
         const int y = x ^ j;
         if (y > x) {
-          const unsigned long long u = sv[x], w = sv[y];
+          const KEY u = sv[x], w = sv[y];
           if ((u > w) == ((x & k) == 0)) { sv[x] = w; sv[y] = u; }
         }
       }
       __syncthreads();
     }
-  for (int x = tid; x < n; x += kThreads) ridx[row0 + x] = (int32_t)(unsigned)sv[x];
+  for (int x = tid; x < n; x += kThreads) ridx[row0 + x] = (int32_t)(sv[x] & (KEY)((((KEY)1) << kShift) - 1));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -728,6 +731,7 @@ hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
   if (a.count <= 0) return hipSuccess;
   const dim3 cells((a.ncell_max + 1 + kThreads - 1) / kThreads, a.count), items((a.nitems_max + kThreads - 1) / kThreads, a.count);
   const dim3 rows(a.lmax + 1, a.count);
+  const bool narrow = a.wmax1 <= 64 && a.nitems_max < (1 << 26);   // 32-bit sort keys (cell << 26 | item)
   hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, -1);
   hipLaunchKernelGGL(k_plan_fill, cells, dim3(kThreads), 0, st, a);
   for (int role = 0; role < a.n_roles; ++role) {
@@ -735,9 +739,15 @@ hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
     if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_count, items, dim3(kThreads), 0, st, a, role);
     hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, role);
     if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_scatter, items, dim3(kThreads), 0, st, a, role);
-    hipLaunchKernelGGL((k_role_sort<512, 0>), rows, dim3(kThreads), 0, st, a, role);
-    hipLaunchKernelGGL((k_role_sort<2048, 512>), rows, dim3(kThreads), 0, st, a, role);
-    hipLaunchKernelGGL((k_role_sort<8192, 2048>), rows, dim3(kThreads), 0, st, a, role);
+    if (narrow) {
+      hipLaunchKernelGGL((k_role_sort<512, 0, uint32_t>), rows, dim3(kThreads), 0, st, a, role);
+      hipLaunchKernelGGL((k_role_sort<2048, 512, uint32_t>), rows, dim3(kThreads), 0, st, a, role);
+      hipLaunchKernelGGL((k_role_sort<8192, 2048, uint32_t>), rows, dim3(kThreads), 0, st, a, role);
+    } else {
+      hipLaunchKernelGGL((k_role_sort<512, 0, unsigned long long>), rows, dim3(kThreads), 0, st, a, role);
+      hipLaunchKernelGGL((k_role_sort<2048, 512, unsigned long long>), rows, dim3(kThreads), 0, st, a, role);
+      hipLaunchKernelGGL((k_role_sort<8192, 2048, unsigned long long>), rows, dim3(kThreads), 0, st, a, role);
+    }
   }
   return hipGetLastError();
 }
