@@ -231,6 +231,7 @@ class Engine {
   int opt_dbg_ = 0;        // timing experiments (LinArgs::dbg); results are wrong when set
   int opt_group_ = 0;      // sequences swept in lockstep by the batch pipeline (0 = auto)
   DevBuf d_prof_;
+  DevBuf d_bpp_band_in_, d_bpp_band_out_, d_bpp_ext_in_, d_bpp_ext_out_, d_bpp_tmp_;   // S = 1 tables of the BPP filter
  public:
   std::vector<long long> last_prof;
  private:
@@ -470,12 +471,15 @@ void Engine::ensure_slots(int S, bool scan, int n_want) {
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   const size_t per_slot = (band + ext) * 2 * sizeof(double) + (scan ? (band + ext) * sizeof(TraceRec) + 16 * (Lmax_ + 2) : 0);
   if (n_slots_ >= want && slots_S_ == S && band_stride_ == band && (slots_scan_ || !scan)) return;
-  d_band_in_.reset(); d_band_out_.reset(); d_ext_in_.reset(); d_ext_out_.reset(); d_tr_band_.reset(); d_tr_ext_.reset(); d_tmp_.reset();
-  d_tr_stack_.reset();
+  // (no reset: DevBuf::alloc keeps what is large enough -- a load_batch per evaluation must not re-allocate the tables; the
+  // trace tables of an earlier scan are given up only when the tables would not fit beside them)
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
-  const size_t budget = (size_t)((double)free_b * 0.6);
+  const size_t held_t = d_band_in_.bytes() + d_band_out_.bytes() + d_ext_in_.bytes() + d_ext_out_.bytes() + d_tmp_.bytes();
+  const size_t held_tr = d_tr_band_.bytes() + d_tr_ext_.bytes() + d_tr_stack_.bytes();
+  const size_t budget = (size_t)((double)(free_b + held_t + held_tr) * 0.6);
   if (per_slot * (size_t)want > budget) want = (int)std::max<size_t>(1, budget / per_slot);
-  if (per_slot * want > free_b) throw HipError("not enough device memory for one table slot");
+  if (!scan && per_slot * (size_t)want > free_b + held_t) { d_tr_band_.reset(); d_tr_ext_.reset(); d_tr_stack_.reset(); }
+  if (per_slot * want > free_b + held_t + held_tr) throw HipError("not enough device memory for one table slot");
   n_slots_ = want; slots_S_ = S; slots_scan_ = scan;
   band_stride_ = band; ext_stride_ = ext;
   d_band_in_.alloc(band * want * sizeof(double));
@@ -646,11 +650,16 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         ++count;
       }
       build_planset(tmp, first, count, d_okbits0_.as<uint32_t>());
-      // table slots for S = 1, one per sequence of the chunk
-      slot_override_ = count;
-      ensure_slots(1, false, count);
-      slot_override_ = 0;
-      if (n_slots_ < count) throw HipError("not enough device memory for the BPP filter tables");
+      // table slots for S = 1, one per sequence of the chunk: buffers of their own, so that the (much larger) slots of the
+      // evaluation pipelines survive a load_batch -- the mini-batch training mode loads before every evaluation
+      {
+        const size_t band1 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext1 = (size_t)(Lmax_ + 1);
+        d_bpp_band_in_.alloc(band1 * count * sizeof(double));
+        d_bpp_band_out_.alloc(band1 * count * sizeof(double));
+        d_bpp_ext_in_.alloc(ext1 * count * sizeof(double));
+        d_bpp_ext_out_.alloc(ext1 * count * sizeof(double));
+        d_bpp_tmp_.alloc(ext1 * 3 * count * sizeof(double));
+      }
       std::vector<int32_t> order(count);
       std::iota(order.begin(), order.end(), 0);
       std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return tmp.h[a2].L > tmp.h[b2].L; });
@@ -673,11 +682,11 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
       a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_zero_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>(); a.b.ndot = nullptr;
       a.okbits = d_okbits0_.as<uint32_t>();
       a.p = tmp.arrays();
-      a.band_in = d_band_in_.as<double>(); a.band_out = d_band_out_.as<double>();
-      a.ext_in = d_ext_in_.as<double>(); a.ext_out = d_ext_out_.as<double>();
+      a.band_in = d_bpp_band_in_.as<double>(); a.band_out = d_bpp_band_out_.as<double>();
+      a.ext_in = d_bpp_ext_in_.as<double>(); a.ext_out = d_bpp_ext_out_.as<double>();
       a.band_stride = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1);
       a.ext_stride = (size_t)(Lmax_ + 1);
-      a.tmp = d_tmp_.as<double>();
+      a.tmp = d_bpp_tmp_.as<double>();
       a.tmp_stride = a.ext_stride;
       a.seq_out = d_rows.as<double>();
       a.out_stride = stride;
@@ -702,7 +711,6 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
       }
       first += count;
     }
-    n_slots_ = 0;  // S = 1 slots are not reusable for the motif DP
   } else {
     for (auto& p : h_plans_) p.bpp_eff = 1.;  // 0 == min_BPP: nbp = total (energy_model.hpp:249-251)
   }

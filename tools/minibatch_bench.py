@@ -1,0 +1,28 @@
+"""Wall time per iteration of the default training mode (mini-batch of 64 + shuffled negatives, Adam).  args: n L iters"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from rnaelem_amd import api, synth, train
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+eng = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+seqs, quals = synth.synth_batch(n, L)
+t_load = [0.0]
+
+def ev_batch(s2, q2, x):
+    t0 = time.perf_counter()
+    eng.load_batch(s2, q2)
+    t_load[0] += time.perf_counter() - t0
+    return eng.train_eval(x) + (eng.seq_stats()[:, 4] != 0,)
+
+ev = train.MiniBatches(seqs, quals, 64, ev_batch, kmer_shuf=2)
+x0 = eng.initial_params(0.0)
+rho = train.regularisation(len(x0), 0.1, 0.1)
+train.minimize_adam(ev, x0, rho, max_iter=3)
+t_load[0] = 0.0
+t0 = time.perf_counter()
+train.minimize_adam(ev, x0, rho, max_iter=iters)
+dt = time.perf_counter() - t0
+print("n=%d L=%d batch 64 + negatives: %.1f ms / iteration (%.1f ms in the two load_batch calls) -> %.0f seq/s" % (
+    n, L, dt / iters * 1e3, t_load[0] / iters * 1e3, 128 * iters / dt))
