@@ -105,6 +105,16 @@ __global__ __launch_bounds__(kThreads) void k3_in_u(TrArgs a) {
   inside_target_u<false>(v.m, v.q, v.in, c, d, i, s, HB, HE);
 }
 
+// ---- one-state automaton (the BPP filter): an exterior step has up to W candidate pairs and ONE state -- instead of one
+// lane walking them with a chain of dependent loads, the lanes of the first wave take one candidate each and the partial
+// log-sums meet in a butterfly (fixed order: deterministic).
+__device__ __forceinline__ void wave_lse_merge(LseAcc& a) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double m2 = __shfl_xor(a.m, off, 64), s2 = __shfl_xor(a.s, off, 64);
+    a.merge(m2, s2);
+  }
+}
+
 // ---- exterior chain of the inside pass + partition functions: one workgroup (128 lanes) per sequence
 __global__ __launch_bounds__(128) void k3_in_ext(TrArgs a) {
   Views v(a);
@@ -113,9 +123,33 @@ __global__ __launch_bounds__(128) void k3_in_ext(TrArgs a) {
   const Constraint c{-1, -1, 0};
   for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00) ? 0. : ELEMDP_NEG_INF;
   __syncthreads();
-  for (int j = 1; j <= v.q.L; ++j) {
-    for (int s = tid; s < S; s += 128) inside_ext_target<false>(v.m, v.q, v.in, c, j, s);
-    __syncthreads();
+  if (a.lay.S == 1) {   // (one state, one split tuple (0,0), one right transition 0 -> 0)
+    const ModelView& m = v.m;
+    const SeqView& q = v.q;
+    const double lam = m.lam(0);
+    const int tf = m.ints[m.lay.right_ent + 1];
+    for (int j = 1; j <= q.L; ++j) {
+      if (tid < 64) {
+        LseAcc acc;
+        const int i0 = (j - q.W > 0) ? j - q.W : 0;
+        for (int i = j - 1 - tid; i >= i0; i -= 64) {   // rule 7
+          const int d = j - i;
+          const bool ok = q.pair_ok(i, d);
+          const double t = q.e_ext[q.cell(i, ok ? d : 0)];
+          const double term = v.in.o(i, 0) + (v.in.at(ST_P, d, i, 0) + lam * t);
+          if (ok && t != ELEMDP_NEG_INF) acc.add(term);
+        }
+        if (tid == 0 && q.unp[j - 1]) acc.add(v.in.o(j - 1, 0) + w_right(m, q, 0, tf, j - 1));   // rule 8
+        wave_lse_merge(acc);
+        if (tid == 0) v.in.o(j, 0) = acc.value();
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int j = 1; j <= v.q.L; ++j) {
+      for (int s = tid; s < S; s += 128) inside_ext_target<false>(v.m, v.q, v.in, c, j, s);
+      __syncthreads();
+    }
   }
   if (tid == 0) {
     const double Zo = part_func(v.m, v.in, true, true), Za = part_func(v.m, v.in, true, false),
@@ -194,9 +228,34 @@ __global__ __launch_bounds__(128) void k3_out_ext(TrArgs a) {
     v.out.o(v.q.L, s) = t;
   }
   __syncthreads();
-  for (int i = v.q.L - 1; i >= 0; --i) {
-    for (int s = tid; s < S; s += 128) outside_ext_target<MODE>(x, i, s);
-    __syncthreads();
+  if (MODE == OUT_NONE && a.lay.S == 1) {   // (BPP filter: no statistics, one state, tuple (0,0))
+    const ModelView& m = v.m;
+    const SeqView& q = v.q;
+    const double lam = m.lam(0);
+    const int tf = m.ints[m.lay.rright_ent + 1];
+    for (int i = q.L - 1; i >= 0; --i) {
+      if (tid < 64) {
+        const double in_c = v.in.o(i, 0);
+        LseAcc acc;
+        const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+        for (int j = i + 1 + tid; j <= jmax; j += 64) {   // rule 7
+          const int d = j - i;
+          const bool ok = q.pair_ok(i, d);
+          const double t = q.e_ext[q.cell(i, ok ? d : 0)];
+          const double term = v.out.o(j, 0) + (v.in.at(ST_P, d, i, 0) + lam * t);
+          if (ok && t != ELEMDP_NEG_INF) acc.add(term);
+        }
+        if (tid == 0 && q.unp[i]) acc.add(v.out.o(i + 1, 0) + w_right(m, q, 0, tf, i));   // rule 8
+        wave_lse_merge(acc);
+        if (tid == 0) v.out.o(i, 0) = (in_c == ELEMDP_NEG_INF) ? ELEMDP_NEG_INF : acc.value();
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int i = v.q.L - 1; i >= 0; --i) {
+      for (int s = tid; s < S; s += 128) outside_ext_target<MODE>(x, i, s);
+      __syncthreads();
+    }
   }
   if (MODE == OUT_TRAIN) flush_stats(a, v, pi, sink, l_en, l_eh);
 }
