@@ -132,13 +132,15 @@ class MiniBatches:
     `kmer_shuf` every record also gets its shuffled negative (seed = evaluation count, as in ShuffledNegatives).
 
     evaluate_batch(seqs, quals, x) -> (fn, gr, sum_eff, n_skipped, skipped flags per sequence); or `pairs`: a
-    distributed.ShardedPairs that evaluates a batch and its negatives over several ranks (then evaluate_batch is unused)."""
+    distributed.ShardedPairs that evaluates a batch and its negatives over several ranks (then evaluate_batch is unused);
+    `evaluate_joint(seqs, quals, x, n_records) -> (fn, gr, sum_eff of the records, n_skipped, skipped flags)`: optional,
+    one evaluation of records + negatives together."""
 
-    def __init__(self, seqs, quals, batch, evaluate_batch, kmer_shuf=None, pairs=None):
+    def __init__(self, seqs, quals, batch, evaluate_batch, kmer_shuf=None, pairs=None, evaluate_joint=None):
         from .api import epoch_permutation, kmer_shuffle
         self._perm, self._shuffle = epoch_permutation, kmer_shuffle
         self.seqs, self.quals, self.batch = seqs, quals, batch if batch > 0 else len(seqs)
-        self.evaluate_batch, self.k, self.pairs = evaluate_batch, kmer_shuf, pairs
+        self.evaluate_batch, self.k, self.pairs, self.evaluate_joint = evaluate_batch, kmer_shuf, pairs, evaluate_joint
         self.order, self.pos, self.n_shuffles, self.count = list(range(len(seqs))), 0, 0, 0
 
     def __call__(self, x):
@@ -158,6 +160,16 @@ class MiniBatches:
             res = self.pairs(x, self.count)
             self.count += 1
             return res
+        if self.k is not None and self.evaluate_joint is not None:
+            # records and their negatives as ONE batch (a mini-batch evaluation is bound by launch latencies, not by the
+            # number of sequences: half the loads and evaluations).  A negative belongs in the sum only if its record was
+            # not skipped (non-finite Z: rare) -- then the two-step evaluation below is the answer.
+            negs = [self._shuffle(s, self.k, self.count) for s in s1]
+            nq = [np.r_[np.zeros(len(s), dtype=np.uint8), np.uint8(1)] for s in negs]
+            fn, gr, eff, nsk, skipped = self.evaluate_joint(s1 + negs, q1 + nq, x, len(s1))
+            if not np.any(skipped[:len(s1)]):
+                self.count += 1
+                return fn, gr, eff, nsk
         fn, gr, eff, nsk, skipped = self.evaluate_batch(s1, q1, x)
         if self.k is not None:
             negs = [self._shuffle(s, self.k, self.count) for s, sk in zip(s1, skipped) if not sk]
