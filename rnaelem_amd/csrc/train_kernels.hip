@@ -108,11 +108,16 @@ __global__ __launch_bounds__(kThreads) void k3_in_u(TrArgs a) {
 // ---- one-state automaton (the BPP filter): an exterior step has up to W candidate pairs and ONE state -- instead of one
 // lane walking them with a chain of dependent loads, the lanes of the first wave take one candidate each and the partial
 // log-sums meet in a butterfly (fixed order: deterministic).
+template <int LANES = 64>
 __device__ __forceinline__ void wave_lse_merge(LseAcc& a) {
-  for (int off = 32; off > 0; off >>= 1) {
-    const double m2 = __shfl_xor(a.m, off, 64), s2 = __shfl_xor(a.s, off, 64);
-    a.merge(m2, s2);
-  }
+  // log of the sum over a group of LANES lanes: group maximum, ONE exponential per lane, group sum (butterflies: every
+  // lane gets the result, in a fixed order)
+  double mx = a.m;
+  for (int off = LANES / 2; off > 0; off >>= 1) { const double o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
+  double sc = (a.m == ELEMDP_NEG_INF) ? 0. : a.s * exp_neg(a.m - mx);
+  for (int off = LANES / 2; off > 0; off >>= 1) sc += __shfl_xor(sc, off, 64);
+  a.m = mx;
+  a.s = (mx == ELEMDP_NEG_INF) ? 0. : sc;
 }
 
 // ---- exterior chain of the inside pass + partition functions: one workgroup (128 lanes) per sequence
@@ -260,6 +265,96 @@ __global__ __launch_bounds__(128) void k3_out_ext(TrArgs a) {
   if (MODE == OUT_TRAIN) flush_stats(a, v, pi, sink, l_en, l_eh);
 }
 
+// ---- BPP filter on small batches (the mini-batch training mode loads 64-128 sequences per evaluation): with one lane
+// per cell a launch lasts as long as its longest chain of dependent loads (~100 split points / items); here a group of
+// kBppLanes lanes takes a cell, its lanes the split points / items, and the partial log-sums meet in a butterfly.  Same sums, another (fixed)
+// order.  One state, one tuple per list.
+constexpr int kBppLanes = 16;   // lanes per cell (a wave takes 64 / kBppLanes cells)
+__global__ __launch_bounds__(kThreads) void k3_bpp_in_wave(TrArgs a) {
+  Views v(a);
+  make_views(a, blockIdx.y, v);
+  const ModelView& m = v.m;
+  const SeqView& q = v.q;
+  const int d = a.d, lane = threadIdx.x % kBppLanes;
+  if (d > q.W) return;
+  const int i = blockIdx.x * (kThreads / kBppLanes) + threadIdx.x / kBppLanes;
+  if (i > q.L - d) return;
+  const int j = i + d;
+  double HB = ELEMDP_NEG_INF, HE = ELEMDP_NEG_INF;
+  if (q.left_ok(i, d)) {   // rule 2 (uniform per wave)
+    LseAcc acc;
+    for (int k = i + q.dmin[i] + lane; k < j; k += kBppLanes)
+      if (bif_valid(q, j, k)) acc.add(bif_term(v.in, i, j, k, 0, 0));
+    wave_lse_merge<kBppLanes>(acc);
+    HB = acc.value();
+  }
+  if (q.e_ok(i, d)) {      // rule 6c
+    LseAcc acc;
+    const double lam = m.lam(0);
+    const int c0 = q.by_outer_off[q.cell(i, d)], c1 = q.by_outer_off[q.cell(i, d) + 1];
+    for (int it = c0 + lane; it < c1; it += kBppLanes) {
+      const LoopItem x = q.items[it];
+      const double term = loop_term(v.in, i, j, x, 0, 0, 0, lam * x.tsc);
+      if (q.item_in[it]) acc.add(term);
+    }
+    wave_lse_merge<kBppLanes>(acc);
+    HE = acc.value();
+  }
+  if (lane == 0) inside_target_u<false>(m, q, v.in, Constraint{-1, -1, 0}, d, i, 0, HB, HE);
+}
+
+__global__ __launch_bounds__(kThreads) void k3_bpp_out_wave(TrArgs a) {
+  Views v(a);
+  make_views(a, blockIdx.y, v);
+  const PassInfo pi = pass_info(a, v);
+  const ModelView& m = v.m;
+  const SeqView& q = v.q;
+  const int d = a.d, lane = threadIdx.x % kBppLanes;
+  if (pi.skip || d > q.W) return;
+  const int i = blockIdx.x * (kThreads / kBppLanes) + threadIdx.x / kBppLanes;
+  if (i > q.L - d) return;
+  const int j = i + d;
+  GpuSink sink;
+  sink.en_ = nullptr;
+  sink.post_[0] = sink.post_[1] = sink.post_[2] = nullptr;
+  sink.eh0 = sink.eh1 = 0.;
+  OutCtx<GpuSink> x{m, q, v.in, v.out, pi.Z, Constraint{-1, -1, 0}, sink};
+  HeavyOut H;
+  H.H1 = H.H2 = H.HP = H.HL = ELEMDP_NEG_INF;
+  if (q.left_ok(i, d)) {
+    if (v.in.at(ST_1, d, i, 0) != ELEMDP_NEG_INF) {   // H1: parents B(i, jj), jj > j
+      LseAcc acc;
+      const int dj = q.dmin[j];
+      if (j < q.L && dj > 0) {
+        const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+        for (int jj = j + dj + lane; jj <= jmax; jj += kBppLanes) acc.add(o1_term(v.in, v.out, i, j, jj, 0, 0));
+      }
+      wave_lse_merge<kBppLanes>(acc);
+      H.H1 = acc.value();
+    }
+    if (v.in.at(ST_2, d, i, 0) != ELEMDP_NEG_INF) {   // H2: parents B(ii, j), ii < i
+      LseAcc acc;
+      const int imin = (j - q.W > 0) ? j - q.W : 0;
+      for (int ii = i - 1 - lane; ii >= imin; ii -= kBppLanes)
+        if (o2_valid(q, i, ii)) acc.add(o2_term(v.in, v.out, i, j, ii, 0, 0));
+      wave_lse_merge<kBppLanes>(acc);
+      H.H2 = acc.value();
+    }
+  }
+  if (q.pair_ok(i, d) && v.in.at(ST_P, d, i, 0) != ELEMDP_NEG_INF) {   // HP: the interior loops around the pair
+    LseAcc acc;
+    const double lam = m.lam(0);
+    const int pc = q.cell(i, d);
+    for (int n = q.by_inner_off[pc] + lane; n < q.by_inner_off[pc + 1]; n += kBppLanes) {
+      const LoopItem it = q.items[q.by_inner_idx[n]];
+      acc.add(oP_term(v.in, v.out, i, j, it, 0, 0, 0, lam * it.tsc));
+    }
+    wave_lse_merge<kBppLanes>(acc);
+    H.HP = acc.value();
+  }
+  if (lane == 0) outside_target_u<OUT_NONE>(x, d, i, 0, H);
+}
+
 // ---- outside, heavy sums of diagonal d
 __global__ __launch_bounds__(kThreads) void k3_out_heavy(TrArgs a) {
   __shared__ double scr[kWaves * 128];
@@ -396,11 +491,15 @@ hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax
   if (G <= 0) return hipSuccess;
   TrArgs a = base;
   a.restricted = 0;
+  // few sequences: a wave per cell (launch time = longest dependent chain); many: a lane per cell (fewer instructions)
+  const bool wave_cells = a.lay.S == 1 && (long long)G * (Lmax + 1) <= 64 * 1024;
+  const int cpbw = kThreads / kBppLanes;
   for (int d = 0; d <= Wmax; ++d) {
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) break;
     a.d = d;
-    hipLaunchKernelGGL(k3_in_u<true>, dim3((ncell + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+    if (wave_cells) hipLaunchKernelGGL(k3_bpp_in_wave, dim3((ncell + cpbw - 1) / cpbw, G), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL(k3_in_u<true>, dim3((ncell + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
   }
   hipLaunchKernelGGL(k3_in_ext, dim3(G), dim3(128), 0, st, a);
   a.schedule = 1;   // "nasi only": terminal O(L, 0), Z = O(L, 0)
@@ -410,7 +509,8 @@ hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) continue;
     a.d = d;
-    hipLaunchKernelGGL((k3_out_u<true, OUT_NONE>), dim3((ncell + kThreads - 1) / kThreads, G), dim3(kThreads), sizeof(double) * 2, st, a);
+    if (wave_cells) hipLaunchKernelGGL(k3_bpp_out_wave, dim3((ncell + cpbw - 1) / cpbw, G), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL((k3_out_u<true, OUT_NONE>), dim3((ncell + kThreads - 1) / kThreads, G), dim3(kThreads), sizeof(double) * 2, st, a);
   }
   hipLaunchKernelGGL(k3_bpp_threshold, dim3(G), dim3(kThreads), 0, st, a, o);
   return hipGetLastError();
