@@ -491,8 +491,9 @@ hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax
   if (G <= 0) return hipSuccess;
   TrArgs a = base;
   a.restricted = 0;
-  // few sequences: a wave per cell (launch time = longest dependent chain); many: a lane per cell (fewer instructions)
-  const bool wave_cells = a.lay.S == 1 && (long long)G * (Lmax + 1) <= 64 * 1024;
+  // the one-state automaton of the filter: kBppLanes lanes per cell (measured faster than a lane per cell at 64 and at
+  // 5 000 sequences: 34 + 56 ms instead of 80 + 60 ms per 2 000 x L=300)
+  const bool wave_cells = a.lay.S == 1;
   const int cpbw = kThreads / kBppLanes;
   for (int d = 0; d <= Wmax; ++d) {
     const int ncell = Lmax - d + 1;
