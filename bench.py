@@ -70,24 +70,31 @@ def cpu_baseline(seqs, quals, x, n_theta):
             "sample": "%d of the %d sequences, 1 eval, %d threads (oracle port, BPP filter included)" % (sample, len(seqs), cores)}
 
 
-def scan_secondary(api, synth, device, n=2000, L=300, pattern="(.....)"):
+class ScanSecondary:
     """BASELINE's secondary metric on a bounded sample of the config-E shape: `elem scan` sequences / second (K4 + K5 sum
-    passes and the K6 Viterbi parse per sequence), steady state, plus the one-off load (BPP filter + plan) time."""
-    import gc
-    gc.collect()
-    eng = api.Engine(pattern, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
-    seqs, quals = synth.synth_batch(n, L)
-    t0 = time.perf_counter()
-    eng.load_batch(seqs, quals)
-    t_load = time.perf_counter() - t0
-    x = eng.initial_params(1.0)
-    eng.scan(x)                      # allocates the table and trace slots
-    t0 = time.perf_counter()
-    eng.scan(x)
-    dt = time.perf_counter() - t0
-    return {"metric": "scan seqs/sec", "value": n / dt, "unit": "seq/s", "load_s": t_load,
-            "with_load": n / (dt + t_load), "log_space_fallback_sequences": int(eng.last_timing()[2]),
-            "workload": "%d synthetic RNAs L=%d, pattern %s (S=%d), W=%d C=%d" % (n, L, pattern, eng.n_state, MAX_SPAN, MAX_ILOOP)}
+    passes and the K6 Viterbi parse per sequence), steady state, plus the one-off load (BPP filter + plan) time.  Two
+    phases around the main measurement, because device memory that another engine has just given back is slow to allocate
+    again: the load is timed BEFORE the main engine exists, the scans run AFTER it is gone (their slots are allocated by an
+    untimed first scan)."""
+
+    def __init__(self, api, synth, device, n=2000, L=300, pattern="(.....)"):
+        self.n, self.L, self.pattern = n, L, pattern
+        self.eng = api.Engine(pattern, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
+        seqs, quals = synth.synth_batch(n, L)
+        t0 = time.perf_counter()
+        self.eng.load_batch(seqs, quals)
+        self.t_load = time.perf_counter() - t0
+
+    def measure(self):
+        eng, n = self.eng, self.n
+        x = eng.initial_params(1.0)
+        eng.scan(x)                      # allocates the table and trace slots
+        t0 = time.perf_counter()
+        eng.scan(x)
+        dt = time.perf_counter() - t0
+        return {"metric": "scan seqs/sec", "value": n / dt, "unit": "seq/s", "load_s": self.t_load,
+                "with_load": n / (dt + self.t_load), "log_space_fallback_sequences": int(eng.last_timing()[2]),
+                "workload": "%d synthetic RNAs L=%d, pattern %s (S=%d), W=%d C=%d" % (n, self.L, self.pattern, eng.n_state, MAX_SPAN, MAX_ILOOP)}
 
 
 def main():
@@ -115,6 +122,7 @@ def main():
 
     from rnaelem_amd import api, synth
     from rnaelem_amd.distributed import ShardedTrainer
+    secondary = ScanSecondary(api, synth, local_rank) if (world == 1 and not args.no_secondary) else None
     eng = api.Engine(PATTERN, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, local_rank)
     seqs, quals = synth.synth_batch(args.n_seq, args.seq_len)
     x = eng.initial_params(1.0)
@@ -174,9 +182,11 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(seqs, quals, x, eng.n_param - 2)
-    if world == 1 and not args.no_secondary:
+    if secondary is not None:
         del trainer, eng
-        line["secondary"] = scan_secondary(api, synth, local_rank)
+        import gc
+        gc.collect()
+        line["secondary"] = secondary.measure()
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
