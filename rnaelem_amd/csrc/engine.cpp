@@ -190,6 +190,9 @@ class Engine {
   int device_ = 0, n_cu_ = 256;
   hipStream_t st_ = nullptr;
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t st2_ = nullptr;                 // second outside pass of the linear pipeline (launch_lin_group)
+  hipEvent_t ev2_[2] = {nullptr, nullptr};
+  bool opt_two_streams_ = true;
   DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_, d_lay_, d_lay0_, d_layr_, d_intsr_;
   std::vector<double> theta_;  // log-probabilities of the last evaluation (softmax Jacobian)
 
@@ -282,7 +285,9 @@ void Engine::init_device() {
   HIP_OK(hipGetDeviceProperties(&prop, device_));
   n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_OK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
   for (auto& e : ev_) HIP_OK(hipEventCreate(&e));
+  for (auto& e : ev2_) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   d_et_.alloc(sizeof(EnergyTables));
   HIP_OK(hipMemcpyAsync(d_et_.as<void>(), &et_, sizeof(EnergyTables), hipMemcpyHostToDevice, st_));
   d_ints_.upload(ints_, st_);
@@ -315,6 +320,8 @@ void Engine::init_device() {
 Engine::~Engine() {
   if (st_) (void)hipStreamSynchronize(st_);
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev2_) if (e) (void)hipEventDestroy(e);
+  if (st2_) (void)hipStreamDestroy(st2_);
   if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -323,6 +330,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "keep_lnbpp") opt_keep_lnbpp_ = v != 0;
   else if (key == "first_pass_only") opt_first_pass_only_ = v != 0;
   else if (key == "profile") opt_profile_ = v != 0;
+  else if (key == "two_streams") opt_two_streams_ = v != 0;
   else if (key == "pipeline") opt_pipeline_ = (int)v;
   else if (key == "group") opt_group_ = (int)v;
   else if (key == "schedule") opt_schedule_ = (int)v;
@@ -916,7 +924,8 @@ void Engine::run_lin_batch() {
     a.grp = c.grp = d_order_.as<int32_t>() + g0;
     a.plans_slot = c.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
     const int Lg = h_plans_[h_order_[g0]].L;
-    HIP_OK(launch_lin_group(a, c, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, st_));
+    HIP_OK(launch_lin_group(a, c, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, st_, opt_two_streams_ ? st2_ : nullptr, ev2_[0],
+                            ev2_[1]));
   }
   int32_t n_flagged = 0;
   HIP_OK(hipMemcpyAsync(&n_flagged, d_flagged_.as<void>(), sizeof(int32_t), hipMemcpyDeviceToHost, st_));

@@ -179,7 +179,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
 // scan: Viterbi parse (max-plus CYK with trace records, then traceback) of a group; uses band_in / ext_in as the CYK table
 hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipStream_t st);
 hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, int Lmax, int Wmax, bool first_pass_only,
-                            hipStream_t st);
+                            hipStream_t st, hipStream_t st2 = nullptr, hipEvent_t ev_in = nullptr, hipEvent_t ev_p1 = nullptr);
 hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax, int Wmax, hipStream_t st);
 hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hipStream_t st);
 

@@ -1724,7 +1724,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
 }
 
 hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, int Lmax, int Wmax, bool first_pass_only,
-                            hipStream_t st) {
+                            hipStream_t st, hipStream_t st2, hipEvent_t ev_in, hipEvent_t ev_p1) {
   if (G <= 0) return hipSuccess;
   LinArgs a = full;
   const int S = a.lay.S, nt = a.lay.n_theta;
@@ -1757,8 +1757,20 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
   if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, false>), dim3(G), dim3(128), lds_ext_in, st, a);
   else hipLaunchKernelGGL((k4_in_ext<false, false>), dim3(G), dim3(128), 0, st, a);
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1 && first_pass_only) break;
+  // schedule 1: the two outside passes are independent (ari-only on the full tables, nasi-only on the compact ones; both
+  // only read the inside tables) -- with a second stream the small second pass runs beside the first (it fills the gaps
+  // of a launch-latency-bound small batch; a large batch gains nothing and loses nothing)
+  const bool two_streams = st2 != nullptr && a.schedule == 1 && !first_pass_only && !a.tile;
+  if (two_streams) {
+    hipError_t e = hipEventRecord(ev_in, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st2, ev_in, 0);
+    if (e != hipSuccess) return e;
+  }
+  const hipStream_t st_main = st;
+  for (int turn = 0; turn < 2; ++turn) {
+    const int pass = two_streams ? 1 - turn : turn;
+    if (pass == 1 && first_pass_only) continue;
+    st = (two_streams && pass == 1) ? st2 : st_main;
     LinArgs b = (a.schedule == 1 && pass == 1) ? compact : a;
     b.pass = pass;
     b.cpb = kThreads / b.lay.S;
@@ -1797,6 +1809,12 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
         if (big_b) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
       }
+  }
+  st = st_main;
+  if (two_streams) {
+    hipError_t e = hipEventRecord(ev_p1, st2);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_p1, 0);
+    if (e != hipSuccess) return e;
   }
   if ((a.schedule == 1 || a.lik_ratio) && !first_pass_only) hipLaunchKernelGGL(k4_combine, dim3(G), dim3(kThreads), 0, st, a, G);
   return hipGetLastError();
