@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the scan measurement (BASELINE's secondary metric)")
+    ap.add_argument("--serial-passes", action="store_true",
+                    help="run the two outside passes on one stream (for kernel traces: with the second stream kernels overlap and "
+                         "their durations no longer add up to the pipeline time)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,6 +127,8 @@ def main():
     from rnaelem_amd.distributed import ShardedTrainer
     secondary = ScanSecondary(api, synth, local_rank) if (world == 1 and not args.no_secondary) else None
     eng = api.Engine(PATTERN, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, local_rank)
+    if args.serial_passes:
+        eng.set_option("two_streams", 0)
     seqs, quals = synth.synth_batch(args.n_seq, args.seq_len)
     x = eng.initial_params(1.0)
     t_load = time.time()
