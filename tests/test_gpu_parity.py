@@ -429,6 +429,38 @@ def test_long_sequences_take_the_unstaged_exterior_path():
         assert_log_close(recs[k]["end"], a["end"], rtol=1e-8, atol=1e-6, what="end")
 
 
+def test_sharded_evaluation_with_device_buffers_equals_the_single_engine_one():
+    """What bench.py / the command line do on N GPUs, on one: every "rank" keeps its contiguous share resident, writes its
+    partial sums into a torch CUDA buffer (elemdp_train_partial with a device pointer), the buffers are summed (the
+    all-reduce), and every rank finishes fn / gr from the sum."""
+    import torch
+    from rnaelem_amd.distributed import assigned_range
+    m = io.read_model(gpath("syn_b.model"))
+    recs = io.read_fastq(gpath("syn_L40_n3.fq")) + io.read_fastq(gpath("syn_L100_n3.fq")) + io.read_fastq(gpath("syn_L150_n8.fq"))
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    x = m["x"]
+    whole = io.engine_from_model(m)
+    whole.load_batch(seqs, quals)
+    ref = whole.train_eval(x)
+    world, total, engines = 3, None, []
+    for rank in range(world):
+        a, b = assigned_range(len(seqs), world, rank)
+        eng = io.engine_from_model(m)
+        eng.load_batch(seqs[a:b], quals[a:b])
+        buf = torch.zeros(eng.partial_len(), dtype=torch.float64, device="cuda")
+        eng.train_partial(x, device_ptr=buf.data_ptr())
+        torch.cuda.synchronize()
+        host = eng.train_partial(x)                              # the same vector through the host path
+        np.testing.assert_allclose(buf.cpu().numpy(), host, rtol=1e-12, atol=1e-14)
+        total = buf if total is None else total + buf
+        engines.append(eng)
+    for eng in engines:
+        fn, gr, eff, nsk = eng.train_finish(total.cpu().numpy())
+        assert fn == pytest.approx(ref[0], rel=1e-11)
+        np.testing.assert_allclose(gr, ref[1], rtol=1e-9, atol=1e-10)
+        assert eff == pytest.approx(ref[2], rel=1e-12) and nsk == ref[3]
+
+
 EVAL_LIK = gload("eval_lik.json")
 
 
