@@ -235,6 +235,8 @@ class Engine {
   int opt_group_ = 0;      // sequences swept in lockstep by the batch pipeline (0 = auto)
   DevBuf d_prof_;
   DevBuf d_bpp_band_in_, d_bpp_band_out_, d_bpp_ext_in_, d_bpp_ext_out_, d_bpp_tmp_;   // S = 1 tables of the BPP filter
+  PlanSet bpp_plan_;   // plan over the unfiltered mask, chunk by chunk (only the filter reads it)
+  DevBuf d_bpp_order_, d_bpp_rows_, d_bpp_kept_, d_okbits_end_, d_nitems_, d_plans_all_;   // scratch kept across loads
  public:
   std::vector<long long> last_prof;
  private:
@@ -421,13 +423,13 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
     lmax = std::max(lmax, (int)p.L);
     wmax1 = std::max(wmax1, (int)p.W + 1);
   }
-  DevBuf d_okbits_end;   // the pair mask by (end, span): scratch of the item enumeration
+  DevBuf& d_okbits_end = d_okbits_end_;   // the pair mask by (end, span): scratch of the item enumeration (kept across loads)
   d_okbits_end.alloc(sizeof(uint32_t) * (size_t)bits_end);
   ps.d_plans.upload(ps.h, st_);
   ps.dmin.alloc(sizeof(int16_t) * dmin_b);
   for (DevBuf* b : {&ps.e_stack, &ps.e_ext, &ps.e_ml, &ps.e_close, &ps.e_hp}) b->alloc(sizeof(double) * cell_b);
   for (DevBuf* b : {&ps.off_outer, &ps.off_inner, &ps.off_left, &ps.off_right, &ps.cursor}) b->alloc(sizeof(int32_t) * off_b);
-  DevBuf d_nitems;
+  DevBuf& d_nitems = d_nitems_;
   d_nitems.alloc(sizeof(int32_t) * count);
   PlanKernelArgs a;
   a.et = d_et_.as<EnergyTables>();
@@ -613,7 +615,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   d_okbits0_.alloc(sizeof(uint32_t) * bits_b);
   d_okbits1_.alloc(sizeof(uint32_t) * bits_b);
   d_ncanon_.alloc(sizeof(int32_t) * n);
-  DevBuf d_plans_all;
+  DevBuf& d_plans_all = d_plans_all_;
   d_plans_all.upload(h_plans_, st_);
   BatchArrays b;
   b.seq = d_seq_.as<uint8_t>(); b.ws = d_ws_.as<double>(); b.unp = d_unp_.as<uint8_t>(); b.ndot = nullptr;
@@ -648,8 +650,8 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
     if (opt_keep_lnbpp_) h_lnbpp_base_.assign(n + 1, 0);
     int64_t cells_cap = 24LL * 1000 * 1000;
     int first = 0;
-    PlanSet tmp;   // (one set of buffers for all chunks: DevBuf::alloc keeps an allocation that is large enough)
-    tmp.inner_only = true;
+    PlanSet& tmp = bpp_plan_;   // (one set of buffers for all chunks and loads: DevBuf::alloc keeps what is large enough;
+    tmp.inner_only = true;      //  bounded by cells_cap: a few GB)
     while (first < n) {
       int count = 0;
       int64_t cells = 0;
@@ -671,7 +673,8 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
       std::vector<int32_t> order(count);
       std::iota(order.begin(), order.end(), 0);
       std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return tmp.h[a2].L > tmp.h[b2].L; });
-      DevBuf d_order, d_rows, d_kept, d_lnbpp;
+      DevBuf& d_order = d_bpp_order_; DevBuf& d_rows = d_bpp_rows_; DevBuf& d_kept = d_bpp_kept_;
+      DevBuf d_lnbpp;
       d_order.upload(order, st_);
       const int stride = 10;
       d_rows.alloc(sizeof(double) * stride * count);
