@@ -193,6 +193,9 @@ class Engine {
   hipStream_t st2_ = nullptr;                 // second outside pass of the linear pipeline (launch_lin_group)
   hipEvent_t ev2_[2] = {nullptr, nullptr};
   bool opt_two_streams_ = true;
+  hipStream_t st3_ = nullptr, st4_ = nullptr;   // the second of two concurrent groups (run_lin_batch) and its second pass
+  hipEvent_t ev3_[2] = {nullptr, nullptr}, ev4_[2] = {nullptr, nullptr};
+  int opt_group_streams_ = 2;
   DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_, d_lay_, d_lay0_, d_layr_, d_intsr_;
   std::vector<double> theta_;  // log-probabilities of the last evaluation (softmax Jacobian)
 
@@ -288,6 +291,10 @@ void Engine::init_device() {
   n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_OK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   HIP_OK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&st3_, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&st4_, hipStreamNonBlocking));
+  for (auto& e : ev3_) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto& e : ev4_) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : ev_) HIP_OK(hipEventCreate(&e));
   for (auto& e : ev2_) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   d_et_.alloc(sizeof(EnergyTables));
@@ -324,6 +331,10 @@ Engine::~Engine() {
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
   for (auto& e : ev2_) if (e) (void)hipEventDestroy(e);
   if (st2_) (void)hipStreamDestroy(st2_);
+  for (auto& e : ev3_) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev4_) if (e) (void)hipEventDestroy(e);
+  if (st3_) (void)hipStreamDestroy(st3_);
+  if (st4_) (void)hipStreamDestroy(st4_);
   if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -333,6 +344,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "first_pass_only") opt_first_pass_only_ = v != 0;
   else if (key == "profile") opt_profile_ = v != 0;
   else if (key == "two_streams") opt_two_streams_ = v != 0;
+  else if (key == "group_streams") opt_group_streams_ = (int)v;
   else if (key == "pipeline") opt_pipeline_ = (int)v;
   else if (key == "group") opt_group_ = (int)v;
   else if (key == "schedule") opt_schedule_ = (int)v;
@@ -922,13 +934,40 @@ void Engine::run_lin_batch() {
   HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
   HIP_OK(hipEventRecord(ev_[1], st_));
   lin_weights();
-  for (int g0 = 0; g0 < n_seq_; g0 += gsz) {
-    const int G = std::min(gsz, n_seq_ - g0);
-    a.grp = c.grp = d_order_.as<int32_t>() + g0;
-    a.plans_slot = c.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
+  // Two groups at a time, each on its own pair of streams and its own half of the table slots: the serial parts of a
+  // group (exterior chains, launch tails) run under the band kernels of the other.  (Not for a handful of sequences,
+  // whose tables debug_tables reads, nor under the phase profile.)
+  const int ns = (opt_group_streams_ >= 2 && n_seq_ >= 64 && n_slots_ >= 64 && !opt_profile_) ? 2 : 1;
+  const int slots_each = n_slots_ / ns;
+  const int n_groups = (n_seq_ + slots_each - 1) / slots_each;
+  const int gsz2 = (ns == 1) ? gsz : (n_seq_ + n_groups - 1) / n_groups;
+  auto shifted = [&](LinArgs x, size_t k) {   // the arguments of a group that uses the slots from k on
+    x.band_in += k * x.band_stride; x.band_out += k * x.band_stride;
+    x.ext_in += k * x.ext_stride; x.ext_out += k * x.ext_stride;
+    if (x.band_in0) x.band_in0 += k * x.band0_stride;
+    if (x.ext_in0) x.ext_in0 += k * x.ext0_stride;
+    x.zs += 4 * k;
+    if (x.part_in) { x.part_in += k * x.part_stride; x.part_h1 += k * x.part_stride; x.part_h2 += k * x.part_stride; }
+    return x;
+  };
+  if (ns == 2) {   // stream B starts behind the weights
+    HIP_OK(hipEventRecord(ev3_[0], st_));
+    HIP_OK(hipStreamWaitEvent(st3_, ev3_[0], 0));
+  }
+  int gi = 0;
+  for (int g0 = 0; g0 < n_seq_; g0 += gsz2, ++gi) {
+    const int G = std::min(gsz2, n_seq_ - g0);
+    const int k = gi % ns;
+    LinArgs ak = shifted(a, (size_t)k * slots_each), ck = shifted(c, (size_t)k * slots_each);
+    ak.grp = ck.grp = d_order_.as<int32_t>() + g0;
+    ak.plans_slot = ck.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
     const int Lg = h_plans_[h_order_[g0]].L;
-    HIP_OK(launch_lin_group(a, c, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, st_, opt_two_streams_ ? st2_ : nullptr, ev2_[0],
-                            ev2_[1]));
+    HIP_OK(launch_lin_group(ak, ck, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, k == 0 ? st_ : st3_,
+                            opt_two_streams_ ? (k == 0 ? st2_ : st4_) : nullptr, k == 0 ? ev2_[0] : ev4_[0], k == 0 ? ev2_[1] : ev4_[1]));
+  }
+  if (ns == 2) {   // ... and the main stream continues behind stream B
+    HIP_OK(hipEventRecord(ev3_[1], st3_));
+    HIP_OK(hipStreamWaitEvent(st_, ev3_[1], 0));
   }
   int32_t n_flagged = 0;
   HIP_OK(hipMemcpyAsync(&n_flagged, d_flagged_.as<void>(), sizeof(int32_t), hipMemcpyDeviceToHost, st_));
