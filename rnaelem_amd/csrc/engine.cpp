@@ -1198,24 +1198,47 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
     a.trace_stack = d_tr_stack_.as<int32_t>(); a.trace_stack_stride = stack_stride;
     a.sc_psihat = d_psi.as<int32_t>(); a.sc_rss = d_rss.as<char>();
     const bool cyk_on_batch = !(opt_dbg_ & 64);
-    for (int g0 = 0; g0 < n; g0 += gsz) {
-      const int G = std::min(gsz, n - g0);
-      a.grp = d_order_.as<int32_t>() + g0;
-      a.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
+    // two groups at a time (as in run_lin_batch): each on its own stream, with its half of the table and trace slots -- the
+    // five exterior chains of a group run under the band kernels of the other
+    const int ns = (opt_group_streams_ >= 2 && n >= 128 && n_slots_ >= 128 && tr_slots >= 2) ? 2 : 1;
+    const int slots_each = n_slots_ / ns, tr_each = tr_slots / ns;
+    const int n_groups = (n + slots_each - 1) / slots_each;
+    const int gsz2 = (ns == 1) ? gsz : (n + n_groups - 1) / n_groups;
+    if (ns == 2) {
+      HIP_OK(hipEventRecord(ev3_[0], st_));
+      HIP_OK(hipStreamWaitEvent(st3_, ev3_[0], 0));
+    }
+    int gi = 0;
+    for (int g0 = 0; g0 < n; g0 += gsz2, ++gi) {
+      const int G = std::min(gsz2, n - g0);
+      const int k = gi % ns;
+      hipStream_t st = (k == 0) ? st_ : st3_;
+      LinArgs ak = a;
+      ak.band_in += (size_t)k * slots_each * a.band_stride; ak.band_out += (size_t)k * slots_each * a.band_stride;
+      ak.ext_in += (size_t)k * slots_each * a.ext_stride; ak.ext_out += (size_t)k * slots_each * a.ext_stride;
+      ak.zs += 4 * (size_t)k * slots_each;
+      ak.tr_band += (size_t)k * tr_each * a.band_stride; ak.tr_ext += (size_t)k * tr_each * a.ext_stride;
+      ak.trace_stack += (size_t)k * tr_each * stack_stride;
+      ak.grp = d_order_.as<int32_t>() + g0;
+      ak.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
       const int Lg = h_plans_[h_order_[g0]].L;
-      HIP_OK(launch_lin_scan_group(a, G, Lg, std::min(Lg, max_span_), 0, st_));
-      HIP_OK(launch_lin_scan_group(a, G, Lg, std::min(Lg, max_span_), 1, st_));
+      HIP_OK(launch_lin_scan_group(ak, G, Lg, std::min(Lg, max_span_), 0, st));
+      HIP_OK(launch_lin_scan_group(ak, G, Lg, std::min(Lg, max_span_), 1, st));
       if (cyk_on_batch)
-        for (int r0 = 0; r0 < G; r0 += tr_slots) {   // K6 on the tables of slots [r0, r0 + R)
-          const int R = std::min(tr_slots, G - r0);
-          LinArgs c = a;
-          c.grp = a.grp + r0;
-          c.plans_slot = a.plans_slot + r0;
-          c.band_in = a.band_in + (size_t)r0 * a.band_stride;
-          c.ext_in = a.ext_in + (size_t)r0 * a.ext_stride;
+        for (int r0 = 0; r0 < G; r0 += tr_each) {   // K6 on the tables of slots [r0, r0 + R)
+          const int R = std::min(tr_each, G - r0);
+          LinArgs c = ak;
+          c.grp = ak.grp + r0;
+          c.plans_slot = ak.plans_slot + r0;
+          c.band_in = ak.band_in + (size_t)r0 * a.band_stride;
+          c.ext_in = ak.ext_in + (size_t)r0 * a.ext_stride;
           const int Lr = h_plans_[h_order_[g0 + r0]].L;
-          HIP_OK(launch_cyk_group(c, R, Lr, std::min(Lr, max_span_), st_));
+          HIP_OK(launch_cyk_group(c, R, Lr, std::min(Lr, max_span_), st));
         }
+    }
+    if (ns == 2) {
+      HIP_OK(hipEventRecord(ev3_[1], st3_));
+      HIP_OK(hipStreamWaitEvent(st_, ev3_[1], 0));
     }
     cyk_done = cyk_on_batch;
     dbg_lap("scan: launches queued");
