@@ -136,8 +136,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the scan measurement (BASELINE's secondary metric)")
     ap.add_argument("--serial-passes", action="store_true",
-                    help="run the two outside passes on one stream (for kernel traces: with the second stream kernels overlap and "
-                         "their durations no longer add up to the pipeline time)")
+                    help="everything on one stream (for kernel traces: with concurrent streams kernels overlap and their durations no "
+                         "longer add up to the pipeline time)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +158,7 @@ def main():
     eng = api.Engine(PATTERN, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, local_rank)
     if args.serial_passes:
         eng.set_option("two_streams", 0)
+        eng.set_option("group_streams", 1)
     seqs, quals = synth.synth_batch(args.n_seq, args.seq_len)
     x = eng.initial_params(1.0)
     t_load = time.time()
