@@ -193,8 +193,10 @@ class Engine {
   hipStream_t st2_ = nullptr;                 // second outside pass of the linear pipeline (launch_lin_group)
   hipEvent_t ev2_[2] = {nullptr, nullptr};
   bool opt_two_streams_ = true;
-  hipStream_t st3_ = nullptr, st4_ = nullptr;   // the second of two concurrent groups (run_lin_batch) and its second pass
-  hipEvent_t ev3_[2] = {nullptr, nullptr}, ev4_[2] = {nullptr, nullptr};
+  // groups evaluated concurrently (run_lin_batch, scan): stream k of gs_ (gs_[0] = st_) with its second-pass stream gs2_[k]
+  static constexpr int kMaxGroupStreams = 4;
+  hipStream_t gs_[kMaxGroupStreams] = {nullptr, nullptr, nullptr, nullptr}, gs2_[kMaxGroupStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t gev_[kMaxGroupStreams][2] = {}, gdone_[kMaxGroupStreams] = {}, gstart_ = nullptr;
   int opt_group_streams_ = 2;
   DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_, d_lay_, d_lay0_, d_layr_, d_intsr_;
   std::vector<double> theta_;  // log-probabilities of the last evaluation (softmax Jacobian)
@@ -291,12 +293,19 @@ void Engine::init_device() {
   n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_OK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   HIP_OK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&st3_, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&st4_, hipStreamNonBlocking));
-  for (auto& e : ev3_) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto& e : ev4_) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  gs_[0] = st_; gs2_[0] = st2_;
+  for (int k = 1; k < kMaxGroupStreams; ++k) {
+    HIP_OK(hipStreamCreateWithFlags(&gs_[k], hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&gs2_[k], hipStreamNonBlocking));
+  }
+  for (int k = 0; k < kMaxGroupStreams; ++k) {
+    if (k) for (auto& e : gev_[k]) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&gdone_[k], hipEventDisableTiming));
+  }
+  HIP_OK(hipEventCreateWithFlags(&gstart_, hipEventDisableTiming));
   for (auto& e : ev_) HIP_OK(hipEventCreate(&e));
   for (auto& e : ev2_) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  gev_[0][0] = ev2_[0]; gev_[0][1] = ev2_[1];
   d_et_.alloc(sizeof(EnergyTables));
   HIP_OK(hipMemcpyAsync(d_et_.as<void>(), &et_, sizeof(EnergyTables), hipMemcpyHostToDevice, st_));
   d_ints_.upload(ints_, st_);
@@ -331,10 +340,13 @@ Engine::~Engine() {
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
   for (auto& e : ev2_) if (e) (void)hipEventDestroy(e);
   if (st2_) (void)hipStreamDestroy(st2_);
-  for (auto& e : ev3_) if (e) (void)hipEventDestroy(e);
-  for (auto& e : ev4_) if (e) (void)hipEventDestroy(e);
-  if (st3_) (void)hipStreamDestroy(st3_);
-  if (st4_) (void)hipStreamDestroy(st4_);
+  for (int k = 0; k < kMaxGroupStreams; ++k) {
+    if (k) for (auto& e : gev_[k]) if (e) (void)hipEventDestroy(e);
+    if (gdone_[k]) (void)hipEventDestroy(gdone_[k]);
+    if (k && gs_[k]) (void)hipStreamDestroy(gs_[k]);
+    if (k && gs2_[k]) (void)hipStreamDestroy(gs2_[k]);
+  }
+  if (gstart_) (void)hipEventDestroy(gstart_);
   if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -937,7 +949,7 @@ void Engine::run_lin_batch() {
   // Two groups at a time, each on its own pair of streams and its own half of the table slots: the serial parts of a
   // group (exterior chains, launch tails) run under the band kernels of the other.  (Not for a handful of sequences,
   // whose tables debug_tables reads, nor under the phase profile.)
-  const int ns = (opt_group_streams_ >= 2 && n_seq_ >= 64 && n_slots_ >= 64 && !opt_profile_) ? 2 : 1;
+  const int ns = (opt_group_streams_ >= 2 && n_seq_ >= 64 && n_slots_ >= 64 && !opt_profile_) ? std::min(opt_group_streams_, kMaxGroupStreams) : 1;
   const int slots_each = n_slots_ / ns;
   const int n_groups = (n_seq_ + slots_each - 1) / slots_each;
   const int gsz2 = (ns == 1) ? gsz : (n_seq_ + n_groups - 1) / n_groups;
@@ -950,9 +962,9 @@ void Engine::run_lin_batch() {
     if (x.part_in) { x.part_in += k * x.part_stride; x.part_h1 += k * x.part_stride; x.part_h2 += k * x.part_stride; }
     return x;
   };
-  if (ns == 2) {   // stream B starts behind the weights
-    HIP_OK(hipEventRecord(ev3_[0], st_));
-    HIP_OK(hipStreamWaitEvent(st3_, ev3_[0], 0));
+  if (ns > 1) {   // the other streams start behind the weights
+    HIP_OK(hipEventRecord(gstart_, st_));
+    for (int k = 1; k < ns; ++k) HIP_OK(hipStreamWaitEvent(gs_[k], gstart_, 0));
   }
   int gi = 0;
   for (int g0 = 0; g0 < n_seq_; g0 += gsz2, ++gi) {
@@ -962,12 +974,12 @@ void Engine::run_lin_batch() {
     ak.grp = ck.grp = d_order_.as<int32_t>() + g0;
     ak.plans_slot = ck.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
     const int Lg = h_plans_[h_order_[g0]].L;
-    HIP_OK(launch_lin_group(ak, ck, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, k == 0 ? st_ : st3_,
-                            opt_two_streams_ ? (k == 0 ? st2_ : st4_) : nullptr, k == 0 ? ev2_[0] : ev4_[0], k == 0 ? ev2_[1] : ev4_[1]));
+    HIP_OK(launch_lin_group(ak, ck, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, gs_[k], opt_two_streams_ ? gs2_[k] : nullptr,
+                            gev_[k][0], gev_[k][1]));
   }
-  if (ns == 2) {   // ... and the main stream continues behind stream B
-    HIP_OK(hipEventRecord(ev3_[1], st3_));
-    HIP_OK(hipStreamWaitEvent(st_, ev3_[1], 0));
+  for (int k = 1; k < ns; ++k) {   // ... and the main stream continues behind them
+    HIP_OK(hipEventRecord(gdone_[k], gs_[k]));
+    HIP_OK(hipStreamWaitEvent(st_, gdone_[k], 0));
   }
   int32_t n_flagged = 0;
   HIP_OK(hipMemcpyAsync(&n_flagged, d_flagged_.as<void>(), sizeof(int32_t), hipMemcpyDeviceToHost, st_));
@@ -1200,19 +1212,19 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
     const bool cyk_on_batch = !(opt_dbg_ & 64);
     // two groups at a time (as in run_lin_batch): each on its own stream, with its half of the table and trace slots -- the
     // five exterior chains of a group run under the band kernels of the other
-    const int ns = (opt_group_streams_ >= 2 && n >= 128 && n_slots_ >= 128 && tr_slots >= 2) ? 2 : 1;
+    const int ns = (opt_group_streams_ >= 2 && n >= 128 && n_slots_ >= 128 && tr_slots >= kMaxGroupStreams) ? std::min(opt_group_streams_, kMaxGroupStreams) : 1;
     const int slots_each = n_slots_ / ns, tr_each = tr_slots / ns;
     const int n_groups = (n + slots_each - 1) / slots_each;
     const int gsz2 = (ns == 1) ? gsz : (n + n_groups - 1) / n_groups;
-    if (ns == 2) {
-      HIP_OK(hipEventRecord(ev3_[0], st_));
-      HIP_OK(hipStreamWaitEvent(st3_, ev3_[0], 0));
+    if (ns > 1) {
+      HIP_OK(hipEventRecord(gstart_, st_));
+      for (int k = 1; k < ns; ++k) HIP_OK(hipStreamWaitEvent(gs_[k], gstart_, 0));
     }
     int gi = 0;
     for (int g0 = 0; g0 < n; g0 += gsz2, ++gi) {
       const int G = std::min(gsz2, n - g0);
       const int k = gi % ns;
-      hipStream_t st = (k == 0) ? st_ : st3_;
+      hipStream_t st = gs_[k];
       LinArgs ak = a;
       ak.band_in += (size_t)k * slots_each * a.band_stride; ak.band_out += (size_t)k * slots_each * a.band_stride;
       ak.ext_in += (size_t)k * slots_each * a.ext_stride; ak.ext_out += (size_t)k * slots_each * a.ext_stride;
@@ -1236,9 +1248,9 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
           HIP_OK(launch_cyk_group(c, R, Lr, std::min(Lr, max_span_), st));
         }
     }
-    if (ns == 2) {
-      HIP_OK(hipEventRecord(ev3_[1], st3_));
-      HIP_OK(hipStreamWaitEvent(st_, ev3_[1], 0));
+    for (int k = 1; k < ns; ++k) {
+      HIP_OK(hipEventRecord(gdone_[k], gs_[k]));
+      HIP_OK(hipStreamWaitEvent(st_, gdone_[k], 0));
     }
     cyk_done = cyk_on_batch;
     dbg_lap("scan: launches queued");

@@ -7,6 +7,8 @@ pattern = sys.argv[3] if len(sys.argv) > 3 else "((.*.))"
 eng = api.Engine(pattern, "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
 if len(sys.argv) > 5:
     eng.set_option("group", int(sys.argv[5]))
+if len(sys.argv) > 6:
+    eng.set_option("group_streams", int(sys.argv[6]))
 seqs, quals = synth.synth_batch(n, L)
 t0 = time.time(); eng.load_batch(seqs, quals); t1 = time.time()
 x = eng.initial_params(1.0)
