@@ -104,24 +104,17 @@ def minibatch_secondary(api, synth, device, n=2000, L=200, iters=12):
     eng = api.Engine(PATTERN, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
     seqs, quals = synth.synth_batch(n, L)
 
-    def ev_batch(s2, q2, x):
-        eng.load_batch(s2, q2)
-        return eng.train_eval(x) + (eng.seq_stats()[:, 4] != 0,)
-
-    def ev_joint(s2, q2, x, n_rec):
-        eng.load_batch(s2, q2)
-        fn, gr, _, nsk = eng.train_eval(x)
-        skipped = eng.seq_stats()[:, 4] != 0
-        return fn, gr, float(eng.bpp_eff()[:n_rec][~skipped[:n_rec]].sum()), nsk, skipped
-
-    ev = train.MiniBatches(seqs, quals, 64, ev_batch, kmer_shuf=2, evaluate_joint=ev_joint)
+    eng2 = api.Engine(PATTERN, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
+    ev = train.MiniBatches(seqs, quals, 64, None, kmer_shuf=2, engines=[eng, eng2])   # (as rnaelem_amd.cli does)
     x0 = eng.initial_params(0.0)
     rho = train.regularisation(len(x0), 0.1, 0.1)
     train.minimize_adam(ev, x0, rho, max_iter=3)
     t0 = time.perf_counter()
     train.minimize_adam(ev, x0, rho, max_iter=iters)
     dt = time.perf_counter() - t0
+    ev._pending["thread"].join()
     eng.close()
+    eng2.close()
     return {"metric": "default-mode train iteration (64 records + 64 shuffled negatives, load + evaluation)", "value": dt / iters * 1e3,
             "unit": "ms", "seq_per_s": 128 * iters / dt, "workload": "%d synthetic RNAs L=%d, pattern %s" % (n, L, PATTERN)}
 

@@ -98,13 +98,9 @@ def cmd_train(a):
             eng.load_batch(s2, q2)
             return eng.train_eval(x) + (eng.seq_stats()[:, 4] != 0,)
 
-        def eval_joint(s2, q2, x, n_rec):
-            eng.load_batch(s2, q2)
-            fn, gr, _, nsk = eng.train_eval(x)
-            skipped = eng.seq_stats()[:, 4] != 0
-            return fn, gr, float(eng.bpp_eff()[:n_rec][~skipped[:n_rec]].sum()), nsk, skipped
-
-        ev = trainer.MiniBatches(seqs, quals, a.batch_size, eval_batch, None if a.no_shuffle else a.kmer_shuf, evaluate_joint=eval_joint)
+        eng2 = api.Engine(pattern, par, a.max_span, a.max_internal_loop, a.min_bpp, a.tau, flags, device)
+        # (double-buffered: the next batch loads on one engine while the other evaluates the current one)
+        ev = trainer.MiniBatches(seqs, quals, a.batch_size, eval_batch, None if a.no_shuffle else a.kmer_shuf, engines=[eng, eng2])
         optimizer = "lbfgsb" if a.no_shuffle else "adam"
     elif not a.no_shuffle:   # default `elem train`: Adam over positives + per-iteration shuffled negatives (main.cpp:132-152)
         neg = api.Engine(pattern, par, a.max_span, a.max_internal_loop, a.min_bpp, a.tau, flags, device)

@@ -134,16 +134,22 @@ class MiniBatches:
     evaluate_batch(seqs, quals, x) -> (fn, gr, sum_eff, n_skipped, skipped flags per sequence); or `pairs`: a
     distributed.ShardedPairs that evaluates a batch and its negatives over several ranks (then evaluate_batch is unused);
     `evaluate_joint(seqs, quals, x, n_records) -> (fn, gr, sum_eff of the records, n_skipped, skipped flags)`: optional,
-    one evaluation of records + negatives together."""
+    one evaluation of records + negatives together; `engines`: two api.Engine objects for the same (double-buffered:
+    the next batch loads on one while the other evaluates; then the callables are unused)."""
 
-    def __init__(self, seqs, quals, batch, evaluate_batch, kmer_shuf=None, pairs=None, evaluate_joint=None):
+    def __init__(self, seqs, quals, batch, evaluate_batch, kmer_shuf=None, pairs=None, evaluate_joint=None, engines=None):
         from .api import epoch_permutation, kmer_shuffle
         self._perm, self._shuffle = epoch_permutation, kmer_shuffle
         self.seqs, self.quals, self.batch = seqs, quals, batch if batch > 0 else len(seqs)
         self.evaluate_batch, self.k, self.pairs, self.evaluate_joint = evaluate_batch, kmer_shuf, pairs, evaluate_joint
         self.order, self.pos, self.n_shuffles, self.count = list(range(len(seqs))), 0, 0, 0
+        # `engines` = two api.Engine objects: the batch of the NEXT evaluation (records + negatives: neither depends on x) is
+        # loaded on one of them by a thread while the other evaluates the current one
+        self.engines = list(engines) if engines else None
+        self._pending = None
 
-    def __call__(self, x):
+    def _next_batch(self):
+        """advances the reader: (records, qualities, evaluation count) of the next evaluation"""
         n = len(self.seqs)
         if n - self.pos < self.batch:
             self.pos = n                                   # the partial last batch is skipped
@@ -154,30 +160,79 @@ class MiniBatches:
             self.pos = 0
         idx = self.order[self.pos:self.pos + self.batch]
         self.pos += self.batch
-        s1, q1 = [self.seqs[i] for i in idx], [self.quals[i] for i in idx]
+        c = self.count
+        self.count += 1
+        return [self.seqs[i] for i in idx], [self.quals[i] for i in idx], c
+
+    def _with_negatives(self, s1, q1, c):
+        negs = [self._shuffle(s, self.k, c) for s in s1]
+        return s1 + negs, q1 + [np.r_[np.zeros(len(s), dtype=np.uint8), np.uint8(1)] for s in negs]
+
+    def _prefetch(self, slot):
+        import threading
+        s1, q1, c = self._next_batch()
+        sa, qa = self._with_negatives(s1, q1, c) if self.k is not None else (s1, q1)
+        eng = self.engines[slot]
+        box = {}
+
+        def work():
+            try:
+                eng.load_batch(sa, qa)
+            except Exception as e:      # re-raised by the evaluation that needs the batch
+                box["error"] = e
+
+        th = threading.Thread(target=work)
+        th.start()
+        return dict(thread=th, box=box, s1=s1, q1=q1, c=c, slot=slot)
+
+    def _call_prefetched(self, x):
+        if self._pending is None:
+            self._pending = self._prefetch(0)
+        cur = self._pending
+        cur["thread"].join()
+        if "error" in cur["box"]:
+            raise cur["box"]["error"]
+        self._pending = self._prefetch(1 - cur["slot"])       # the next batch loads while this one is evaluated
+        eng, n_rec = self.engines[cur["slot"]], len(cur["s1"])
+        fn, gr, eff, nsk = eng.train_eval(x)
+        skipped = eng.seq_stats()[:, 4] != 0
+        if self.k is None:
+            return fn, gr, eff, nsk
+        if not np.any(skipped[:n_rec]):
+            return fn, gr, float(eng.bpp_eff()[:n_rec].sum()), nsk
+        # a record was skipped: its negative must be left out -- the two-step evaluation on the same engine
+        eng.load_batch(cur["s1"], cur["q1"])
+        fn, gr, eff, nsk = eng.train_eval(x)
+        sk = eng.seq_stats()[:, 4] != 0
+        negs = [self._shuffle(s, self.k, cur["c"]) for s, dead in zip(cur["s1"], sk) if not dead]
+        if negs:
+            eng.load_batch(negs, [np.r_[np.zeros(len(s), dtype=np.uint8), np.uint8(1)] for s in negs])
+            fn2, gr2, _, nsk2 = eng.train_eval(x)
+            fn, gr, nsk = fn + fn2, np.asarray(gr) + np.asarray(gr2), nsk + nsk2
+        return fn, gr, eff, nsk
+
+    def __call__(self, x):
+        if self.engines is not None:
+            return self._call_prefetched(x)
+        s1, q1, c = self._next_batch()
         if self.pairs is not None:
             self.pairs.load(s1, q1)
-            res = self.pairs(x, self.count)
-            self.count += 1
-            return res
+            return self.pairs(x, c)
         if self.k is not None and self.evaluate_joint is not None:
             # records and their negatives as ONE batch (a mini-batch evaluation is bound by launch latencies, not by the
             # number of sequences: half the loads and evaluations).  A negative belongs in the sum only if its record was
             # not skipped (non-finite Z: rare) -- then the two-step evaluation below is the answer.
-            negs = [self._shuffle(s, self.k, self.count) for s in s1]
-            nq = [np.r_[np.zeros(len(s), dtype=np.uint8), np.uint8(1)] for s in negs]
-            fn, gr, eff, nsk, skipped = self.evaluate_joint(s1 + negs, q1 + nq, x, len(s1))
+            sa, qa = self._with_negatives(s1, q1, c)
+            fn, gr, eff, nsk, skipped = self.evaluate_joint(sa, qa, x, len(s1))
             if not np.any(skipped[:len(s1)]):
-                self.count += 1
                 return fn, gr, eff, nsk
         fn, gr, eff, nsk, skipped = self.evaluate_batch(s1, q1, x)
         if self.k is not None:
-            negs = [self._shuffle(s, self.k, self.count) for s, sk in zip(s1, skipped) if not sk]
+            negs = [self._shuffle(s, self.k, c) for s, sk in zip(s1, skipped) if not sk]
             if negs:
                 quals = [np.r_[np.zeros(len(s), dtype=np.uint8), np.uint8(1)] for s in negs]
                 fn2, gr2, _, nsk2, _ = self.evaluate_batch(negs, quals, x)
                 fn, gr, nsk = fn + fn2, np.asarray(gr) + np.asarray(gr2), nsk + nsk2
-        self.count += 1
         return fn, gr, eff, nsk
 
 

@@ -24,7 +24,11 @@ def ev_joint(s2, q2, x, n_rec):
     skipped = eng.seq_stats()[:, 4] != 0
     return fn, gr, float(eng.bpp_eff()[:n_rec][~skipped[:n_rec]].sum()), nsk, skipped
 
-ev = train.MiniBatches(seqs, quals, 64, ev_batch, kmer_shuf=2, evaluate_joint=None if "--two-step" in sys.argv else ev_joint)
+if "--two-step" in sys.argv or "--joint" in sys.argv:
+    ev = train.MiniBatches(seqs, quals, 64, ev_batch, kmer_shuf=2, evaluate_joint=None if "--two-step" in sys.argv else ev_joint)
+else:   # the command line's way: two engines, the next batch loads while the current one is evaluated
+    eng2 = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+    ev = train.MiniBatches(seqs, quals, 64, None, kmer_shuf=2, engines=[eng, eng2])
 x0 = eng.initial_params(0.0)
 rho = train.regularisation(len(x0), 0.1, 0.1)
 train.minimize_adam(ev, x0, rho, max_iter=3)
