@@ -112,7 +112,7 @@ def minibatch_secondary(api, synth, device, n=2000, L=200, iters=12):
     t0 = time.perf_counter()
     train.minimize_adam(ev, x0, rho, max_iter=iters)
     dt = time.perf_counter() - t0
-    ev._pending["thread"].join()
+    ev.finish()
     eng.close()
     eng2.close()
     return {"metric": "default-mode train iteration (64 records + 64 shuffled negatives, load + evaluation)", "value": dt / iters * 1e3,

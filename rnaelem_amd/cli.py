@@ -112,6 +112,8 @@ def cmd_train(a):
         ev = trainer.ShuffledNegatives(seqs, eng.train_eval, lambda: eng.seq_stats()[:, 4] != 0, eval_neg, a.kmer_shuf)
         optimizer = "adam"
     res = trainer.train(ev, x0, a.rho_s if a.theta_softmax else a.rho_theta, a.rho_lambda, a.max_iter, a.epsilon, optimizer, log, vary)
+    if hasattr(ev, "finish"):
+        ev.finish()
     if rank == 0:
         d = eng.describe()
         rows, k = [], 0

@@ -185,6 +185,12 @@ class MiniBatches:
         th.start()
         return dict(thread=th, box=box, s1=s1, q1=q1, c=c, slot=slot)
 
+    def finish(self):
+        """waits for the batch that was prefetched for an evaluation that never came (call before the engines go away)"""
+        if self._pending is not None:
+            self._pending["thread"].join()
+            self._pending = None
+
     def _call_prefetched(self, x):
         if self._pending is None:
             self._pending = self._prefetch(0)

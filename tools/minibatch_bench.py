@@ -36,5 +36,7 @@ t_load[0] = 0.0
 t0 = time.perf_counter()
 train.minimize_adam(ev, x0, rho, max_iter=iters)
 dt = time.perf_counter() - t0
+if hasattr(ev, "finish"):
+    ev.finish()
 print("n=%d L=%d batch 64 + negatives: %.1f ms / iteration (%.1f ms in the two load_batch calls) -> %.0f seq/s" % (
     n, L, dt / iters * 1e3, t_load[0] / iters * 1e3, 128 * iters / dt))
