@@ -2,7 +2,7 @@
 """Generate tests/golden/* from the compiled reference (oracle/_ref).  Runs only where
 /root/reference exists (build container); the GPU box uses the committed fixtures.
 
-    make -C oracle ref && python tools/make_golden.py
+    make -C oracle ref && python tests/golden/make_golden.py
 
 Fixtures are data only: copies of the reference's own test *data* files (0.fq, 1.fq, {0..3}.model,
 the `ubox` lines of 1.0.ps, material/positive.fa) and outputs of the reference run on stated inputs.
@@ -17,7 +17,7 @@ import sys
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from rnaelem_amd import synth  # noqa: E402
 

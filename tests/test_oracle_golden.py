@@ -1,6 +1,6 @@
 """Pins the CPU oracle (oracle/elem_oracle.cpp) against the reference.
 
-Sources of truth, all committed under tests/golden/ (generator: tools/make_golden.py):
+Sources of truth, all committed under tests/golden/ (generator: tests/golden/make_golden.py):
   * the reference's own known-answer tests: PATH_COUNT / EMISSION_COUNT (RNAelem-test/test.cpp:88-203),
     BPP_RNAFOLD (test-exact.cpp:86-138, RNAfold 2.3.1 dot plot), FastqIO (test-exact.cpp:38-52);
   * outputs of the compiled reference (oracle/_ref) on stated inputs: automata, energy tables,
