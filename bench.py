@@ -12,6 +12,8 @@ over the N ranks (strong scaling, as the metric is quoted).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (a child `torch.distributed.run`,
+started before this process touches the GPU); under a launcher WORLD_SIZE must equal --gpus or the run is refused.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -39,12 +41,13 @@ def algorithmic_bytes_per_seq(L, S, W=MAX_SPAN):
 
 
 def cpu_baseline(seqs, quals, x, n_theta):
-    """Reference CPU path (oracle/_ref, kind 'reference') or the oracle port, on a bounded sample."""
+    """Reference CPU path (oracle/_ref, kind 'reference') or the oracle port, on bounded samples: all host cores, and one
+    thread (SURVEY.md section 8d asks for both)."""
     cores = len(os.sched_getaffinity(0))
-    sample = min(len(seqs), max(8, cores * 6))
     from rnaelem_amd import synth
     ref = os.path.join(REPO, "oracle", "_ref", "ref_dump")
-    if os.path.exists(ref):
+
+    def run_ref(sample, threads):
         with tempfile.TemporaryDirectory() as td:
             fq, mdl = os.path.join(td, "s.fq"), os.path.join(td, "m.model")
             synth.write_fastq(fq, seqs[:sample], quals[:sample])
@@ -56,44 +59,71 @@ def cpu_baseline(seqs, quals, x, n_theta):
                 f.write("pattern: %s\ntheta: [%s]\n" % (PATTERN, ",".join("[" + ",".join("%.17g" % v for v in r) + "]" for r in rows)))
                 f.write("ene-param: ~T2004~\nmax-span: %d\nmax-internal-loop: %d\ntheta-softmax: 0\nrho-theta: 0.1\n" % (MAX_SPAN, MAX_ILOOP))
                 f.write("rho-lambda: 0.1\ntau: 0.1\nlambda: [%.17g,%.17g]\nlambda-prior: 0\nmin-bpp: 0.0001\n" % (x[-2], x[-1]))
-            out = subprocess.run([ref, "time", fq, str(cores), "1", mdl], capture_output=True, text=True, timeout=900)
-            if out.returncode == 0:
-                r = json.loads(out.stdout.strip().split("\n")[-1])
-                return {"value": r["seq_per_sec"], "unit": "seq/s", "cores": cores, "kind": "reference",
-                        "sample": "%d of the %d sequences, 1 eval, %d threads (RNAelemTrainer::operator(), BPP filter included)" % (sample, len(seqs), cores)}
-    from oracle import pyoracle as po
-    o = po.make_oracle(PATTERN, MAX_SPAN, MAX_ILOOP, min_bpp=1e-4, tau=0.1)
-    t0 = time.time()
-    o.train_eval(x, seqs[:sample], quals[:sample], n_threads=cores)
-    dt = time.time() - t0
-    return {"value": sample / dt, "unit": "seq/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %d sequences, 1 eval, %d threads (oracle port, BPP filter included)" % (sample, len(seqs), cores)}
+            out = subprocess.run([ref, "time", fq, str(threads), "1", mdl], capture_output=True, text=True, timeout=900)
+            if out.returncode != 0:
+                return None
+            return json.loads(out.stdout.strip().split("\n")[-1])["seq_per_sec"]
+
+    def run_port(sample, threads):
+        from oracle import pyoracle as po
+        o = po.make_oracle(PATTERN, MAX_SPAN, MAX_ILOOP, min_bpp=1e-4, tau=0.1)
+        t0 = time.time()
+        o.train_eval(x, seqs[:sample], quals[:sample], n_threads=threads)
+        return sample / (time.time() - t0)
+
+    kind, run = ("reference", run_ref) if os.path.exists(ref) else ("port", run_port)
+    what = "RNAelemTrainer::operator()" if kind == "reference" else "oracle port"
+    s_all, s_one = min(len(seqs), max(8, cores * 6)), min(len(seqs), 24)
+    v_all = run(s_all, cores)
+    if v_all is None:      # the reference binary failed on this box: the port
+        kind, run, what = "port", run_port, "oracle port"
+        v_all = run(s_all, cores)
+    v_one = run(s_one, 1)
+    return {"value": v_all, "unit": "seq/s", "cores": cores, "kind": kind,
+            "sample": "%d of the %d sequences, 1 eval, %d threads (%s, BPP filter included)" % (s_all, len(seqs), cores, what),
+            "one_thread": {"value": v_one, "unit": "seq/s", "cores": 1,
+                           "sample": "%d of the %d sequences, 1 eval, 1 thread (%s, BPP filter included)" % (s_one, len(seqs), what)}}
+
+
+def scan_algorithmic_bytes_per_seq(L, S, W=MAX_SPAN):
+    """scan = 7*T + T_trace + 3*T_b per sequence (three inside-type passes write T each, two outside
+    passes read + write 2*T each, the Viterbi pass writes 5 int32 per (cell, structural state, state), K1 = 3 plain tables)."""
+    T = (L + 1) * (W + 1) * 7 * S * 8 + (L + 1) * S * 8
+    T_trace = (L + 1) * (W + 1) * 7 * S * 20
+    T_b = (L + 1) * (W + 1) * 7 * 8
+    return 7 * T + T_trace + 3 * T_b
 
 
 class ScanSecondary:
-    """BASELINE's secondary metric on a bounded sample of the config-E shape: `elem scan` sequences / second (K4 + K5 sum
-    passes and the K6 Viterbi parse per sequence), steady state, plus the one-off load (BPP filter + plan) time.  Two
-    phases around the main measurement, because device memory that another engine has just given back is slow to allocate
-    again: the load is timed BEFORE the main engine exists, the scans run AFTER it is gone (their slots are allocated by an
-    untimed first scan)."""
+    """BASELINE's secondary metric on the config-E shape: `elem scan` sequences / second of a FRESH batch -- a scan visits
+    every sequence once, so the BPP filter + plan (load_batch) belong in it: value = n / (load + scan).  An untimed scan of
+    another batch of the same shape comes first (it allocates the table and trace slots: fresh device memory costs ~20 ms / GB,
+    a one-off of the process, not of the batch)."""
 
-    def __init__(self, api, synth, device, n=2000, L=300, pattern="(.....)"):
-        self.n, self.L, self.pattern = n, L, pattern
+    def __init__(self, api, synth, device, n=10000, L=300, pattern="(.....)"):
+        self.n, self.L, self.pattern, self.synth = n, L, pattern, synth
         self.eng = api.Engine(pattern, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
-        seqs, quals = synth.synth_batch(n, L)
-        t0 = time.perf_counter()
+        self.x = self.eng.initial_params(1.0)
+        seqs, quals = synth.synth_batch(n, L, seed=77 + L)
         self.eng.load_batch(seqs, quals)
-        self.t_load = time.perf_counter() - t0
+        self.eng.scan(self.x)
 
     def measure(self):
         eng, n = self.eng, self.n
-        x = eng.initial_params(1.0)
-        eng.scan(x)                      # allocates the table and trace slots
+        seqs, quals = self.synth.synth_batch(n, self.L)
         t0 = time.perf_counter()
-        eng.scan(x)
-        dt = time.perf_counter() - t0
-        return {"metric": "scan seqs/sec", "value": n / dt, "unit": "seq/s", "load_s": self.t_load,
-                "with_load": n / (dt + self.t_load), "log_space_fallback_sequences": int(eng.last_timing()[2]),
+        eng.load_batch(seqs, quals)
+        t1 = time.perf_counter()
+        eng.scan(self.x)
+        t2 = time.perf_counter()
+        alg = scan_algorithmic_bytes_per_seq(self.L, eng.n_state) * n
+        ach = alg / (t2 - t0) / 1e9
+        return {"metric": "scan seqs/sec (BPP filter + plan + K4/K5 sum passes + K6 Viterbi parse, fresh batch)", "value": n / (t2 - t0),
+                "unit": "seq/s", "load_s": t1 - t0, "scan_s": t2 - t1, "resident_rate": n / (t2 - t1),
+                "log_space_fallback_sequences": int(eng.last_timing()[2]),
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                             "traffic": None, "algorithmic_bytes_per_seq": alg // n,
+                             "note": "7*T + T_trace + 3*T_b (SURVEY section 8d) over the wall time of load + scan"},
                 "workload": "%d synthetic RNAs L=%d, pattern %s (S=%d), W=%d C=%d" % (n, self.L, self.pattern, eng.n_state, MAX_SPAN, MAX_ILOOP)}
 
 
@@ -119,6 +149,14 @@ def minibatch_secondary(api, synth, device, n=2000, L=200, iters=12):
             "unit": "ms", "seq_per_s": 128 * iters / dt, "workload": "%d synthetic RNAs L=%d, pattern %s" % (n, L, PATTERN)}
 
 
+def launcher_command(n, argv, port=None):
+    """the child that runs the N ranks of `bench.py --gpus N` (one process per GPU, RCCL): python -m torch.distributed.run"""
+    if port is None:
+        port = 29500 + (os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(REPO, "bench.py")] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,12 +171,24 @@ def main():
                          "longer add up to the pipeline time)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launch the ranks as a CHILD before this process makes any GPU call (never re-exec a process that touched the GPU)
+        import torch
+        have = torch.cuda.device_count()       # (counting devices does not initialise the GPU)
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: this machine has %d GPU(s); refusing to report a %d-GPU number" % (args.gpus, have, args.gpus))
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(launcher_command(args.gpus, sys.argv[1:]), env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d: refusing to run (the line would report the wrong n_gpus)" % (world, args.gpus))
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK %d, %d device(s))" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
@@ -147,7 +197,7 @@ def main():
 
     from rnaelem_amd import api, synth
     from rnaelem_amd.distributed import ShardedTrainer
-    secondary = ScanSecondary(api, synth, local_rank) if (world == 1 and not args.no_secondary) else None
+    secondary = world == 1 and not args.no_secondary
     eng = api.Engine(PATTERN, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, local_rank)
     if args.serial_passes:
         eng.set_option("two_streams", 0)
@@ -175,10 +225,24 @@ def main():
         kern_ms.append(eng.last_timing()[1])
     barrier()
     dt = time.perf_counter() - t0
+    # second timed point of SURVEY section 8(d): x0 as the CLI builds it, lambda = (0,0)
+    x00 = eng.initial_params(0.0)
+    trainer(x00)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        trainer(x00)
+    barrier()
+    dt00 = (time.perf_counter() - t0) / 3
+    shard_sizes = [n_local]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt00], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt00 = float(t[0].item()), float(t[1].item())
+        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([n_local], dtype=torch.int64, device="cuda"))
+        shard_sizes = [int(v.item()) for v in sizes]
+        assert dist.get_world_size() == args.gpus and sum(shard_sizes) == args.n_seq
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -198,6 +262,9 @@ def main():
         "metric": "train-iter seqs/sec (inside+outside)", "value": args.n_seq * args.steps / dt, "unit": "seq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "shard_sizes": shard_sizes,
+        "second_point": {"x": "x0 of the CLI defaults, lambda = (0,0)", "value": args.n_seq / dt00, "unit": "seq/s", "ms_per_step": dt00 * 1e3,
+                         "steps": 3},
         "config": {"workload": "%d synthetic RNAs L=%d, pattern %s, W=%d C=%d min_bpp=1e-4 T2004, x0 lambda=(1,1), one (fn,gr) eval per step" % (
             args.n_seq, args.seq_len, PATTERN, MAX_SPAN, MAX_ILOOP), "n_seq": args.n_seq, "seq_len": args.seq_len, "pattern": PATTERN,
             "sharding": "contiguous ranges per rank, 1 all-reduce of %d doubles per step" % eng.partial_len(),
@@ -210,12 +277,13 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(seqs, quals, x, eng.n_param - 2)
-    if secondary is not None:
+    if secondary:
         del trainer, eng
         import gc
         gc.collect()
-        line["secondary"] = secondary.measure()
-        del secondary
+        sec = ScanSecondary(api, synth, local_rank)      # (untimed: engine, a first batch, the scan that allocates the slots)
+        line["secondary"] = sec.measure()
+        del sec
         gc.collect()
         line["secondary_default_mode"] = minibatch_secondary(api, synth, local_rank)   # (its buffers persist: 3 untimed iterations)
     print(json.dumps(line))

@@ -1555,7 +1555,6 @@ int orc_scan_seq(orc_model* h, const uint8_t* seq, int L, const uint8_t* qual, o
                  double* end, double* inner, int32_t* psihat, char* rss_out, double* EN_out) {
   try { /* motif_scanner.hpp:215-260 */
     Model& m = h->m;
-    if (m.no_rss()) die("scan with no-rss is not supported by the oracle");
     Seq q;
     q.prepare(m, to_vec(seq, L), "");
     q.set_ws(vector<int>(qual, qual + L + 1));

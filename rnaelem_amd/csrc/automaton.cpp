@@ -225,12 +225,104 @@ std::string Automaton::to_json() const {
   o << "],\"loop_loop\":[";
   for (size_t i = 0; i < quads_.size(); ++i)
     o << (i ? "," : "") << "[" << quads_[i][0] << "," << quads_[i][1] << "," << quads_[i][2] << "," << quads_[i][3] << "]";
-  o << "]}";
+  o << "]";
+  // static liveness per plane P,E,M,B,1,2,L,O (see liveness()): lists of state ids
+  const Liveness lv = liveness();
+  for (int which = 0; which < 2; ++which) {
+    o << (which ? ",\"useful\":[" : ",\"inside_live\":[");
+    for (int e = 0; e < 8; ++e) {
+      std::vector<int> ids;
+      for (int s = 0; s < S(); ++s) if ((which ? lv.useful : lv.inside_live)[e][s]) ids.push_back(s);
+      if (e) o << ",";
+      list(ids);
+    }
+    o << "]";
+  }
+  o << "}";
   return o.str();
 }
 
-void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0) const {
+Automaton::Liveness Automaton::liveness() const {
   const int S_ = S(), m = M();
+  Liveness lv;
+  for (auto& v : lv.inside_live) v.assign(S_, 0);
+  for (auto& v : lv.useful) v.assign(S_, 0);
+  std::vector<std::array<int, 3>> sp;   // (parent, (l,h), (h,r))
+  for (int s = 0; s < S_; ++s)
+    for (auto const& p : splits(s)) sp.push_back({s, p[0], p[1]});
+  auto& I = lv.inside_live;
+  bool changed = true;
+  auto set = [&](std::vector<char>& v, int s) { if (!v[s]) { v[s] = 1; changed = true; } };
+  // inside: initial values L(i,i,(k,k)) = 1, O(0,(0,0)) = 1 (motif_trainer.hpp:89-98), then the rules to a fixed point
+  for (int s = 0; s < S_; ++s) if (loop_flag_[s] && states_[s].l == states_[s].r) I[ST_L][s] = 1;
+  I[ST_O][state_id(0, 0)] = 1;
+  while (changed) {
+    changed = false;
+    for (int s = 0; s < S_; ++s) {
+      for (int c : pair_[s]) if (I[ST_E][c] || I[ST_P][c]) set(I[ST_P], s);           // rules 1a, 1b
+      for (int c : right_[s]) {
+        if (I[ST_2][c]) set(I[ST_2], s);                                              // 3a
+        if (loop_flag_[s] && I[ST_L][c]) set(I[ST_L], s);                             // L <- L
+        if (I[ST_O][c]) set(I[ST_O], s);                                              // 8
+      }
+      if (I[ST_P][s]) set(I[ST_2], s);                                                // 3b
+      if (I[ST_2][s] || I[ST_B][s]) set(I[ST_1], s);                                  // 4a, 4b
+      for (int c : left_[s]) if (I[ST_M][c]) set(I[ST_M], s);                         // 5a
+      if (I[ST_B][s]) set(I[ST_M], s);                                                // 5b
+      if (I[ST_M][s] || (loop_flag_[s] && I[ST_L][s])) set(I[ST_E], s);               // 6a, 6b
+    }
+    for (auto const& t : sp) {
+      if (I[ST_1][t[1]] && I[ST_2][t[2]]) set(I[ST_B], t[0]);                         // 2
+      if (I[ST_O][t[1]] && I[ST_P][t[2]]) set(I[ST_O], t[0]);                         // 7
+    }
+    for (auto const& q : quads_)
+      if (I[ST_P][q[1]] && I[ST_L][q[2]] && I[ST_L][q[3]]) set(I[ST_E], q[0]);        // 6c
+  }
+  // outside: from the terminals down; a child is reached when it and its siblings are inside-live
+  auto& U = lv.useful;
+  auto reach = [&](int e, int s) { if (I[e][s]) set(U[e], s); };
+  for (int t : {state_id(0, 0), state_id(0, m - 1), state_id(0, m - 2)}) if (t >= 0) reach(ST_O, t);
+  changed = true;
+  while (changed) {
+    changed = false;
+    for (int s = 0; s < S_; ++s) {
+      if (U[ST_O][s]) for (int c : right_[s]) reach(ST_O, c);
+      if (U[ST_P][s]) for (int c : pair_[s]) { reach(ST_E, c); reach(ST_P, c); }
+      if (U[ST_2][s]) { for (int c : right_[s]) reach(ST_2, c); reach(ST_P, s); }
+      if (U[ST_1][s]) { reach(ST_2, s); reach(ST_B, s); }
+      if (U[ST_M][s]) { for (int c : left_[s]) reach(ST_M, c); reach(ST_B, s); }
+      if (U[ST_E][s]) { reach(ST_M, s); if (loop_flag_[s]) reach(ST_L, s); }
+      if (U[ST_L][s]) for (int c : right_[s]) reach(ST_L, c);
+    }
+    for (auto const& t : sp) {
+      if (U[ST_B][t[0]] && I[ST_1][t[1]] && I[ST_2][t[2]]) { reach(ST_1, t[1]); reach(ST_2, t[2]); }
+      if (U[ST_O][t[0]] && I[ST_O][t[1]] && I[ST_P][t[2]]) { reach(ST_O, t[1]); reach(ST_P, t[2]); }
+    }
+    for (auto const& q : quads_)
+      if (U[ST_E][q[0]] && I[ST_P][q[1]] && I[ST_L][q[2]] && I[ST_L][q[3]]) { reach(ST_P, q[1]); reach(ST_L, q[2]); reach(ST_L, q[3]); }
+  }
+  return lv;
+}
+
+void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0, bool prune) const {
+  const int S_ = S(), m = M();
+  Liveness lv;
+  if (prune) lv = liveness();
+  const auto& I = lv.inside_live;
+  const auto& U = lv.useful;
+  // a transition is kept when its parent is useful and its children are inside-live in at least one of the rules that
+  // walk the list (the children are then useful, too)
+  auto live_right = [&](int s, int c) {
+    return !prune || (U[ST_2][s] && I[ST_2][c]) || (U[ST_L][s] && I[ST_L][c]) || (U[ST_O][s] && I[ST_O][c]);
+  };
+  auto live_left = [&](int s, int c) { return !prune || (U[ST_M][s] && I[ST_M][c]); };
+  auto live_pair = [&](int s, int c) { return !prune || (U[ST_P][s] && (I[ST_E][c] || I[ST_P][c])); };
+  auto live_split = [&](int s, int a, int b) {
+    return !prune || (U[ST_B][s] && I[ST_1][a] && I[ST_2][b]) || (U[ST_O][s] && I[ST_O][a] && I[ST_P][b]);
+  };
+  auto live_quad = [&](const std::array<int, 4>& q) {
+    return !prune || (U[ST_E][q[0]] && I[ST_P][q[1]] && I[ST_L][q[2]] && I[ST_L][q[3]]);
+  };
   AutomatonLayout& A = *lay;
   ints->clear();
   A.S = S_;
@@ -270,21 +362,21 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     return true;
   };
   for (int s = 0; s < S_; ++s) {
-    for (int c : right_[s]) if (keep({s, c})) { right.add(s, {c, tau_right(s, c)}); rright.add(c, {s, tau_right(s, c)}); }
-    for (int c : left_[s]) if (keep({s, c})) { left.add(s, {c, tau_left(s, c)}); rleft.add(c, {s, tau_left(s, c)}); }
-    for (int c : pair_[s]) if (keep({s, c})) { pair.add(s, {c, tau_pair(s, c)}); rpair.add(c, {s, tau_pair(s, c)}); }
+    for (int c : right_[s]) if (keep({s, c}) && live_right(s, c)) { right.add(s, {c, tau_right(s, c)}); rright.add(c, {s, tau_right(s, c)}); }
+    for (int c : left_[s]) if (keep({s, c}) && live_left(s, c)) { left.add(s, {c, tau_left(s, c)}); rleft.add(c, {s, tau_left(s, c)}); }
+    for (int c : pair_[s]) if (keep({s, c}) && live_pair(s, c)) { pair.add(s, {c, tau_pair(s, c)}); rpair.add(c, {s, tau_pair(s, c)}); }
   }
   Csr split(S_, 2), split1(S_, 2), split2(S_, 2);
   for (int s = 0; s < S_; ++s)
     for (auto const& p : splits(s)) {
-      if (!keep({s, p[0], p[1]})) continue;
+      if (!keep({s, p[0], p[1]}) || !live_split(s, p[0], p[1])) continue;
       split.add(s, {p[0], p[1]});
       split1.add(p[0], {s, p[1]});
       split2.add(p[1], {s, p[0]});
     }
   Csr quad(S_, 3), quad1(S_, 3), quad2(S_, 3), quad3(S_, 3);
   for (auto const& q : quads_) {
-    if (!keep({q[0], q[1], q[2], q[3]})) continue;
+    if (!keep({q[0], q[1], q[2], q[3]}) || !live_quad(q)) continue;
     quad.add(q[0], {q[1], q[2], q[3]});
     quad1.add(q[1], {q[0], q[2], q[3]});
     quad2.add(q[2], {q[0], q[1], q[3]});

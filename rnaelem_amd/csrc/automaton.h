@@ -49,7 +49,18 @@ class Automaton {
   // only_state0: keep only transitions among state 0 = (0,0), the background state 'z'.  Outside values of an
   // evaluation whose only terminal is O(L,(0,0)) vanish on every other state (no transition leads from (0,0) to
   // another state), so that pass can be swept on this one-state automaton over the same tables.
-  void flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0 = false) const;
+  // prune: drop every list entry that cannot carry weight in ANY sequence (see liveness()): the lists of the inside direction
+  // keep a transition only when its parent is useful and all its children are inside-live, the lists of the outside direction are
+  // the same entries regrouped by child.  Table entries of useless (plane, state) pairs then stay 0 / log 0; partition functions,
+  // posteriors, expected counts and the Viterbi parse are unchanged (they only see parses that reach a terminal).
+  void flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0 = false, bool prune = false) const;
+
+  // Static liveness of the (structural state, interval state) pairs, from the rule table alone in the
+  // boolean semiring: inside_live[e][s] = some sequence gives inside(., ., e, s) a non-zero weight; useful[e][s] = inside-live
+  // and reachable from a terminal O(L, (0,0) | (0,M-1) | (0,M-2)) through transitions whose siblings are inside-live, i.e. the
+  // entry can occur in a complete parse.  e = ST_P .. ST_L, ST_O (8 planes).
+  struct Liveness { std::vector<char> inside_live[8], useful[8]; };
+  Liveness liveness() const;
 
  private:
   std::string pattern_, reg_;

@@ -57,6 +57,26 @@ struct StateError : std::runtime_error {
       throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
   } while (0)
 
+// Makes `device` the calling thread's current HIP device for the lifetime of the guard and restores the previous one.  Every
+// computing entry point of an Engine takes one: the current device is a per-thread setting, so a handle used from another
+// host thread (the prefetch thread of the mini-batch loop), or a second handle on another GPU, must not inherit whatever
+// device was current.
+class DeviceGuard {
+ public:
+  explicit DeviceGuard(int device) {
+    if (device < 0) return;
+    if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+    if (prev_ != device) { HIP_OK(hipSetDevice(device)); changed_ = true; }
+  }
+  ~DeviceGuard() { if (changed_ && prev_ >= 0) (void)hipSetDevice(prev_); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+
+ private:
+  int prev_ = -1;
+  bool changed_ = false;
+};
+
 // owning device buffer
 class DevBuf {
  public:
@@ -176,6 +196,9 @@ class Engine {
   int group_cap_ = 8192;   // most sequences swept in lockstep (a first scan uses fewer: fresh table memory costs ~20 ms / GB)
   TrArgs log_pipeline_args();
   void init_device();
+  void flatten_automaton();
+  void upload_automaton();
+  bool opt_prune_ = true;   // transition lists pruned to the transitions of complete parses (Automaton::flatten)
   void require_device() const;
   bool has_device_ = false;
   int want_device_ = -1;
@@ -187,7 +210,7 @@ class Engine {
   bool linear_ok_ = true;
   int flags_, max_span_, max_iloop_;
   double min_bpp_, tau_;
-  int device_ = 0, n_cu_ = 256;
+  int device_ = -1, n_cu_ = 256;   // device_ < 0: no HIP device (host-only handle)
   hipStream_t st_ = nullptr;
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t st2_ = nullptr;                 // second outside pass of the linear pipeline (launch_lin_group)
@@ -260,11 +283,8 @@ Engine::Engine(const elemdp_model_desc& d)
   if (par == "~T2004~") par = read_file(default_data_dir() + "/turner2004.elempar");
   else if (par == "~A2007~") par = read_file(default_data_dir() + "/andronescu2007.elempar");
   parse_energy_text(par, &et_);
-  au_.flatten(&lay_, &ints_);
-  au_.flatten(&layr_, &intsr_, true);
   flatten_trivial(&lay0_, &ints0_);
-  layc_ = layr_;
-  layc_.S = 1;   // same one-state lists, compact tables
+  flatten_automaton();
   // the linear schedule needs state 0 = (0,0) to be closed under every transition family
   linear_ok_ = au_.state(0).l == 0 && au_.state(0).r == 0;
   for (int c : au_.right(0)) linear_ok_ = linear_ok_ && c == 0;
@@ -279,6 +299,27 @@ Engine::Engine(const elemdp_model_desc& d)
   // Without a GPU the handle still serves the host-only calls (describe, initial_params,
   // train_finish); everything that computes raises ELEMDP_ENODEV -- there is no CPU path.
   if (has_device_) init_device();
+}
+
+// the flat transition lists of the pattern automaton (pruned to the transitions that can occur in a complete parse unless
+// option "prune" = 0) and of its restriction to state (0,0)
+void Engine::flatten_automaton() {
+  au_.flatten(&lay_, &ints_, false, opt_prune_);
+  au_.flatten(&layr_, &intsr_, true, opt_prune_);
+  layc_ = layr_;
+  layc_.S = 1;   // same one-state lists, compact tables
+}
+
+void Engine::upload_automaton() {
+  d_ints_.upload(ints_, st_);
+  d_intsr_.upload(intsr_, st_);
+  d_lay_.alloc(sizeof(AutomatonLayout));
+  d_layr_.alloc(sizeof(AutomatonLayout));
+  d_layc_.alloc(sizeof(AutomatonLayout));
+  HIP_OK(hipMemcpyAsync(d_lay_.as<void>(), &lay_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
+  HIP_OK(hipMemcpyAsync(d_layr_.as<void>(), &layr_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
+  HIP_OK(hipMemcpyAsync(d_layc_.as<void>(), &layc_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
+  HIP_OK(hipStreamSynchronize(st_));
 }
 
 void Engine::require_device() const {
@@ -308,17 +349,10 @@ void Engine::init_device() {
   gev_[0][0] = ev2_[0]; gev_[0][1] = ev2_[1];
   d_et_.alloc(sizeof(EnergyTables));
   HIP_OK(hipMemcpyAsync(d_et_.as<void>(), &et_, sizeof(EnergyTables), hipMemcpyHostToDevice, st_));
-  d_ints_.upload(ints_, st_);
   d_ints0_.upload(ints0_, st_);
-  d_lay_.alloc(sizeof(AutomatonLayout));
-  d_layr_.alloc(sizeof(AutomatonLayout));
-  d_intsr_.upload(intsr_, st_);
-  HIP_OK(hipMemcpyAsync(d_layr_.as<void>(), &layr_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
+  upload_automaton();
   d_lay0_.alloc(sizeof(AutomatonLayout));
-  d_layc_.alloc(sizeof(AutomatonLayout));
-  HIP_OK(hipMemcpyAsync(d_layc_.as<void>(), &layc_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   d_lin_.alloc(sizeof(double) * (kLinEth + au_.n_theta() + 1));
-  HIP_OK(hipMemcpyAsync(d_lay_.as<void>(), &lay_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   HIP_OK(hipMemcpyAsync(d_lay0_.as<void>(), &lay0_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   d_params_.alloc(sizeof(ParamBlock) + sizeof(double) * (au_.n_theta() + 1));
   d_params0_.alloc(sizeof(ParamBlock) + sizeof(double));
@@ -336,6 +370,8 @@ void Engine::init_device() {
 }
 
 Engine::~Engine() {
+  if (!has_device_) return;
+  DeviceGuard dg(device_);
   if (st_) (void)hipStreamSynchronize(st_);
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
   for (auto& e : ev2_) if (e) (void)hipEventDestroy(e);
@@ -362,6 +398,11 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "schedule") opt_schedule_ = (int)v;
   else if (key == "dbg") opt_dbg_ = (int)v;
   else if (key == "tile") opt_tile_ = (int)v;
+  else if (key == "prune") {
+    opt_prune_ = v != 0;
+    flatten_automaton();
+    if (has_device_) { DeviceGuard dg(device_); HIP_OK(hipStreamSynchronize(st_)); upload_automaton(); }
+  }
   else throw ArgError("unknown option: " + key);
 }
 
@@ -558,11 +599,14 @@ DpArgs Engine::base_args(const AutomatonLayout& lay, const int32_t* d_ints, cons
 void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* qual, const int32_t* qoff, const char* fix,
                         int n) {
   require_device();
+  DeviceGuard dg(device_);
+  // a rejected batch leaves the handle without a batch (ELEMDP_ESTATE for what follows) instead of the new sizes over the old
+  // device buffers
+  n_seq_ = 0;
   if (n <= 0 || !seq || !off || !qual || !qoff) throw ArgError("load_batch: empty batch or null pointer");
   const bool fixmode = flags_ & ELEMDP_DBG_FIX_RSS;
   if (fixmode && !fix) throw ArgError("load_batch: ELEMDP_DBG_FIX_RSS needs fix_rss strings");
   const bool no_rss = flags_ & ELEMDP_NO_RSS;
-  n_seq_ = n;
   h_plans_.assign(n, SeqPlan());
   h_seq_off_.assign(off, off + n + 1);
   h_qual_off_.assign(qoff, qoff + n + 1);
@@ -774,6 +818,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   d_seq_out_.alloc(sizeof(double) * (size_t)out_stride_ * n);
   n_slots_ = 0;
   HIP_OK(hipStreamSynchronize(st_));
+  n_seq_ = n;   // committed: everything above succeeded
 }
 
 // Sequences swept in lockstep: as many as fit in ~55 % of the free device memory (at most 8192), then balanced so that all
@@ -1038,6 +1083,7 @@ void Engine::run_train(bool) {
 
 void Engine::train_partial(const double* x, int n_param_in, void* partial, bool device_ptr) {
   require_device();
+  DeviceGuard dg(device_);
   if (n_seq_ <= 0) throw StateError("train_eval before load_batch");
   if (n_param_in != n_param()) throw ArgError("n_param mismatch");
   HIP_OK(hipEventRecord(ev_[0], st_));
@@ -1086,6 +1132,8 @@ void Engine::train_finish(const double* r, double* fn, double* gr, double* sum_e
 }
 
 void Engine::seq_stats(double* out, int n) {
+  require_device();
+  DeviceGuard dg(device_);
   if (n != n_seq_) throw ArgError("seq_stats: n_seq mismatch");
   std::vector<double> h((size_t)out_stride_ * n);
   HIP_OK(hipMemcpy(h.data(), d_seq_out_.as<void>(), sizeof(double) * h.size(), hipMemcpyDeviceToHost));
@@ -1095,6 +1143,8 @@ void Engine::seq_stats(double* out, int n) {
 
 void Engine::debug_tables(double* inside, double* outside, double* inside_o, double* outside_o, double* ENo, double* ENx,
                           double* EH) {
+  require_device();
+  DeviceGuard dg(device_);
   if (n_seq_ != 1) throw StateError("debug_tables needs a batch of exactly one sequence");
   if (n_slots_ < 1) throw StateError("debug_tables before train_eval");
   const SeqPlan& p = h_plans_[0];
@@ -1131,6 +1181,8 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
 }
 
 void Engine::batch_pairs(int idx, uint8_t* kept, double* lnbpp, int cap) {
+  require_device();
+  DeviceGuard dg(device_);
   if (idx < 0 || idx >= n_seq_) throw ArgError("batch_pairs: bad sequence index");
   const SeqPlan& p = h_plans_[idx];
   const int nc = (p.L + 1) * (p.W + 1);
@@ -1150,9 +1202,11 @@ void Engine::batch_pairs(int idx, uint8_t* kept, double* lnbpp, int cap) {
 
 void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   require_device();
+  DeviceGuard dg(device_);
   if (n_seq_ <= 0) throw StateError("scan before load_batch");
   if (n_param_in != n_param()) throw ArgError("n_param mismatch");
-  if (flags_ & ELEMDP_NO_RSS) throw ArgError("scan is not available in --no-rss mode");
+  // (--no-rss: load_batch cleared the pair mask, so every sweep reduces to the exterior chain = the profile-HMM
+  // forward / backward / Viterbi of motif_model.hpp:171-206 under the scanner functors, motif_scanner.hpp:186-214)
   if (!out) throw ArgError("scan: null output");
   upload_params(x, lay_, false);
   const int nt = au_.n_theta(), n = n_seq_, S = au_.S();

@@ -26,7 +26,8 @@ class ShardedTrainer:
         self.total = len(seqs)
         a, b = assigned_range(self.total, world, rank)
         self.range = (a, b)
-        engine.load_batch(seqs[a:b], quals[a:b])
+        if b > a:      # (more ranks than records: this rank contributes an all-zero partial vector)
+            engine.load_batch(seqs[a:b], quals[a:b])
         self._buf = None
         self._device = use_device_buffer
         if world > 1:
@@ -40,12 +41,14 @@ class ShardedTrainer:
         if self.world == 1:
             return eng.train_eval(x)
         import torch.distributed as dist
-        if self._device:
+        if self.range[1] == self.range[0]:
+            self._buf.zero_()
+        elif self._device:
             eng.train_partial(x, device_ptr=self._buf.data_ptr())
         else:
             self._buf.copy_(self._torch.from_numpy(eng.train_partial(x)))
         dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
-        return eng.train_finish(self._buf.cpu().numpy())
+        return eng.train_finish(self._buf.cpu().numpy(), x=x)
 
 
 def torch_all_reduce(partial):

@@ -76,12 +76,19 @@ def minimize_lbfgsb(evaluate, x0, rho, max_iter=300, epsilon=1e-3, log=None, var
                 message=info["task"] if isinstance(info["task"], str) else info["task"].decode())
 
 
-def minimize_adam(evaluate, x0, rho, max_iter=100, alpha=0.1, beta1=0.9, beta2=0.999, eps=1e-8, log=None):
-    """`elem train` with shuffled negatives / mini-batches (optimizer.hpp:127-160), operation by operation."""
+def minimize_adam(evaluate, x0, rho, max_iter=100, alpha=0.1, beta1=0.9, beta2=0.999, eps=1e-8, log=None, vary=None):
+    """`elem train` with shuffled negatives / mini-batches (optimizer.hpp:127-160), operation by operation.  `vary`
+    (--param-set): the other parameters are pinned to x0 by bounds of type 3, which Adam::after_update clips to after every
+    step (set_mask_bounds, motif_mask_trainer.hpp:66-108)."""
     obj = Objective(evaluate, rho, log)
     x = np.asarray(x0, dtype=np.float64).copy()
     n = len(x)
     lower = np.r_[np.full(n - 2, -np.inf), 0.0, 0.0]
+    upper = np.full(n, np.inf)
+    if vary is not None:
+        fixed = np.ones(n, dtype=bool)
+        fixed[[int(i) for i in vary]] = False
+        lower[fixed] = upper[fixed] = x[fixed]
     m, v = np.zeros(n), np.zeros(n)
     b1t, b2t = beta1, beta2
     t = 0
@@ -93,7 +100,7 @@ def minimize_adam(evaluate, x0, rho, max_iter=100, alpha=0.1, beta1=0.9, beta2=0
         m += (1.0 - beta1) * (g - m)
         v += (1.0 - beta2) * (g * g - v)
         x = x - alpha * (m / (1.0 - b1t)) / (np.sqrt(v / (1.0 - b2t)) + eps)
-        x = np.maximum(x, lower)
+        x = np.minimum(np.maximum(x, lower), upper)
         if float(np.dot(g, g)) < (y + 1.0) * 1e-8 or t >= max_iter:
             break
     return dict(x=x, f=obj.trace[-1][1], n_iter=t - 1, n_eval=obj.n_eval, trace=obj.trace, message="adam")
@@ -251,5 +258,5 @@ def train(evaluate, x0, rho_theta=0.1, rho_lambda=0.1, max_iter=300, epsilon=1e-
     if optimizer == "lbfgsb":
         return minimize_lbfgsb(evaluate, x0, rho, max_iter, epsilon, log, vary)
     if optimizer == "adam":
-        return minimize_adam(evaluate, x0, rho, max_iter, log=log)
+        return minimize_adam(evaluate, x0, rho, max_iter, log=log, vary=vary)
     raise ValueError("optimizer must be 'lbfgsb' or 'adam'")

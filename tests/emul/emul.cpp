@@ -270,7 +270,10 @@ double prepare(const Emu& E, HostPlan& P, const uint8_t* seq, int L, const uint8
   plan_init(E, P, seq, L, qual, fix);
   int total = plan_mask(E, P, fix);
   double eff = 1.0;
-  if (P.have_fix) {
+  if (E.flags & F_NO_RSS) {   // --no-rss: no pair is ever parsable, as Engine::load_batch clears the mask (motif_model.hpp:57, 171-206)
+    std::fill(P.okbits.begin(), P.okbits.end(), 0u);
+    eff = 0.;
+  } else if (P.have_fix) {
     int nbp = 0;
     for (int i = 0; i <= L; ++i) for (int d = 1; d <= P.W && i + d <= L; ++d) nbp += P.ok(i, d);
     eff = (double)nbp / (double)total;
@@ -305,6 +308,12 @@ void* emu_create(const char* pattern, const char* par_text, int max_span, int ma
     E->max_span = max_span; E->max_iloop = max_iloop; E->min_bpp = min_bpp; E->tau = tau; E->flags = flags;
     return E;
   } catch (std::exception& e) { g_err = e.what(); return nullptr; }
+}
+// re-flattens the automaton with / without the static pruning of the transition lists (Automaton::flatten)
+void emu_set_prune(void* h, int prune) {
+  Emu* E = (Emu*)h;
+  E->au->flatten(&E->lay, &E->ints, false, prune != 0);
+  E->au->flatten(&E->lay_r, &E->ints_r, true, prune != 0);
 }
 void emu_destroy(void* h) { delete (Emu*)h; }
 int emu_n_param(void* h) { return ((Emu*)h)->au->n_theta() + 2; }

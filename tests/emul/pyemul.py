@@ -21,6 +21,7 @@ def lib():
         L.emu_n_param.argtypes = [C.c_void_p]
         L.emu_n_state.argtypes = [C.c_void_p]
         L.emu_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.emu_set_prune.argtypes = [C.c_void_p, C.c_int]
         L.emu_energy_table.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int]
         L.emu_hairpin_energy.restype = C.c_double
         L.emu_hairpin_energy.argtypes = [C.c_void_p, u8, C.c_int, C.c_int, C.c_int]
@@ -59,6 +60,9 @@ class Emul:
             lib().emu_destroy(self.h)
         except Exception:
             pass
+
+    def set_prune(self, on):
+        lib().emu_set_prune(self.h, int(bool(on)))
 
     def describe(self):
         buf = C.create_string_buffer(1 << 20)

@@ -277,3 +277,89 @@ def test_plan_enumeration_from_the_end_major_mask_is_identical():
             e.train_seq(x, s, q)
     assert L.emu_enum_checked() >= before + 12
     assert L.emu_enum_mismatches() == 0
+
+
+# ---- static pruning of the transition lists (Automaton::flatten(prune), the engine's default) -------------------
+PLANES = "PEMB12LO"
+
+
+def useful_mask(e):
+    """[8][S] booleans: (plane, state) pairs that can occur in a complete parse (Automaton::liveness)."""
+    d = e.describe()
+    m = np.zeros((8, e.S), dtype=bool)
+    for k, ids in enumerate(d["useful"]):
+        m[k, ids] = True
+    return m
+
+
+def assert_pruned_tables(got, want, mask7, what):
+    """pruned tables: equal to the oracle's on the useful (plane, state) pairs (the other entries never reach a terminal: the
+    pruned rules leave some of them at log 0, and nothing reads them)"""
+    assert_log_close(got[:, :, mask7], want[:, :, mask7], rtol=1e-10, what=what)
+
+
+@pytest.mark.parametrize("pattern", sorted(HMM))
+def test_liveness_is_consistent(pattern):
+    e = Emul(pattern, PAR)
+    d = e.describe()
+    for k in range(8):
+        assert set(d["useful"][k]) <= set(d["inside_live"][k]), (pattern, PLANES[k])
+    s00 = d["state"].index([0, 0])
+    assert s00 in d["useful"][7] and s00 in d["useful"][6]   # background: O and L of (0,0) are always in a parse
+
+
+@pytest.mark.parametrize("model,fq", CASES)
+@pytest.mark.parametrize("linear", [None, 0, 1])
+def test_pruned_train_rules_match_oracle(model, fq, linear):
+    o, e, x = model_pair(model)
+    e.set_prune(True)
+    um = useful_mask(e)
+    full = fq in ("tiny.fq", "0.fq", "syn_L40_n3.fq")
+    for rid, seq, qual in po.read_fastq(gpath(fq)):
+        a = o.train_seq(seq, qual, tables=full)
+        b = e.train_seq(x, seq, qual, tables=full, linear=linear)
+        for k in ("Zo", "Zari", "Znasi"):
+            assert_log_close(b[k], a[k], rtol=1e-11, what=k)
+        assert_log_close(b["inside_o"][:, um[7]], a["inside_o"][:, um[7]], rtol=1e-10, what="inside_o")
+        if full:
+            assert_pruned_tables(b["inside"], a["inside"], um[:7], "inside table")
+        if a["skipped"] or (linear == 1 and not np.isfinite(a["Znasi"])):
+            continue
+        assert b["skipped"] == 0
+        assert b["f"] == pytest.approx(a["f"], rel=1e-10, abs=1e-12)
+        for k in ("ENo", "ENx", "EHo", "EHx"):
+            np.testing.assert_allclose(b[k], a[k], rtol=1e-9, atol=1e-11, err_msg=k)
+        if linear != 1:
+            assert_log_close(b["outside_o"], a["outside_o"], rtol=1e-10, what="outside_o")
+            if full:
+                assert_log_close(b["outside"], a["outside"], rtol=1e-10, what="outside table")
+
+
+@pytest.mark.parametrize("model,fq", SCAN)
+@pytest.mark.parametrize("linear", [False, True])
+def test_pruned_scan_matches_oracle(model, fq, linear):
+    o, e, x = model_pair(model)
+    e.set_prune(True)
+    for rid, seq, qual in po.read_fastq(gpath(fq)):
+        a = o.scan_seq(seq, qual)
+        b = e.scan_seq(x, seq, qual, linear=linear)
+        assert (a["Ys"], a["Ye"]) == (b["Ys"], b["Ye"])
+        for k in ("ZL", "ZeL", "PyNL"):
+            assert_log_close(b[k], a[k], rtol=1e-10, atol=1e-10, what=k)
+        for k in ("start", "end", "inner"):
+            assert_log_close(b[k], a[k], rtol=1e-9, atol=1e-9, what=k)
+        assert b["exist_prob"] == pytest.approx(a["exist_prob"], rel=1e-10)
+        assert list(a["psihat"]) == list(b["psihat"])
+        assert a["rss"] == b["rss"]
+        np.testing.assert_allclose(b["EN"], a["EN"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("pattern,seq,rss,count", PATH_COUNTS)
+def test_reference_path_counts_pruned(pattern, seq, rss, count):
+    e = Emul(pattern, PAR, BIG, BIG, 0.0, 1.0, DBG_FLAGS)
+    e.set_prune(True)
+    x = np.zeros(e.n_param)
+    x[-2:] = 1.0
+    for linear in (None, 0):
+        r = e.train_seq(x, po.encode_seq(seq), np.ones(len(seq) + 1, dtype=np.uint8), fix_rss=rss, linear=linear)
+        assert np.exp(r["Zo"]) == pytest.approx(count, rel=1e-13)
