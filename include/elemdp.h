@@ -85,9 +85,10 @@ int elemdp_describe(const elemdp_handle* h, char* buf, int32_t cap);
  * table slots (default 2 per CU), "keep_lnbpp" = keep ln BPP of the filter for elemdp_batch_pairs,
  * "first_pass_only" = debug: stop a train evaluation after the first outside pass; "pipeline" = 4 (default: scaled-linear
  * batch pipeline) / 3 (log-space batch pipeline) / 2 (fused kernel); "group" = sequences swept in lockstep (0 = as many as
- * fit); "schedule" = 1 (default: ari-only + one-state nasi-only outside passes) / 0 (the reference's two passes); "tile" =
- * tiled split sums; "two_streams" = second outside pass on a second stream (default 1); "group_streams" = groups evaluated concurrently
- * (default 2); "profile" = in-kernel phase clocks
+ * fit); "schedule" = 1 (default: ari-only + one-state nasi-only outside passes) / 0 (the reference's two passes);
+ * "prune" = 1 (default: transition lists without the transitions that cannot occur in a complete parse) / 0 (the complete
+ * lists of the reference's automaton); "two_streams" = second outside pass on a second stream (default 1); "group_streams" =
+ * groups evaluated concurrently (default 2); "profile" = in-kernel phase clocks
  * for elemdp_debug_profile; "dbg" = switch phases off (measurements only). */
 int elemdp_set_option(elemdp_handle* h, const char* key, double value);
 

@@ -311,7 +311,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   const auto& I = lv.inside_live;
   const auto& U = lv.useful;
   // a transition is kept when its parent is useful and its children are inside-live in at least one of the rules that
-  // walk the list (the children are then useful, too)
+  // walk the list (the children are then useful, too); arguments are reference state ids
   auto live_right = [&](int s, int c) {
     return !prune || (U[ST_2][s] && I[ST_2][c]) || (U[ST_L][s] && I[ST_L][c]) || (U[ST_O][s] && I[ST_O][c]);
   };
@@ -323,19 +323,36 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   auto live_quad = [&](const std::array<int, 4>& q) {
     return !prune || (U[ST_E][q[0]] && I[ST_P][q[1]] && I[ST_L][q[2]] && I[ST_L][q[3]]);
   };
+  // Internal state order: with the pruned lists, the states that can take part in a bifurcation (useful in plane B, 1 or 2)
+  // come first -- the kernels stage only that prefix of the rows of those planes.  (0,0) stays state 0; the relative order
+  // of the others is the reference's, so every list keeps its order (the Viterbi tie rule depends on it).  ref_of[k] =
+  // reference id of internal state k, id_of = the inverse.
+  std::vector<int> ref_of, id_of(S_, -1);
+  int n_front = S_;
+  if (prune) {
+    auto front = [&](int s) { return s == 0 || U[ST_B][s] || U[ST_1][s] || U[ST_2][s]; };
+    for (int s = 0; s < S_; ++s) if (front(s)) ref_of.push_back(s);
+    n_front = (int)ref_of.size();
+    for (int s = 0; s < S_; ++s) if (!front(s)) ref_of.push_back(s);
+  } else {
+    for (int s = 0; s < S_; ++s) ref_of.push_back(s);
+  }
+  for (int k = 0; k < S_; ++k) id_of[ref_of[k]] = k;
+
   AutomatonLayout& A = *lay;
   ints->clear();
   A.S = S_;
   A.n_active = only_state0 ? 1 : S_;
+  A.n_front = only_state0 ? 1 : n_front;
   A.M = m;
   A.n_theta = n_theta();
   A.n_rows = n_rows();
-  A.s00 = state_id(0, 0);
-  A.s0m1 = state_id(0, m - 1);
-  A.s0m2 = state_id(0, m - 2);
+  A.s00 = id_of[state_id(0, 0)];
+  A.s0m1 = id_of[state_id(0, m - 1)];
+  A.s0m2 = id_of[state_id(0, m - 2)];
   auto per_state = [&](auto fn) {
     int32_t pos = (int32_t)ints->size();
-    for (int s = 0; s < S_; ++s) ints->push_back(fn(states_[s]));
+    for (int k = 0; k < S_; ++k) ints->push_back(fn(states_[ref_of[k]]));
     return pos;
   };
   A.st_l = per_state([&](const IntervalState& s) { return s.l; });
@@ -347,10 +364,11 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   A.st_w_r = per_state([&](const IntervalState& s) { return (int)is_weighted(node_[s.r]); });
   A.st_w_l = per_state([&](const IntervalState& s) { return (int)is_weighted(node_[s.l]); });
   A.st_lam = per_state([&](const IntervalState& s) { return s.l == s.r ? 0 : 1; });
+  A.st_ref = per_state([&](const IntervalState& s) { return s.id; });
   A.row_off = (int32_t)ints->size();
   for (int v : row_off_) ints->push_back(v);
 
-  // tau applies to a self-loop on the emitting node (motif_model.hpp:250-251, 278-279, 352-353)
+  // tau applies to a self-loop on the emitting node (motif_model.hpp:250-251, 278-279, 352-353); reference ids
   auto tau_right = [&](int par, int ch) { return (int)(states_[par].r == states_[ch].r && node_[states_[par].r] == '.'); };
   auto tau_left = [&](int par, int ch) { return (int)(states_[par].l == states_[ch].l && node_[states_[par].l] == '.'); };
   auto tau_pair = [&](int par, int ch) { return (int)(states_[par].r == states_[ch].r && node_[states_[ch].r] == ')'); };
@@ -361,26 +379,35 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     for (int v : ids) if (v != 0) return false;
     return true;
   };
+  // (parents in internal order, the children of a parent in the reference's list order; s, c = reference ids)
+  for (int k = 0; k < S_; ++k) {
+    const int s = ref_of[k];
+    for (int c : right_[s]) if (keep({s, c}) && live_right(s, c)) { right.add(k, {id_of[c], tau_right(s, c)}); }
+    for (int c : left_[s]) if (keep({s, c}) && live_left(s, c)) { left.add(k, {id_of[c], tau_left(s, c)}); }
+    for (int c : pair_[s]) if (keep({s, c}) && live_pair(s, c)) { pair.add(k, {id_of[c], tau_pair(s, c)}); }
+  }
+  // the reverse lists enumerate the parents of a child in the REFERENCE's parent order (as before the renumbering)
   for (int s = 0; s < S_; ++s) {
-    for (int c : right_[s]) if (keep({s, c}) && live_right(s, c)) { right.add(s, {c, tau_right(s, c)}); rright.add(c, {s, tau_right(s, c)}); }
-    for (int c : left_[s]) if (keep({s, c}) && live_left(s, c)) { left.add(s, {c, tau_left(s, c)}); rleft.add(c, {s, tau_left(s, c)}); }
-    for (int c : pair_[s]) if (keep({s, c}) && live_pair(s, c)) { pair.add(s, {c, tau_pair(s, c)}); rpair.add(c, {s, tau_pair(s, c)}); }
+    for (int c : right_[s]) if (keep({s, c}) && live_right(s, c)) rright.add(id_of[c], {id_of[s], tau_right(s, c)});
+    for (int c : left_[s]) if (keep({s, c}) && live_left(s, c)) rleft.add(id_of[c], {id_of[s], tau_left(s, c)});
+    for (int c : pair_[s]) if (keep({s, c}) && live_pair(s, c)) rpair.add(id_of[c], {id_of[s], tau_pair(s, c)});
   }
   Csr split(S_, 2), split1(S_, 2), split2(S_, 2);
   for (int s = 0; s < S_; ++s)
     for (auto const& p : splits(s)) {
       if (!keep({s, p[0], p[1]}) || !live_split(s, p[0], p[1])) continue;
-      split.add(s, {p[0], p[1]});
-      split1.add(p[0], {s, p[1]});
-      split2.add(p[1], {s, p[0]});
+      split.add(id_of[s], {id_of[p[0]], id_of[p[1]]});
+      split1.add(id_of[p[0]], {id_of[s], id_of[p[1]]});
+      split2.add(id_of[p[1]], {id_of[s], id_of[p[0]]});
     }
   Csr quad(S_, 3), quad1(S_, 3), quad2(S_, 3), quad3(S_, 3);
   for (auto const& q : quads_) {
     if (!keep({q[0], q[1], q[2], q[3]}) || !live_quad(q)) continue;
-    quad.add(q[0], {q[1], q[2], q[3]});
-    quad1.add(q[1], {q[0], q[2], q[3]});
-    quad2.add(q[2], {q[0], q[1], q[3]});
-    quad3.add(q[3], {q[0], q[1], q[2]});
+    const int q0 = id_of[q[0]], q1 = id_of[q[1]], q2 = id_of[q[2]], q3 = id_of[q[3]];
+    quad.add(q0, {q1, q2, q3});
+    quad1.add(q1, {q0, q2, q3});
+    quad2.add(q2, {q0, q1, q3});
+    quad3.add(q3, {q0, q1, q2});
   }
   auto put = [&](const Csr& c, int32_t* off, int32_t* ent) { auto p = c.emit(ints); *off = p.first; *ent = p.second; };
   // small part: unary transition lists (staged in LDS together with the per-state attributes)
@@ -390,6 +417,48 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   put(rright, &A.rright_off, &A.rright_ent);
   put(rleft, &A.rleft_off, &A.rleft_ent);
   put(rpair, &A.rpair_off, &A.rpair_ent);
+  // pairs (s1, t) of the factorised rule 2: the kept splits (s; s1, t), closed under t' in right(t) (the tail of unpaired
+  // bases behind the last stem of a multiloop part grows by right emissions); internal ids, split order
+  {
+    std::vector<std::array<int, 3>> ap;   // (s1, t, tgt)
+    auto find = [&](int s1, int t) { for (size_t k = 0; k < ap.size(); ++k) if (ap[k][0] == s1 && ap[k][1] == t) return (int)k; return -1; };
+    for (int k = 0; k < S_; ++k)
+      for (size_t e = 0; e + 1 < split.rows[k].size(); e += 2) {
+        const int s1 = split.rows[k][e], t = split.rows[k][e + 1];
+        // (entries kept only for rule 7 pair an O state with a P state: they never carry weight in rule 2)
+        if (prune && !(U[ST_B][ref_of[k]] && I[ST_1][ref_of[s1]] && I[ST_2][ref_of[t]])) continue;
+        if (find(s1, t) < 0) ap.push_back({s1, t, k});
+      }
+    for (size_t k = 0; k < ap.size(); ++k) {   // closure (the list grows while it is walked)
+      const int s1 = ap[k][0], t = ap[k][1];
+      for (size_t e = 0; e + 1 < right.rows[t].size(); e += 2) {
+        const int tc = right.rows[t][e];
+        if (prune && !I[ST_2][ref_of[tc]]) continue;
+        if (find(s1, tc) < 0) ap.push_back({s1, tc, -1});
+      }
+    }
+    const int n_ap = (int)ap.size();
+    A.n_ap = n_ap;
+    A.ap_s1 = (int32_t)ints->size(); for (auto const& x : ap) ints->push_back(x[0]);
+    A.ap_t = (int32_t)ints->size(); for (auto const& x : ap) ints->push_back(x[1]);
+    A.ap_tgt = (int32_t)ints->size(); for (auto const& x : ap) ints->push_back(x[2]);
+    Csr chain(std::max(n_ap, 1), 2), rchain(std::max(n_ap, 1), 2), by_s1(S_, 1), by_t(S_, 1);
+    for (int k = 0; k < n_ap; ++k) {
+      const int s1 = ap[k][0], t = ap[k][1];
+      by_s1.add(s1, {k});
+      by_t.add(t, {k});
+      for (size_t e = 0; e + 1 < right.rows[t].size(); e += 2) {
+        const int kc = find(s1, right.rows[t][e]);
+        if (kc < 0) continue;
+        chain.add(k, {kc, right.rows[t][e + 1]});
+        rchain.add(kc, {k, right.rows[t][e + 1]});
+      }
+    }
+    put(chain, &A.ap_chain_off, &A.ap_chain_ent);
+    put(rchain, &A.ap_rchain_off, &A.ap_rchain_ent);
+    put(by_s1, &A.ap_by_s1_off, &A.ap_by_s1_ent);
+    put(by_t, &A.ap_by_t_off, &A.ap_by_t_ent);
+  }
   A.n_small = (int32_t)ints->size();
   // big part: tuple lists of the bifurcation and interior-loop rules -- first the ones the inside direction reads (by
   // parent), then the ones of the outside direction (by child): a kernel stages the small part and its own run
@@ -416,12 +485,12 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
 void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   AutomatonLayout& A = *lay;
   ints->clear();
-  A.S = 1; A.n_active = 1; A.M = 1; A.n_theta = 0; A.n_rows = 0;
+  A.S = 1; A.n_active = 1; A.n_front = 1; A.M = 1; A.n_theta = 0; A.n_rows = 0;
   A.s00 = A.s0m1 = A.s0m2 = 0;
   auto one = [&](int32_t v) { int32_t p = (int32_t)ints->size(); ints->push_back(v); return p; };
   A.st_l = one(0); A.st_r = one(0); A.st_is_loop = one(1);
   A.st_row_r = one(-1); A.st_row_l = one(-1); A.st_pair_r = one(0);
-  A.st_w_r = one(0); A.st_w_l = one(0); A.st_lam = one(0);
+  A.st_w_r = one(0); A.st_w_l = one(0); A.st_lam = one(0); A.st_ref = one(0);
   A.row_off = one(0);
   auto csr = [&](int width, int32_t* off, int32_t* ent) {
     *off = (int32_t)ints->size();
@@ -431,6 +500,10 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   };
   csr(2, &A.right_off, &A.right_ent); csr(2, &A.left_off, &A.left_ent); csr(2, &A.pair_off, &A.pair_ent);
   csr(2, &A.rright_off, &A.rright_ent); csr(2, &A.rleft_off, &A.rleft_ent); csr(2, &A.rpair_off, &A.rpair_ent);
+  A.n_ap = 1;                                          // the pair ((0,0), (0,0)), target (0,0), its own chain predecessor
+  A.ap_s1 = one(0); A.ap_t = one(0); A.ap_tgt = one(0);
+  csr(2, &A.ap_chain_off, &A.ap_chain_ent); csr(2, &A.ap_rchain_off, &A.ap_rchain_ent);
+  csr(1, &A.ap_by_s1_off, &A.ap_by_s1_ent); csr(1, &A.ap_by_t_off, &A.ap_by_t_ent);
   A.n_small = (int32_t)ints->size();
   csr(2, &A.split_off, &A.split_ent); csr(3, &A.quad_off, &A.quad_ent);
   A.split_tgt = A.quad_tgt = one(0);

@@ -24,6 +24,8 @@ enum TransType : int {
 struct AutomatonLayout {
   int32_t S;        // interval states (= stride of the state axis of every table)
   int32_t n_active; // states [0, n_active) are swept: S, or 1 in the restricted automaton of the no-motif pass
+  int32_t n_front;  // states [0, n_front) are the only ones that can take part in a bifurcation (non-zero in planes B, 1, 2
+                    // of a complete parse); the split-sum kernels stage only this prefix of a row.  S without pruning.
   int32_t M;        // pattern nodes incl. 'z' and 'o'
   int32_t n_theta;  // total theta entries (n_param - 2)
   int32_t n_rows;   // theta rows
@@ -36,6 +38,7 @@ struct AutomatonLayout {
   int32_t st_pair_r;         // node r is ')'
   int32_t st_w_r, st_w_l;    // position weight applies to node r / l ('.', '(' or ')': motif_model.hpp:131-134)
   int32_t st_lam;            // 0 if l==r else 1 (motif_model.hpp:117-121)
+  int32_t st_ref;            // id of the state in the reference's order (profile_hmm.hpp:228-260); tables are exported in it
   int32_t row_off;           // n_rows+1 offsets of theta rows in the parameter vector
   // forward lists: (child, tau_flag) pairs, 2 ints per entry
   int32_t right_off, right_ent;  // loop_right_trans  (profile_hmm.hpp:389-401)
@@ -59,6 +62,14 @@ struct AutomatonLayout {
   // target (= grouping) state of every flat entry of the seven tuple lists above, for lane-per-tuple gathers
   int32_t split_tgt, split1_tgt, split2_tgt, quad_tgt, quad1_tgt, quad2_tgt, quad3_tgt;
   int32_t n_split, n_quad;  // entries per split* list / per quad* list
+  // Rule 2 through the pair-sparse factorisation (lin_rules.h): "pairs" p = (s1, t) of a state s1 of plane 1 and a state t
+  // of plane 2 with s1.r == t.l, closed under the right-emission predecessors of t.  Per pair: ap_s1, ap_t, ap_tgt (the
+  // parent s of the split (s; s1, t), or -1).  ap_chain: CSR by pair p -> (p', tau flag) with t' in right(t) (inside
+  // direction); ap_rchain: the same entries by p' -> (p, tau flag); ap_by_s1 / ap_by_t: CSR by state -> pair ids.
+  int32_t n_ap;
+  int32_t ap_s1, ap_t, ap_tgt;
+  int32_t ap_chain_off, ap_chain_ent, ap_rchain_off, ap_rchain_ent;
+  int32_t ap_by_s1_off, ap_by_s1_ent, ap_by_t_off, ap_by_t_ent;
   int32_t n_small;  // the first n_small ints (per-state attributes, unary lists) are staged in LDS;
                     // the tuple lists behind them are read from global memory (ModelView::big)
   int32_t big_in_end;  // the tuple lists behind n_small come in two runs: [n_small, big_in_end) = lists of the inside

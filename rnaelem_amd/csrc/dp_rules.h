@@ -160,6 +160,8 @@ struct SeqView {
   const double* xwi = nullptr; size_t xwi_stride = 0;
   // items in the by_inner / by_left / by_right orders and their weights: order o (1..3) at xwi + o * 2 * xwi_stride
   const LoopItem* items_inner = nullptr; const LoopItem* items_left = nullptr; const LoopItem* items_right = nullptr;
+  // the pair mask indexed by (end j, span): bit j * (W+1) + span <=> pair cell (j - span, span)  (k_mask_by_end)
+  const uint32_t* okbits_end = nullptr;
 
   ELEMDP_HD int cell(int i, int d) const { return i * (W + 1) + d; }
   ELEMDP_HD bool pair_ok(int i, int d) const {  // is_parsable<ST_P>
@@ -186,7 +188,30 @@ struct TableView {
   }
   ELEMDP_HD double& at(int e, int d, int i, int s) const { return band[idx(e, d, i, s)]; }
   ELEMDP_HD double& o(int j, int s) const { return ext[(uint32_t)j * (uint32_t)S + (uint32_t)s]; }
+  // pair table of the factorised rule 2 (scaled-linear pipeline, lin_rules.h): [d][i][p], p < nA pairs (s1, t)
+  double* ap = nullptr;
+  int32_t nA = 0;
+  ELEMDP_HD uint32_t aidx(int d, int i, int p) const { return ((uint32_t)d * (uint32_t)(L + 1) + (uint32_t)i) * (uint32_t)nA + (uint32_t)p; }
+  ELEMDP_HD double& a(int d, int i, int p) const { return ap[aidx(d, i, p)]; }
 };
+
+// calls fn(n) for every set bit bit0 + n of a pair mask with n in [lo, hi], ascending (walks the 32-bit words)
+template <class F> ELEMDP_HD void for_mask_bits(const uint32_t* m, int bit0, int lo, int hi, F fn) {
+  if (hi < lo) return;
+  const int b = bit0 + lo, e = bit0 + hi;
+  int w = b >> 5;
+  uint32_t word = m[w] & (~0u << (b & 31));
+  for (;;) {
+    while (word) {
+      const int bit = (w << 5) + __builtin_ctz(word);
+      if (bit > e) return;
+      fn(bit - bit0);
+      word &= word - 1;
+    }
+    if (((w + 1) << 5) > e) return;
+    word = m[++w];
+  }
+}
 
 ELEMDP_HD bool m_ok(const ModelView& m, const SeqView& q, int i, int d) {  // is_parsable<ST_M>
   return 0 < i && i + d < q.L && d <= q.W && m.m_min <= d;

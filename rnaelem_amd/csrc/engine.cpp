@@ -253,12 +253,11 @@ class Engine {
   int64_t n_cells_total_ = 0;
   bool tables_linear_ = false;           // the resident tables hold scaled linear values (debug_tables converts)
   int n_flagged_last_ = 0;
-  DevBuf d_part_in_, d_part_h1_, d_part_h2_;   // tile partial sums of the split rules, per slot [4][Lmax+1][S]
+  DevBuf d_a_in_, d_a_out_, d_a_in0_, d_a_out0_;   // pair tables of the factorised rule 2 (lin_rules.h), per slot [W+1][Lmax+1][n_ap]
   DevBuf d_plans_sorted_;   // plan records in processing (h_order_) order
   DevBuf d_ews_, d_xwc_, d_xwi_, d_lin_, d_layc_, d_zs_, d_flagged_, d_band_in0_, d_band_out0_, d_ext_in0_, d_ext_out0_;
   int lin_slots_ = 0;
   int opt_schedule_ = 1;   // 1 = linear (ari pass + one-state nasi pass), 0 = the reference's two full passes
-  int opt_tile_ = 0;       // 1: split sums tiled over 4 diagonals (2.5x less table traffic, same speed: see DESIGN.md)
   int opt_dbg_ = 0;        // timing experiments (LinArgs::dbg); results are wrong when set
   int opt_group_ = 0;      // sequences swept in lockstep by the batch pipeline (0 = auto)
   DevBuf d_prof_;
@@ -308,6 +307,7 @@ void Engine::flatten_automaton() {
   au_.flatten(&layr_, &intsr_, true, opt_prune_);
   layc_ = layr_;
   layc_.S = 1;   // same one-state lists, compact tables
+  lin_slots_ = 0;   // (the pair tables of the linear pipeline are sized by the automaton's pair list)
 }
 
 void Engine::upload_automaton() {
@@ -397,7 +397,6 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "group") opt_group_ = (int)v;
   else if (key == "schedule") opt_schedule_ = (int)v;
   else if (key == "dbg") opt_dbg_ = (int)v;
-  else if (key == "tile") opt_tile_ = (int)v;
   else if (key == "prune") {
     opt_prune_ = v != 0;
     flatten_automaton();
@@ -904,7 +903,8 @@ int Engine::prepare_lin(LinArgs& a, bool sched1) {
   const int S = au_.S();
   {
     const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext = (size_t)(Lmax_ + 1);
-    slot_override_ = balanced_group((band + ext) * (S + 1) * 2 * sizeof(double) + ext * S * 3 * sizeof(double));
+    slot_override_ = balanced_group((band + ext) * (S + 1) * 2 * sizeof(double) + ext * S * 3 * sizeof(double) +
+                                    (size_t)(Wmax_ + 1) * (Lmax_ + 1) * (lay_.n_ap + 1) * 2 * sizeof(double));
   }
   ensure_slots(S, false, n_seq_);
   slot_override_ = 0;
@@ -914,9 +914,11 @@ int Engine::prepare_lin(LinArgs& a, bool sched1) {
   const size_t band0 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext0 = (size_t)(Lmax_ + 1);
   if (lin_slots_ != n_slots_) {
     d_zs_.alloc(sizeof(double) * 4 * n_slots_);
-    d_part_in_.alloc(sizeof(double) * 4 * (size_t)(Lmax_ + 1) * S * n_slots_);
-    d_part_h1_.alloc(sizeof(double) * 4 * (size_t)(Lmax_ + 1) * S * n_slots_);
-    d_part_h2_.alloc(sizeof(double) * 4 * (size_t)(Lmax_ + 1) * S * n_slots_);
+    const size_t acell = (size_t)(Wmax_ + 1) * (Lmax_ + 1);
+    d_a_in_.alloc(sizeof(double) * acell * lay_.n_ap * n_slots_);
+    d_a_out_.alloc(sizeof(double) * acell * lay_.n_ap * n_slots_);
+    d_a_in0_.alloc(sizeof(double) * acell * n_slots_);
+    d_a_out0_.alloc(sizeof(double) * acell * n_slots_);
     d_band_in0_.alloc(sizeof(double) * band0 * n_slots_);
     d_band_out0_.alloc(sizeof(double) * band0 * n_slots_);
     d_ext_in0_.alloc(sizeof(double) * ext0 * n_slots_);
@@ -948,13 +950,13 @@ int Engine::prepare_lin(LinArgs& a, bool sched1) {
   a.ext_in0 = sched1 ? d_ext_in0_.as<double>() : nullptr;
   a.band0_stride = band0; a.ext0_stride = ext0;
   a.zs = d_zs_.as<double>();
-  a.part_in = d_part_in_.as<double>(); a.part_h1 = d_part_h1_.as<double>(); a.part_h2 = d_part_h2_.as<double>();
-  a.part_stride = 4 * (size_t)(Lmax_ + 1) * S;
-  a.tile_d0 = -1;
-  a.tile = opt_tile_;
+  a.a_in = d_a_in_.as<double>(); a.a_out = d_a_out_.as<double>();
+  a.a_stride = (size_t)(Wmax_ + 1) * (Lmax_ + 1) * lay_.n_ap;
+  a.a_in0 = sched1 ? d_a_in0_.as<double>() : nullptr;
+  a.a0_stride = (size_t)(Wmax_ + 1) * (Lmax_ + 1);
+  a.okbits_end = d_okbits_end_.as<uint32_t>();
   a.lmax = Lmax_;
   a.nword_max = nword_max_;
-  a.tile_has_old = 0;
   a.seq_out = d_seq_out_.as<double>();
   a.out_stride = out_stride_;
   a.schedule = sched1 ? 1 : 0;
@@ -985,7 +987,8 @@ void Engine::run_lin_batch() {
   c.ext_in = d_ext_in0_.as<double>(); c.ext_out = d_ext_out0_.as<double>();
   c.band_stride = band0; c.ext_stride = ext0;
   c.band_in0 = nullptr; c.ext_in0 = nullptr;
-  c.part_in = c.part_h1 = c.part_h2 = nullptr;   // the one-state pass sums directly
+  c.a_in = d_a_in0_.as<double>(); c.a_out = d_a_out0_.as<double>();
+  c.a_stride = c.a0_stride; c.a_in0 = nullptr;
   c.n_stage = (layc_.n_ints <= 4096) ? layc_.n_ints : layc_.n_small;
   HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n_seq_, st_));
   HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
@@ -1004,7 +1007,8 @@ void Engine::run_lin_batch() {
     if (x.band_in0) x.band_in0 += k * x.band0_stride;
     if (x.ext_in0) x.ext_in0 += k * x.ext0_stride;
     x.zs += 4 * k;
-    if (x.part_in) { x.part_in += k * x.part_stride; x.part_h1 += k * x.part_stride; x.part_h2 += k * x.part_stride; }
+    x.a_in += k * x.a_stride; x.a_out += k * x.a_stride;
+    if (x.a_in0) x.a_in0 += k * x.a0_stride;
     return x;
   };
   if (ns > 1) {   // the other streams start behind the weights
@@ -1160,19 +1164,38 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
   std::vector<double> cum(L + 1, 0.);   // log2 of prod_{p<j} psb[base(p)]
   if (lin) for (int t = 0; t < L; ++t) cum[t + 1] = cum[t] + h_lin_[kLinPl2 + h_seq_[p.seq_base + t]];
   const double ln2 = 0.69314718055994530942, NEGINF = -std::numeric_limits<double>::infinity();
+  auto ref_id = [&](int s) { return ints_[lay_.st_ref + s]; };   // tables are exported in the reference's state order
   auto conv = [&](double v, double scale_log2) { return !lin ? v : (v > 0. ? std::log(v) - scale_log2 * ln2 : NEGINF); };
   auto reorder = [&](const std::vector<double>& t, double* dst, bool outside_tab) {  // [e][d][i][s] -> [i][d][e][s]
     for (int i = 0; i <= L; ++i) for (int d = 0; d <= W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s) {
       double sc = (i + d <= L) ? cum[i + d] - cum[i] : 0.;
       if (outside_tab) sc = cum[L] - sc;
-      dst[(((size_t)i * (W + 1) + d) * 7 + e) * S + s] =
+      dst[(((size_t)i * (W + 1) + d) * 7 + e) * S + ref_id(s)] =
           (i + d <= L) ? conv(t[(((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s], sc) : NEGINF;
     }
   };
   if (inside) reorder(fetch(d_band_in_, band), inside, false);
-  if (outside) reorder(fetch(d_band_out_, band), outside, true);
-  if (inside_o) { auto h = fetch(d_ext_in_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) inside_o[(size_t)j * S + s] = conv(h[(size_t)j * S + s], cum[j]); }
-  if (outside_o) { auto h = fetch(d_ext_out_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) outside_o[(size_t)j * S + s] = conv(h[(size_t)j * S + s], cum[L] - cum[j]); }
+  if (outside) {
+    std::vector<double> to = fetch(d_band_out_, band);
+    if (lin && lay_.n_ap > 0 && d_a_out_.bytes() >= sizeof(double) * (size_t)(W + 1) * (L + 1) * lay_.n_ap) {
+      // the linear pipeline keeps only the direct part (rules 4a, 3a) of the plane-2 outside values; what arrives through
+      // rule 2 is HA(k,l,t) = sum_i sum_{p=(s1,t)} outA(i,l,p) 1(i,k,s1) (lin_rules.h) -- added here for the export
+      const int nA = lay_.n_ap;
+      const std::vector<double> ti = fetch(d_band_in_, band), ao = fetch(d_a_out_, (size_t)(W + 1) * (L + 1) * nA);
+      auto at = [&](int e, int d, int i, int s2) { return (((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s2; };
+      for (int d = 0; d <= W; ++d) for (int i = 0; i + d <= L; ++i) for (int p = 0; p < nA; ++p) {
+        const int s1 = ints_[lay_.ap_s1 + p], t = ints_[lay_.ap_t + p];
+        if (!(ti[at(ST_2, d, i, t)] != 0.)) continue;
+        double acc = 0.;
+        for (int b = 1; d + b <= W && i - b >= 0; ++b)
+          acc += ao[((size_t)(d + b) * (L + 1) + (i - b)) * nA + p] * ti[at(ST_1, b, i - b, s1)];
+        to[at(ST_2, d, i, t)] += acc;
+      }
+    }
+    reorder(to, outside, true);
+  }
+  if (inside_o) { auto h = fetch(d_ext_in_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) inside_o[(size_t)j * S + ref_id(s)] = conv(h[(size_t)j * S + s], cum[j]); }
+  if (outside_o) { auto h = fetch(d_ext_out_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) outside_o[(size_t)j * S + ref_id(s)] = conv(h[(size_t)j * S + s], cum[L] - cum[j]); }
   std::vector<double> o = fetch(d_seq_out_, out_stride_);
   const int nt = au_.n_theta();
   if (ENo) std::copy(o.begin() + 6, o.begin() + 6 + nt, ENo);
@@ -1283,6 +1306,7 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
       ak.band_in += (size_t)k * slots_each * a.band_stride; ak.band_out += (size_t)k * slots_each * a.band_stride;
       ak.ext_in += (size_t)k * slots_each * a.ext_stride; ak.ext_out += (size_t)k * slots_each * a.ext_stride;
       ak.zs += 4 * (size_t)k * slots_each;
+      ak.a_in += (size_t)k * slots_each * a.a_stride; ak.a_out += (size_t)k * slots_each * a.a_stride;
       ak.tr_band += (size_t)k * tr_each * a.band_stride; ak.tr_ext += (size_t)k * tr_each * a.ext_stride;
       ak.trace_stack += (size_t)k * tr_each * stack_stride;
       ak.grp = d_order_.as<int32_t>() + g0;

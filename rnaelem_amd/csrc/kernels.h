@@ -151,12 +151,11 @@ struct LinArgs {
   // scan, Viterbi pass on the batch pipeline: trace tables per slot (same indexing as the band / ext tables), outputs
   TraceRec* tr_band; TraceRec* tr_ext; int32_t* sc_psihat; char* sc_rss; int32_t* trace_stack; int32_t trace_stack_stride;
   long long* prof;                // optional [16] shader-clock sums per phase (thread 0 of every workgroup), or null
-  // tiling of the split sums over kTile diagonals: pairs whose operands were both final before the tile started are
-  // summed by k4_in_old / k4_out_old into part_* (per slot [level][i][s]); the per-diagonal kernels add the rest
-  double* part_in; double* part_h1; double* part_h2; size_t part_stride;   // (part_stride = doubles per slot and array)
-  int32_t tile_d0;                // first diagonal of the running tile, or -1: this launch sums all split points itself
-  int32_t tile;                   // 1: tile the split sums (k4_in_old / k4_out_old); 0 (default): every diagonal sums its own
-  int32_t tile_has_old;           // part_* of the running tile are valid (0: the tile has no old pairs, e.g. the outside tile at W)
+  // rule 2, factorised (lin_rules.h): pair tables [d][i][p] per slot (a_stride doubles each), the compact copy of the pair
+  // ((0,0),(0,0)) for the no-motif pass, and the end-indexed pair mask (bits_base indexing, like okbits)
+  double* a_in; double* a_out; size_t a_stride;
+  double* a_in0; size_t a0_stride;
+  const uint32_t* okbits_end;
   int32_t lmax, nword_max;        // longest sequence of the launch / most pair-mask words of a sequence (LDS sizing)
   int32_t wmax;                   // largest span of the launch (sizes the position window staged in LDS)
   int32_t n_stage;                // ints of the automaton blob staged in LDS: n_ints (whole blob) or n_small

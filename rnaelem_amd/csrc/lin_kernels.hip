@@ -157,6 +157,10 @@ __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) 
   v.out.band = a.band_out + (size_t)g * a.band_stride;
   v.out.ext = a.ext_out + (size_t)g * a.ext_stride;
   v.in.L = v.out.L = p.L; v.in.W = v.out.W = p.W; v.in.S = v.out.S = a.lay.S;
+  v.in.ap = a.a_in ? a.a_in + (size_t)g * a.a_stride : nullptr;
+  v.out.ap = a.a_out ? a.a_out + (size_t)g * a.a_stride : nullptr;
+  v.in.nA = v.out.nA = a.lay.n_ap;
+  q.okbits_end = a.okbits_end ? a.okbits_end + p.bits_base : nullptr;
   v.row = a.seq_out + (size_t)n * a.out_stride;
   v.zs = a.zs + (size_t)g * 4;
 }
@@ -211,7 +215,34 @@ __global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
 // window of positions the workgroup touches, small int arrays, the automaton blob, and the dmin / base / unpaired
 // windows.  With the context in LDS the unary phase has a single level of global loads (the tables themselves).
 struct BlockLds {
-  int lin, ews, ints, dm, cnts, pre, base, blob, bits, dmin16, seq8, unp8, total;   // byte offsets
+  int lin, ews, ints, dm, cnts, pre, base, blob, bits, bits2, dmin16, seq8, unp8, total;   // byte offsets
+};
+// LDS doubles of the item-record area of k4_in / k5_cyk (one role) and of k4_out (three roles)
+constexpr int kRecIn = 1024, kRecOut = 2560;
+// Walks the set bits bit0 + n, n in [lo, hi], of a pair mask (ascending): next() returns n, or -1 at the end.
+struct BitIter {
+  const uint32_t* m;
+  int bit0, e, w;
+  uint32_t word;
+  __device__ __forceinline__ void init(const uint32_t* mask, int b0, int lo, int hi) {
+    m = mask; bit0 = b0; e = b0 + hi;
+    const int b = b0 + (lo > 0 ? lo : 0);
+    w = b >> 5;
+    word = (hi >= lo) ? (mask[w] & (~0u << (b & 31))) : 0u;
+    if (hi < lo) e = -1;
+  }
+  __device__ __forceinline__ int next() {
+    for (;;) {
+      if (word) {
+        const int bit = (w << 5) + __builtin_ctz(word);
+        word &= word - 1;
+        if (bit > e) { word = 0u; e = -1; return -1; }
+        return bit - bit0;
+      }
+      if (((w + 1) << 5) > e) return -1;
+      word = m[++w];
+    }
+  }
 };
 __host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int win, int n_stage, int nv = 0) {
   BlockLds b;
@@ -225,7 +256,9 @@ __host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int wi
   b.pre = o; o += (nv + 1) * 4;
   b.base = o; o += nv * 4;
   b.blob = o; o += n_stage * 4;
-  b.bits = o; o += (((cpb + 2) * (win - cpb) + 31) / 32 + 2) * 4;   // pair-mask words of cells (i0-1 .. i0+cpb) x (0 .. W)
+  // pair-mask words of the rows i0-1 .. i0+cpb+W (k4_out also reads the stems that start at the cells' ends); win = cpb + W + 3
+  b.bits = o; o += ((win * (win - cpb - 2) + 31) / 32 + 3) * 4;
+  b.bits2 = o; o += (((cpb + 1) * (win - cpb - 2) + 31) / 32 + 3) * 4;   // end-indexed mask, rows i0+d .. i0+d+cpb (k4_in)
   b.dmin16 = o; o += ((win + 1) / 2) * 4;
   b.seq8 = o; o += ((win + 3) / 4) * 4;
   b.unp8 = o; o += ((win + 3) / 4) * 4;
@@ -258,11 +291,16 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   const int n_lin = kLinEth + a.lay.n_theta;
   const int big_lo = (PART == 0) ? a.lay.n_small : a.lay.big_in_end, big_hi = (PART == 0) ? a.lay.big_in_end : a.lay.n_ints;
   uint32_t* lbits = reinterpret_cast<uint32_t*>(raw + B.bits);
-  // pair mask: bits of the cells (i0-1, .) .. (i0+nc-1, .)  (bit index = i * (W+1) + d)
+  uint32_t* lbits2 = reinterpret_cast<uint32_t*>(raw + B.bits2);
+  // pair mask: bits of the cells (i0-1, .) .. (i0+nc-1, .)  (bit index = i * (W+1) + d); the outside kernel also walks the
+  // stems that START at the ends j = i + d of its cells (rule 2, factorised): rows up to i0+nc-1+d.  The inside kernel
+  // walks the stems that END there: rows i0+d .. i0+nc-1+d of the end-indexed mask (second window).
   const int W1 = v.q.W + 1;
-  const int bit0 = ((i0 > 0) ? i0 - 1 : 0) * W1, bit1 = (i0 + nc) * W1;   // [bit0, bit1)
-  const int w0 = bit0 >> 5, w1 = (bit1 + 31) >> 5;
+  const int last_row = (PART == 1) ? ((i0 + nc + d <= L + 1) ? i0 + nc + d : L + 1) : i0 + nc;
+  const int bit0 = ((i0 > 0) ? i0 - 1 : 0) * W1, bit1 = last_row * W1;   // [bit0, bit1)
+  const int w0 = bit0 >> 5, w1 = ((bit1 + 31) >> 5) + 1;
   const int wend = (int)((((long long)(L + 1) * W1) + 31) >> 5);
+  const int e0 = ((i0 + d) * W1) >> 5, e1 = (PART == 0) ? ((((i0 + d + nc) * W1 + 31) >> 5) + 1) : e0;
   // ALL loads of the context are issued before the first LDS store (clamped addresses, fixed unrolling): one round trip
   // for the whole context instead of one per array (a plain copy loop waits for its loads before it stores)
   constexpr int kU = 4;
@@ -276,6 +314,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   }
   const double r_lin = a.lin[tid < n_lin ? tid : 0];
   const uint32_t r_bits = v.q.okbits[(tid < w1 - w0 && w0 + tid < wend) ? w0 + tid : 0];
+  const uint32_t r_bits2 = (PART == 0) ? v.q.okbits_end[(tid < e1 - e0 && e0 + tid < wend) ? e0 + tid : 0] : 0u;
   const int pw = p0 + (tid < len ? tid : 0);
   const double r_ews = v.q.ews[pw];
   const int16_t r_dmin = v.q.dmin[pw];
@@ -290,6 +329,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   }
   if (tid < n_lin) llin[tid] = r_lin;
   if (tid < w1 - w0) lbits[tid] = (w0 + tid < wend) ? r_bits : 0u;
+  if (PART == 0 && tid < e1 - e0) lbits2[tid] = (e0 + tid < wend) ? r_bits2 : 0u;
   if (tid < len) {
     lews[tid] = r_ews;
     ldmin[tid] = r_dmin;
@@ -301,6 +341,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   for (int t = tid + kU * kThreads; t < n_bg; t += kThreads) blob[a.lay.n_small + t] = a.ints[big_lo + t];
   for (int t = tid + kThreads; t < n_lin; t += kThreads) llin[t] = a.lin[t];
   for (int t = tid + kThreads; t < w1 - w0; t += kThreads) lbits[t] = (w0 + t < wend) ? v.q.okbits[w0 + t] : 0u;
+  if (PART == 0) for (int t = tid + kThreads; t < e1 - e0; t += kThreads) lbits2[t] = (e0 + t < wend) ? v.q.okbits_end[e0 + t] : 0u;
   for (int t = tid + kThreads; t < len; t += kThreads) {
     const int p = p0 + t;
     lews[t] = v.q.ews[p];
@@ -322,6 +363,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   v.q.unp = lunp - p0;
   v.q.seq = lseq - p0;
   v.q.okbits = lbits - w0;
+  if (PART == 0) v.q.okbits_end = lbits2 - e0;
   return c;
 }
 
@@ -332,6 +374,29 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
 // once per workgroup, 2*kChunk loads in flight per lane) and the dependent chain per diagonal stays short.
 constexpr int kChunkIn = ELEMDP_KCI;    // split points per staging round, inside  (2 segments each)
 constexpr int kChunkOut = ELEMDP_KCO;   // split points per staging round, outside (4 segments each)
+
+// Which element of a staged operand row a lane copies.  Only the first NU = n_front states of a row can be non-zero in the
+// planes of the bifurcation rule (B, 1, 2) of a complete parse (Automaton::flatten puts them first), so a staged row is
+// nc * NU doubles instead of nc * S, and the lanes that are left over take further split points of the same round: lane =
+// (sub, cell c, state k), `nsub` split points per load instruction, kChunk * nsub per staging round.  LDS image of one
+// split point: [c * NU + k] (CU = cpb * NU doubles).
+struct StageMap {
+  int NU, CU, nsub, sub, r, goff, cell;
+  bool act;
+};
+__device__ __forceinline__ StageMap stage_map(int n_front, int S, int cpb, int nc, int tid) {
+  StageMap m;
+  m.NU = n_front;
+  m.CU = cpb * n_front;
+  m.nsub = kThreads / m.CU;            // >= 1: cpb * S <= kThreads
+  m.sub = tid / m.CU;
+  m.r = tid - m.sub * m.CU;
+  m.cell = m.r / n_front;
+  const int k = m.r - m.cell * n_front;
+  m.act = m.sub < m.nsub && m.cell < nc;
+  m.goff = m.act ? m.cell * S + k : 0;
+  return m;
+}
 
 // Item sums without serial chains: the interior-loop items of all cells of the workgroup (CSR ranges given by
 // `range(c, &first, &last)`) form one flat list; work item = (item, state tuple), tuple fastest, so the lanes of a wave
@@ -459,141 +524,6 @@ __device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r,
   __syncthreads();
 }
 
-// ---- inside, "old" split sums of a whole tile of kTile diagonals d0 .. d0+kTile-1 (launched before k4_in(d0)):
-//   part_in[t][i][s] = sum_{t < a < d0} sum_tuples 1(i, i+a, s1) * 2(i+a, i+d0+t, s2)
-// i.e. all pairs of split operands that were final before the tile started.  The point of doing them together: a row
-// 1(i,a,.) serves every level t, and a row 2(k,b,.) serves the kTile targets (k-a, d0+t) with a + b = d0 + t, so a chunk
-// of kOldA split points needs kOldA + (kOldA+kTile-1) staged segments for kOldA*kTile (a, t) products instead of two
-// segments per product: ~2.5x less table traffic than summing diagonal by diagonal.
-constexpr int kTile = ELEMDP_TILE;
-constexpr int kOldA = 4;
-constexpr int kOldB = kOldA + kTile - 1;
-constexpr int kTileStart = 8;   // diagonals below are summed directly (few split points)
-constexpr int kOldOwn = 8;      // (level, cell, tuple) products per lane held in registers
-template <bool BIG>
-__global__ __launch_bounds__(kThreads) void k4_in_old(LinArgs a) {
-  extern __shared__ double lds[];
-  __shared__ AutomatonLayout s_lay;
-  stage_layout(a, &s_lay, kThreads);
-  unsigned bx, by;
-  swizzled_block(bx, by);
-  LViews v(s_lay);
-  make_lviews(a, by, v);
-  const AutomatonLayout& A = s_lay;
-  const int S = a.lay.S, d0 = a.tile_d0, cpb = a.cpb, tid = threadIdx.x;
-  const int L = v.q.L, W = v.q.W;
-  if (d0 > W) return;                       // (k4_in returns for such diagonals, too: the partials are never read)
-  const int ncell = L - d0 + 1, i0 = bx * cpb;
-  if (i0 >= ncell) return;
-  const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
-  const int CS = cpb * S, CS2 = (cpb + kOldA - 1) * S;
-  double* acc = lds;                       // [kTile][CS]
-  double* st1 = acc + kTile * CS;          // [kOldA][CS]   rows 1(i0+c, a0+u, .)
-  double* st2 = st1 + kOldA * CS;          // [kOldB][CS2]  rows 2(i0+a0+c', b_lo+v, .)
-  // (the tuple lists are read once per lane, from global memory: no copy of the automaton blob, one more workgroup per CU)
-  int* dm = reinterpret_cast<int*>(st2 + kOldB * CS2);
-  for (int t = tid; t < kTile * CS; t += kThreads) acc[t] = 0.;
-  if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
-  const int32_t* G = a.ints;
-  __syncthreads();
-  int a_lo = d0;
-  for (int c = 0; c < nc; ++c) { const int x = dm[c]; if (x > 0 && x < a_lo) a_lo = x; }
-  if (a_lo < 1) a_lo = 1;
-  const int nsp = A.n_split;
-  const double* B = v.in.band;
-  // products owned by this lane: w = (t * nc + c) * nsp + tuple
-  int o1[kOldOwn], o2[kOldOwn], otg[kOldOwn], olv[kOldOwn];
-  double pacc[kOldOwn];
-  const int nwork = kTile * nc * nsp;
-#pragma unroll
-  for (int r = 0; r < kOldOwn; ++r) {
-    const int w = tid + r * kThreads;
-    o1[r] = -1; o2[r] = 0; otg[r] = 0; olv[r] = 0; pacc[r] = 0.;
-    if (w < nwork) {
-      const int tc = w / nsp, tu = w - tc * nsp;
-      const int t = tc / nc, c = tc - t * nc;
-      const int x = dm[c];
-      if (x > 0 && x <= d0 + t && d0 + t <= W && i0 + c + d0 + t <= L) {   // left_ok(i, d0+t) and the target exists
-        o1[r] = c * S + G[A.split_ent + 2 * tu];
-        o2[r] = c * S + G[A.split_ent + 2 * tu + 1];
-        otg[r] = t * CS + c * S + G[A.split_tgt + tu];
-        olv[r] = t;
-      }
-    }
-  }
-  for (int a0 = a_lo; a0 < d0; a0 += kOldA) {
-    const int b_lo = d0 - a0 - kOldA + 1;   // staged diagonals of plane 2: b_lo .. b_lo + kOldB - 1
-    // one element per lane and segment, all loads of the chunk issued before the first use (clamped addresses, masked values)
-    const int n1e = nc * S, n2e = (nc + kOldA - 1) * S;
-    {
-      const int r = (tid < n1e) ? tid : 0;
-      double x[kOldA];
-#pragma unroll
-      for (int u = 0; u < kOldA; ++u) {
-        const int aa = (a0 + u < d0) ? a0 + u : d0 - 1;
-        x[u] = B[v.in.idx(ST_1, aa, i0, 0) + r];
-      }
-      double y[kOldB][2];
-#pragma unroll
-      for (int vv = 0; vv < kOldB; ++vv) {
-        const int b = b_lo + vv;
-        const int bc = (b >= 1 && b < d0) ? b : 1;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int e = tid + h * kThreads;
-          const int k = i0 + a0 + e / S;
-          const bool ok = e < n2e && b >= 1 && b < d0 && k + b <= L;
-          y[vv][h] = B[v.in.idx(ST_2, bc, ok ? i0 + a0 : 0, 0) + (ok ? e : 0)];
-          if (!ok) y[vv][h] = 0.;
-        }
-      }
-      if (tid < n1e) {
-#pragma unroll
-        for (int u = 0; u < kOldA; ++u) st1[u * CS + tid] = (a0 + u < d0) ? x[u] : 0.;
-      }
-#pragma unroll
-      for (int vv = 0; vv < kOldB; ++vv) {
-        if (tid < n2e) st2[vv * CS2 + tid] = y[vv][0];
-        if (tid + kThreads < n2e) st2[vv * CS2 + tid + kThreads] = y[vv][1];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kOldOwn; ++r)
-      if (o1[r] >= 0) {
-        const int t = olv[r];
-#pragma unroll
-        for (int u = 0; u < kOldA; ++u) {
-          const int aa = a0 + u;
-          if (aa > t && aa < d0)   // (a <= t: the partner 2(i+a, d0+t-a) is not final yet -- k4_in adds that term)
-            pacc[r] = fma(st1[u * CS + o1[r]], st2[(t - u + kOldA - 1) * CS2 + u * S + o2[r]], pacc[r]);
-        }
-      }
-    for (int w = tid + kOldOwn * kThreads; w < nwork; w += kThreads) {   // (patterns with more tuples than lanes)
-      const int tc = w / nsp, tu = w - tc * nsp;
-      const int t = tc / nc, c = tc - t * nc;
-      const int x = dm[c];
-      if (!(x > 0 && x <= d0 + t && d0 + t <= W && i0 + c + d0 + t <= L)) continue;
-      const int p1 = c * S + G[A.split_ent + 2 * tu], p2 = c * S + G[A.split_ent + 2 * tu + 1];
-      double sum = 0.;
-      for (int u = 0; u < kOldA; ++u) {
-        const int aa = a0 + u;
-        if (aa > t && aa < d0) sum = fma(st1[u * CS + p1], st2[(t - u + kOldA - 1) * CS2 + u * S + p2], sum);
-      }
-      if (sum != 0.) atomicAdd(&acc[t * CS + c * S + G[A.split_tgt + tu]], sum);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < kOldOwn; ++r) if (o1[r] >= 0 && pacc[r] != 0.) atomicAdd(&acc[otg[r]], pacc[r]);
-  __syncthreads();
-  double* part = a.part_in + (size_t)by * a.part_stride;
-  for (int e = tid; e < kTile * nc * S; e += kThreads) {
-    const int t = e / (nc * S), r = e - t * (nc * S);
-    part[((size_t)t * (L + 1) + i0) * S + r] = acc[t * CS + r];
-  }
-}
-
 template <bool BIG, bool CON>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
@@ -614,86 +544,72 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   const int CS = cpb * S, ncS = nc * S;
   double* hb = lds;
   double* he = hb + CS;
-  double* st1 = he + CS;               // [kChunkIn][CS]  rows 1(i, i+a, .)
-  double* st2 = st1 + kChunkIn * CS;   // [kChunkIn][CS]  rows 2(i+a, j, .)
-  const BlockLds BL = block_lds((2 + 2 * kChunkIn) * CS, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
+  double* st1 = he + CS;                     // item records (kRecIn doubles)
+  const BlockLds BL = block_lds(2 * CS + kRecIn, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
   const BlockCtx cx = stage_context<BIG, 0>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   for (int t = tid; t < 2 * CS; t += kThreads) lds[t] = 0.;
   __syncthreads();
   pc.mark<0>();
-  // rule 2: B(i,j,tgt) = sum_{a = k-i} sum_tuples 1(i,i+a,s1) * 2(i+a,j,s2);  1(i,i+a,.) = 0 for a < dmin[i]
-  int a_lo = d;
-  for (int c = 0; c < nc; ++c) { const int x = dm[c]; if (x > 0 && x < a_lo) a_lo = x; }
-  const int nsp = A.n_split;
   const double* B = v.in.band;
-  if (a.dbg & 1) a_lo = d;
-  // every lane owns up to kOwn (cell, tuple) products, decoded once; the sums stay in registers over all rounds
-  constexpr int kOwn = 2;
-  int po1[kOwn], po2[kOwn], ptg[kOwn];
-  double pacc[kOwn];
-#pragma unroll
-  for (int r = 0; r < kOwn; ++r) {
-    const int w = tid + r * kThreads;
-    po1[r] = -1; po2[r] = 0; ptg[r] = 0; pacc[r] = 0.;
-    if (w < nc * nsp) {
-      const int c = w / nsp, t = w - c * nsp;
-      const int x = dm[c];
-      if (x > 0 && x <= d) {   // left_ok(i, d)
-        po1[r] = c * S + G[A.split_ent + 2 * t]; po2[r] = c * S + G[A.split_ent + 2 * t + 1]; ptg[r] = c * S + G[A.split_tgt + t];
+  // rule 2, factorised (lin_rules.h, lin_inside_apair): lane = (cell, pair p = (s1, t)).  A(i,j,p) = the tail step from
+  // A(i,j-1,.) plus one term per stem (k, j) that ends at j and starts behind i; B(i,j,tgt(p)) += A(i,j,p).  The stems are
+  // walked four at a time: their operand loads (1(i,k,s1), P(k,j,t), exp(lambda e_ml)) are in flight together.
+  {
+    const int nA = A.n_ap;
+    const int32_t* I = v.m.ints;
+    const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
+    const int W1 = v.q.W + 1;
+    const int nwork = (a.dbg & 1) ? 0 : nc * nA;
+    for (int w = tid; w < nwork; w += kThreads) {
+      const int c = w / nA, p = w - c * nA;
+      const int i = i0 + c, j = i + d;
+      const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p], tgt = I[A.ap_tgt + p];
+      const int dmi = dm[c];
+      double av = 0.;
+      if (dmi > 0 && dmi < d) {          // 1(i,k,.) != 0 needs k - i >= dmin[i], and k < j
+        if (v.q.unp[j - 1]) {
+          const int e0 = I[A.ap_chain_off + p], e1 = I[A.ap_chain_off + p + 1];
+          for (int e = e0; e < e1; ++e) {
+            const int pc2 = I[A.ap_chain_ent + 2 * e], tf = I[A.ap_chain_ent + 2 * e + 1];
+            if (CON && !allow_right(v.m, con, v.q.L, j, t, I[A.ap_t + pc2])) continue;
+            av = fma(v.in.a(d - 1, i, pc2), lw_right(v.m, v.q, t, tf, j - 1), av);
+          }
+        }
+        const double* xml = v.q.xwc + (size_t)(lamk(v.m, t) * 5 + XT_ML) * v.q.xwc_stride;
+        BitIter it;
+        it.init(v.q.okbits_end, j * W1, 1, d - dmi);      // spans of the stems: k = j - sp >= i + dmin[i]
+        for (;;) {
+          const int sp0 = it.next();
+          if (sp0 < 0) break;
+          const int sp1 = it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
+          const int q1 = sp1 < 0 ? sp0 : sp1, q2 = sp2 < 0 ? sp0 : sp2, q3 = sp3 < 0 ? sp0 : sp3;
+          const double a0 = B[v.in.idx(ST_1, d - sp0, i, s1)], b0 = B[v.in.idx(ST_P, sp0, j - sp0, t)], c0 = xml[v.q.cell(j - sp0, sp0)];
+          const double a1 = B[v.in.idx(ST_1, d - q1, i, s1)], b1 = B[v.in.idx(ST_P, q1, j - q1, t)], c1 = xml[v.q.cell(j - q1, q1)];
+          const double a2 = B[v.in.idx(ST_1, d - q2, i, s1)], b2 = B[v.in.idx(ST_P, q2, j - q2, t)], c2 = xml[v.q.cell(j - q2, q2)];
+          const double a3 = B[v.in.idx(ST_1, d - q3, i, s1)], b3 = B[v.in.idx(ST_P, q3, j - q3, t)], c3 = xml[v.q.cell(j - q3, q3)];
+          av = fma(a0, b0 * c0, av);
+          if (sp1 >= 0) av = fma(a1, b1 * c1, av);
+          if (sp2 >= 0) av = fma(a2, b2 * c2, av);
+          if (sp3 >= 0) av = fma(a3, b3 * c3, av);
+          if (sp3 < 0) break;
+        }
       }
+      v.in.a(d, i, p) = av;
+      if (a.a_in0 != nullptr && s1 == A.s00 && t == A.s00)   // compact copy for the no-motif pass
+        a.a_in0[(size_t)by * a.a0_stride + (size_t)d * (v.in.L + 1) + i] = av;
+      if (tgt >= 0 && av != 0.) atomicAdd(&hb[c * S + tgt], av);
     }
   }
-  // split points handled here: all of [a_lo, d) -- or, inside a tile that started at d0 (level t = d - d0), only those
-  // with an operand of span >= d0: a in [a_lo, t] (2(i+a, d-a) is new) and a in [d0, d) (1(i, i+a) is new); k4_in_old
-  // summed the others into part_in.  The list is walked as q = 0 .. n1+n2: a = a_lo + q  |  d0 + (q - n1).
-  const int d0 = (a.tile_d0 >= 0) ? a.tile_d0 : d;
-  const int tl = d - d0;
-  const int n1 = (a.tile_d0 >= 0) ? ((tl >= a_lo) ? tl - a_lo + 1 : 0) : ((d > a_lo) ? d - a_lo : 0);
-  const int n2 = (a.tile_d0 >= 0 && !(a.dbg & 1)) ? tl : 0;
-  const int nf = (a.dbg & 1) ? 0 : n1 + n2;
-  for (int q0 = 0; q0 < nf; q0 += kChunkIn) {
-    const int kc = (kChunkIn < nf - q0) ? kChunkIn : nf - q0;
-    if (tid < ncS) {
-#pragma unroll
-      for (int u = 0; u < kChunkIn; ++u) {
-        const int q = q0 + ((u < kc) ? u : 0);
-        const int aa = (q < n1) ? a_lo + q : d0 + (q - n1);
-        const double x1 = B[v.in.idx(ST_1, aa, i0, 0) + tid];
-        const double x2 = B[v.in.idx(ST_2, d - aa, i0 + aa, 0) + tid];
-        st1[u * CS + tid] = (u < kc) ? x1 : 0.;
-        st2[u * CS + tid] = (u < kc) ? x2 : 0.;
-      }
-    }
-    __syncthreads();
-    pc.mark<1>();
-#pragma unroll
-    for (int r = 0; r < kOwn; ++r)
-      if (po1[r] >= 0) {
-#pragma unroll
-        for (int u = 0; u < kChunkIn; ++u) pacc[r] = fma(st1[u * CS + po1[r]], st2[u * CS + po2[r]], pacc[r]);
-      }
-    for (int w = tid + kOwn * kThreads; w < nc * nsp; w += kThreads) {   // (patterns with more tuples than lanes)
-      const int c = w / nsp, t = w - c * nsp;
-      const int x = dm[c];
-      if (x <= 0 || x > d) continue;
-      const int o1 = c * S + G[A.split_ent + 2 * t], o2 = c * S + G[A.split_ent + 2 * t + 1];
-      double acc = 0.;
-      for (int u = 0; u < kc; ++u) acc = fma(st1[u * CS + o1], st2[u * CS + o2], acc);
-      if (acc != 0.) atomicAdd(&hb[c * S + G[A.split_tgt + t]], acc);
-    }
-    __syncthreads();
-    pc.mark<2>();
-  }
-#pragma unroll
-  for (int r = 0; r < kOwn; ++r) if (po1[r] >= 0 && pacc[r] != 0.) atomicAdd(&hb[ptg[r]], pacc[r]);
+  __syncthreads();
+  pc.mark<1>();
   // rule 6c: E(i,j,tgt) += sum_items P(k,l,s1) * L(i,k,s2) * L(l,j,s3) * exp(lambda * tsc): work item = (item, tuple), the
   // item records staged in the (now free) operand staging area, one round of table loads per work item
   const int nq = (a.dbg & 2) ? 0 : A.n_quad;
   {
     const int n_rec = outer_ranges(v, i0, nc, d, nq > 0, tid, cnts, pre, base);
-    const OuterRecs R = outer_recs(st1, 2 * kChunkIn * CS);
+    const OuterRecs R = outer_recs(st1, kRecIn);
     for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
       const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
       outer_stage<true>(v, R, p0, np, nc, tid, pre, base);
@@ -733,8 +649,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   if (tid < nc * NA && !(a.dbg & 4)) {
     const int c = tid / NA, s = tid - c * NA;
     const int i = i0 + c;
-    double HB = hb[c * S + s];
-    if (a.tile_d0 >= 0) HB += a.part_in[(size_t)by * a.part_stride + ((size_t)tl * (v.in.L + 1) + i) * S + s];
+    const double HB = hb[c * S + s];
     const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
     const Cell7 r = lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, HB, he[c * S + s], con);
     if (a.band_in0 != nullptr && s == A.s00) {   // compact copy of state (0,0) for the no-motif pass
@@ -984,143 +899,6 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, 128);
 }
 
-// ---- outside, "old" split sums of a tile d0, d0-1, .., d0-kTile+1 (level t: d = d0 - t), launched before k4_out(d0):
-//   WHICH = 1:  part_h1[t][i][s] = sum_{b > t} sum_tuples out B(i, d+b, par) * in 2(i+d, b, s2)        (parents jj = j + b)
-//   WHICH = 2:  part_h2[t][i][s] = sum_{b > t} sum_tuples out B(i-b, d+b, par) * in 1(i-b, b, s1)      (parents ii = i - b)
-// i.e. the parents B of span D = d + b > d0, final before the tile started.  Chunks of kOldA parent spans D: the out-B
-// rows of one D serve all kTile levels and an inside row (., b) serves the kTile pairs (D, t) with D - d0 + t = b.
-template <int WHICH, bool BIG>
-__global__ __launch_bounds__(kThreads) void k4_out_old(LinArgs a) {
-  extern __shared__ double lds[];
-  __shared__ AutomatonLayout s_lay;
-  stage_layout(a, &s_lay, kThreads);
-  unsigned bx, by;
-  swizzled_block(bx, by);
-  LViews v(s_lay);
-  make_lviews(a, by, v);
-  const LPass pi = lpass(a, v);
-  const AutomatonLayout& A = s_lay;
-  const int S = a.lay.S, d0 = a.tile_d0, cpb = a.cpb, tid = threadIdx.x;
-  const int L = v.q.L, W = v.q.W;
-  if (pi.skip) return;
-  // (a sequence whose own W is <= d0 has no parents beyond the tile: the loop over D is empty and zeros are written)
-  const int dlow = (d0 - kTile + 1 > 0) ? d0 - kTile + 1 : 0;     // lowest diagonal of the tile: it has the most cells
-  const int ncell = L - dlow + 1, i0 = bx * cpb;
-  if (i0 >= ncell) return;
-  const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
-  const int CS = cpb * S, CS2 = (cpb + kTile - 1) * S;
-  // WHICH 1: sO = out B(i0+c, D) [kOldA][CS],  sI = in 2(jb+c', b) [kOldB][CS2], jb = i0 + d0 - (kTile-1)
-  // WHICH 2: sO = out B(kb_u+c', D) [kOldA][CS2], kb_u = i0 - (D-d0) - (kTile-1),  sI = in 1(i0+c-b, b) [kOldB][CS]
-  const int CSO = (WHICH == 1) ? CS : CS2, CSI = (WHICH == 1) ? CS2 : CS;
-  double* acc = lds;                    // [kTile][CS]
-  double* sO = acc + kTile * CS;        // [kOldA][CSO]
-  double* sI = sO + kOldA * CSO;        // [kOldB][CSI]
-  int* dm = reinterpret_cast<int*>(sI + kOldB * CSI);
-  for (int t = tid; t < kTile * CS; t += kThreads) acc[t] = 0.;
-  if (tid < cpb) dm[tid] = (tid < nc) ? (int)v.q.dmin[i0 + tid] : 0;
-  const int32_t* G = a.ints;
-  __syncthreads();
-  const int nsp = A.n_split;
-  const int ent = (WHICH == 1) ? A.split1_ent : A.split2_ent, tgl = (WHICH == 1) ? A.split1_tgt : A.split2_tgt;
-  const double* IB = v.in.band;
-  const double* OB = v.out.band;
-  int o1[kOldOwn], o2[kOldOwn], otg[kOldOwn], olv[kOldOwn];
-  double pacc[kOldOwn];
-  const int nwork = kTile * nc * nsp;
-  auto target_ok = [&](int t, int c) {   // left_ok(i, d) for the level's diagonal d = d0 - t, and the cell exists
-    const int d = d0 - t, x = dm[c];
-    return d >= 0 && x > 0 && x <= d && i0 + c + d <= L;
-  };
-#pragma unroll
-  for (int r = 0; r < kOldOwn; ++r) {
-    const int w = tid + r * kThreads;
-    o1[r] = -1; o2[r] = 0; otg[r] = 0; olv[r] = 0; pacc[r] = 0.;
-    if (w < nwork) {
-      const int tc = w / nsp, tu = w - tc * nsp;
-      const int t = tc / nc, c = tc - t * nc;
-      if (target_ok(t, c)) {
-        const int par = G[ent + 2 * tu], sib = G[ent + 2 * tu + 1];
-        // WHICH 1: out row index c, inside row index c + kTile-1-t ; WHICH 2: the other way round
-        o1[r] = ((WHICH == 1) ? c : c + kTile - 1 - t) * S + par;
-        o2[r] = ((WHICH == 1) ? c + kTile - 1 - t : c) * S + sib;
-        otg[r] = t * CS + c * S + G[tgl + tu];
-        olv[r] = t;
-      }
-    }
-  }
-  for (int D0 = d0 + 1; D0 <= W; D0 += kOldA) {
-    const int b_lo = D0 - d0;   // staged inside diagonals b_lo .. b_lo + kOldB - 1
-    {
-      double x[kOldA][2], y[kOldB][2];
-#pragma unroll
-      for (int u = 0; u < kOldA; ++u) {
-        const int D = D0 + u;
-        const int Dc = (D <= W) ? D : W;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int e = tid + h * kThreads;
-          const int cell = ((WHICH == 1) ? i0 : i0 - (D - d0) - (kTile - 1)) + e / S;
-          const bool ok = e < ((WHICH == 1) ? nc * S : (nc + kTile - 1) * S) && D <= W && cell >= 0 && cell + D <= L;
-          const int base = (WHICH == 1) ? i0 : i0 - (D - d0) - (kTile - 1);
-          x[u][h] = OB[v.out.idx(ST_B, Dc, ok ? base : 0, 0) + (ok ? e : 0)];
-          if (!ok) x[u][h] = 0.;
-        }
-      }
-#pragma unroll
-      for (int vv = 0; vv < kOldB; ++vv) {
-        const int b = b_lo + vv;
-        const int bc = (b <= W) ? b : W;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int e = tid + h * kThreads;
-          const int base = (WHICH == 1) ? i0 + d0 - (kTile - 1) : i0 - b;
-          const int cell = base + e / S;
-          const bool ok = e < ((WHICH == 1) ? (nc + kTile - 1) * S : nc * S) && b <= W && cell >= 0 && cell + b <= L;
-          y[vv][h] = IB[v.in.idx((WHICH == 1) ? ST_2 : ST_1, bc, ok ? base : 0, 0) + (ok ? e : 0)];
-          if (!ok) y[vv][h] = 0.;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kOldA; ++u) {
-        if (tid < CSO) sO[u * CSO + tid] = x[u][0];
-        if (tid + kThreads < CSO) sO[u * CSO + tid + kThreads] = x[u][1];
-      }
-#pragma unroll
-      for (int vv = 0; vv < kOldB; ++vv) {
-        if (tid < CSI) sI[vv * CSI + tid] = y[vv][0];
-        if (tid + kThreads < CSI) sI[vv * CSI + tid + kThreads] = y[vv][1];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kOldOwn; ++r)
-      if (o1[r] >= 0) {
-        const int t = olv[r];
-#pragma unroll
-        for (int u = 0; u < kOldA; ++u) pacc[r] = fma(sO[u * CSO + o1[r]], sI[(u + t) * CSI + o2[r]], pacc[r]);
-      }
-    for (int w = tid + kOldOwn * kThreads; w < nwork; w += kThreads) {   // (patterns with more tuples than lanes)
-      const int tc = w / nsp, tu = w - tc * nsp;
-      const int t = tc / nc, c = tc - t * nc;
-      if (!target_ok(t, c)) continue;
-      const int p1 = ((WHICH == 1) ? c : c + kTile - 1 - t) * S + G[ent + 2 * tu];
-      const int p2 = ((WHICH == 1) ? c + kTile - 1 - t : c) * S + G[ent + 2 * tu + 1];
-      double sum = 0.;
-      for (int u = 0; u < kOldA; ++u) sum = fma(sO[u * CSO + p1], sI[(u + t) * CSI + p2], sum);
-      if (sum != 0.) atomicAdd(&acc[t * CS + c * S + G[tgl + tu]], sum);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < kOldOwn; ++r) if (o1[r] >= 0 && pacc[r] != 0.) atomicAdd(&acc[otg[r]], pacc[r]);
-  __syncthreads();
-  double* part = ((WHICH == 1) ? a.part_h1 : a.part_h2) + (size_t)by * a.part_stride;
-  for (int e = tid; e < kTile * nc * S; e += kThreads) {
-    const int t = e / (nc * S), r = e - t * (nc * S);
-    part[((size_t)t * (L + 1) + i0) * S + r] = acc[t * CS + r];
-  }
-}
-
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
 template <int MODE, bool BIG>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
@@ -1133,6 +911,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   swizzled_block(bx, by);
   LViews v(a.lay);
   make_lviews(a, by, v);
+  const int16_t* g_dmin = v.q.dmin;   // (the whole array: stage_context redirects v.q.dmin to the window of the workgroup)
   const LPass pi = lpass(a, v);
   const AutomatonLayout& A = a.lay;
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = a.lay.n_theta;
@@ -1148,11 +927,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* hl = hp + CS;
   double* l_en = hl + CS;
   double* l_eh = l_en + nt;
-  double* sOB1 = l_eh + 2;               // [kChunkOut][CS] out B(i, i+d+b, .)      (H1)
-  double* sI2 = sOB1 + kChunkOut * CS;   //                 in  2(j, j+b, .)
-  double* sOB2 = sI2 + kChunkOut * CS;   //                 out B(i-b, j, .)        (H2)
-  double* sI1 = sOB2 + kChunkOut * CS;   //                 in  1(i-b, i, .)
-  const BlockLds BL = block_lds((4 + 4 * kChunkOut) * CS + nt + 2, cpb, kLinEth + nt, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb);
+  double* sOB1 = l_eh + 2;                     // item records of the three roles (kRecOut doubles)
+  const BlockLds BL = block_lds(4 * CS + nt + 2 + kRecOut, cpb, kLinEth + nt, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb);
   const BlockCtx cx = stage_context<BIG, 1>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   if (pi.skip) return;   // (tested here: the loads behind `pi` travel with those of the context instead of before them)
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
@@ -1166,103 +942,76 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   scan_sink<MODE>(a, v, sink);
   const TableView& in = v.in;
   const TableView& out = v.out;
-  const int nsp = A.n_split, nq = (a.dbg & 2) ? 0 : A.n_quad;
-  // H1: 1(i,j,tgt) as the "1" child of B(i,j+b,par), sibling 2(j,j+b,s2);  H2: 2(i,j,tgt) as the "2" child of
-  // B(i-b,j,par), sibling 1(i-b,i,s1);  b = 1 .. W-d.  Cells whose parent would leave [0,L] are masked.
-  bool any_lok = false;
-  for (int c = 0; c < nc; ++c) { const int x = dm[c]; any_lok = any_lok || (x > 0 && x <= d); }
-  // inside a tile (top diagonal d0, level t = d0 - d) only the parents computed in the tile are summed here: b <= t
-  const int tl = (a.tile_d0 >= 0) ? a.tile_d0 - d : 0;
-  const int bfull = (a.tile_d0 >= 0) ? ((tl < W - d) ? tl : W - d) : W - d;
-  const int bmax = (any_lok && !(a.dbg & 1)) ? bfull : 0;
-  constexpr int kOwn = 2;
-  int qa1[kOwn], qa2[kOwn], qat[kOwn], qb1[kOwn], qb2[kOwn], qbt[kOwn];
-  double acc1[kOwn], acc2[kOwn];
-#pragma unroll
-  for (int r = 0; r < kOwn; ++r) {
-    const int w = tid + r * kThreads;
-    qa1[r] = -1; qa2[r] = qat[r] = qb1[r] = qb2[r] = qbt[r] = 0; acc1[r] = acc2[r] = 0.;
-    if (w < nc * nsp) {
-      const int c = w / nsp, t = w - c * nsp;
-      const int x = dm[c];
-      if (x > 0 && x <= d) {   // left_ok(i, d)
-        qa1[r] = c * S + G[A.split1_ent + 2 * t]; qa2[r] = c * S + G[A.split1_ent + 2 * t + 1]; qat[r] = c * S + G[A.split1_tgt + t];
-        qb1[r] = c * S + G[A.split2_ent + 2 * t]; qb2[r] = c * S + G[A.split2_ent + 2 * t + 1]; qbt[r] = c * S + G[A.split2_tgt + t];
+  const int nq = (a.dbg & 2) ? 0 : A.n_quad;
+  const double* IB = in.band;
+  const double* OB = out.band;
+  // rule 2, factorised, outside direction (lin_rules.h: lheavy_o1 / lheavy_o2):
+  //   h1[c][s1] = H1 = sum over the stems (j, l) that start at the cell's end j = i + d:  outA(i,l,p) * P(j,l,t) * xml(j,l)
+  //   h2[c][t]  = HA = sum_{ii < i} outA(ii,j,p) * 1(ii,i,s1), only where the cell itself is a stem P(i,j)
+  // lanes = (cell, pair); stems four at a time.  Both read outA of larger spans only (earlier launches).
+  {
+    const int nA = A.n_ap;
+    const int32_t* I = v.m.ints;
+    const int W1 = W + 1;
+    const int nwork = (a.dbg & 1) ? 0 : nc * nA;
+    for (int w = tid; w < nwork; w += kThreads) {
+      const int c = w / nA, p = w - c * nA;
+      const int i = i0 + c, j = i + d;
+      const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
+      const int dmi = dm[c];
+      if (dmi > 0 && dmi <= d && IB[in.idx(ST_1, d, i, s1)] != 0.) {     // left_ok(i, d) and a live child 1(i,j,s1)
+        const int hi = (W - d < L - j) ? W - d : L - j;
+        const double* xml = v.q.xwc + (size_t)(lamk(v.m, t) * 5 + XT_ML) * v.q.xwc_stride;
+        double acc = 0.;
+        BitIter it;
+        it.init(v.q.okbits, j * W1, 1, hi);
+        for (;;) {
+          const int sp0 = it.next();
+          if (sp0 < 0) break;
+          const int sp1 = it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
+          const int q1 = sp1 < 0 ? sp0 : sp1, q2 = sp2 < 0 ? sp0 : sp2, q3 = sp3 < 0 ? sp0 : sp3;
+          const double a0 = out.a(d + sp0, i, p), b0 = IB[in.idx(ST_P, sp0, j, t)], c0 = xml[v.q.cell(j, sp0)];
+          const double a1 = out.a(d + q1, i, p), b1 = IB[in.idx(ST_P, q1, j, t)], c1 = xml[v.q.cell(j, q1)];
+          const double a2 = out.a(d + q2, i, p), b2 = IB[in.idx(ST_P, q2, j, t)], c2 = xml[v.q.cell(j, q2)];
+          const double a3 = out.a(d + q3, i, p), b3 = IB[in.idx(ST_P, q3, j, t)], c3 = xml[v.q.cell(j, q3)];
+          acc = fma(a0, b0 * c0, acc);
+          if (sp1 >= 0) acc = fma(a1, b1 * c1, acc);
+          if (sp2 >= 0) acc = fma(a2, b2 * c2, acc);
+          if (sp3 >= 0) acc = fma(a3, b3 * c3, acc);
+          if (sp3 < 0) break;
+        }
+        if (acc != 0.) atomicAdd(&h1[c * S + s1], acc);
       }
     }
-  }
-  // Addresses of the staged rows as base + bb * stride (the kernels are bound by instruction issue: recomputing four table
-  // indices with their clamps per load was ~60 instructions per load).  Row of the parent span d + bb: one diagonal
-  // further per bb; the H2 rows start one cell earlier per bb.  A lane whose parent leaves [0, L] reads offset 0 of the
-  // same rows (inside the plane) and stores 0.
-  const uint32_t dstride = (uint32_t)(L + 1) * (uint32_t)S;
-  const int li = i0 + ((tid < ncS) ? tid / S : 0);
-  const int b1max = L - li - d, b2max = li;   // ok1 <=> bb <= b1max, ok2 <=> bb <= b2max
-  const double* pOB = out.band + out.idx(ST_B, d, i0, 0) + ((tid < ncS) ? tid : 0);
-  const double* pI2 = in.band + in.idx(ST_2, 0, i0 + d, 0) + ((tid < ncS) ? tid : 0);
-  const double* pI1 = in.band + in.idx(ST_1, 0, i0, 0) + ((tid < ncS) ? tid : 0);
-  for (int b0 = 1; b0 <= bmax; b0 += kChunkOut) {
-    const int kc = (kChunkOut < bmax - b0 + 1) ? kChunkOut : bmax - b0 + 1;
-    if (tid < ncS) {
-#pragma unroll
-      for (int u = 0; u < kChunkOut; ++u) {
-        const int bb = b0 + u;
-        const bool ok1 = u < kc && bb <= b1max, ok2 = u < kc && bb <= b2max;
-        const uint32_t o1 = ok1 ? (uint32_t)bb * dstride : 0u, o2 = ok2 ? (uint32_t)bb * (dstride - (uint32_t)S) : 0u;
-        const double x1 = pOB[o1];
-        const double x2 = pI2[o1];
-        const double x3 = pOB[o2];
-        const double x4 = pI1[o2];
-        sOB1[u * CS + tid] = ok1 ? x1 : 0.;
-        sI2[u * CS + tid] = ok1 ? x2 : 0.;
-        sOB2[u * CS + tid] = ok2 ? x3 : 0.;
-        sI1[u * CS + tid] = ok2 ? x4 : 0.;
-      }
-    }
-    __syncthreads();
-    pc.mark<6>();
-#pragma unroll
-    for (int r = 0; r < kOwn; ++r)
-      if (qa1[r] >= 0) {
-#pragma unroll
-        for (int u = 0; u < kChunkOut; ++u) {
-          acc1[r] = fma(sOB1[u * CS + qa1[r]], sI2[u * CS + qa2[r]], acc1[r]);
-          acc2[r] = fma(sOB2[u * CS + qb1[r]], sI1[u * CS + qb2[r]], acc2[r]);
+    // HA: the few stem cells of the workgroup, work item = (stem cell, parent row ii = i - b, pair)
+    int n_stem = 0;
+    for (int c = 0; c < nc; ++c) n_stem += v.q.pair_ok(i0 + c, d) ? 1 : 0;
+    if (n_stem > 0 && !(a.dbg & 1)) {
+      const int nb = W - d;                   // b = 1 .. nb: parent span d + b <= W
+      const int per = nb * nA;
+      for (int c = 0; c < nc; ++c) {
+        const int i = i0 + c, j = i + d;
+        if (!v.q.pair_ok(i, d)) continue;
+        for (int w = tid; w < per; w += kThreads) {
+          const int b = 1 + w / nA, p = w - (b - 1) * nA;
+          const int ii = i - b;
+          if (ii < 0) continue;
+          const int dmi = g_dmin[ii];
+          if (dmi <= 0 || b < dmi) continue;     // 1(ii, i, .) is 0 (o2_valid)
+          const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
+          const double term = out.a(d + b, ii, p) * IB[in.idx(ST_1, b, ii, s1)];
+          if (term != 0.) atomicAdd(&h2[c * S + t], term);
         }
       }
-    for (int w = tid + kOwn * kThreads; w < nc * nsp; w += kThreads) {   // (patterns with more tuples than lanes)
-      const int c = w / nsp, t = w - c * nsp;
-      const int x = dm[c];
-      if (x <= 0 || x > d) continue;
-      {
-        const int o1 = c * S + G[A.split1_ent + 2 * t], o2 = c * S + G[A.split1_ent + 2 * t + 1];
-        double acc = 0.;
-        for (int u = 0; u < kc; ++u) acc = fma(sOB1[u * CS + o1], sI2[u * CS + o2], acc);
-        if (acc != 0.) atomicAdd(&h1[c * S + G[A.split1_tgt + t]], acc);
-      }
-      {
-        const int o1 = c * S + G[A.split2_ent + 2 * t], o2 = c * S + G[A.split2_ent + 2 * t + 1];
-        double acc = 0.;
-        for (int u = 0; u < kc; ++u) acc = fma(sOB2[u * CS + o1], sI1[u * CS + o2], acc);
-        if (acc != 0.) atomicAdd(&h2[c * S + G[A.split2_tgt + t]], acc);
-      }
     }
-    __syncthreads();
-    pc.mark<7>();
   }
-#pragma unroll
-  for (int r = 0; r < kOwn; ++r)
-    if (qa1[r] >= 0) {
-      if (acc1[r] != 0.) atomicAdd(&h1[qat[r]], acc1[r]);
-      if (acc2[r] != 0.) atomicAdd(&h2[qbt[r]], acc2[r]);
-    }
+  __syncthreads();
+  pc.mark<6>();
   // HP / HL: the three roles of a cell in the interior loops around it (rule 6c) -- inner pair P(i,j,tgt) of E(it.i,it.j,par)
   // (with the energy statistic of the rule), left loop L(i,j,tgt) = L(it.i,it.k), right loop L(i,j,tgt) = L(it.l,it.j) --
   // as ONE flat list of work items (role, item, tuple): CSR range per (role, cell) -> LDS prefix; the item records and
   // their weights are staged into the (now free) operand staging area by all lanes with one round of loads; a work item
   // then needs a single round of table loads, selected by role without branches.
-  const double* IB = in.band;
-  const double* OB = out.band;
   {
     const int nv = 3 * nc;
     for (int vc = tid; vc < nv; vc += kThreads) {
@@ -1284,7 +1033,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     __syncthreads();
     const int n_rec = pre[nv];
     // record area: LoopItem it[cap], double xw[2][cap], int meta[cap] (role << 16 | cell)
-    const int cap = (4 * kChunkOut * CS * 8) / 40;
+    const int cap = (kRecOut * 8) / 40;
     LoopItem* r_it = reinterpret_cast<LoopItem*>(sOB1);
     double* r_xw = reinterpret_cast<double*>(r_it + cap);
     int* r_meta = reinterpret_cast<int*>(r_xw + 2 * cap);
@@ -1357,12 +1106,19 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
     HeavyOut H;
     H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
-    if (a.tile_d0 >= 0 && a.tile_has_old) {
-      const size_t po = (size_t)by * a.part_stride + ((size_t)tl * (L + 1) + (i0 + c)) * S + s;
-      H.H1 += a.part_h1[po];
-      H.H2 += a.part_h2[po];
+    h1[c * S + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
+  }
+  __syncthreads();
+  // outside values of the pair entries of the cells (lin_outside_apair): out B of the target + the tail step from
+  // (i, d+1), with the statistics of the tail emissions
+  if (!(a.dbg & 1)) {
+    const int nA = A.n_ap;
+    LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
+    for (int w = tid; w < nc * nA; w += kThreads) {
+      const int c = w / nA, p = w - c * nA;
+      const int tgt = v.m.ints[A.ap_tgt + p];
+      lin_outside_apair<MODE>(x, d, i0 + c, p, tgt >= 0 ? h1[c * S + tgt] : 0.);
     }
-    lin_outside_target_u<MODE>(x, d, i0 + c, s, H);
   }
   pc.mark<11>();
   if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, kThreads);
@@ -1454,11 +1210,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   const double NEG = ELEMDP_NEG_INF;
   unsigned long long* kb = reinterpret_cast<unsigned long long*>(lds);   // [CS] best key, rule 2
   unsigned long long* ke = kb + CS;                                      // [CS] best key, rule 6c
-  double* st1 = lds + 2 * CS;           // [kChunkIn][CS]  rows 1(i, i+a, .)
-  double* st2 = st1 + kChunkIn * CS;    // [kChunkIn][CS]  rows 2(i+a, j, .)
-  unsigned* ob = reinterpret_cast<unsigned*>(st2 + kChunkIn * CS);       // [CS] first ordinal reaching the best, rule 2
-  unsigned* oe = ob + CS;                                                //                                      rule 6c
-  const BlockLds BL = block_lds((3 + 2 * kChunkIn) * CS, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
+  double* st1 = lds + 2 * CS;                  // [KC][CU]  rows 1(i, i+a, front states)
+  double* st2 = st1 + kChunkIn * kThreads;     // [KC][CU]  rows 2(i+a, j, front states)
+  unsigned* ob = reinterpret_cast<unsigned*>(st2 + kChunkIn * kThreads);   // [CS] first ordinal reaching the best, rule 2
+  unsigned* oe = ob + CS;                                                  //                                      rule 6c
+  const BlockLds BL = block_lds(3 * CS + 2 * kChunkIn * kThreads, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
   const BlockCtx cx = stage_context<BIG, 0>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
@@ -1470,6 +1226,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   for (int c = 0; c < nc; ++c) { const int x = dm[c]; if (x > 0 && x < a_lo) a_lo = x; }
   const int nsp = A.n_split;
   const double* B = v.in.band;
+  const StageMap sm = stage_map(A.n_front, S, cpb, nc, tid);
+  const int NU = sm.NU, CU = sm.CU, KC = kChunkIn * sm.nsub;
   int po1[KOWN], po2[KOWN], pa[KOWN];
   double pv[KOWN];
 #pragma unroll
@@ -1479,28 +1237,32 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
     if (w < nc * nsp) {
       const int c = w / nsp, t = w - c * nsp;
       const int x = dm[c];
-      if (x > 0 && x <= d) { po1[r] = c * S + G[A.split_ent + 2 * t]; po2[r] = c * S + G[A.split_ent + 2 * t + 1]; }   // left_ok(i, d)
+      const int s1 = G[A.split_ent + 2 * t], s2 = G[A.split_ent + 2 * t + 1];
+      // left_ok(i, d); a tuple with a state behind the front is log 0 in rule 2 (it serves rule 7)
+      if (x > 0 && x <= d && s1 < NU && s2 < NU) { po1[r] = c * NU + s1; po2[r] = c * NU + s2; }
     }
   }
-  for (int q0 = a_lo; q0 < d; q0 += kChunkIn) {
-    const int kc = (kChunkIn < d - q0) ? kChunkIn : d - q0;
-    if (tid < ncS) {
+  for (int q0 = a_lo; q0 < d; q0 += KC) {
+    if (sm.act) {
 #pragma unroll
       for (int u = 0; u < kChunkIn; ++u) {
-        const int aa = q0 + ((u < kc) ? u : 0);
-        const double x1 = B[v.in.idx(ST_1, aa, i0, 0) + tid];
-        const double x2 = B[v.in.idx(ST_2, d - aa, i0 + aa, 0) + tid];
-        st1[u * CS + tid] = (u < kc) ? x1 : NEG;
-        st2[u * CS + tid] = (u < kc) ? x2 : NEG;
+        const int q = q0 + u * sm.nsub + sm.sub;
+        const bool ok = q < d;
+        const int aa = ok ? q : q0;
+        const double x1 = B[v.in.idx(ST_1, aa, i0, 0) + sm.goff];
+        const double x2 = B[v.in.idx(ST_2, d - aa, i0 + aa, 0) + sm.goff];
+        st1[(u * sm.nsub + sm.sub) * CU + sm.r] = ok ? x1 : NEG;
+        st2[(u * sm.nsub + sm.sub) * CU + sm.r] = ok ? x2 : NEG;
       }
     }
     __syncthreads();
+    // staged slot v holds split point q0 + v (v = u * nsub + sub): ascending, as the tie rule needs
 #pragma unroll
     for (int r = 0; r < KOWN; ++r)
       if (po1[r] >= 0) {
-#pragma unroll
-        for (int u = 0; u < kChunkIn; ++u) {
-          const double y = st1[u * CS + po1[r]] + st2[u * CS + po2[r]];
+#pragma unroll 4
+        for (int u = 0; u < KC; ++u) {
+          const double y = st1[u * CU + po1[r]] + st2[u * CU + po2[r]];
           if (pv[r] < y) { pv[r] = y; pa[r] = q0 + u; }
         }
       }
@@ -1532,7 +1294,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   const int nq = A.n_quad;
   {
     const int n_rec = outer_ranges(v, i0, nc, d, true, tid, cnts, pre, base);
-    const OuterRecs R = outer_recs(st1, 2 * kChunkIn * CS);
+    const OuterRecs R = outer_recs(st1, 2 * kChunkIn * kThreads);
 #pragma unroll 1
     for (int sweep = 0; sweep < 2; ++sweep) {
       for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
@@ -1651,8 +1413,7 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
   a.lmax = Lmax;
-  a.tile_d0 = -1;
-  const size_t lds = block_lds((3 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
+  const size_t lds = block_lds(3 * a.cpb * S + 2 * kChunkIn * kThreads, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const long long products = (long long)a.cpb * a.lay.n_split;   // (cell, tuple) products of a workgroup
   const int kown = products <= 2 * kThreads ? 2 : products <= 4 * kThreads ? 4 : products <= 8 * kThreads ? 8 : 0;
@@ -1679,12 +1440,11 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
   a.lmax = Lmax;
-  a.tile_d0 = -1;
   a.schedule = 0;   // terminals (ari, nasi), Z = Z(ari,nasi): pass 0 of the reference schedule
   a.pass = 0;
   a.scan = 1;
-  const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
-  const size_t lds_out = block_lds((4 + 4 * kChunkOut) * a.cpb * S + nt + 2, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
+  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
+  const size_t lds_out = block_lds(4 * a.cpb * S + nt + 2 + kRecOut, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
@@ -1731,27 +1491,17 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   a.cpb = kThreads / S;
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
-  const size_t lds_in = block_lds((2 + 2 * kChunkIn) * a.cpb * S, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
+  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const size_t lds_stat = sizeof(double) * (nt + 2);
-  a.tile_d0 = -1;
-  const size_t lds_old = sizeof(double) * ((size_t)(kTile + kOldA) * a.cpb * S + (size_t)kOldB * (a.cpb + kOldA - 1) * S) +
-                         sizeof(int32_t) * ((size_t)a.cpb + 2);
-  const bool tiled = a.part_in != nullptr && a.tile;
   if (!a.no_rss)
     for (int d = 0; d <= Wmax; ++d) {
       const int ncell = Lmax - d + 1;
       if (ncell <= 0) break;
       a.d = d;
-      if (tiled && d >= kTileStart && (d - kTileStart) % kTile == 0) {   // a new tile starts: sum its old pairs first
-        a.tile_d0 = d;
-        if (big) hipLaunchKernelGGL(k4_in_old<true>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_old, st, a);
-        else hipLaunchKernelGGL(k4_in_old<false>, dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_old, st, a);
-      }
       if (big) hipLaunchKernelGGL((k4_in<true, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
       else hipLaunchKernelGGL((k4_in<false, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
     }
-  a.tile_d0 = -1;
   a.lmax = Lmax;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
@@ -1760,7 +1510,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   // schedule 1: the two outside passes are independent (ari-only on the full tables, nasi-only on the compact ones; both
   // only read the inside tables) -- with a second stream the small second pass runs beside the first (it fills the gaps
   // of a launch-latency-bound small batch; a large batch gains nothing and loses nothing)
-  const bool two_streams = st2 != nullptr && a.schedule == 1 && !first_pass_only && !a.tile;
+  const bool two_streams = st2 != nullptr && a.schedule == 1 && !first_pass_only;
   if (two_streams) {
     hipError_t e = hipEventRecord(ev_in, st);
     if (e == hipSuccess) e = hipStreamWaitEvent(st2, ev_in, 0);
@@ -1776,36 +1526,16 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
     b.cpb = kThreads / b.lay.S;
     if (b.cpb > ELEMDP_CPB_MAX) b.cpb = ELEMDP_CPB_MAX;
     b.wmax = Wmax;
-    const size_t lds_b = block_lds((4 + 4 * kChunkOut) * b.cpb * b.lay.S + nt + 2, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, staged_ints(b.lay, b.n_stage, 1), 3 * b.cpb).total;
+    const size_t lds_b = block_lds(4 * b.cpb * b.lay.S + nt + 2 + kRecOut, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, staged_ints(b.lay, b.n_stage, 1), 3 * b.cpb).total;
     const bool big_b = b.n_stage >= b.lay.n_ints;
     b.lmax = Lmax;
     if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(nt + 2, kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
     else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), lds_stat, st, b);
-    const bool tiled_b = b.part_h1 != nullptr && a.tile;
-    const size_t lds_oold = sizeof(double) * ((size_t)(kTile + kOldA + kOldB) * (b.cpb + kTile - 1) * b.lay.S) +
-                            sizeof(int32_t) * ((size_t)b.cpb + 2);
-    b.tile_d0 = -1;
-    b.tile_has_old = 0;
     if (!b.no_rss)
       for (int d = Wmax; d >= 0; --d) {
         const int ncell = Lmax - d + 1;
         if (ncell <= 0) continue;
         b.d = d;
-        if (tiled_b && (Wmax - d) % kTile == 0) {   // a new tile starts at d: sum the parents beyond it first
-          b.tile_d0 = d;
-          b.tile_has_old = d < Wmax ? 1 : 0;
-          if (b.tile_has_old) {
-            const int dlow = (d - kTile + 1 > 0) ? d - kTile + 1 : 0;
-            const dim3 grid((Lmax - dlow + 1 + b.cpb - 1) / b.cpb, G);
-            if (big_b) {
-              hipLaunchKernelGGL((k4_out_old<1, true>), grid, dim3(kThreads), lds_oold, st, b);
-              hipLaunchKernelGGL((k4_out_old<2, true>), grid, dim3(kThreads), lds_oold, st, b);
-            } else {
-              hipLaunchKernelGGL((k4_out_old<1, false>), grid, dim3(kThreads), lds_oold, st, b);
-              hipLaunchKernelGGL((k4_out_old<2, false>), grid, dim3(kThreads), lds_oold, st, b);
-            }
-          }
-        }
         if (big_b) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
       }

@@ -64,17 +64,53 @@ ELEMDP_HD int lamk(const ModelView& m, int s) { return m.ints[m.lay.st_lam + s];
 ELEMDP_HD double xw_cell(const SeqView& q, int k, int term, int cell) { return q.xwc[(size_t)(k * 5 + term) * q.xwc_stride + cell]; }
 ELEMDP_HD double xw_item(const SeqView& q, int k, int it) { return q.xwi[(size_t)k * q.xwi_stride + it]; }
 
-// ---- heavy sums, serial forms (CPU emulation, one-state passes) ----------------------------------
+// ---- rule 2 through the pair-sparse factorisation ---------------------------------------------------
+// B(i,j,s) = sum_k sum_{(s1,t) in split(s)} 1(i,k,s1) * 2(k,j,t) costs O(W) terms per cell and tuple.  But 2(k,j,.) is a stem
+// P(k,l,.) followed by a tail of unpaired bases (rules 3a, 3b), and the pairs that survive the BPP filter are few.  With
+//     A(i,j,(s1,t)) := sum_{i<k<j} 1(i,k,s1) * 2(k,j,t)
+// rules 3a / 3b give a recurrence along the row (the tail grows by one right emission, or a stem ends at j):
+//     A(i,j,(s1,t)) = [unp(j-1)] sum_{t' in right(t)} A(i,j-1,(s1,t')) w_right(t,t',j-1)
+//                   + sum_{k: (k,j) kept, i<k} 1(i,k,s1) P(k,j,t) xml(k,j)
+// and B(i,j,s) = sum of A(i,j,p) over the pairs p = (s1,t) with (s; s1,t) a split.  (The guards of rule 3a hold by
+// themselves: 2(k,j-1,t') != 0 implies left_ok(k,.) for both spans, and j-k < d <= W.)  Same sums as the reference
+// (energy_model.hpp:358-365 x motif_model.hpp:368-381) in another association; one O(pairs ending at j) loop per cell
+// instead of O(W) operand rows.  The table T.ap holds A per (diagonal, cell, pair).
+template <bool CON = false>
+ELEMDP_HD double lin_inside_apair(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int p,
+                                  const Constraint& con = Constraint{-1, -1, 0}) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const int j = i + d;
+  const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
+  double a = 0.;
+  if (d >= 1 && q.unp[j - 1])
+    for (int e = I[A.ap_chain_off + p]; e < I[A.ap_chain_off + p + 1]; ++e) {
+      const int pc = I[A.ap_chain_ent + 2 * e], tf = I[A.ap_chain_ent + 2 * e + 1];
+      if (CON && !allow_right(m, con, q.L, j, t, I[A.ap_t + pc])) continue;
+      a = fma(T.a(d - 1, i, pc), lw_right(m, q, t, tf, j - 1), a);
+    }
+  const int kl = lamk(m, t);
+  // stems (k, j) that end at j and start behind i: spans 1 .. d-1 of row j of the end-indexed pair mask
+  for_mask_bits(q.okbits_end, j * (q.W + 1), 1, d - 1, [&](int sp) {
+    const int k = j - sp;
+    a = fma(T.at(ST_1, k - i, i, s1), T.at(ST_P, sp, k, t) * xw_cell(q, kl, XT_ML, q.cell(k, sp)), a);
+  });
+  T.a(d, i, p) = a;
+  return a;
+}
+// all pairs of one cell (serial form: CPU emulation)
+template <bool CON = false>
+ELEMDP_HD void lin_inside_cell_pairs(const ModelView& m, const SeqView& q, const TableView& T, int d, int i,
+                                     const Constraint& con = Constraint{-1, -1, 0}) {
+  for (int p = 0; p < m.lay.n_ap; ++p) lin_inside_apair<CON>(m, q, T, d, i, p, con);
+}
+// B(i,j,s) from the pair table of the same cell
 ELEMDP_HD double lheavy_bif(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
   const AutomatonLayout& A = m.lay;
-  const int32_t* G = m.big;
-  const int j = i + d;
+  const int32_t* I = m.ints;
   double a = 0.;
-  for (int k = i + q.dmin[i]; k < j; ++k) {
-    if (!bif_valid(q, j, k)) continue;
-    for (int t = G[A.split_off + s]; t < G[A.split_off + s + 1]; ++t)
-      a = fma(T.at(ST_1, k - i, i, G[A.split_ent + 2 * t]), T.at(ST_2, j - k, k, G[A.split_ent + 2 * t + 1]), a);
-  }
+  for (int p = 0; p < A.n_ap; ++p)
+    if (I[A.ap_tgt + p] == s) a += T.a(d, i, p);
   return a;
 }
 ELEMDP_HD double lloop_term(const TableView& T, int i, int j, const LoopItem& x, int s1, int s2, int s3) {
@@ -371,33 +407,72 @@ template <int MODE, class Sink> ELEMDP_HD void lin_outside_ext_target(LinOutCtx<
   x.out.o(i, s) = lin_outside_ext_part<MODE>(x, i, s, 0, 1);
 }
 
-// serial heavy sums of the outside pass
+// ---- rule 2 in the outside direction, factorised (see lin_inside_apair) ----------------------------
+// With outA(i,l,(s1,t)) := d Z / d A(i,l,(s1,t)):
+//     outA(i,j,p)   = outB(i,j,tgt(p)) + [unp(j)] sum_{p'' : p in chain(p'')} outA(i,j+1,p'') w_right(t'',t,j)     (+ statistics)
+//     out1(i,k,s1)  = sum_{stems (k,l)} sum_{p=(s1,t)} outA(i,l,p) P(k,l,t) xml(k,l)                                  ("H1")
+//     out2(k,l,t)   = [direct part: rules 4a, 3a over the plane-2 table] + HA(k,l,t),
+//     HA(k,l,t)     = sum_{i<k} sum_{p=(s1,t)} outA(i,l,p) 1(i,k,s1)       -- needed only where a stem P(k,l) takes it (rule 3b)
+// The plane-2 OUTSIDE table therefore holds the direct part only (debug_tables adds HA for the export).
+// H1: cell (i,d) in the role 1(i,k,s), k = i + d
 template <class Sink> ELEMDP_HD double lheavy_o1(LinOutCtx<Sink>& x, int d, int i, int s) {
   const ModelView& m = x.m; const SeqView& q = x.q;
-  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
-  const int j = i + d;
+  const AutomatonLayout& A = m.lay; const int32_t* I = m.ints;
+  const int k = i + d;
+  const int hi = (q.W - d < q.L - k) ? q.W - d : q.L - k;   // stems (k, k+sp): the parent B(i, k+sp) stays in the band
   double a = 0.;
-  const int dj = q.dmin[j];
-  if (j < q.L && dj > 0) {
-    const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
-    for (int jj = j + dj; jj <= jmax; ++jj)
-      for (int u = G[A.split1_off + s]; u < G[A.split1_off + s + 1]; ++u)
-        a = fma(x.out.at(ST_B, jj - i, i, G[A.split1_ent + 2 * u]), x.in.at(ST_2, jj - j, j, G[A.split1_ent + 2 * u + 1]), a);
+  for_mask_bits(q.okbits, k * (q.W + 1), 1, hi, [&](int sp) {
+    const int c = q.cell(k, sp);
+    for (int e = I[A.ap_by_s1_off + s]; e < I[A.ap_by_s1_off + s + 1]; ++e) {
+      const int p = I[A.ap_by_s1_ent + e], t = I[A.ap_t + p];
+      a = fma(x.out.a(d + sp, i, p), x.in.at(ST_P, sp, k, t) * xw_cell(q, lamk(m, t), XT_ML, c), a);
+    }
+  });
+  return a;
+}
+// HA: cell (i,d) in the role of the stem cell (k,l) = (i, i+d), state t of plane 2 / P
+template <class Sink> ELEMDP_HD double lheavy_o2(LinOutCtx<Sink>& x, int d, int i, int t) {
+  const ModelView& m = x.m; const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay; const int32_t* I = m.ints;
+  const int j = i + d;
+  const int imin = (j - q.W > 0) ? j - q.W : 0;
+  double a = 0.;
+  for (int ii = i - 1; ii >= imin; --ii) {
+    if (!o2_valid(q, i, ii)) continue;          // 1(ii, i, .) is log 0
+    for (int e = I[A.ap_by_t_off + t]; e < I[A.ap_by_t_off + t + 1]; ++e) {
+      const int p = I[A.ap_by_t_ent + e];
+      a = fma(x.out.a(j - ii, ii, p), x.in.at(ST_1, i - ii, ii, I[A.ap_s1 + p]), a);
+    }
   }
   return a;
 }
-template <class Sink> ELEMDP_HD double lheavy_o2(LinOutCtx<Sink>& x, int d, int i, int s) {
+// outside value of the pair entry (i,d,p), after the unary phase of the cell wrote out B; statistics of the tail emissions
+// (oB_tgt = the outside value of B(i,d,tgt(p)) just computed by the unary phase; ignored when the pair has no target)
+template <int MODE, class Sink> ELEMDP_HD void lin_outside_apair(LinOutCtx<Sink>& x, int d, int i, int p, double oB_tgt) {
   const ModelView& m = x.m; const SeqView& q = x.q;
-  const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
+  const AutomatonLayout& A = m.lay; const int32_t* I = m.ints;
   const int j = i + d;
-  double a = 0.;
-  const int imin = (j - q.W > 0) ? j - q.W : 0;
-  for (int ii = i - 1; ii >= imin; --ii) {
-    if (!o2_valid(q, i, ii)) continue;
-    for (int u = G[A.split2_off + s]; u < G[A.split2_off + s + 1]; ++u)
-      a = fma(x.out.at(ST_B, j - ii, ii, G[A.split2_ent + 2 * u]), x.in.at(ST_1, i - ii, ii, G[A.split2_ent + 2 * u + 1]), a);
+  const double a_in = x.in.a(d, i, p);
+  if (a_in == 0.) { x.out.a(d, i, p) = 0.; return; }
+  const int t = I[A.ap_t + p], tgt = I[A.ap_tgt + p];
+  double a = (tgt >= 0 && q.left_ok(i, d)) ? oB_tgt : 0.;
+  if (d + 1 <= q.W && j < q.L && q.unp[j]) {
+    const double inz = a_in * x.invZ;
+    for (int e = I[A.ap_rchain_off + p]; e < I[A.ap_rchain_off + p + 1]; ++e) {
+      const int pp = I[A.ap_rchain_ent + 2 * e], tf = I[A.ap_rchain_ent + 2 * e + 1];
+      const int par = I[A.ap_t + pp];
+      const double term = x.out.a(d + 1, i, pp) * lw_right(m, q, par, tf, j);
+      if (!lstat_right<MODE>(x, j, par, t, term * inz)) continue;
+      a += term;
+    }
   }
-  return a;
+  x.out.a(d, i, p) = a;
+}
+template <int MODE, class Sink> ELEMDP_HD void lin_outside_cell_pairs(LinOutCtx<Sink>& x, int d, int i) {
+  for (int p = 0; p < x.m.lay.n_ap; ++p) {
+    const int tgt = x.m.ints[x.m.lay.ap_tgt + p];
+    lin_outside_apair<MODE>(x, d, i, p, tgt >= 0 ? x.out.at(ST_B, d, i, tgt) : 0.);
+  }
 }
 // HP and the energy statistic of rule 6c: the posterior of (item, tuple) is term * inside P(i,j,s) / Z
 template <int MODE, class Sink> ELEMDP_HD double lheavy_oP(LinOutCtx<Sink>& x, int d, int i, int s) {
@@ -456,7 +531,7 @@ template <class Sink> ELEMDP_HD double lheavy_oL(LinOutCtx<Sink>& x, int d, int 
 
 // band target (i,d,s), outside direction, given the heavy sums (H1 -> state 1, H2 -> 2, HP -> P, HL -> L)
 template <int MODE, class Sink>
-ELEMDP_HD void lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, const HeavyOut& H) {
+ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, const HeavyOut& H) {   // returns out B(i,d,s)
   const ModelView& m = x.m;
   const SeqView& q = x.q;
   const TableView& in = x.in;
@@ -568,7 +643,7 @@ ELEMDP_HD void lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, con
   // 1: heavy sum H1 ; B: child of M (5b) and 1 (4b) ; 2: child of 1 (4a), 2(i,j+1,par) (3a), heavy sum H2
   const double o1 = (in1 != 0.) ? H.H1 : 0.;
   const double oB = (inB != 0.) ? (mok ? oM : 0.) + o1 : 0.;
-  const double o2 = (in2 != 0.) ? o1 + s2 + H.H2 : 0.;
+  const double o2 = (in2 != 0.) ? o1 + s2 : 0.;   // direct part (rules 4a, 3a); the rule-2 part reaches P as H.H2 = HA
   out.at(ST_1, d, i, s) = o1;
   out.at(ST_B, d, i, s) = oB;
   out.at(ST_2, d, i, s) = o2;
@@ -582,7 +657,7 @@ ELEMDP_HD void lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, con
         const int par = G[A.split2_ent + 2 * u], s2i = G[A.split2_ent + 2 * u + 1];
         a = fma(out.o(j, par), in.o(i, s2i) * (lamk(m, par) ? xex1 : xex0), a);
       }
-    const double t3b = o2 * xml;
+    const double t3b = (o2 + H.H2) * xml;
     lstat_energy<MODE>(x, s, e_ml, t3b * inPz);
     oP = a + oP1b + t3b + H.HP;
   }
@@ -596,6 +671,7 @@ ELEMDP_HD void lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, con
     oL = t6b + sL + H.HL;
   }
   out.at(ST_L, d, i, s) = oL;
+  return oB;
 }
 
 template <int MODE, class Sink> ELEMDP_HD void lin_outside_target(LinOutCtx<Sink>& x, int d, int i, int s) {
@@ -603,7 +679,7 @@ template <int MODE, class Sink> ELEMDP_HD void lin_outside_target(LinOutCtx<Sink
   HeavyOut H;
   const bool lok = q.left_ok(i, d);
   H.H1 = (lok && x.in.at(ST_1, d, i, s) != 0.) ? lheavy_o1(x, d, i, s) : 0.;
-  H.H2 = (lok && x.in.at(ST_2, d, i, s) != 0.) ? lheavy_o2(x, d, i, s) : 0.;
+  H.H2 = (q.pair_ok(i, d) && x.in.at(ST_P, d, i, s) != 0.) ? lheavy_o2(x, d, i, s) : 0.;
   H.HP = q.pair_ok(i, d) ? lheavy_oP<MODE>(x, d, i, s) : 0.;
   H.HL = (x.m.ints[x.m.lay.st_is_loop + s] && x.in.at(ST_L, d, i, s) != 0.) ? lheavy_oL(x, d, i, s) : 0.;
   lin_outside_target_u<MODE>(x, d, i, s, H);

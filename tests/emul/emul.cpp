@@ -46,7 +46,7 @@ struct HostPlan {
   int L, W, C;
   std::vector<uint8_t> seq, unp, item_in;
   std::vector<double> ws;
-  std::vector<uint32_t> okbits;
+  std::vector<uint32_t> okbits, okbits_end;   // okbits_end: the same pairs indexed by (end, span), filled by view()
   std::vector<int16_t> dmin;
   std::vector<double> e_stack, e_ext, e_ml, e_close, e_hp;
   std::vector<LoopItem> items;
@@ -62,9 +62,14 @@ struct HostPlan {
   }
   void set_ok(int i, int d) { int c = i * (W + 1) + d; okbits[c >> 5] |= 1u << (c & 31); }
 
-  SeqView view() const {
+  SeqView view() {
     SeqView q;
     q.L = L; q.W = W; q.C = C;
+    okbits_end.assign(okbits.size() + 2, 0u);   // (k_mask_by_end on the GPU)
+    for (int i = 0; i <= L; ++i)
+      for (int d = 1; d <= W && i + d <= L; ++d)
+        if (ok(i, d)) { const int c = (i + d) * (W + 1) + d; okbits_end[c >> 5] |= 1u << (c & 31); }
+    q.okbits_end = okbits_end.data();
     q.seq = seq.data(); q.ws = ws.data(); q.okbits = okbits.data(); q.dmin = dmin.data(); q.unp = unp.data();
     q.e_stack = e_stack.data(); q.e_ext = e_ext.data(); q.e_ml = e_ml.data(); q.e_close = e_close.data(); q.e_hp = e_hp.data();
     q.items = items.data(); q.by_outer_off = by_outer_off.data();
@@ -196,10 +201,12 @@ ModelView make_view(const AutomatonLayout& lay, const std::vector<int32_t>& ints
 }
 
 struct Tab {
-  std::vector<double> band, ext;
+  std::vector<double> band, ext, ap;
   TableView v;
-  Tab(int L, int W, int S) : band((size_t)7 * (W + 1) * (L + 1) * S, NEG), ext((size_t)(L + 1) * S, NEG) {
+  Tab(int L, int W, int S, int nA = 0) : band((size_t)7 * (W + 1) * (L + 1) * S, NEG), ext((size_t)(L + 1) * S, NEG),
+                                         ap((size_t)(W + 1) * (L + 1) * nA + 1, 0.) {
     v.band = band.data(); v.ext = ext.data(); v.L = L; v.W = W; v.S = S;
+    v.ap = ap.data(); v.nA = nA;
   }
 };
 
@@ -385,9 +392,12 @@ int emu_train_seq(void* h, const double* x, const uint8_t* seq, int L, const uin
     out9[8] = (double)P.items.size();
     auto copy_tab = [&](Tab& T, double* dst) {  // -> reference index order [i][d][e][s]
       for (int i = 0; i <= L; ++i) for (int d = 0; d <= P.W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s)
-        dst[(((size_t)i * (P.W + 1) + d) * 7 + e) * S + s] = (i + d <= L) ? T.v.at(e, d, i, s) : NEG;
+        dst[(((size_t)i * (P.W + 1) + d) * 7 + e) * S + E.ints[E.lay.st_ref + s]] = (i + d <= L) ? T.v.at(e, d, i, s) : NEG;
     };
-    if (inside_o) std::copy(in.ext.begin(), in.ext.end(), inside_o);
+    auto copy_ext = [&](Tab& T, double* dst) {   // (states in the reference's order, AutomatonLayout::st_ref)
+      for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) dst[(size_t)j * S + E.ints[E.lay.st_ref + s]] = T.v.o(j, s);
+    };
+    if (inside_o) copy_ext(in, inside_o);
     if (inside) copy_tab(in, inside);
     if (!(std::isfinite(Zo) && std::isfinite(Za))) { out9[5] = 1; return 0; }
     std::vector<double> eno(nt + 1, 0.), enx(nt + 1, 0.);
@@ -395,7 +405,7 @@ int emu_train_seq(void* h, const double* x, const uint8_t* seq, int L, const uin
     CpuSink s1{eno.data(), eho, {nullptr, nullptr, nullptr}};
     run_outside<OUT_TRAIN>(m, q, in, out, Zo, c, s1, true, true);
     if (outside) copy_tab(out, outside);
-    if (outside_o) std::copy(out.ext.begin(), out.ext.end(), outside_o);
+    if (outside_o) copy_ext(out, outside_o);
     const bool positive = !(P.ws[L] > NEG);
     CpuSink s2{enx.data(), ehx, {nullptr, nullptr, nullptr}};
     double Zx = positive ? Za : Zn;
@@ -449,12 +459,14 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
     std::vector<double> cum(L + 1, 0.);   // log2 of prod_{p<j} psb
     for (int p = 0; p < L; ++p) cum[p + 1] = cum[p] + lin[kLinPl2 + seq[p]];
     const double ln2 = 0.69314718055994530942;
-    Tab in(L, P.W, S), out(L, P.W, S);
+    Tab in(L, P.W, S, m.lay.n_ap), out(L, P.W, S, m.lay.n_ap);
     std::fill(in.band.begin(), in.band.end(), 0.); std::fill(in.ext.begin(), in.ext.end(), 0.);
     std::fill(out.band.begin(), out.band.end(), 0.); std::fill(out.ext.begin(), out.ext.end(), 0.);
     for (int d = 0; d <= q.W; ++d)
-      for (int i = 0; i + d <= q.L; ++i)
+      for (int i = 0; i + d <= q.L; ++i) {
+        lin_inside_cell_pairs(m, q, in.v, d, i);     // rule 2, factorised: the pair table of the cell first
         for (int s = 0; s < S; ++s) lin_inside_target(m, q, in.v, d, i, s);
+      }
     for (int s = 0; s < S; ++s) in.v.o(0, s) = (s == m.lay.s00) ? 1. : 0.;
     for (int j = 1; j <= L; ++j)
       for (int s = 0; s < S; ++s) lin_inside_ext_target(m, q, in.v, j, s);
@@ -466,10 +478,10 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
       for (int i = 0; i <= L; ++i) for (int d = 0; d <= P.W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s) {
         double sc = (i + d <= L) ? cum[i + d] - cum[i] : 0.;
         if (outside_tab) sc = cum[L] - sc;
-        dst[(((size_t)i * (P.W + 1) + d) * 7 + e) * S + s] = (i + d <= L) ? tolog(T.v.at(e, d, i, s), sc) : NEG;
+        dst[(((size_t)i * (P.W + 1) + d) * 7 + e) * S + E.ints[E.lay.st_ref + s]] = (i + d <= L) ? tolog(T.v.at(e, d, i, s), sc) : NEG;
       }
     };
-    if (inside_o) for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) inside_o[(size_t)j * S + s] = tolog(in.v.o(j, s), cum[j]);
+    if (inside_o) for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) inside_o[(size_t)j * S + E.ints[E.lay.st_ref + s]] = tolog(in.v.o(j, s), cum[j]);
     if (inside) copy_tab(in, inside, false);
     auto bad = [](double z) { return !(z > 0.) || !std::isfinite(z); };
     if (bad(Zo) || bad(Za) || (schedule == 1 && bad(Zn))) { out9[5] = 2; return 0; }
@@ -485,18 +497,33 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
       if (ari) { out.v.o(L, mm.lay.s0m1) = 1.; out.v.o(L, mm.lay.s0m2) = 1.; }
       for (int i = L - 1; i >= 0; --i)
         for (int s = 0; s < NA; ++s) lin_outside_ext_target<OUT_TRAIN>(xo, i, s);
+      std::fill(out.ap.begin(), out.ap.end(), 0.);
       for (int d = q.W; d >= 0; --d)
-        for (int i = 0; i + d <= L; ++i)
+        for (int i = 0; i + d <= L; ++i) {
           for (int s = 0; s < NA; ++s) lin_outside_target<OUT_TRAIN>(xo, d, i, s);
+          lin_outside_cell_pairs<OUT_TRAIN>(xo, d, i);
+        }
+    };
+    // export only: the plane-2 outside table holds the direct part (rules 4a, 3a); the reference's value adds what arrives
+    // through rule 2, HA(k,l,t) = sum_i sum_{p=(s1,t)} outA(i,l,p) 1(i,k,s1), wherever the inside value is non-zero
+    auto complete_plane2 = [&]() {
+      LinOutCtx<CpuSink>* none = nullptr; (void)none;
+      double en0[1] = {0}, eh0[2] = {0, 0};
+      CpuSink sink{en0, eh0, {nullptr, nullptr, nullptr}};
+      LinOutCtx<CpuSink> xo{m, q, in.v, out.v, 1., sink};
+      for (int d = 0; d <= q.W; ++d)
+        for (int i = 0; i + d <= L; ++i)
+          for (int t = 0; t < S; ++t)
+            if (q.left_ok(i, d) && in.v.at(ST_2, d, i, t) != 0.) out.v.at(ST_2, d, i, t) += lheavy_o2(xo, d, i, t);
     };
     if (schedule == 0) {
       run_out(m, Zo, true, true, enA, ehA);
-      if (outside) copy_tab(out, outside, true);
-      if (outside_o) for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) outside_o[(size_t)j * S + s] = tolog(out.v.o(j, s), cum[L] - cum[j]);
+      if (outside) { complete_plane2(); copy_tab(out, outside, true); }
+      if (outside_o) for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) outside_o[(size_t)j * S + E.ints[E.lay.st_ref + s]] = tolog(out.v.o(j, s), cum[L] - cum[j]);
       run_out(m, positive ? Za : Zn, positive, !positive, enB, ehB);
     } else {
       run_out(m, Za, true, false, enA, ehA);
-      if (outside) copy_tab(out, outside, true);
+      if (outside) { complete_plane2(); copy_tab(out, outside, true); }
       std::fill(out.band.begin(), out.band.end(), 0.); std::fill(out.ext.begin(), out.ext.end(), 0.);
       run_out(mr, Zn, false, true, enB, ehB);
       const double pa = Za / Zo, pn = Zn / Zo;
@@ -617,13 +644,15 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
       for (size_t n = 0; n < ni; ++n) xwi[(size_t)k * ni + n] = lin_weight(m.lambda[k], P.items[n].tsc);
     }
     q.ews = ews.data(); q.xwc = xwc.data(); q.xwc_stride = nc; q.xwi = xwi.data(); q.xwi_stride = ni;
-    Tab in(L, P.W, S), out(L, P.W, S);
-    auto zero = [](Tab& T) { std::fill(T.band.begin(), T.band.end(), 0.); std::fill(T.ext.begin(), T.ext.end(), 0.); };
+    Tab in(L, P.W, S, m.lay.n_ap), out(L, P.W, S, m.lay.n_ap);
+    auto zero = [](Tab& T) { std::fill(T.band.begin(), T.band.end(), 0.); std::fill(T.ext.begin(), T.ext.end(), 0.); std::fill(T.ap.begin(), T.ap.end(), 0.); };
     auto run_in = [&](const Constraint& c, bool con) {
       zero(in);
       for (int d = 0; d <= q.W; ++d)
-        for (int i = 0; i + d <= q.L; ++i)
+        for (int i = 0; i + d <= q.L; ++i) {
+          if (con) lin_inside_cell_pairs<true>(m, q, in.v, d, i, c); else lin_inside_cell_pairs<false>(m, q, in.v, d, i, c);
           for (int s = 0; s < S; ++s) { if (con) lin_inside_target<true>(m, q, in.v, d, i, s, c); else lin_inside_target<false>(m, q, in.v, d, i, s, c); }
+        }
       for (int s = 0; s < S; ++s) in.v.o(0, s) = (s == m.lay.s00) ? 1. : 0.;
       for (int j = 1; j <= L; ++j)
         for (int s = 0; s < S; ++s) { if (con) lin_inside_ext_target<true>(m, q, in.v, j, s, c); else lin_inside_ext_target<false>(m, q, in.v, j, s, c); }
@@ -644,7 +673,10 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
       LinOutCtx<CpuLinSink> xo{m, q, in.v, out.v, 1. / ZLm, s1, c0};
       out.v.o(L, m.lay.s00) = 1.; out.v.o(L, m.lay.s0m1) = 1.; out.v.o(L, m.lay.s0m2) = 1.;
       for (int i = L - 1; i >= 0; --i) for (int s = 0; s < S; ++s) lin_outside_ext_target<OUT_SCAN>(xo, i, s);
-      for (int d = q.W; d >= 0; --d) for (int i = 0; i + d <= L; ++i) for (int s = 0; s < S; ++s) lin_outside_target<OUT_SCAN>(xo, d, i, s);
+      for (int d = q.W; d >= 0; --d) for (int i = 0; i + d <= L; ++i) {
+        for (int s = 0; s < S; ++s) lin_outside_target<OUT_SCAN>(xo, d, i, s);
+        lin_outside_cell_pairs<OUT_SCAN>(xo, d, i);
+      }
     }
     auto tolog = [](double v) { return v > 0. ? std::log(v) : NEG; };
     std::vector<double> lPys(L), lPyi(L), lPye(L + 1);
@@ -660,7 +692,10 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
       LinOutCtx<CpuLinSink> xo{m, q, in.v, out.v, 1. / ZeLm, s2, c1};
       out.v.o(L, m.lay.s00) = 1.; out.v.o(L, m.lay.s0m1) = 1.; out.v.o(L, m.lay.s0m2) = 1.;
       for (int i = L - 1; i >= 0; --i) for (int s = 0; s < S; ++s) lin_outside_ext_target<OUT_END>(xo, i, s);
-      for (int d = q.W; d >= 0; --d) for (int i = 0; i + d <= L; ++i) for (int s = 0; s < S; ++s) lin_outside_target<OUT_END>(xo, d, i, s);
+      for (int d = q.W; d >= 0; --d) for (int i = 0; i + d <= L; ++i) {
+        for (int s = 0; s < S; ++s) lin_outside_target<OUT_END>(xo, d, i, s);
+        lin_outside_cell_pairs<OUT_END>(xo, d, i);
+      }
     }
     for (int p = 0; p <= L; ++p) lPye[p] = tolog(Pye[p]);
     const int Ye = last_argmax(lPye.data(), L + 1);

@@ -362,21 +362,6 @@ def test_pipelines_agree_and_linear_pipeline_is_the_one_measured():
         assert res[pipe][2:] == res[4][2:]
 
 
-def test_tiled_split_sums_give_the_same_result():
-    """option "tile": the split sums of four diagonals at a time from one staging of the older operand rows
-    (k4_in_old / k4_out_old) -- same fn / gr on a ragged batch (different L and W per sequence)."""
-    m = io.read_model(gpath("syn_b.model"))
-    recs = io.read_fastq(gpath("syn_L40_n3.fq")) + io.read_fastq(gpath("syn_L100_n3.fq")) + io.read_fastq(gpath("syn_L150_n8.fq"))
-    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
-    eng = io.engine_from_model(m)
-    eng.load_batch(seqs, quals)
-    a = eng.train_eval(m["x"])
-    eng.set_option("tile", 1)
-    b = eng.train_eval(m["x"])
-    assert b[0] == pytest.approx(a[0], rel=1e-12)
-    np.testing.assert_allclose(b[1], a[1], rtol=1e-10, atol=1e-11)
-
-
 def test_linear_pipeline_hands_out_of_range_sequences_to_the_log_pipeline():
     """lambda = 40 puts the partition functions (~e^1000 and beyond) outside the double range of the scaled-linear tables:
     those sequences are flagged and re-evaluated in log space, the result still matches the oracle."""

@@ -27,7 +27,7 @@ def check_scan_case(case, eng, m):
             ref = arr(r[k])
             assert np.array_equal(np.isneginf(ref), np.isneginf(g[k])), k
             mk = ~np.isneginf(ref)
-            np.testing.assert_allclose(g[k][mk], ref[mk], rtol=2e-5, atol=1e-300)
+            np.testing.assert_allclose(g[k][mk], ref[mk], rtol=2e-5, atol=1e-9)
         assert g["exist_prob"] == pytest.approx(r["exist_prob"], rel=2e-5)
     return recs, got
 
