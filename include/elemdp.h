@@ -88,7 +88,10 @@ int elemdp_describe(const elemdp_handle* h, char* buf, int32_t cap);
  * fit); "schedule" = 1 (default: ari-only + one-state nasi-only outside passes) / 0 (the reference's two passes);
  * "prune" = 1 (default: transition lists without the transitions that cannot occur in a complete parse) / 0 (the complete
  * lists of the reference's automaton); "two_streams" = second outside pass on a second stream (default 1); "group_streams" =
- * groups evaluated concurrently (default 2); "profile" = in-kernel phase clocks
+ * groups evaluated concurrently (default 2); "max_resident" = most sequences kept resident at a time (0 = as many as the device
+ * memory holds): a larger batch is STREAMED -- elemdp_train_eval / elemdp_scan then run it in chunks of that size, the BPP
+ * filter + plan of chunk k+1 being built (second inner engine, second host thread) while chunk k is evaluated, and the chunks'
+ * partial sums added in chunk order; set before elemdp_load_batch; "profile" = in-kernel phase clocks
  * for elemdp_debug_profile; "dbg" = switch phases off (measurements only). */
 int elemdp_set_option(elemdp_handle* h, const char* key, double value);
 
@@ -126,6 +129,19 @@ int elemdp_train_finish(elemdp_handle* h, const double* reduced, double* fn, dou
 /* Host-only: tells the handle which x a following elemdp_train_finish refers to (needed for the
  * softmax chain rule, motif_trainer.hpp:251-261) when elemdp_train_partial ran in another handle. */
 int elemdp_set_finish_params(elemdp_handle* h, const double* x, int32_t n_param);
+
+/* In-library collective for hosts without their own (the reference binary with INTEGRATION.md's shim): one process (or
+ * thread) per GPU, one handle each.  Rank 0 obtains an id with elemdp_comm_unique_id (128 bytes, ncclUniqueId) and hands
+ * it to the other ranks by whatever means the host has (a file, MPI, a socket); every rank then calls elemdp_comm_init on
+ * its handle.  From then on elemdp_train_eval all-reduces (sum, fp64, elemdp_partial_len doubles) the partial vector over
+ * RCCL / xGMI on the engine's stream before it finishes fn / gr, so every rank returns the values of the WHOLE batch --
+ * the replacement of the array job + result files of motif_array_trainer.hpp:20-58 (submit_array_job / collect_fn_gr_eff).
+ * A rank whose share of the batch is empty calls elemdp_train_eval without a batch: it contributes zeros.
+ * librccl.so is loaded on the first call (dlopen); without it these return ELEMDP_ENODEV. */
+#define ELEMDP_COMM_ID_BYTES 128
+int elemdp_comm_unique_id(void* id_out);
+int elemdp_comm_init(elemdp_handle* h, int32_t rank, int32_t world, const void* id);
+int elemdp_comm_destroy(elemdp_handle* h);
 
 /* per-sequence diagnostics of the last train evaluation: 5 doubles per sequence
  * [Z(ari,nasi), Z(ari), Z(nasi), f_n, skipped] (motif_trainer.hpp:108-112, 204-227) */

@@ -24,7 +24,8 @@ SYMBOLS = ["elemdp_last_error", "elemdp_abi_version", "elemdp_set_data_dir", "el
            "elemdp_n_param", "elemdp_n_state", "elemdp_n_node", "elemdp_initial_params", "elemdp_describe",
            "elemdp_set_option", "elemdp_load_batch", "elemdp_batch_bpp_eff", "elemdp_batch_pairs", "elemdp_train_eval",
            "elemdp_partial_len", "elemdp_train_partial", "elemdp_train_finish", "elemdp_set_finish_params", "elemdp_train_seq_stats",
-           "elemdp_debug_tables", "elemdp_scan", "elemdp_last_timing", "elemdp_debug_profile", "elemdp_kernel_name", "elemdp_kmer_shuffle", "elemdp_epoch_permutation"]
+           "elemdp_debug_tables", "elemdp_scan", "elemdp_last_timing", "elemdp_debug_profile", "elemdp_kernel_name", "elemdp_kmer_shuffle", "elemdp_epoch_permutation",
+           "elemdp_comm_unique_id", "elemdp_comm_init", "elemdp_comm_destroy"]
 
 
 class ModelDesc(C.Structure):
@@ -80,6 +81,9 @@ def load_library():
         L.elemdp_epoch_permutation.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
         L.elemdp_kmer_shuffle.argtypes = [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
         L.elemdp_debug_profile.argtypes = [hp, dp, C.c_int32]
+        L.elemdp_comm_unique_id.argtypes = [C.c_char_p]
+        L.elemdp_comm_init.argtypes = [hp, C.c_int32, C.c_int32, C.c_char_p]
+        L.elemdp_comm_destroy.argtypes = [hp]
         _lib = L
     return _lib
 
@@ -222,6 +226,22 @@ class Engine:
         fn, eff, nsk = C.c_double(), C.c_double(), C.c_int32()
         self._check(self._lib.elemdp_train_finish(self._h, _dp(reduced), C.byref(fn), _dp(gr), C.byref(eff), C.byref(nsk)))
         return fn.value, gr, eff.value, nsk.value
+
+    # ---- in-library collective (RCCL) for hosts without torch.distributed
+    @staticmethod
+    def comm_unique_id():
+        """128-byte id (ncclUniqueId) that rank 0 creates and hands to the other ranks"""
+        buf = C.create_string_buffer(128)
+        rc = load_library().elemdp_comm_unique_id(buf)
+        if rc < 0:
+            raise ElemdpError(rc, load_library().elemdp_last_error().decode())
+        return buf.raw
+
+    def comm_init(self, rank, world, uid):
+        self._check(self._lib.elemdp_comm_init(self._h, rank, world, C.c_char_p(uid)))
+
+    def comm_destroy(self):
+        self._check(self._lib.elemdp_comm_destroy(self._h))
 
     def seq_stats(self):
         out = np.zeros((self.n_seq, 5))

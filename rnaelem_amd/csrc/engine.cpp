@@ -22,6 +22,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -76,6 +77,45 @@ class DeviceGuard {
   int prev_ = -1;
   bool changed_ = false;
 };
+
+// RCCL entry points, resolved at run time: the library has no link-time dependency on librccl (hosts that bring their own
+// collective -- torch.distributed in rnaelem_amd/distributed.py -- never load it)
+struct Rccl {
+  typedef struct { char internal[128]; } UniqueId;           // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+  typedef void* Comm;                                         // ncclComm_t
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  static constexpr int kDouble = 8, kSum = 0;                 // ncclFloat64, ncclSum
+  static Rccl& get() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+      tried = true;
+      void* lib = nullptr;
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+      if (lib) {
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+      }
+    }
+    return r;
+  }
+  bool ok() const { return GetUniqueId && CommInitRank && AllReduce && CommDestroy; }
+};
+#define RCCL_OK(expr)                                                                                                     \
+  do {                                                                                                                    \
+    int r_ = (expr);                                                                                                      \
+    if (r_ != 0)                                                                                                          \
+      throw elemdp::HipError(std::string(#expr) + ": " +                                                                  \
+                             (elemdp::Rccl::get().GetErrorString ? elemdp::Rccl::get().GetErrorString(r_) : "rccl error")); \
+  } while (0)
 
 // owning device buffer
 class DevBuf {
@@ -164,11 +204,15 @@ class Engine {
   bool softmax() const { return flags_ & ELEMDP_THETA_SOFTMAX; }
 
   void load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* qual, const int32_t* qoff, const char* fix, int n);
-  void train_partial(const double* x, int n_param, void* partial, bool device_ptr);
+  // reduce: all-reduce the vector over the communicator of elemdp_comm_init (if any) before it is handed out
+  void train_partial(const double* x, int n_param, void* partial, bool device_ptr, bool reduce = false);
   void train_finish(const double* reduced, double* fn, double* gr, double* sum_eff, int32_t* n_skipped);
   void scan(const double* x, int n_param, elemdp_scan_out* out);
   int partial_len() const { return 4 + 2 * au_.n_theta() + 4; }
   void set_option(const std::string& key, double v);
+  void comm_init(int rank, int world, const void* id);
+  void comm_destroy();
+  bool has_comm() const { return comm_ != nullptr; }
 
   int n_seq() const { return n_seq_; }
   const std::vector<SeqPlan>& plans() const { return h_plans_; }
@@ -202,6 +246,30 @@ class Engine {
   void require_device() const;
   bool has_device_ = false;
   int want_device_ = -1;
+  Rccl::Comm comm_ = nullptr;   // in-library collective (elemdp_comm_init): all-reduce of the partial vector in train_eval
+  int comm_rank_ = 0, comm_world_ = 1;
+  // ---- streaming: a batch that is not kept resident as a whole (option "max_resident", or more sequences than the device
+  // memory holds).  The handle then keeps the host copy of the input and two inner engines on the same device: chunk k is
+  // evaluated (or scanned) on one while the other runs load_batch (BPP filter + plan) of chunk k+1 on a second host thread;
+  // the partial vectors of the chunks are summed in chunk order.  The reference streams its records the same way
+  // (motif_trainer.hpp:124-153 over fastq_io.hpp:132-167) and recomputes the BPP filter in every evaluation, too.
+  bool streaming_ = false;
+  int st_chunk_ = 0, opt_max_resident_ = 0;
+  std::vector<uint8_t> st_seq_, st_qual_;
+  std::vector<char> st_fix_;
+  std::vector<double> st_rows_;                             // [Z(ari,nasi), Z(ari), Z(nasi), f, skipped] per sequence
+  std::unique_ptr<Engine> sub_[2];
+  std::vector<std::pair<std::string, double>> opt_log_;     // options to replay on the inner engines
+  elemdp_model_desc desc_;
+  std::string desc_pattern_, desc_par_;
+  bool desc_has_par_ = false;
+  bool should_stream(const int32_t* off, int n);
+  void stream_setup(const uint8_t* seq, const int32_t* off, const uint8_t* qual, const int32_t* qoff, const char* fix, int n);
+  void stream_load_chunk(int k, Engine& e);
+  void stream_subs();
+  template <class Work> void stream_chunks(Work work);
+  void stream_train(const double* x, int n_param, void* partial, bool device_ptr, bool reduce);
+  void stream_scan(const double* x, int n_param, elemdp_scan_out* out);
 
   Automaton au_;
   EnergyTables et_;
@@ -271,7 +339,10 @@ class Engine {
 
 Engine::Engine(const elemdp_model_desc& d)
     : au_(d.pattern ? d.pattern : ""), flags_(d.flags), max_span_(d.max_span), max_iloop_(d.max_iloop), min_bpp_(d.min_bpp),
-      tau_(d.tau) {
+      tau_(d.tau), desc_(d) {
+  desc_pattern_ = d.pattern ? d.pattern : "";
+  desc_has_par_ = d.energy_param != nullptr;
+  if (desc_has_par_) desc_par_ = d.energy_param;
   if ((flags_ & ELEMDP_NO_RSS) && (flags_ & ELEMDP_NO_PROFILE)) throw ArgError("no-rss, no-profile are exclusive.");
   if ((flags_ & ELEMDP_NO_RSS) && au_.reg_pattern().find(')') != std::string::npos)
     throw ArgError("search pattern must not include pair when no-rss mode");
@@ -369,9 +440,28 @@ void Engine::init_device() {
   HIP_OK(hipStreamSynchronize(st_));
 }
 
+void Engine::comm_init(int rank, int world, const void* id) {
+  require_device();
+  if (!id || world < 1 || rank < 0 || rank >= world) throw ArgError("elemdp_comm_init: bad rank / world / id");
+  Rccl& r = Rccl::get();
+  if (!r.ok()) throw HipError("no HIP device available for the collective: librccl.so could not be loaded");
+  DeviceGuard dg(device_);
+  comm_destroy();
+  Rccl::UniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  RCCL_OK(r.CommInitRank(&comm_, world, uid, rank));
+  comm_rank_ = rank;
+  comm_world_ = world;
+}
+
+void Engine::comm_destroy() {
+  if (comm_) { DeviceGuard dg(device_); (void)Rccl::get().CommDestroy(comm_); comm_ = nullptr; comm_world_ = 1; comm_rank_ = 0; }
+}
+
 Engine::~Engine() {
   if (!has_device_) return;
   DeviceGuard dg(device_);
+  comm_destroy();
   if (st_) (void)hipStreamSynchronize(st_);
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
   for (auto& e : ev2_) if (e) (void)hipEventDestroy(e);
@@ -387,6 +477,7 @@ Engine::~Engine() {
 }
 
 void Engine::set_option(const std::string& key, double v) {
+  if (key == "max_resident") { opt_max_resident_ = (int)v; return; }
   if (key == "slots") opt_slots_ = (int)v;
   else if (key == "keep_lnbpp") opt_keep_lnbpp_ = v != 0;
   else if (key == "first_pass_only") opt_first_pass_only_ = v != 0;
@@ -403,6 +494,8 @@ void Engine::set_option(const std::string& key, double v) {
     if (has_device_) { DeviceGuard dg(device_); HIP_OK(hipStreamSynchronize(st_)); upload_automaton(); }
   }
   else throw ArgError("unknown option: " + key);
+  opt_log_.emplace_back(key, v);                       // (replayed on the inner engines of a streamed batch)
+  for (auto& e : sub_) if (e) e->set_option(key, v);
 }
 
 void Engine::set_theta_from(const double* x) {
@@ -602,6 +695,8 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   // a rejected batch leaves the handle without a batch (ELEMDP_ESTATE for what follows) instead of the new sizes over the old
   // device buffers
   n_seq_ = 0;
+  streaming_ = false;
+  if (n > 0 && seq && off && qual && qoff && should_stream(off, n)) { stream_setup(seq, off, qual, qoff, fix, n); return; }
   if (n <= 0 || !seq || !off || !qual || !qoff) throw ArgError("load_batch: empty batch or null pointer");
   const bool fixmode = flags_ & ELEMDP_DBG_FIX_RSS;
   if (fixmode && !fix) throw ArgError("load_batch: ELEMDP_DBG_FIX_RSS needs fix_rss strings");
@@ -818,6 +913,151 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   n_slots_ = 0;
   HIP_OK(hipStreamSynchronize(st_));
   n_seq_ = n;   // committed: everything above succeeded
+}
+
+// ---- streaming --------------------------------------------------------------------------------------------------------
+bool Engine::should_stream(const int32_t* off, int n) {
+  if (opt_max_resident_ > 0) return n > opt_max_resident_;
+  // resident needs per sequence: plan (terms, CSR offsets, items in four orders, their weights) + its share of the table
+  // slots; a batch whose plan alone would take more than half of the free device memory is streamed
+  double cells = 0;
+  for (int k = 0; k < n; ++k) {
+    const double L = off[k + 1] - off[k], W = std::min<double>(L, max_span_);
+    cells += (L + 1) * (W + 1);
+  }
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+  const size_t held = d_band_in_.bytes() + d_band_out_.bytes() + d_band_in0_.bytes() + d_band_out0_.bytes() + d_xwc_.bytes() + d_xwi_.bytes();
+  return cells * 600.0 > 0.5 * (double)(free_b + held);
+}
+
+void Engine::stream_setup(const uint8_t* seq, const int32_t* off, const uint8_t* qual, const int32_t* qoff, const char* fix, int n) {
+  if ((flags_ & ELEMDP_DBG_FIX_RSS) && !fix) throw ArgError("load_batch: ELEMDP_DBG_FIX_RSS needs fix_rss strings");
+  h_seq_off_.assign(off, off + n + 1);
+  h_qual_off_.assign(qoff, qoff + n + 1);
+  h_plans_.assign(n, SeqPlan());
+  double cells = 0;
+  for (int k = 0; k < n; ++k) {
+    const int L = off[k + 1] - off[k];
+    if (L <= 0) throw ArgError("load_batch: empty sequence");
+    if (qoff[k + 1] - qoff[k] != L + 1) throw ArgError("bad seq format. (quality must have L+1 entries)");
+    h_plans_[k].L = L;
+    h_plans_[k].W = std::min(L, max_span_);
+    h_plans_[k].positive = qual[qoff[k + 1] - 1] == 0;
+    cells += (double)(L + 1) * (h_plans_[k].W + 1);
+  }
+  st_seq_.assign(seq + off[0], seq + off[n]);
+  st_qual_.assign(qual + qoff[0], qual + qoff[n]);
+  if (fix) st_fix_.assign(fix + off[0], fix + off[n]); else st_fix_.clear();
+  if (opt_max_resident_ > 0) st_chunk_ = opt_max_resident_;
+  else {   // two inner engines, each with a fifth of the free memory for its plan
+    size_t free_b = 0, total_b = 0;
+    HIP_OK(hipMemGetInfo(&free_b, &total_b));
+    const double per_seq = cells / n * 600.0;
+    st_chunk_ = (int)std::max(256.0, std::min((double)n, 0.2 * (double)free_b / per_seq));
+  }
+  st_rows_.clear();
+  // (the buffers of an earlier resident batch would only stand in the way of the inner engines)
+  for (DevBuf* b : {&d_band_in_, &d_band_out_, &d_ext_in_, &d_ext_out_, &d_tmp_, &d_band_in0_, &d_band_out0_, &d_xwc_, &d_xwi_,
+                    &d_a_in_, &d_a_out_, &d_a_in0_, &d_a_out0_, &d_tr_band_, &d_tr_ext_})
+    b->reset();
+  n_slots_ = 0; lin_slots_ = 0;
+  streaming_ = true;
+  n_seq_ = n;
+}
+
+void Engine::stream_subs() {
+  for (auto& e : sub_) {
+    if (e) continue;
+    elemdp_model_desc d = desc_;
+    d.pattern = desc_pattern_.c_str();
+    d.energy_param = desc_has_par_ ? desc_par_.c_str() : nullptr;
+    d.device = device_;
+    e.reset(new Engine(d));
+    for (auto const& kv : opt_log_) e->set_option(kv.first, kv.second);
+  }
+}
+
+void Engine::stream_load_chunk(int k, Engine& e) {
+  const int c0 = k * st_chunk_, c1 = std::min(n_seq_, c0 + st_chunk_);
+  std::vector<int32_t> off(c1 - c0 + 1), qoff(c1 - c0 + 1);
+  for (int t = c0; t <= c1; ++t) { off[t - c0] = h_seq_off_[t] - h_seq_off_[c0]; qoff[t - c0] = h_qual_off_[t] - h_qual_off_[c0]; }
+  const size_t s0 = (size_t)(h_seq_off_[c0] - h_seq_off_[0]), q0 = (size_t)(h_qual_off_[c0] - h_qual_off_[0]);
+  e.load_batch(st_seq_.data() + s0, off.data(), st_qual_.data() + q0, qoff.data(), st_fix_.empty() ? nullptr : st_fix_.data() + s0, c1 - c0);
+}
+
+// work(k, c0, c1, engine): chunk k = sequences [c0, c1) is resident on `engine`; the next chunk loads meanwhile
+template <class Work> void Engine::stream_chunks(Work work) {
+  stream_subs();
+  const int nchunks = (n_seq_ + st_chunk_ - 1) / st_chunk_;
+  stream_load_chunk(0, *sub_[0]);
+  for (int k = 0; k < nchunks; ++k) {
+    Engine& cur = *sub_[k & 1];
+    std::exception_ptr err;
+    std::thread th;
+    if (k + 1 < nchunks)
+      th = std::thread([&, k] {
+        try { stream_load_chunk(k + 1, *sub_[(k + 1) & 1]); } catch (...) { err = std::current_exception(); }
+      });
+    try {
+      work(k, k * st_chunk_, std::min(n_seq_, (k + 1) * st_chunk_), cur);
+    } catch (...) {
+      if (th.joinable()) th.join();
+      throw;
+    }
+    if (th.joinable()) th.join();
+    if (err) std::rethrow_exception(err);
+  }
+}
+
+void Engine::stream_train(const double* x, int n_param_in, void* partial, bool device_ptr, bool reduce) {
+  if (n_param_in != n_param()) throw ArgError("n_param mismatch");
+  set_theta_from(x);
+  const int np = partial_len();
+  std::vector<double> total(np, 0.), part(np);
+  st_rows_.assign((size_t)5 * n_seq_, 0.);
+  last_ms[0] = last_ms[1] = last_ms[2] = 0.;
+  stream_chunks([&](int, int c0, int c1, Engine& e) {
+    e.train_partial(x, n_param_in, part.data(), false, false);
+    for (int t = 0; t < np; ++t) total[t] += part[t];
+    e.seq_stats(st_rows_.data() + (size_t)5 * c0, c1 - c0);
+    for (int t = c0; t < c1; ++t) h_plans_[t].bpp_eff = e.plans()[t - c0].bpp_eff;
+    for (int t = 0; t < 3; ++t) last_ms[t] += e.last_ms[t];
+  });
+  if (comm_ && reduce) {
+    HIP_OK(hipMemcpyAsync(d_partial_.as<void>(), total.data(), sizeof(double) * np, hipMemcpyHostToDevice, st_));
+    RCCL_OK(Rccl::get().AllReduce(d_partial_.as<void>(), d_partial_.as<void>(), (size_t)np, Rccl::kDouble, Rccl::kSum, comm_, st_));
+    HIP_OK(hipMemcpyAsync(total.data(), d_partial_.as<void>(), sizeof(double) * np, hipMemcpyDeviceToHost, st_));
+    HIP_OK(hipStreamSynchronize(st_));
+  }
+  if (device_ptr) HIP_OK(hipMemcpy(partial, total.data(), sizeof(double) * np, hipMemcpyHostToDevice));
+  else std::memcpy(partial, total.data(), sizeof(double) * np);
+}
+
+void Engine::stream_scan(const double* x, int n_param_in, elemdp_scan_out* out) {
+  if (n_param_in != n_param()) throw ArgError("n_param mismatch");
+  if (!out) throw ArgError("scan: null output");
+  const int nt = au_.n_theta();
+  std::vector<double> en(nt, 0.), en_k(nt);
+  last_ms[0] = last_ms[1] = last_ms[2] = 0.;
+  stream_chunks([&](int, int c0, int c1, Engine& e) {
+    (void)c1;
+    const size_t so = (size_t)(h_seq_off_[c0] - h_seq_off_[0]), qo = (size_t)(h_qual_off_[c0] - h_qual_off_[0]);
+    elemdp_scan_out o = *out;   // the chunk's slices of the caller's arrays (batch offsets)
+    if (o.start) o.start += so;
+    if (o.inner) o.inner += so;
+    if (o.end) o.end += qo;
+    if (o.psihat) o.psihat += so;
+    if (o.rss) o.rss += so;
+    if (o.ys) o.ys += c0;
+    if (o.ye) o.ye += c0;
+    if (o.exist_prob) o.exist_prob += c0;
+    o.en = out->en ? en_k.data() : nullptr;
+    e.scan(x, n_param_in, &o);
+    if (out->en) for (int t = 0; t < nt; ++t) en[t] += en_k[t];
+    for (int t = 0; t < 3; ++t) last_ms[t] += e.last_ms[t];
+  });
+  if (out->en) std::copy(en.begin(), en.end(), out->en);
 }
 
 // Sequences swept in lockstep: as many as fit in ~55 % of the free device memory (at most 8192), then balanced so that all
@@ -1085,14 +1325,23 @@ void Engine::run_train(bool) {
   }
 }
 
-void Engine::train_partial(const double* x, int n_param_in, void* partial, bool device_ptr) {
+void Engine::train_partial(const double* x, int n_param_in, void* partial, bool device_ptr, bool reduce) {
   require_device();
   DeviceGuard dg(device_);
-  if (n_seq_ <= 0) throw StateError("train_eval before load_batch");
+  if (streaming_) { stream_train(x, n_param_in, partial, device_ptr, reduce); return; }
+  if (n_seq_ <= 0 && !(comm_ && reduce)) throw StateError("train_eval before load_batch");
   if (n_param_in != n_param()) throw ArgError("n_param mismatch");
   HIP_OK(hipEventRecord(ev_[0], st_));
   upload_params(x, lay_, false);
-  run_train(false);
+  if (n_seq_ > 0) {
+    run_train(false);
+  } else {   // a rank without a share of the batch: zeros into the all-reduce
+    HIP_OK(hipMemsetAsync(d_partial_.as<void>(), 0, sizeof(double) * partial_len(), st_));
+    HIP_OK(hipEventRecord(ev_[1], st_));
+    HIP_OK(hipEventRecord(ev_[2], st_));
+  }
+  if (comm_ && reduce)   // sum over the ranks, in place, on the engine's stream (RCCL over xGMI)
+    RCCL_OK(Rccl::get().AllReduce(d_partial_.as<void>(), d_partial_.as<void>(), (size_t)partial_len(), Rccl::kDouble, Rccl::kSum, comm_, st_));
   HIP_OK(hipMemcpyAsync(partial, d_partial_.as<void>(), sizeof(double) * partial_len(),
                         device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st_));
   HIP_OK(hipEventRecord(ev_[3], st_));
@@ -1139,6 +1388,11 @@ void Engine::seq_stats(double* out, int n) {
   require_device();
   DeviceGuard dg(device_);
   if (n != n_seq_) throw ArgError("seq_stats: n_seq mismatch");
+  if (streaming_) {
+    if ((int)st_rows_.size() != 5 * n) throw StateError("seq_stats before train_eval");
+    std::copy(st_rows_.begin(), st_rows_.end(), out);
+    return;
+  }
   std::vector<double> h((size_t)out_stride_ * n);
   HIP_OK(hipMemcpy(h.data(), d_seq_out_.as<void>(), sizeof(double) * h.size(), hipMemcpyDeviceToHost));
   for (int k = 0; k < n; ++k)
@@ -1149,7 +1403,7 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
                           double* EH) {
   require_device();
   DeviceGuard dg(device_);
-  if (n_seq_ != 1) throw StateError("debug_tables needs a batch of exactly one sequence");
+  if (n_seq_ != 1 || streaming_) throw StateError("debug_tables needs a resident batch of exactly one sequence");
   if (n_slots_ < 1) throw StateError("debug_tables before train_eval");
   const SeqPlan& p = h_plans_[0];
   const int S = au_.S(), L = p.L, W = p.W;
@@ -1206,6 +1460,7 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
 void Engine::batch_pairs(int idx, uint8_t* kept, double* lnbpp, int cap) {
   require_device();
   DeviceGuard dg(device_);
+  if (streaming_) throw StateError("batch_pairs needs a resident batch (the handle streams this one in chunks)");
   if (idx < 0 || idx >= n_seq_) throw ArgError("batch_pairs: bad sequence index");
   const SeqPlan& p = h_plans_[idx];
   const int nc = (p.L + 1) * (p.W + 1);
@@ -1226,6 +1481,7 @@ void Engine::batch_pairs(int idx, uint8_t* kept, double* lnbpp, int cap) {
 void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   require_device();
   DeviceGuard dg(device_);
+  if (streaming_) { stream_scan(x, n_param_in, out); return; }
   if (n_seq_ <= 0) throw StateError("scan before load_batch");
   if (n_param_in != n_param()) throw ArgError("n_param mismatch");
   // (--no-rss: load_batch cleared the pair mask, so every sweep reduces to the exterior chain = the profile-HMM
@@ -1594,8 +1850,30 @@ int elemdp_train_eval(elemdp_handle* h, const double* x, int32_t n_param, double
   ELEMDP_TRY
   if (!h || !x) throw elemdp::ArgError("elemdp_train_eval: null argument");
   std::vector<double> partial(h->e->partial_len());
-  h->e->train_partial(x, n_param, partial.data(), false);
+  h->e->train_partial(x, n_param, partial.data(), false, true);   // (summed over the ranks when a communicator is set)
   h->e->train_finish(partial.data(), fn, gr, sum_eff, n_skipped);
+  ELEMDP_CATCH
+}
+int elemdp_comm_unique_id(void* id_out) {
+  ELEMDP_TRY
+  if (!id_out) throw elemdp::ArgError("elemdp_comm_unique_id: null argument");
+  elemdp::Rccl& r = elemdp::Rccl::get();
+  if (!r.ok()) throw elemdp::HipError("no HIP device available for the collective: librccl.so could not be loaded");
+  elemdp::Rccl::UniqueId uid;
+  RCCL_OK(r.GetUniqueId(&uid));
+  std::memcpy(id_out, &uid, sizeof(uid));
+  ELEMDP_CATCH
+}
+int elemdp_comm_init(elemdp_handle* h, int32_t rank, int32_t world, const void* id) {
+  ELEMDP_TRY
+  if (!h) throw elemdp::ArgError("null handle");
+  h->e->comm_init(rank, world, id);
+  ELEMDP_CATCH
+}
+int elemdp_comm_destroy(elemdp_handle* h) {
+  ELEMDP_TRY
+  if (!h) throw elemdp::ArgError("null handle");
+  h->e->comm_destroy();
   ELEMDP_CATCH
 }
 int elemdp_train_seq_stats(elemdp_handle* h, double* out, int32_t n_seq) {

@@ -569,20 +569,36 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
       const int dmi = dm[c];
       double av = 0.;
       if (dmi > 0 && dmi < d) {          // 1(i,k,.) != 0 needs k - i >= dmin[i], and k < j
-        if (v.q.unp[j - 1]) {
-          const int e0 = I[A.ap_chain_off + p], e1 = I[A.ap_chain_off + p + 1];
-          for (int e = e0; e < e1; ++e) {
-            const int pc2 = I[A.ap_chain_ent + 2 * e], tf = I[A.ap_chain_ent + 2 * e + 1];
-            if (CON && !allow_right(v.m, con, v.q.L, j, t, I[A.ap_t + pc2])) continue;
-            av = fma(v.in.a(d - 1, i, pc2), lw_right(v.m, v.q, t, tf, j - 1), av);
-          }
-        }
         const double* xml = v.q.xwc + (size_t)(lamk(v.m, t) * 5 + XT_ML) * v.q.xwc_stride;
         BitIter it;
         it.init(v.q.okbits_end, j * W1, 1, d - dmi);      // spans of the stems: k = j - sp >= i + dmin[i]
+        // tail step: the (at most kUnary, else looped) predecessors' values are in flight with the first stems
+        const int e0 = I[A.ap_chain_off + p], ne = v.q.unp[j - 1] ? I[A.ap_chain_off + p + 1] - e0 : 0;
+        double pv[kUnary];
+#pragma unroll
+        for (int u = 0; u < kUnary; ++u) pv[u] = v.in.a(d - 1, i, u < ne ? I[A.ap_chain_ent + 2 * (e0 + u)] : p);
+        bool first = true;
         for (;;) {
           const int sp0 = it.next();
-          if (sp0 < 0) break;
+          if (sp0 < 0) {
+            if (!first) break;
+            // (no stem ends here: only the tail step)
+          }
+          if (first) {
+            first = false;
+#pragma unroll
+            for (int u = 0; u < kUnary; ++u)
+              if (u < ne) {
+                const int pc2 = I[A.ap_chain_ent + 2 * (e0 + u)], tf = I[A.ap_chain_ent + 2 * (e0 + u) + 1];
+                if (!CON || allow_right(v.m, con, v.q.L, j, t, I[A.ap_t + pc2])) av = fma(pv[u], lw_right(v.m, v.q, t, tf, j - 1), av);
+              }
+            for (int u = kUnary; u < ne; ++u) {
+              const int pc2 = I[A.ap_chain_ent + 2 * (e0 + u)], tf = I[A.ap_chain_ent + 2 * (e0 + u) + 1];
+              if (CON && !allow_right(v.m, con, v.q.L, j, t, I[A.ap_t + pc2])) continue;
+              av = fma(v.in.a(d - 1, i, pc2), lw_right(v.m, v.q, t, tf, j - 1), av);
+            }
+            if (sp0 < 0) break;
+          }
           const int sp1 = it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
           const int q1 = sp1 < 0 ? sp0 : sp1, q2 = sp2 < 0 ? sp0 : sp2, q3 = sp3 < 0 ? sp0 : sp3;
           const double a0 = B[v.in.idx(ST_1, d - sp0, i, s1)], b0 = B[v.in.idx(ST_P, sp0, j - sp0, t)], c0 = xml[v.q.cell(j - sp0, sp0)];
@@ -911,7 +927,6 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   swizzled_block(bx, by);
   LViews v(a.lay);
   make_lviews(a, by, v);
-  const int16_t* g_dmin = v.q.dmin;   // (the whole array: stage_context redirects v.q.dmin to the window of the workgroup)
   const LPass pi = lpass(a, v);
   const AutomatonLayout& A = a.lay;
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = a.lay.n_theta;
@@ -959,7 +974,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       const int i = i0 + c, j = i + d;
       const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
       const int dmi = dm[c];
-      if (dmi > 0 && dmi <= d && IB[in.idx(ST_1, d, i, s1)] != 0.) {     // left_ok(i, d) and a live child 1(i,j,s1)
+      if (dmi > 0 && dmi <= d) {     // left_ok(i, d)  (a dead child 1(i,j,s1) drops the sum in the unary phase)
         const int hi = (W - d < L - j) ? W - d : L - j;
         const double* xml = v.q.xwc + (size_t)(lamk(v.m, t) * 5 + XT_ML) * v.q.xwc_stride;
         double acc = 0.;
@@ -996,9 +1011,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           const int b = 1 + w / nA, p = w - (b - 1) * nA;
           const int ii = i - b;
           if (ii < 0) continue;
-          const int dmi = g_dmin[ii];
-          if (dmi <= 0 || b < dmi) continue;     // 1(ii, i, .) is 0 (o2_valid)
-          const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
+          const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];   // (1(ii, i, .) is 0 where it is not parsable)
           const double term = out.a(d + b, ii, p) * IB[in.idx(ST_1, b, ii, s1)];
           if (term != 0.) atomicAdd(&h2[c * S + t], term);
         }

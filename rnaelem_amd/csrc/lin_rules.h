@@ -452,19 +452,33 @@ template <int MODE, class Sink> ELEMDP_HD void lin_outside_apair(LinOutCtx<Sink>
   const ModelView& m = x.m; const SeqView& q = x.q;
   const AutomatonLayout& A = m.lay; const int32_t* I = m.ints;
   const int j = i + d;
-  const double a_in = x.in.a(d, i, p);
-  if (a_in == 0.) { x.out.a(d, i, p) = 0.; return; }
   const int t = I[A.ap_t + p], tgt = I[A.ap_tgt + p];
+  const bool step = d + 1 <= q.W && j < q.L && q.unp[j];
+  const int e0 = I[A.ap_rchain_off + p], ne = step ? I[A.ap_rchain_off + p + 1] - e0 : 0;
+  // (the parents' values are fetched together with the inside value: one round trip; lists longer than kUnary follow)
+  const double a_in = x.in.a(d, i, p);
+  double op[kUnary];
+#pragma unroll
+  for (int u = 0; u < kUnary; ++u) op[u] = x.out.a(step ? d + 1 : d, i, u < ne ? I[A.ap_rchain_ent + 2 * (e0 + u)] : p);
   double a = (tgt >= 0 && q.left_ok(i, d)) ? oB_tgt : 0.;
-  if (d + 1 <= q.W && j < q.L && q.unp[j]) {
+  if (a_in != 0.) {
     const double inz = a_in * x.invZ;
-    for (int e = I[A.ap_rchain_off + p]; e < I[A.ap_rchain_off + p + 1]; ++e) {
-      const int pp = I[A.ap_rchain_ent + 2 * e], tf = I[A.ap_rchain_ent + 2 * e + 1];
+    for (int u = 0; u < ne; ++u) {
+      const int pp = I[A.ap_rchain_ent + 2 * (e0 + u)], tf = I[A.ap_rchain_ent + 2 * (e0 + u) + 1];
       const int par = I[A.ap_t + pp];
-      const double term = x.out.a(d + 1, i, pp) * lw_right(m, q, par, tf, j);
+      double o = 0.;
+      if (u < kUnary) {
+#pragma unroll
+        for (int k = 0; k < kUnary; ++k) o = (k == u) ? op[k] : o;     // (a select chain: no dynamic register indexing)
+      } else {
+        o = x.out.a(d + 1, i, pp);
+      }
+      const double term = o * lw_right(m, q, par, tf, j);
       if (!lstat_right<MODE>(x, j, par, t, term * inz)) continue;
       a += term;
     }
+  } else {
+    a = 0.;
   }
   x.out.a(d, i, p) = a;
 }

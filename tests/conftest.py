@@ -16,3 +16,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: let torch initialise its HIP runtime BEFORE libelemdp creates its first stream, as bench.py and the command
+    line do (torch ships its own ROCm libraries; with the order reversed its device query has been seen to come back empty)."""
+    if "not gpu" in (config.getoption("markexpr", "") or ""):
+        return
+    if any(item.get_closest_marker("gpu") for item in items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.zeros(1, device="cuda")
+        except Exception:      # noqa: BLE001  (no torch / no GPU: the gpu tests will say so themselves)
+            pass

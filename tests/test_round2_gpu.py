@@ -249,3 +249,73 @@ def test_full_size_gradient_subsample_against_the_oracle():
     assert fa - fr == pytest.approx(fo, rel=1e-7)
     np.testing.assert_allclose(ga - gr, go, rtol=1e-6, atol=1e-6)     # (differences of sums of 10^4 terms)
     assert ea - er == pytest.approx(eo, rel=1e-9)
+
+
+def test_in_library_collective_with_one_rank():
+    """elemdp_comm_init / elemdp_train_eval with a communicator (RCCL, dlopen'ed): a world of one rank all-reduces in place
+    and returns the single-rank numbers; a rank without a batch contributes zeros (and gets the zeros of its world of one)."""
+    m = io.read_model(gpath("syn_b.model"))
+    recs = io.read_fastq(gpath("syn_L150_n8.fq"))
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    eng = io.engine_from_model(m)
+    eng.load_batch(seqs, quals)
+    ref = eng.train_eval(m["x"])
+    uid = api.Engine.comm_unique_id()
+    assert len(uid) == 128
+    eng.comm_init(0, 1, uid)
+    got = eng.train_eval(m["x"])
+    assert got[0] == pytest.approx(ref[0], rel=1e-12) and got[2:] == ref[2:]
+    np.testing.assert_allclose(got[1], ref[1], rtol=1e-10, atol=1e-12)
+    eng.comm_destroy()
+    again = eng.train_eval(m["x"])
+    assert again[0] == pytest.approx(ref[0], rel=1e-12)
+    empty = io.engine_from_model(m)
+    with pytest.raises(api.ElemdpError):
+        empty.train_eval(m["x"])                  # no batch and no communicator: ELEMDP_ESTATE
+    empty.comm_init(0, 1, api.Engine.comm_unique_id())
+    fn, gr, eff, nsk = empty.train_eval(m["x"])
+    assert fn == 0.0 and eff == 0.0 and nsk == 0 and not np.any(gr)
+
+
+def test_streamed_batch_gives_the_resident_numbers():
+    """option "max_resident": a batch larger than the budget is evaluated / scanned in chunks (BPP filter + plan of the next
+    chunk built on a second inner engine while the current one runs) -- same fn / gr (1e-11), per-sequence statistics,
+    bpp_eff and scan records as the resident path, on a ragged batch with both labels."""
+    m = io.read_model(gpath("syn_b.model"))
+    seqs, quals = [], []
+    for L, n in ((60, 30), (200, 25), (110, 30), (35, 18)):
+        s_, q_ = synth.synth_batch(n, L, seed=500 + L)
+        seqs += s_
+        quals += q_
+    for k in range(0, len(seqs), 7):
+        quals[k][-1] = 5
+    x = m["x"]
+    res = io.engine_from_model(m)
+    res.load_batch(seqs, quals)
+    ref = res.train_eval(x)
+    ref_stats, ref_eff = res.seq_stats(), res.bpp_eff()
+    ref_recs, ref_en = res.scan(x)
+    eng = io.engine_from_model(m)
+    eng.set_option("max_resident", 40)          # 103 sequences -> chunks of 40, 40, 23
+    eng.load_batch(seqs, quals)
+    got = eng.train_eval(x)
+    assert got[0] == pytest.approx(ref[0], rel=1e-11) and got[2] == pytest.approx(ref[2], rel=1e-12) and got[3] == ref[3]
+    np.testing.assert_allclose(got[1], ref[1], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(eng.seq_stats(), ref_stats, rtol=1e-11, atol=1e-12)
+    np.testing.assert_array_equal(eng.bpp_eff(), ref_eff)
+    part = eng.train_partial(x)                  # the partial / finish pair of the multi-GPU path streams, too
+    fin = eng.train_finish(part)
+    assert fin[0] == pytest.approx(ref[0], rel=1e-11)
+    recs, en = eng.scan(x)
+    for a, b in zip(recs, ref_recs):
+        assert (a["Ys"], a["Ye"], a["rss"]) == (b["Ys"], b["Ye"], b["rss"]) and list(a["psihat"]) == list(b["psihat"])
+        assert_log_close(a["start"], b["start"], rtol=1e-10, atol=1e-10, what="start")
+        assert_log_close(a["end"], b["end"], rtol=1e-10, atol=1e-10, what="end")
+        assert a["exist_prob"] == pytest.approx(b["exist_prob"], rel=1e-10)
+    np.testing.assert_allclose(en, ref_en, rtol=1e-10, atol=1e-12)
+    with pytest.raises(api.ElemdpError):
+        eng.pairs(0)                             # needs a resident batch
+    eng.set_option("max_resident", 0)
+    eng.load_batch(seqs, quals)                  # back to resident
+    again = eng.train_eval(x)
+    assert again[0] == pytest.approx(ref[0], rel=1e-12)
