@@ -122,6 +122,7 @@ struct ModelView {
   int32_t lam_same;      // lambda[0] == lambda[1]
   int32_t no_prf;        // --no-profile: theta terms are 0 and no emission counts
   int32_t m_min;         // minimal span of a multiloop cell M: 2*(2+turn)=10, or 4 with NO_TURN
+  int32_t dbg = 0;       // timing experiments only (LinArgs::dbg): 32 skips the rule-7 gather of the outside unary phase
 
   ELEMDP_HD int st_l(int s) const { return ints[lay.st_l + s]; }
   ELEMDP_HD int st_r(int s) const { return ints[lay.st_r + s]; }
@@ -849,7 +850,8 @@ template <class Sink> ELEMDP_HD double heavy_oL(OutCtx<Sink>& x, int d, int i, i
   return a.value();
 }
 
-struct HeavyOut { double H1, H2, HP, HL; };
+// (ext_in_hp: HP already holds the rule-7 term of the P child -- the scaled-linear kernels gather it with the other heavy sums)
+struct HeavyOut { double H1, H2, HP, HL; bool ext_in_hp = false; };
 
 // band target (i,d,s), outside direction, given the heavy sums.  Requires every larger diagonal and the
 // whole exterior chain outside_o to be final.

@@ -133,6 +133,7 @@ __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) 
   v.m.lam_same = pb->lam_same;
   v.m.no_prf = a.no_prf;
   v.m.m_min = a.m_min;
+  v.m.dbg = a.dbg;
   SeqView& q = v.q;
   q.L = p.L; q.W = p.W; q.C = p.C;
   q.seq = a.b.seq + p.seq_base;
@@ -998,15 +999,24 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         if (acc != 0.) atomicAdd(&h1[c * S + s1], acc);
       }
     }
-    // HA: the few stem cells of the workgroup, work item = (stem cell, parent row ii = i - b, pair)
+    // HA: the few stem cells of the workgroup, work item = (stem cell, parent row ii = i - b, pair); and the rule-7 term
+    // of their P states (child of the exterior chain: out O(j,par) * in O(i,s2) * exp(lambda e_ext)), work item = (stem
+    // cell, split entry), added to the HP sums -- one round of loads for both
     int n_stem = 0;
     for (int c = 0; c < nc; ++c) n_stem += v.q.pair_ok(i0 + c, d) ? 1 : 0;
     if (n_stem > 0 && !(a.dbg & 1)) {
       const int nb = W - d;                   // b = 1 .. nb: parent span d + b <= W
       const int per = nb * nA;
+      const int nsp7 = A.n_split;
       for (int c = 0; c < nc; ++c) {
         const int i = i0 + c, j = i + d;
         if (!v.q.pair_ok(i, d)) continue;
+        if (!(a.dbg & 32))
+          for (int u = tid; u < nsp7; u += kThreads) {
+            const int par = G[A.split2_ent + 2 * u], s2i = G[A.split2_ent + 2 * u + 1], tg = G[A.split2_tgt + u];
+            const double term = out.o(j, par) * (in.o(i, s2i) * xw_cell(v.q, lamk(v.m, par), XT_EXT, v.q.cell(i, d)));
+            if (term != 0.) atomicAdd(&hp[c * S + tg], term);
+          }
         for (int w = tid; w < per; w += kThreads) {
           const int b = 1 + w / nA, p = w - (b - 1) * nA;
           const int ii = i - b;
@@ -1119,12 +1129,13 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
     HeavyOut H;
     H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
+    H.ext_in_hp = true;
     h1[c * S + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
   }
   __syncthreads();
   // outside values of the pair entries of the cells (lin_outside_apair): out B of the target + the tail step from
   // (i, d+1), with the statistics of the tail emissions
-  if (!(a.dbg & 1)) {
+  if (!(a.dbg & 1) && !(a.dbg & 128)) {
     const int nA = A.n_ap;
     LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
     for (int w = tid; w < nc * nA; w += kThreads) {
@@ -1549,7 +1560,8 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
         const int ncell = Lmax - d + 1;
         if (ncell <= 0) continue;
         b.d = d;
-        if (big_b) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
+        if (big_b && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);   // (timing experiment: no statistics)
+        else if (big_b) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
       }
   }

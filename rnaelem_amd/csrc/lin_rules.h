@@ -666,7 +666,7 @@ ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, c
   double oP = 0.;
   if (inP != 0.) {
     double a = 0.;
-    if (xex0 != 0. || xex1 != 0.)
+    if ((xex0 != 0. || xex1 != 0.) && !H.ext_in_hp)
       for (int u = G[A.split2_off + s]; u < G[A.split2_off + s + 1]; ++u) {
         const int par = G[A.split2_ent + 2 * u], s2i = G[A.split2_ent + 2 * u + 1];
         a = fma(out.o(j, par), in.o(i, s2i) * (lamk(m, par) ? xex1 : xex0), a);

@@ -7,7 +7,7 @@ eng = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
 seqs, quals = synth.synth_batch(n, L)
 eng.load_batch(seqs, quals)
 x = eng.initial_params(1.0)
-for dbg in (0, 1, 2, 4, 3, 7):
+for dbg in [int(v) for v in sys.argv[3:]] or (0, 1, 2, 4, 3, 7):
     eng.set_option("dbg", dbg)
     try:
         eng.train_eval(x)
