@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libelemdp.so")
-SOURCES = ["kernels.hip", "train_kernels.hip", "lin_kernels.hip", "engine.cpp", "automaton.cpp", "energy_tables.cpp"]
+SOURCES = ["kernels.hip", "train_kernels.hip", "lin_kernels.hip", "bpp_kernels.hip", "engine.cpp", "automaton.cpp", "energy_tables.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable"]

@@ -1,0 +1,363 @@
+// bpp_kernels.hip -- the BPP filter K1 (EnergyModel::set_seq .. fill_bpp_tables .. lnBPP, RNAelem/energy_model.hpp:188-276) in
+// the LINEAR semiring, without a plan of the unfiltered pair mask.
+//
+// The filter is the plain McCaskill partition function (the one-state automaton, lambda = 1, no emissions) followed by
+// ln BPP(i,j) = ln(inside P * outside P / Z) >= ln(min_bpp).  Round 1 ran it in log space over an interior-loop item list of
+// the UNFILTERED canonical mask (~10x the items of the final plan: building that list was more than half of
+// elemdp_load_batch).  Here:
+//   * band tables hold Boltzmann weights (a span is at most W bases, so the values stay far inside the double range
+//     whatever the sequence length); only the two exterior chains, whose values grow with L, are kept as logarithms,
+//     and the outside band values are divided by Z from the start (rule 7 enters as exp(ln O(i) + ln outO(j) - ln Z));
+//   * rule 2 is factorised as in lin_rules.h (A(i,j) = sum_k 1(i,k) 2(k,j) by a recurrence along the row + the stems that
+//     end at j);
+//   * the interior loops of rule 6c are enumerated in place from the pair mask, 16 lanes per cell, loop_energy evaluated on
+//     the fly (the same energy_rules.h functions the plan builder calls) -- each candidate is needed once per direction, so
+//     materialising the list only cost bandwidth.
+// Same sums as k3_bpp_* (train_kernels.hip), which stay for spans beyond the linear range (W > kBppLinMaxSpan).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "plan_rules.h"
+
+namespace elemdp {
+namespace {
+
+constexpr int kLanes = 16;                  // lanes per cell
+constexpr int kCells = kThreads / kLanes;   // cells per workgroup
+enum { BP_P = 0, BP_E, BP_M, BP_B, BP_1, BP_2, BP_A, BP_IN_PLANES };   // inside planes
+enum { BO_P = 0, BO_E, BO_M, BO_2, BO_A, BO_OUT_PLANES };              // outside planes (divided by Z)
+enum { XW_STACK = 0, XW_EXT, XW_ML, XW_CLOSE, XW_HP };
+
+struct Seq {
+  int L, W, C;
+  const uint8_t* seq;
+  const uint32_t* ok;     // canonical pair mask, bit i * (W+1) + d
+  const int16_t* dmin;
+  const double* xw;       // + term * xw_stride + cell
+  size_t xw_stride;
+  double* tin;            // + plane * t_stride + d * (L+1) + i
+  double* tout;
+  size_t t_stride;
+  double* lo_in;          // ln O(j), j = 0 .. L
+  double* lo_out;         // ln outO(j) - ln Z
+  __device__ __forceinline__ bool pair_ok(int i, int d) const {
+    if (i < 0 || d < 0 || d > W || i + d > L) return false;
+    const int c = i * (W + 1) + d;
+    return (ok[c >> 5] >> (c & 31)) & 1u;
+  }
+  __device__ __forceinline__ int cell(int i, int d) const { return i * (W + 1) + d; }
+  __device__ __forceinline__ double x(int term, int c) const { return xw[(size_t)term * xw_stride + c]; }
+  __device__ __forceinline__ double& in(int plane, int d, int i) const { return tin[(size_t)plane * t_stride + (size_t)d * (L + 1) + i]; }
+  __device__ __forceinline__ double& out(int plane, int d, int i) const { return tout[(size_t)plane * t_stride + (size_t)d * (L + 1) + i]; }
+  __device__ __forceinline__ bool left_ok(int i, int d) const {
+    if (d > W || d < 0 || i + d > L) return false;
+    const int dm = dmin[i];
+    return dm > 0 && d >= dm;
+  }
+  __device__ __forceinline__ bool m_ok(int i, int d, int m_min) const { return 0 < i && i + d < L && d <= W && m_min <= d; }
+};
+
+__device__ __forceinline__ Seq make_seq(const BppLinArgs& a, int n) {
+  const SeqPlan p = a.plans[n];
+  Seq q;
+  q.L = p.L; q.W = p.W; q.C = p.C;
+  q.seq = a.seq + p.seq_base;
+  q.ok = a.okbits + p.bits_base;
+  q.dmin = a.dmin + p.dmin_base;
+  q.xw = a.xw + p.cell_base; q.xw_stride = a.xw_stride;
+  q.tin = a.tin + p.cell_base; q.tout = a.tout + p.cell_base; q.t_stride = a.t_stride;
+  q.lo_in = a.lo_in + p.dmin_base; q.lo_out = a.lo_out + p.dmin_base;
+  return q;
+}
+
+__device__ __forceinline__ double group_sum(double v) {   // sum over the kLanes lanes of a cell
+#pragma unroll
+  for (int o = kLanes / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kLanes);
+  return v;
+}
+
+// set bits bit0 + n, n in [lo, hi], of a mask: calls f(n) (ascending)
+template <class F> __device__ __forceinline__ void for_bits(const uint32_t* m, int bit0, int lo, int hi, F f) {
+  if (hi < lo) return;
+  const int b = bit0 + lo, e = bit0 + hi;
+  int w = b >> 5;
+  uint32_t word = m[w] & (~0u << (b & 31));
+  for (;;) {
+    while (word) {
+      const int bit = (w << 5) + __builtin_ctz(word);
+      if (bit > e) return;
+      f(bit - bit0);
+      word &= word - 1;
+    }
+    if (((w + 1) << 5) > e) return;
+    word = m[++w];
+  }
+}
+
+// ---- exp of the structural terms of every canonical pair, and dmin
+__global__ __launch_bounds__(kThreads) void k6_terms(BppLinArgs a) {
+  const SeqPlan p = a.plans[blockIdx.y];
+  const int L = p.L, W = p.W;
+  const int ncell = (L + 1) * (W + 1);
+  if ((int)(blockIdx.x * kThreads) >= ncell) return;
+  const Seq q = make_seq(a, blockIdx.y);
+  if (blockIdx.x == 0) {
+    int16_t* dmin = a.dmin + p.dmin_base;
+    for (int i = threadIdx.x; i <= L; i += kThreads) {
+      int dm = 0;
+      for (int d = 1; d <= W && i + d <= L; ++d)
+        if (q.pair_ok(i, d)) { dm = d; break; }
+      dmin[i] = (int16_t)dm;
+    }
+  }
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= ncell) return;
+  const int i = c / (W + 1), d = c - i * (W + 1);
+  double v[5] = {0., 0., 0., 0., 0.};
+  if (q.pair_ok(i, d)) {
+    const PlanCfg cfg{a.no_ene, a.min_span, 0};
+    const PairTerms t = pair_terms(*a.et, cfg, q.seq, L, nullptr, i, d, q.pair_ok(i + 1, d - 2));
+    const double e[5] = {t.stack, t.ext, t.ml, t.close, t.hp};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = (e[k] == ELEMDP_NEG_INF) ? 0. : exp(e[k]);
+  }
+  double* xw = a.xw + p.cell_base;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) xw[(size_t)k * a.xw_stride + c] = v[k];
+}
+
+// ---- inside, diagonal d: kCells cells per workgroup, kLanes lanes per cell
+__global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
+  const Seq q = make_seq(a, blockIdx.y);
+  const int d = a.d, lane = threadIdx.x % kLanes;
+  if (d > q.W) return;
+  const int i = blockIdx.x * kCells + threadIdx.x / kLanes;
+  if (i > q.L - d) return;
+  const int j = i + d, L = q.L, W = q.W;
+  const bool pok = q.pair_ok(i, d), lok = q.left_ok(i, d), mok = q.m_ok(i, d, a.m_min);
+  const bool eok = i > 0 && d + 2 <= W && q.pair_ok(i - 1, d + 2);
+  const int dmi = q.dmin[i];
+  // rule 2, factorised: the stems (k, j) that end at j and start behind i + dmin[i]
+  double A = 0.;
+  if (dmi > 0 && dmi < d)
+    for (int sp = 1 + lane; sp <= d - dmi; sp += kLanes)
+      if (q.pair_ok(j - sp, sp)) A = fma(q.in(BP_1, d - sp, i), q.in(BP_P, sp, j - sp) * q.x(XW_ML, q.cell(j - sp, sp)), A);
+  A = group_sum(A);
+  // rule 6c, inside set: inner pairs (k, l), i <= k, l <= j, (k-i) + (j-l) <= C, (k,l) != (i,j); lanes take the left ends k
+  double HE = 0.;
+  if (eok) {
+    const EnergyTables& et = *a.et;
+    const int amax = (q.C < d - 2) ? q.C : d - 2;
+    for (int da = lane; da <= amax; da += kLanes) {
+      const int k = i + da;
+      const int lmin = (k + 2 > j - (q.C - da)) ? k + 2 : j - (q.C - da);
+      for_bits(q.ok, k * (W + 1), lmin - k, (j - k < W) ? j - k : W, [&](int sp) {
+        const int l = k + sp;
+        if (da == 0 && l == j) return;
+        const double tsc = a.no_ene ? 0. : loop_energy(et, q.seq, i - 1, j, k, l - 1);
+        if (tsc == ELEMDP_NEG_INF) return;
+        HE = fma(q.in(BP_P, sp, k), exp(tsc), HE);
+      });
+    }
+  }
+  HE = group_sum(HE);
+  if (lane != 0) return;
+  if (dmi > 0 && dmi < d) A += q.in(BP_A, d - 1, i);      // the tail grows by the unpaired base j-1
+  const int c = q.cell(i, d), c_up = eok ? q.cell(i - 1, d + 2) : c;
+  double vP = 0.;
+  if (pok && d >= 2) vP = fma(q.in(BP_P, d - 2, i + 1), q.x(XW_STACK, c), q.in(BP_E, d - 2, i + 1));   // rules 1b, 1a
+  const double vB = lok ? A : 0.;
+  const double s2 = (lok && q.left_ok(i, d - 1)) ? q.in(BP_2, d - 1, i) : 0.;                             // rule 3a
+  const double v2 = lok ? fma(vP, pok ? q.x(XW_ML, c) : 0., s2) : 0.;                                     // rule 3b
+  const double v1 = lok ? v2 + vB : 0.;                                                                   // rules 4a, 4b
+  const double sM = (mok && q.m_ok(i + 1, d - 1, a.m_min)) ? q.in(BP_M, d - 1, i + 1) : 0.;               // rule 5a
+  const double vM = mok ? sM + vB : 0.;                                                                   // rule 5b
+  const double vE = eok ? fma(vM, q.x(XW_CLOSE, c_up), q.x(XW_HP, c_up) + HE) : 0.;                       // rules 6a, 6b (L = 1), 6c
+  q.in(BP_P, d, i) = vP; q.in(BP_E, d, i) = vE; q.in(BP_M, d, i) = vM; q.in(BP_B, d, i) = vB;
+  q.in(BP_1, d, i) = v1; q.in(BP_2, d, i) = v2; q.in(BP_A, d, i) = A;
+  (void)L;
+}
+
+// ---- exterior chains in log space, one wave per sequence: ln O(j) (rules 7, 8) and ln outO(i) - ln Z
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o, 64); v = (w > v) ? w : v; }
+  return v;
+}
+__device__ __forceinline__ double wave_add(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_lse(double t) {   // log sum exp over the lanes (t = -inf: no term)
+  const double m = wave_max(t);
+  if (m == ELEMDP_NEG_INF) return m;
+  const double s = wave_add(t == ELEMDP_NEG_INF ? 0. : exp(t - m));
+  return m + log(s);
+}
+__global__ __launch_bounds__(64) void k6_in_ext(BppLinArgs a) {
+  const Seq q = make_seq(a, blockIdx.x);
+  const int lane = threadIdx.x, L = q.L, W = q.W;
+  if (lane == 0) q.lo_in[0] = 0.;
+  __syncthreads();
+  for (int j = 1; j <= L; ++j) {
+    double t = (lane == 0) ? q.lo_in[j - 1] : ELEMDP_NEG_INF;    // rule 8
+    for (int sp = 1 + lane; sp <= W && sp <= j; sp += 64) {      // rule 7: pairs (j - sp, j)
+      const int i = j - sp;
+      if (!q.pair_ok(i, sp)) continue;
+      const double w = q.in(BP_P, sp, i) * q.x(XW_EXT, q.cell(i, sp));
+      if (w > 0.) {
+        const double u = q.lo_in[i] + log(w);
+        t = (t == ELEMDP_NEG_INF) ? u : (t > u ? t + log1p(exp(u - t)) : u + log1p(exp(t - u)));
+      }
+    }
+    const double r = wave_lse(t);
+    if (lane == 0) q.lo_in[j] = r;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(64) void k6_out_ext(BppLinArgs a) {
+  const Seq q = make_seq(a, blockIdx.x);
+  const int lane = threadIdx.x, L = q.L, W = q.W;
+  const double lz = q.lo_in[L];
+  if (lane == 0) q.lo_out[L] = -lz;          // terminal O(L): outside 1, divided by Z
+  __syncthreads();
+  for (int i = L - 1; i >= 0; --i) {
+    double t = (lane == 0) ? q.lo_out[i + 1] : ELEMDP_NEG_INF;
+    for (int sp = 1 + lane; sp <= W && i + sp <= L; sp += 64) {
+      if (!q.pair_ok(i, sp)) continue;
+      const double w = q.in(BP_P, sp, i) * q.x(XW_EXT, q.cell(i, sp));
+      if (w > 0.) {
+        const double u = q.lo_out[i + sp] + log(w);
+        t = (t == ELEMDP_NEG_INF) ? u : (t > u ? t + log1p(exp(u - t)) : u + log1p(exp(t - u)));
+      }
+    }
+    const double r = wave_lse(t);
+    if (lane == 0) q.lo_out[i] = r;
+    __syncthreads();
+  }
+}
+
+// ---- outside, diagonal d (values divided by Z)
+__global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
+  const Seq q = make_seq(a, blockIdx.y);
+  const int d = a.d, lane = threadIdx.x % kLanes;
+  if (d > q.W) return;
+  const int i = blockIdx.x * kCells + threadIdx.x / kLanes;
+  if (i > q.L - d) return;
+  const int j = i + d, L = q.L, W = q.W;
+  const bool pok = q.pair_ok(i, d), lok = q.left_ok(i, d), mok = q.m_ok(i, d, a.m_min);
+  const bool up_ok = i > 0 && d + 2 <= W && q.pair_ok(i - 1, d + 2);
+  const double inP = q.in(BP_P, d, i), inA = q.in(BP_A, d, i), in1 = q.in(BP_1, d, i);
+  // H1: 1(i,j) under B(i,l) through a stem (j, l) that starts at j
+  double H1 = 0.;
+  if (lok && in1 != 0.) {
+    const int hi = (W - d < L - j) ? W - d : L - j;
+    for (int sp = 1 + lane; sp <= hi; sp += kLanes)
+      if (q.pair_ok(j, sp)) H1 = fma(q.out(BO_A, d + sp, i), q.in(BP_P, sp, j) * q.x(XW_ML, q.cell(j, sp)), H1);
+  }
+  H1 = group_sum(H1);
+  // HA: what reaches 2(i,j) through rule 2 (taken by the stem P(i,j) only), and HP: the interior loops around the stem
+  double HA = 0., HP = 0.;
+  if (pok && inP != 0.) {
+    const int bmax = (W - d < i) ? W - d : i;
+    for (int b = 1 + lane; b <= bmax; b += kLanes) HA = fma(q.out(BO_A, d + b, i - b), q.in(BP_1, b, i - b), HA);
+    const EnergyTables& et = *a.et;
+    const int amax = (q.C < i - 1) ? q.C : i - 1;      // outside set: k - i' <= C; closing pair starts at i' - 1 >= 0
+    for (int da = lane; da <= amax; da += kLanes) {
+      const int io = i - da;                            // outer E cell (io, jo), closing pair cell (io - 1, jo - io + 2)
+      const int hi = (W < L - io + 1) ? W : L - io + 1;
+      for_bits(q.ok, (io - 1) * (W + 1), j - io + 2, hi, [&](int spc) {
+        const int jo = io + spc - 2;
+        if (da == 0 && jo == j) return;
+        const double tsc = a.no_ene ? 0. : loop_energy(et, q.seq, io - 1, jo, i, j - 1);
+        if (tsc == ELEMDP_NEG_INF) return;
+        HP = fma(q.out(BO_E, jo - io, io), exp(tsc), HP);
+      });
+    }
+  }
+  HA = group_sum(HA);
+  HP = group_sum(HP);
+  if (lane != 0) return;
+  const double inE = q.in(BP_E, d, i), inM = q.in(BP_M, d, i), inB = q.in(BP_B, d, i), in2 = q.in(BP_2, d, i);
+  const int c = q.cell(i, d), c_up = up_ok ? q.cell(i - 1, d + 2) : c;
+  const double opP = up_ok ? q.out(BO_P, d + 2, i - 1) : 0.;
+  const double oE = (up_ok && inE != 0.) ? opP : 0.;                                                        // rule 1a
+  const double oP1b = (up_ok && pok && inP != 0.) ? opP * q.x(XW_STACK, c_up) : 0.;                          // rule 1b
+  const bool doM = mok && q.m_ok(i - 1, d + 1, a.m_min);
+  const double sM = (doM && inM != 0.) ? q.out(BO_M, d + 1, i - 1) : 0.;                                     // rule 5a
+  const double oM = (inM != 0.) ? fma(oE, up_ok ? q.x(XW_CLOSE, c_up) : 0., sM) : 0.;                        // rule 6a
+  const double o1 = (in1 != 0.) ? H1 : 0.;
+  const double oB = (inB != 0.) ? (mok ? oM : 0.) + o1 : 0.;                                                 // rules 5b, 4b
+  const bool do2 = lok && q.left_ok(i, d + 1) && j < L;
+  const double s2 = (do2 && in2 != 0.) ? q.out(BO_2, d + 1, i) : 0.;                                         // rule 3a
+  const double o2 = (in2 != 0.) ? o1 + s2 : 0.;                                                              // rule 4a (direct part)
+  double oP = 0.;
+  if (inP != 0.) {
+    const double xe = pok ? q.x(XW_EXT, c) : 0.;
+    const double r7 = (xe != 0.) ? exp(q.lo_in[i] + q.lo_out[j]) * xe : 0.;                                  // rule 7 (lo_out holds - ln Z)
+    oP = r7 + oP1b + (o2 + HA) * (pok ? q.x(XW_ML, c) : 0.) + HP;                                            // rules 3b, 6c
+  }
+  double oA = 0.;
+  if (inA != 0.) oA = (lok ? oB : 0.) + ((d + 1 <= W && j < L) ? q.out(BO_A, d + 1, i) : 0.);
+  q.out(BO_P, d, i) = oP; q.out(BO_E, d, i) = oE; q.out(BO_M, d, i) = oM; q.out(BO_2, d, i) = o2; q.out(BO_A, d, i) = oA;
+}
+
+// ---- ln BPP >= ln min_bpp: the filtered mask, the number of kept pairs, optionally ln BPP of every candidate
+__global__ __launch_bounds__(kThreads) void k6_threshold(BppLinArgs a) {
+  __shared__ int cnt[kThreads / 64];
+  const SeqPlan p = a.plans[blockIdx.x];
+  const Seq q = make_seq(a, blockIdx.x);
+  const int L = p.L, W = p.W;
+  const int ncell = (L + 1) * (W + 1), nword = (ncell + 31) / 32;
+  int kept = 0;
+  for (int wd = threadIdx.x; wd < nword; wd += kThreads) {
+    const uint32_t in_bits = q.ok[wd];
+    uint32_t out_bits = 0;
+    for (int k = 0; k < 32; ++k) {
+      if (!((in_bits >> k) & 1u)) continue;
+      const int cc = wd * 32 + k;
+      const int i = cc / (W + 1), d = cc - i * (W + 1);
+      const double pr = q.in(BP_P, d, i) * q.out(BO_P, d, i);     // (the outside value is already divided by Z)
+      const double ln = (pr > 0.) ? log(pr) : ELEMDP_NEG_INF;
+      if (a.lnbpp) a.lnbpp[p.cell_base + cc] = ln;
+      if (a.log_min_bpp <= ln) { out_bits |= 1u << k; ++kept; }
+    }
+    a.okbits_out[p.bits_base + wd] = out_bits;
+  }
+  for (int off = 32; off > 0; off >>= 1) kept += __shfl_down(kept, off, 64);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = kept;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int w = 0; w < kThreads / 64; ++w) tot += cnt[w];
+    a.kept[blockIdx.x] = tot;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hipStream_t st) {
+  if (G <= 0) return hipSuccess;
+  BppLinArgs a = base;
+  const int ncell_max = (Lmax + 1) * (Wmax + 1);
+  hipLaunchKernelGGL(k6_terms, dim3((ncell_max + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+  for (int d = 0; d <= Wmax; ++d) {
+    const int ncell = Lmax - d + 1;
+    if (ncell <= 0) break;
+    a.d = d;
+    hipLaunchKernelGGL(k6_in, dim3((ncell + kCells - 1) / kCells, G), dim3(kThreads), 0, st, a);
+  }
+  hipLaunchKernelGGL(k6_in_ext, dim3(G), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(k6_out_ext, dim3(G), dim3(64), 0, st, a);
+  for (int d = Wmax; d >= 0; --d) {
+    const int ncell = Lmax - d + 1;
+    if (ncell <= 0) continue;
+    a.d = d;
+    hipLaunchKernelGGL(k6_out, dim3((ncell + kCells - 1) / kCells, G), dim3(kThreads), 0, st, a);
+  }
+  hipLaunchKernelGGL(k6_threshold, dim3(G), dim3(kThreads), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace elemdp

@@ -126,11 +126,14 @@ class DevBuf {
   DevBuf& operator=(const DevBuf&) = delete;
   // (an allocation that is large enough and at most twice too large is kept: fresh device memory costs ~20 ms / GB, and
   // the plan sets of a load are rebuilt chunk after chunk with similar sizes; bytes() is the capacity)
-  void alloc(size_t bytes) {
+  // slack: allocate an eighth more than asked for -- buffers whose size depends on the data (interior-loop items of a batch):
+  // the next batch of the same shape then fits without a re-allocation
+  // (such a buffer is also never given up for a smaller one: the last chunk of a load is smaller than the others)
+  void alloc(size_t bytes, bool slack = false) {
     bytes = bytes ? bytes : 8;
-    if (p_ && bytes <= bytes_ && bytes_ <= 2 * bytes + (size_t(1) << 20)) return;
+    if (p_ && bytes <= bytes_ && (slack || bytes_ <= 2 * bytes + (size_t(1) << 20))) return;
     reset();
-    bytes_ = bytes;
+    bytes_ = slack ? bytes + bytes / 8 : bytes;
     HIP_OK(hipMalloc(&p_, bytes_));
   }
   void reset() { if (p_) { (void)hipFree(p_); p_ = nullptr; bytes_ = 0; } }
@@ -332,6 +335,8 @@ class Engine {
   DevBuf d_bpp_band_in_, d_bpp_band_out_, d_bpp_ext_in_, d_bpp_ext_out_, d_bpp_tmp_;   // S = 1 tables of the BPP filter
   PlanSet bpp_plan_;   // plan over the unfiltered mask, chunk by chunk (only the filter reads it)
   DevBuf d_bpp_order_, d_bpp_rows_, d_bpp_kept_, d_okbits_end_, d_nitems_, d_plans_all_;   // scratch kept across loads
+  DevBuf d_bpp_plans_, d_bpp_xw_, d_bpp_dmin_;   // linear-semiring filter (bpp_kernels.hip)
+  bool opt_bpp_log_ = false;                      // option "bpp_log": the log-space filter over the unfiltered plan
  public:
   std::vector<long long> last_prof;
  private:
@@ -488,6 +493,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "group") opt_group_ = (int)v;
   else if (key == "schedule") opt_schedule_ = (int)v;
   else if (key == "dbg") opt_dbg_ = (int)v;
+  else if (key == "bpp_log") opt_bpp_log_ = v != 0;
   else if (key == "prune") {
     opt_prune_ = v != 0;
     flatten_automaton();
@@ -583,9 +589,10 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   DevBuf& d_okbits_end = d_okbits_end_;   // the pair mask by (end, span): scratch of the item enumeration (kept across loads)
   d_okbits_end.alloc(sizeof(uint32_t) * (size_t)bits_end);
   ps.d_plans.upload(ps.h, st_);
-  ps.dmin.alloc(sizeof(int16_t) * dmin_b);
-  for (DevBuf* b : {&ps.e_stack, &ps.e_ext, &ps.e_ml, &ps.e_close, &ps.e_hp}) b->alloc(sizeof(double) * cell_b);
-  for (DevBuf* b : {&ps.off_outer, &ps.off_inner, &ps.off_left, &ps.off_right, &ps.cursor}) b->alloc(sizeof(int32_t) * off_b);
+  const bool chunked = ps.inner_only;   // the plan of the unfiltered mask is rebuilt chunk after chunk: its buffers only grow
+  ps.dmin.alloc(sizeof(int16_t) * dmin_b, chunked);
+  for (DevBuf* b : {&ps.e_stack, &ps.e_ext, &ps.e_ml, &ps.e_close, &ps.e_hp}) b->alloc(sizeof(double) * cell_b, chunked);
+  for (DevBuf* b : {&ps.off_outer, &ps.off_inner, &ps.off_left, &ps.off_right, &ps.cursor}) b->alloc(sizeof(int32_t) * off_b, chunked);
   DevBuf& d_nitems = d_nitems_;
   d_nitems.alloc(sizeof(int32_t) * count);
   PlanKernelArgs a;
@@ -617,10 +624,10 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   ps.n_items = ib;
   if (getenv("ELEMDP_PLAN_DEBUG")) fprintf(stderr, "planset: %d sequences, %lld items, largest %d, cells %lld\n", count, (long long)ib, a.nitems_max, (long long)ncell_max);
   ps.d_plans.upload(ps.h, st_);
-  ps.items.alloc(sizeof(LoopItem) * ib);
-  ps.item_in.alloc(ib);
-  for (DevBuf* b : {&ps.idx_inner, &ps.idx_left, &ps.idx_right}) b->alloc(sizeof(int32_t) * ib);
-  if (ps.permuted) for (DevBuf* b : {&ps.items_inner, &ps.items_left, &ps.items_right}) b->alloc(sizeof(LoopItem) * (ib + 1));
+  ps.items.alloc(sizeof(LoopItem) * ib, true);
+  ps.item_in.alloc(ib, true);
+  for (DevBuf* b : {&ps.idx_inner, &ps.idx_left, &ps.idx_right}) b->alloc(sizeof(int32_t) * ib, true);
+  if (ps.permuted) for (DevBuf* b : {&ps.items_inner, &ps.items_left, &ps.items_right}) b->alloc(sizeof(LoopItem) * (ib + 1), true);
   a.plans = ps.d_plans.as<SeqPlan>();
   a.p = ps.arrays();
   HIP_OK(launch_plan_items(a, st_));
@@ -758,6 +765,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
       if (!open.empty()) throw ArgError("bad rss: unbalanced");
     }
   }
+  dbg_lap("load: host arrays");
   h_order_.resize(n);
   std::iota(h_order_.begin(), h_order_.end(), 0);
   std::stable_sort(h_order_.begin(), h_order_.end(), [&](int a, int b) { return h_plans_[a].L > h_plans_[b].L; });
@@ -789,6 +797,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   HIP_OK(hipMemcpyAsync(ncanon.data(), d_ncanon_.as<void>(), sizeof(int32_t) * n, hipMemcpyDeviceToHost, st_));
   HIP_OK(hipStreamSynchronize(st_));
   for (int k = 0; k < n; ++k) h_plans_[k].n_canonical = ncanon[k];
+  dbg_lap("load: uploads + canonical mask");
   h_lnbpp_.clear();
   h_lnbpp_base_.clear();
 
@@ -807,9 +816,70 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
       h_plans_[k].bpp_eff = (double)nbp / (double)ncanon[k];
     }
   } else if (min_bpp_ > 0) {
-    // ---- K1: BPP filter, in chunks (the plan of the unfiltered mask is large and only needed here)
     final_bits = d_okbits1_.as<uint32_t>();
     if (opt_keep_lnbpp_) h_lnbpp_base_.assign(n + 1, 0);
+    if (Wmax_ <= kBppLinMaxSpan && !opt_bpp_log_) {
+      // ---- K1: BPP filter in the linear semiring (bpp_kernels.hip): no plan of the unfiltered mask; chunks by table memory
+      const int64_t cells_cap = 64LL * 1000 * 1000;     // 17 doubles per cell: ~9 GB per chunk
+      int first = 0;
+      while (first < n) {
+        int count = 0;
+        int64_t cells = 0, pos = 0;
+        int lmax = 0, wmax = 0;
+        std::vector<SeqPlan> hp;
+        while (first + count < n) {
+          SeqPlan p = h_plans_[first + count];
+          const int64_t nc = (int64_t)(p.L + 1) * (p.W + 1);
+          if (count > 0 && cells + nc > cells_cap) break;
+          p.cell_base = cells; p.dmin_base = pos;
+          cells += nc; pos += p.L + 1;
+          lmax = std::max(lmax, (int)p.L); wmax = std::max(wmax, (int)p.W);
+          hp.push_back(p);
+          ++count;
+        }
+        d_bpp_plans_.upload(hp, st_);
+        d_bpp_xw_.alloc(sizeof(double) * 5 * (size_t)cells, true);
+        d_bpp_band_in_.alloc(sizeof(double) * 7 * (size_t)cells, true);
+        d_bpp_band_out_.alloc(sizeof(double) * 5 * (size_t)cells, true);
+        d_bpp_ext_in_.alloc(sizeof(double) * (size_t)pos, true);
+        d_bpp_ext_out_.alloc(sizeof(double) * (size_t)pos, true);
+        d_bpp_dmin_.alloc(sizeof(int16_t) * (size_t)pos, true);
+        d_bpp_kept_.alloc(sizeof(int32_t) * count, true);
+        DevBuf d_lnbpp;
+        BppLinArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.et = d_et_.as<EnergyTables>();
+        a.plans = d_bpp_plans_.as<SeqPlan>();
+        a.seq = d_seq_.as<uint8_t>();
+        a.okbits = d_okbits0_.as<uint32_t>();
+        a.dmin = d_bpp_dmin_.as<int16_t>();
+        a.xw = d_bpp_xw_.as<double>(); a.xw_stride = (size_t)cells;
+        a.tin = d_bpp_band_in_.as<double>(); a.tout = d_bpp_band_out_.as<double>(); a.t_stride = (size_t)cells;
+        a.lo_in = d_bpp_ext_in_.as<double>(); a.lo_out = d_bpp_ext_out_.as<double>();
+        a.no_ene = (flags_ & ELEMDP_NO_ENERGY) ? 1 : 0;
+        a.min_span = min_span;
+        a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
+        a.okbits_out = d_okbits1_.as<uint32_t>();
+        a.kept = d_bpp_kept_.as<int32_t>();
+        a.log_min_bpp = std::log(min_bpp_);
+        if (opt_keep_lnbpp_) { d_lnbpp.alloc(sizeof(double) * cells); a.lnbpp = d_lnbpp.as<double>(); }
+        HIP_OK(launch_bpp_lin(a, count, lmax, wmax, st_));
+        std::vector<int32_t> kept(count);
+        HIP_OK(hipMemcpyAsync(kept.data(), d_bpp_kept_.as<void>(), sizeof(int32_t) * count, hipMemcpyDeviceToHost, st_));
+        HIP_OK(hipStreamSynchronize(st_));
+        for (int k = 0; k < count; ++k) h_plans_[first + k].bpp_eff = (double)kept[k] / (double)ncanon[first + k];
+        dbg_lap("load: BPP filter, linear (chunk)");
+        if (opt_keep_lnbpp_) {
+          const size_t base = h_lnbpp_.size();
+          h_lnbpp_.resize(base + cells);
+          HIP_OK(hipMemcpy(h_lnbpp_.data() + base, d_lnbpp.as<void>(), sizeof(double) * cells, hipMemcpyDeviceToHost));
+          for (int k = 0; k < count; ++k) h_lnbpp_base_[first + k] = (int64_t)base + hp[k].cell_base;
+        }
+        first += count;
+      }
+    } else {
+    // ---- K1 in log space over a plan of the unfiltered mask (bands wider than the linear range; option "bpp_log")
+    // ---- K1: BPP filter, in chunks (the plan of the unfiltered mask is large and only needed here)
     int64_t cells_cap = 24LL * 1000 * 1000;
     int first = 0;
     PlanSet& tmp = bpp_plan_;   // (one set of buffers for all chunks and loads: DevBuf::alloc keeps what is large enough;
@@ -822,15 +892,16 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         ++count;
       }
       build_planset(tmp, first, count, d_okbits0_.as<uint32_t>());
+      dbg_lap("load: plan of the unfiltered mask (chunk)");
       // table slots for S = 1, one per sequence of the chunk: buffers of their own, so that the (much larger) slots of the
       // evaluation pipelines survive a load_batch -- the mini-batch training mode loads before every evaluation
       {
         const size_t band1 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext1 = (size_t)(Lmax_ + 1);
-        d_bpp_band_in_.alloc(band1 * count * sizeof(double));
-        d_bpp_band_out_.alloc(band1 * count * sizeof(double));
-        d_bpp_ext_in_.alloc(ext1 * count * sizeof(double));
-        d_bpp_ext_out_.alloc(ext1 * count * sizeof(double));
-        d_bpp_tmp_.alloc(ext1 * 3 * count * sizeof(double));
+        d_bpp_band_in_.alloc(band1 * count * sizeof(double), true);
+        d_bpp_band_out_.alloc(band1 * count * sizeof(double), true);
+        d_bpp_ext_in_.alloc(ext1 * count * sizeof(double), true);
+        d_bpp_ext_out_.alloc(ext1 * count * sizeof(double), true);
+        d_bpp_tmp_.alloc(ext1 * 3 * count * sizeof(double), true);
       }
       std::vector<int32_t> order(count);
       std::iota(order.begin(), order.end(), 0);
@@ -876,6 +947,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
       HIP_OK(hipMemcpyAsync(kept.data(), d_kept.as<void>(), sizeof(int32_t) * count, hipMemcpyDeviceToHost, st_));
       HIP_OK(hipStreamSynchronize(st_));
       for (int k = 0; k < count; ++k) h_plans_[first + k].bpp_eff = (double)kept[k] / (double)ncanon[first + k];
+      dbg_lap("load: BPP filter (chunk)");
       if (opt_keep_lnbpp_) {
         const size_t base = h_lnbpp_.size();
         h_lnbpp_.resize(base + cells);
@@ -883,6 +955,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         for (int k = 0; k < count; ++k) h_lnbpp_base_[first + k] = (int64_t)base + tmp.h[k].cell_base;
       }
       first += count;
+    }
     }
   } else {
     for (auto& p : h_plans_) p.bpp_eff = 1.;  // 0 == min_BPP: nbp = total (energy_model.hpp:249-251)
@@ -892,6 +965,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
     HIP_OK(hipMemcpyAsync(d_okbits1_.as<void>(), d_okbits0_.as<void>(), sizeof(uint32_t) * bits_b, hipMemcpyDeviceToDevice, st_));
   plan_.permuted = true;
   build_planset(plan_, 0, n, d_okbits1_.as<uint32_t>());
+  dbg_lap("load: plan of the filtered mask");
   for (int k = 0; k < n; ++k) { plan_.h[k].bpp_eff = h_plans_[k].bpp_eff; plan_.h[k].n_canonical = h_plans_[k].n_canonical; }
   plan_.d_plans.upload(plan_.h, st_);
   for (int k = 0; k < n; ++k) h_plans_[k] = plan_.h[k];
@@ -905,13 +979,14 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   n_cells_total_ = 0;
   for (auto const& pl : h_plans_) n_cells_total_ += (int64_t)(pl.L + 1) * (pl.W + 1);
   d_xwc_.alloc(sizeof(double) * 10 * (size_t)n_cells_total_);
-  d_xwi_.alloc(sizeof(double) * (8 * (size_t)plan_.n_items + 1));   // 4 orders x 2 lambda classes
+  d_xwi_.alloc(sizeof(double) * (8 * (size_t)plan_.n_items + 1), true);   // 4 orders x 2 lambda classes
   d_flagged_.alloc(sizeof(int32_t) * ((size_t)n + 1));
   lin_slots_ = 0;
   out_stride_ = 6 + 2 * au_.n_theta() + 4;
   d_seq_out_.alloc(sizeof(double) * (size_t)out_stride_ * n);
   n_slots_ = 0;
   HIP_OK(hipStreamSynchronize(st_));
+  dbg_lap("load: weights / output buffers");
   n_seq_ = n;   // committed: everything above succeeded
 }
 

@@ -117,6 +117,25 @@ struct BppOut {
   double* lnbpp;          // optional ln BPP per cell (cell_base indexing) or null
   double log_min_bpp;
 };
+// arguments of the linear-semiring BPP filter (bpp_kernels.hip): a chunk of sequences, `plans` = their records with
+// cell_base / dmin_base counted from the start of the chunk (seq_base, bits_base: batch level)
+constexpr int kBppLinMaxSpan = 256;   // widest band whose Boltzmann weights stay inside the double range
+struct BppLinArgs {
+  const EnergyTables* et;
+  const SeqPlan* plans;
+  const uint8_t* seq;
+  const uint32_t* okbits;          // canonical pair mask
+  int16_t* dmin;                   // [dmin_base + i]: smallest canonical span starting at i (0: none)
+  double* xw; size_t xw_stride;    // exp of the five structural terms [term][cell_base + i * (W+1) + d]
+  double* tin; double* tout; size_t t_stride;   // band tables [plane][cell_base + d * (L+1) + i]: 7 inside / 5 outside planes
+  double* lo_in; double* lo_out;   // exterior chains as logarithms [dmin_base + j]
+  int32_t no_ene, min_span, m_min, d;
+  uint32_t* okbits_out;            // filtered mask (bits_base indexing)
+  int32_t* kept;                   // kept pairs per sequence of the chunk
+  double* lnbpp;                   // optional ln BPP per candidate [cell_base + i * (W+1) + d], or null
+  double log_min_bpp;
+};
+hipError_t launch_bpp_lin(const BppLinArgs& a, int G, int Lmax, int Wmax, hipStream_t st);
 // arguments of the scaled-linear train pipeline (lin_kernels.hip, rules in lin_rules.h)
 struct LinArgs {
   AutomatonLayout lay;            // automaton swept by this launch: the full one, or the compact one-state one (S = 1)

@@ -319,3 +319,34 @@ def test_streamed_batch_gives_the_resident_numbers():
     eng.load_batch(seqs, quals)                  # back to resident
     again = eng.train_eval(x)
     assert again[0] == pytest.approx(ref[0], rel=1e-12)
+
+
+def test_linear_bpp_filter_equals_the_log_space_filter_and_the_oracle():
+    """K1 in the linear semiring without a plan of the unfiltered mask (bpp_kernels.hip, the default) against the log-space
+    filter over the item list (option "bpp_log") on a ragged batch: identical kept sets, ln BPP to 1e-9; and against the
+    oracle on a sequence long enough (L = 1500) that only the logarithmic exterior chains keep Z in range."""
+    seqs, quals = [], []
+    for L, n in ((40, 6), (300, 12), (97, 9), (7, 3), (160, 10)):
+        s_, q_ = synth.synth_batch(n, L, seed=900 + L)
+        seqs += s_
+        quals += q_
+    res = {}
+    for mode in (0, 1):
+        eng = api.Engine("(.)", "~T2004~", 50, 30, 1e-4)
+        eng.set_option("bpp_log", mode)
+        eng.set_option("keep_lnbpp", 1)
+        eng.load_batch(seqs, quals)
+        res[mode] = ([eng.pairs(k, with_lnbpp=True) for k in range(len(seqs))], eng.bpp_eff())
+    for (ka, la), (kb, lb) in zip(res[0][0], res[1][0]):
+        assert np.array_equal(ka, kb)
+        assert_log_close(la, lb, rtol=1e-9, atol=1e-9, what="lnbpp")
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    (long_seq,), (long_q,) = synth.synth_batch(1, 1500, seed=31)
+    eng = api.Engine("(.)", "~T2004~", 50, 30, 1e-4)
+    eng.set_option("keep_lnbpp", 1)
+    eng.load_batch([long_seq], [long_q])
+    o = po.make_oracle("(.)", 50, 30, min_bpp=1e-4)
+    ln_o, kept_o, eff_o, lnz_o = o.bpp(long_seq)
+    kept, ln = eng.pairs(0, with_lnbpp=True)
+    assert np.array_equal(kept, kept_o) and eng.bpp_eff()[0] == eff_o
+    assert_log_close(ln, ln_o, rtol=1e-9, atol=1e-9, what="lnbpp, L = 1500")
