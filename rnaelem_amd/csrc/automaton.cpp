@@ -304,8 +304,9 @@ Automaton::Liveness Automaton::liveness() const {
   return lv;
 }
 
-void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0, bool prune) const {
+void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0, bool prune, bool shadow) const {
   const int S_ = S(), m = M();
+  const int ST = S_ + (shadow ? 1 : 0);   // states of the flattened automaton (the shadow of (0,0) is the last one)
   Liveness lv;
   if (prune) lv = liveness();
   const auto& I = lv.inside_live;
@@ -341,9 +342,10 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
 
   AutomatonLayout& A = *lay;
   ints->clear();
-  A.S = S_;
-  A.n_active = only_state0 ? 1 : S_;
-  A.n_front = only_state0 ? 1 : n_front;
+  A.S = ST;
+  A.n_active = only_state0 ? 1 : ST;
+  A.n_front = only_state0 ? 1 : (shadow ? ST : n_front);
+  A.shadow = shadow ? S_ : -1;
   A.M = m;
   A.n_theta = n_theta();
   A.n_rows = n_rows();
@@ -353,6 +355,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   auto per_state = [&](auto fn) {
     int32_t pos = (int32_t)ints->size();
     for (int k = 0; k < S_; ++k) ints->push_back(fn(states_[ref_of[k]]));
+    if (shadow) ints->push_back(fn(states_[0]));
     return pos;
   };
   A.st_l = per_state([&](const IntervalState& s) { return s.l; });
@@ -373,7 +376,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   auto tau_left = [&](int par, int ch) { return (int)(states_[par].l == states_[ch].l && node_[states_[par].l] == '.'); };
   auto tau_pair = [&](int par, int ch) { return (int)(states_[par].r == states_[ch].r && node_[states_[ch].r] == ')'); };
 
-  Csr right(S_, 2), left(S_, 2), pair(S_, 2), rright(S_, 2), rleft(S_, 2), rpair(S_, 2);
+  Csr right(ST, 2), left(ST, 2), pair(ST, 2), rright(ST, 2), rleft(ST, 2), rpair(ST, 2);
   auto keep = [&](std::initializer_list<int> ids) {
     if (!only_state0) return true;
     for (int v : ids) if (v != 0) return false;
@@ -392,7 +395,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     for (int c : left_[s]) if (keep({s, c}) && live_left(s, c)) rleft.add(id_of[c], {id_of[s], tau_left(s, c)});
     for (int c : pair_[s]) if (keep({s, c}) && live_pair(s, c)) rpair.add(id_of[c], {id_of[s], tau_pair(s, c)});
   }
-  Csr split(S_, 2), split1(S_, 2), split2(S_, 2);
+  Csr split(ST, 2), split1(ST, 2), split2(ST, 2);
   for (int s = 0; s < S_; ++s)
     for (auto const& p : splits(s)) {
       if (!keep({s, p[0], p[1]}) || !live_split(s, p[0], p[1])) continue;
@@ -400,7 +403,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
       split1.add(id_of[p[0]], {id_of[s], id_of[p[1]]});
       split2.add(id_of[p[1]], {id_of[s], id_of[p[0]]});
     }
-  Csr quad(S_, 3), quad1(S_, 3), quad2(S_, 3), quad3(S_, 3);
+  Csr quad(ST, 3), quad1(ST, 3), quad2(ST, 3), quad3(ST, 3);
   for (auto const& q : quads_) {
     if (!keep({q[0], q[1], q[2], q[3]}) || !live_quad(q)) continue;
     const int q0 = id_of[q[0]], q1 = id_of[q[1]], q2 = id_of[q[2]], q3 = id_of[q[3]];
@@ -408,6 +411,30 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     quad1.add(q1, {q0, q2, q3});
     quad2.add(q2, {q0, q1, q3});
     quad3.add(q3, {q0, q1, q2});
+  }
+  if (shadow) {
+    // the transitions among state 0 once more for the shadow state.  Forward lists (by parent): row 0 holds children 0 only
+    // ((0,0) is closed).  Reverse lists (by child): row 0 also names the other parents of (0,0) -- the shadow keeps the
+    // entries whose states are all 0, i.e. it is reachable from the shadow alone.
+    auto copy_row = [&](Csr& c, int width_states, bool reverse) {
+      std::vector<int32_t> row;
+      for (size_t e = 0; e + c.width <= c.rows[0].size(); e += c.width) {
+        bool all0 = true;
+        for (int k = 0; k < width_states; ++k) all0 = all0 && c.rows[0][e + k] == 0;
+        if (!all0) {
+          if (!reverse) throw std::runtime_error("shadow state: (0,0) is not closed");
+          continue;
+        }
+        for (int k = 0; k < c.width; ++k) row.push_back(k < width_states ? S_ : c.rows[0][e + k]);
+      }
+      c.rows[S_] = row;
+    };
+    for (Csr* c : {&right, &left, &pair}) copy_row(*c, 1, false);   // (state, tau flag)
+    for (Csr* c : {&rright, &rleft, &rpair}) copy_row(*c, 1, true);
+    copy_row(split, 2, false);
+    for (Csr* c : {&split1, &split2}) copy_row(*c, 2, true);
+    copy_row(quad, 3, false);
+    for (Csr* c : {&quad1, &quad2, &quad3}) copy_row(*c, 3, true);
   }
   auto put = [&](const Csr& c, int32_t* off, int32_t* ent) { auto p = c.emit(ints); *off = p.first; *ent = p.second; };
   // small part: unary transition lists (staged in LDS together with the per-state attributes)
@@ -422,18 +449,19 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   {
     std::vector<std::array<int, 3>> ap;   // (s1, t, tgt)
     auto find = [&](int s1, int t) { for (size_t k = 0; k < ap.size(); ++k) if (ap[k][0] == s1 && ap[k][1] == t) return (int)k; return -1; };
-    for (int k = 0; k < S_; ++k)
+    auto ref = [&](int k) { return k < S_ ? ref_of[k] : 0; };   // (the shadow state has the liveness of (0,0))
+    for (int k = 0; k < ST; ++k)
       for (size_t e = 0; e + 1 < split.rows[k].size(); e += 2) {
         const int s1 = split.rows[k][e], t = split.rows[k][e + 1];
         // (entries kept only for rule 7 pair an O state with a P state: they never carry weight in rule 2)
-        if (prune && !(U[ST_B][ref_of[k]] && I[ST_1][ref_of[s1]] && I[ST_2][ref_of[t]])) continue;
+        if (prune && !(U[ST_B][ref(k)] && I[ST_1][ref(s1)] && I[ST_2][ref(t)])) continue;
         if (find(s1, t) < 0) ap.push_back({s1, t, k});
       }
     for (size_t k = 0; k < ap.size(); ++k) {   // closure (the list grows while it is walked)
       const int s1 = ap[k][0], t = ap[k][1];
       for (size_t e = 0; e + 1 < right.rows[t].size(); e += 2) {
         const int tc = right.rows[t][e];
-        if (prune && !I[ST_2][ref_of[tc]]) continue;
+        if (prune && !I[ST_2][ref(tc)]) continue;
         if (find(s1, tc) < 0) ap.push_back({s1, tc, -1});
       }
     }
@@ -442,7 +470,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     A.ap_s1 = (int32_t)ints->size(); for (auto const& x : ap) ints->push_back(x[0]);
     A.ap_t = (int32_t)ints->size(); for (auto const& x : ap) ints->push_back(x[1]);
     A.ap_tgt = (int32_t)ints->size(); for (auto const& x : ap) ints->push_back(x[2]);
-    Csr chain(std::max(n_ap, 1), 2), rchain(std::max(n_ap, 1), 2), by_s1(S_, 1), by_t(S_, 1);
+    Csr chain(std::max(n_ap, 1), 2), rchain(std::max(n_ap, 1), 2), by_s1(ST, 1), by_t(ST, 1);
     for (int k = 0; k < n_ap; ++k) {
       const int s1 = ap[k][0], t = ap[k][1];
       by_s1.add(s1, {k});
@@ -485,7 +513,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
 void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   AutomatonLayout& A = *lay;
   ints->clear();
-  A.S = 1; A.n_active = 1; A.n_front = 1; A.M = 1; A.n_theta = 0; A.n_rows = 0;
+  A.S = 1; A.n_active = 1; A.n_front = 1; A.shadow = -1; A.M = 1; A.n_theta = 0; A.n_rows = 0;
   A.s00 = A.s0m1 = A.s0m2 = 0;
   auto one = [&](int32_t v) { int32_t p = (int32_t)ints->size(); ints->push_back(v); return p; };
   A.st_l = one(0); A.st_r = one(0); A.st_is_loop = one(1);

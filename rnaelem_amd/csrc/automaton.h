@@ -53,7 +53,11 @@ class Automaton {
   // keep a transition only when its parent is useful and all its children are inside-live, the lists of the outside direction are
   // the same entries regrouped by child.  Table entries of useless (plane, state) pairs then stay 0 / log 0; partition functions,
   // posteriors, expected counts and the Viterbi parse are unchanged (they only see parses that reach a terminal).
-  void flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0 = false, bool prune = false) const;
+  // shadow: append a copy of state 0 = (0,0) as state S, closed under the same transitions but isolated from every other
+  // state (requires that state 0 is closed, Engine::linear_ok_).  One outside sweep with the "has motif" terminals on the
+  // states of the pattern and the "no motif" terminal on the shadow then yields both outside passes of the train schedule.
+  void flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0 = false, bool prune = false,
+               bool shadow = false) const;
 
   // Static liveness of the (structural state, interval state) pairs, from the rule table alone in the
   // boolean semiring: inside_live[e][s] = some sequence gives inside(., ., e, s) a non-zero weight; useful[e][s] = inside-live

@@ -26,6 +26,7 @@ struct AutomatonLayout {
   int32_t n_active; // states [0, n_active) are swept: S, or 1 in the restricted automaton of the no-motif pass
   int32_t n_front;  // states [0, n_front) are the only ones that can take part in a bifurcation (non-zero in planes B, 1, 2
                     // of a complete parse); the split-sum kernels stage only this prefix of a row.  S without pruning.
+  int32_t shadow;   // id of the shadow copy of state (0,0) (Automaton::flatten), or -1
   int32_t M;        // pattern nodes incl. 'z' and 'o'
   int32_t n_theta;  // total theta entries (n_param - 2)
   int32_t n_rows;   // theta rows

@@ -318,15 +318,18 @@ class Engine {
   // 4 = scaled-linear batch pipeline (lin_kernels.hip), 3 = log-space batch pipeline, 2 = fused one-workgroup-per-sequence kernel
   int opt_pipeline_ = 4;
   // scaled-linear pipeline
-  AutomatonLayout layc_;                 // the one-state automaton over compact (S = 1) tables
+  AutomatonLayout lays_;                 // the automaton with the shadow copy of (0,0): both outside passes in one sweep
+  std::vector<int32_t> intss_;
+  DevBuf d_lays_, d_intss_;
+  int tables_S_ = 0;                     // state stride of the tables of the last linear evaluation (debug_tables)
   std::vector<double> h_lin_;            // linear parameter block of the last evaluation
   std::vector<uint8_t> h_seq_;           // base codes of the batch (table export)
   int64_t n_cells_total_ = 0;
   bool tables_linear_ = false;           // the resident tables hold scaled linear values (debug_tables converts)
   int n_flagged_last_ = 0;
-  DevBuf d_a_in_, d_a_out_, d_a_in0_, d_a_out0_;   // pair tables of the factorised rule 2 (lin_rules.h), per slot [W+1][Lmax+1][n_ap]
+  DevBuf d_a_in_, d_a_out_;   // pair tables of the factorised rule 2 (lin_rules.h), per slot [W+1][Lmax+1][n_ap]
   DevBuf d_plans_sorted_;   // plan records in processing (h_order_) order
-  DevBuf d_ews_, d_xwc_, d_xwi_, d_lin_, d_layc_, d_zs_, d_flagged_, d_band_in0_, d_band_out0_, d_ext_in0_, d_ext_out0_;
+  DevBuf d_ews_, d_xwc_, d_xwi_, d_lin_, d_zs_, d_flagged_;
   int lin_slots_ = 0;
   int opt_schedule_ = 1;   // 1 = linear (ari pass + one-state nasi pass), 0 = the reference's two full passes
   int opt_dbg_ = 0;        // timing experiments (LinArgs::dbg); results are wrong when set
@@ -381,8 +384,8 @@ Engine::Engine(const elemdp_model_desc& d)
 void Engine::flatten_automaton() {
   au_.flatten(&lay_, &ints_, false, opt_prune_);
   au_.flatten(&layr_, &intsr_, true, opt_prune_);
-  layc_ = layr_;
-  layc_.S = 1;   // same one-state lists, compact tables
+  if (linear_ok_ && au_.S() < 127) au_.flatten(&lays_, &intss_, false, opt_prune_, true);
+  else { lays_ = lay_; lays_.shadow = -1; intss_ = ints_; }
   lin_slots_ = 0;   // (the pair tables of the linear pipeline are sized by the automaton's pair list)
 }
 
@@ -391,10 +394,11 @@ void Engine::upload_automaton() {
   d_intsr_.upload(intsr_, st_);
   d_lay_.alloc(sizeof(AutomatonLayout));
   d_layr_.alloc(sizeof(AutomatonLayout));
-  d_layc_.alloc(sizeof(AutomatonLayout));
+  d_lays_.alloc(sizeof(AutomatonLayout));
+  d_intss_.upload(intss_, st_);
   HIP_OK(hipMemcpyAsync(d_lay_.as<void>(), &lay_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   HIP_OK(hipMemcpyAsync(d_layr_.as<void>(), &layr_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
-  HIP_OK(hipMemcpyAsync(d_layc_.as<void>(), &layc_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
+  HIP_OK(hipMemcpyAsync(d_lays_.as<void>(), &lays_, sizeof(AutomatonLayout), hipMemcpyHostToDevice, st_));
   HIP_OK(hipStreamSynchronize(st_));
 }
 
@@ -1002,7 +1006,7 @@ bool Engine::should_stream(const int32_t* off, int n) {
   }
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-  const size_t held = d_band_in_.bytes() + d_band_out_.bytes() + d_band_in0_.bytes() + d_band_out0_.bytes() + d_xwc_.bytes() + d_xwi_.bytes();
+  const size_t held = d_band_in_.bytes() + d_band_out_.bytes() + d_xwc_.bytes() + d_xwi_.bytes();
   return cells * 600.0 > 0.5 * (double)(free_b + held);
 }
 
@@ -1033,8 +1037,7 @@ void Engine::stream_setup(const uint8_t* seq, const int32_t* off, const uint8_t*
   }
   st_rows_.clear();
   // (the buffers of an earlier resident batch would only stand in the way of the inner engines)
-  for (DevBuf* b : {&d_band_in_, &d_band_out_, &d_ext_in_, &d_ext_out_, &d_tmp_, &d_band_in0_, &d_band_out0_, &d_xwc_, &d_xwi_,
-                    &d_a_in_, &d_a_out_, &d_a_in0_, &d_a_out0_, &d_tr_band_, &d_tr_ext_})
+  for (DevBuf* b : {&d_band_in_, &d_band_out_, &d_ext_in_, &d_ext_out_, &d_tmp_, &d_xwc_, &d_xwi_, &d_a_in_, &d_a_out_, &d_tr_band_, &d_tr_ext_})
     b->reset();
   n_slots_ = 0; lin_slots_ = 0;
   streaming_ = true;
@@ -1141,8 +1144,7 @@ int Engine::balanced_group(size_t per_slot_bytes) {
   if (opt_group_ > 0) return opt_group_;
   size_t free_b = 0, total_b = 0;
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
-  const size_t held = d_band_in_.bytes() + d_band_out_.bytes() + d_ext_in_.bytes() + d_ext_out_.bytes() + d_band_in0_.bytes() +
-                      d_band_out0_.bytes();
+  const size_t held = d_band_in_.bytes() + d_band_out_.bytes() + d_ext_in_.bytes() + d_ext_out_.bytes();
   const size_t budget = (size_t)((double)(free_b + held) * 0.55);
   long cap = (long)(budget / std::max<size_t>(per_slot_bytes, 1));
   cap = std::max(1L, std::min(cap, (long)group_cap_));
@@ -1215,35 +1217,32 @@ void Engine::lin_weights() {
 }
 
 int Engine::prepare_lin(LinArgs& a, bool sched1) {
-  const int S = au_.S();
+  // schedule 1 sweeps the automaton with the shadow copy of (0,0) (one state more per table row); the scan and schedule 0
+  // the plain one.  The slots are sized for the wider row.
+  const bool shadow = sched1 && lays_.shadow >= 0;
+  const AutomatonLayout& L = shadow ? lays_ : lay_;
+  const int S = L.S, Sa = std::max(lay_.S, lays_.S), nap = std::max(lay_.n_ap, lays_.n_ap);
   {
     const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext = (size_t)(Lmax_ + 1);
-    slot_override_ = balanced_group((band + ext) * (S + 1) * 2 * sizeof(double) + ext * S * 3 * sizeof(double) +
-                                    (size_t)(Wmax_ + 1) * (Lmax_ + 1) * (lay_.n_ap + 1) * 2 * sizeof(double));
+    slot_override_ = balanced_group((band + ext) * Sa * 2 * sizeof(double) + ext * Sa * 3 * sizeof(double) +
+                                    (size_t)(Wmax_ + 1) * (Lmax_ + 1) * nap * 2 * sizeof(double));
   }
-  ensure_slots(S, false, n_seq_);
+  ensure_slots(Sa, false, n_seq_);
   slot_override_ = 0;
   // (if the allocation had to shrink, rebalance for the slots we got)
   const int n_groups = (n_seq_ + n_slots_ - 1) / n_slots_;
   const int gsz = (n_seq_ + n_groups - 1) / n_groups;
-  const size_t band0 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext0 = (size_t)(Lmax_ + 1);
   if (lin_slots_ != n_slots_) {
     d_zs_.alloc(sizeof(double) * 4 * n_slots_);
     const size_t acell = (size_t)(Wmax_ + 1) * (Lmax_ + 1);
-    d_a_in_.alloc(sizeof(double) * acell * lay_.n_ap * n_slots_);
-    d_a_out_.alloc(sizeof(double) * acell * lay_.n_ap * n_slots_);
-    d_a_in0_.alloc(sizeof(double) * acell * n_slots_);
-    d_a_out0_.alloc(sizeof(double) * acell * n_slots_);
-    d_band_in0_.alloc(sizeof(double) * band0 * n_slots_);
-    d_band_out0_.alloc(sizeof(double) * band0 * n_slots_);
-    d_ext_in0_.alloc(sizeof(double) * ext0 * n_slots_);
-    d_ext_out0_.alloc(sizeof(double) * ext0 * n_slots_);
+    d_a_in_.alloc(sizeof(double) * acell * nap * n_slots_);
+    d_a_out_.alloc(sizeof(double) * acell * nap * n_slots_);
     lin_slots_ = n_slots_;
   }
   std::memset(&a, 0, sizeof(a));
-  a.lay = lay_;
-  a.layp = d_lay_.as<AutomatonLayout>();
-  a.ints = d_ints_.as<int32_t>();
+  a.lay = L;
+  a.layp = shadow ? d_lays_.as<AutomatonLayout>() : d_lay_.as<AutomatonLayout>();
+  a.ints = shadow ? d_intss_.as<int32_t>() : d_ints_.as<int32_t>();
   a.params = d_params_.as<double>();
   a.lin = d_lin_.as<double>();
   a.no_prf = (flags_ & ELEMDP_NO_PROFILE) ? 1 : 0;
@@ -1261,14 +1260,9 @@ int Engine::prepare_lin(LinArgs& a, bool sched1) {
   a.ext_in = d_ext_in_.as<double>(); a.ext_out = d_ext_out_.as<double>();
   a.band_stride = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;
   a.ext_stride = (size_t)(Lmax_ + 1) * S;
-  a.band_in0 = sched1 ? d_band_in0_.as<double>() : nullptr;
-  a.ext_in0 = sched1 ? d_ext_in0_.as<double>() : nullptr;
-  a.band0_stride = band0; a.ext0_stride = ext0;
   a.zs = d_zs_.as<double>();
   a.a_in = d_a_in_.as<double>(); a.a_out = d_a_out_.as<double>();
-  a.a_stride = (size_t)(Wmax_ + 1) * (Lmax_ + 1) * lay_.n_ap;
-  a.a_in0 = sched1 ? d_a_in0_.as<double>() : nullptr;
-  a.a0_stride = (size_t)(Wmax_ + 1) * (Lmax_ + 1);
+  a.a_stride = (size_t)(Wmax_ + 1) * (Lmax_ + 1) * L.n_ap;
   a.okbits_end = d_okbits_end_.as<uint32_t>();
   a.lmax = Lmax_;
   a.nword_max = nword_max_;
@@ -1283,33 +1277,20 @@ int Engine::prepare_lin(LinArgs& a, bool sched1) {
     HIP_OK(hipMemsetAsync(d_prof_.as<void>(), 0, sizeof(long long) * 16 * 64, st_));
     a.prof = d_prof_.as<long long>();
   }
-  a.n_stage = (lay_.n_ints <= 4096 && !(opt_dbg_ & 8)) ? lay_.n_ints : lay_.n_small;
+  a.n_stage = (L.n_ints <= 4096 && !(opt_dbg_ & 8)) ? L.n_ints : L.n_small;
+  tables_S_ = S;
   return gsz;
 }
 
 void Engine::run_lin_batch() {
-  const int S = au_.S();
-  const bool sched1 = opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_ && lay_.s00 == 0;
-  const size_t band0 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext0 = (size_t)(Lmax_ + 1);
+  const bool sched1 = opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_ && lay_.s00 == 0 && lays_.shadow >= 0;
   LinArgs a;
   const int gsz = prepare_lin(a, sched1);
-  (void)S;
-  LinArgs c = a;   // the no-motif pass: one-state automaton, compact tables
-  c.lay = layc_;
-  c.layp = d_layc_.as<AutomatonLayout>();
-  c.ints = d_intsr_.as<int32_t>();
-  c.band_in = d_band_in0_.as<double>(); c.band_out = d_band_out0_.as<double>();
-  c.ext_in = d_ext_in0_.as<double>(); c.ext_out = d_ext_out0_.as<double>();
-  c.band_stride = band0; c.ext_stride = ext0;
-  c.band_in0 = nullptr; c.ext_in0 = nullptr;
-  c.a_in = d_a_in0_.as<double>(); c.a_out = d_a_out0_.as<double>();
-  c.a_stride = c.a0_stride; c.a_in0 = nullptr;
-  c.n_stage = (layc_.n_ints <= 4096) ? layc_.n_ints : layc_.n_small;
   HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n_seq_, st_));
   HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
   HIP_OK(hipEventRecord(ev_[1], st_));
   lin_weights();
-  // Two groups at a time, each on its own pair of streams and its own half of the table slots: the serial parts of a
+  // Two groups at a time, each on its own stream and its own half of the table slots: the serial parts of a
   // group (exterior chains, launch tails) run under the band kernels of the other.  (Not for a handful of sequences,
   // whose tables debug_tables reads, nor under the phase profile.)
   const int ns = (opt_group_streams_ >= 2 && n_seq_ >= 64 && n_slots_ >= 64 && !opt_profile_) ? std::min(opt_group_streams_, kMaxGroupStreams) : 1;
@@ -1319,11 +1300,8 @@ void Engine::run_lin_batch() {
   auto shifted = [&](LinArgs x, size_t k) {   // the arguments of a group that uses the slots from k on
     x.band_in += k * x.band_stride; x.band_out += k * x.band_stride;
     x.ext_in += k * x.ext_stride; x.ext_out += k * x.ext_stride;
-    if (x.band_in0) x.band_in0 += k * x.band0_stride;
-    if (x.ext_in0) x.ext_in0 += k * x.ext0_stride;
     x.zs += 4 * k;
     x.a_in += k * x.a_stride; x.a_out += k * x.a_stride;
-    if (x.a_in0) x.a_in0 += k * x.a0_stride;
     return x;
   };
   if (ns > 1) {   // the other streams start behind the weights
@@ -1334,12 +1312,11 @@ void Engine::run_lin_batch() {
   for (int g0 = 0; g0 < n_seq_; g0 += gsz2, ++gi) {
     const int G = std::min(gsz2, n_seq_ - g0);
     const int k = gi % ns;
-    LinArgs ak = shifted(a, (size_t)k * slots_each), ck = shifted(c, (size_t)k * slots_each);
-    ak.grp = ck.grp = d_order_.as<int32_t>() + g0;
-    ak.plans_slot = ck.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
+    LinArgs ak = shifted(a, (size_t)k * slots_each);
+    ak.grp = d_order_.as<int32_t>() + g0;
+    ak.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
     const int Lg = h_plans_[h_order_[g0]].L;
-    HIP_OK(launch_lin_group(ak, ck, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, gs_[k], opt_two_streams_ ? gs2_[k] : nullptr,
-                            gev_[k][0], gev_[k][1]));
+    HIP_OK(launch_lin_group(ak, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, gs_[k]));
   }
   for (int k = 1; k < ns; ++k) {   // ... and the main stream continues behind them
     HIP_OK(hipEventRecord(gdone_[k], gs_[k]));
@@ -1481,7 +1458,11 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
   if (n_seq_ != 1 || streaming_) throw StateError("debug_tables needs a resident batch of exactly one sequence");
   if (n_slots_ < 1) throw StateError("debug_tables before train_eval");
   const SeqPlan& p = h_plans_[0];
-  const int S = au_.S(), L = p.L, W = p.W;
+  const int Sref = au_.S(), L = p.L, W = p.W;
+  // (a schedule-1 evaluation of the linear pipeline leaves tables with one more state per row: the shadow of (0,0))
+  const int S = (tables_linear_ && tables_S_ > 0) ? tables_S_ : Sref;
+  const AutomatonLayout& TL = (S == lays_.S && lays_.shadow >= 0 && S != Sref) ? lays_ : lay_;
+  const std::vector<int32_t>& TI = (&TL == &lays_) ? intss_ : ints_;
   const size_t band = (size_t)7 * (W + 1) * (L + 1) * S, ext = (size_t)(L + 1) * S;
   auto fetch = [&](const DevBuf& src, size_t cnt) {
     std::vector<double> h(cnt);
@@ -1493,27 +1474,28 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
   std::vector<double> cum(L + 1, 0.);   // log2 of prod_{p<j} psb[base(p)]
   if (lin) for (int t = 0; t < L; ++t) cum[t + 1] = cum[t] + h_lin_[kLinPl2 + h_seq_[p.seq_base + t]];
   const double ln2 = 0.69314718055994530942, NEGINF = -std::numeric_limits<double>::infinity();
-  auto ref_id = [&](int s) { return ints_[lay_.st_ref + s]; };   // tables are exported in the reference's state order
+  auto ref_id = [&](int s) { return TI[TL.st_ref + s]; };   // tables are exported in the reference's state order
   auto conv = [&](double v, double scale_log2) { return !lin ? v : (v > 0. ? std::log(v) - scale_log2 * ln2 : NEGINF); };
   auto reorder = [&](const std::vector<double>& t, double* dst, bool outside_tab) {  // [e][d][i][s] -> [i][d][e][s]
     for (int i = 0; i <= L; ++i) for (int d = 0; d <= W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s) {
+      if (s == TL.shadow) continue;
       double sc = (i + d <= L) ? cum[i + d] - cum[i] : 0.;
       if (outside_tab) sc = cum[L] - sc;
-      dst[(((size_t)i * (W + 1) + d) * 7 + e) * S + ref_id(s)] =
+      dst[(((size_t)i * (W + 1) + d) * 7 + e) * Sref + ref_id(s)] =
           (i + d <= L) ? conv(t[(((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s], sc) : NEGINF;
     }
   };
   if (inside) reorder(fetch(d_band_in_, band), inside, false);
   if (outside) {
     std::vector<double> to = fetch(d_band_out_, band);
-    if (lin && lay_.n_ap > 0 && d_a_out_.bytes() >= sizeof(double) * (size_t)(W + 1) * (L + 1) * lay_.n_ap) {
+    if (lin && TL.n_ap > 0 && d_a_out_.bytes() >= sizeof(double) * (size_t)(W + 1) * (L + 1) * TL.n_ap) {
       // the linear pipeline keeps only the direct part (rules 4a, 3a) of the plane-2 outside values; what arrives through
       // rule 2 is HA(k,l,t) = sum_i sum_{p=(s1,t)} outA(i,l,p) 1(i,k,s1) (lin_rules.h) -- added here for the export
-      const int nA = lay_.n_ap;
+      const int nA = TL.n_ap;
       const std::vector<double> ti = fetch(d_band_in_, band), ao = fetch(d_a_out_, (size_t)(W + 1) * (L + 1) * nA);
       auto at = [&](int e, int d, int i, int s2) { return (((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s2; };
       for (int d = 0; d <= W; ++d) for (int i = 0; i + d <= L; ++i) for (int p = 0; p < nA; ++p) {
-        const int s1 = ints_[lay_.ap_s1 + p], t = ints_[lay_.ap_t + p];
+        const int s1 = TI[TL.ap_s1 + p], t = TI[TL.ap_t + p];
         if (!(ti[at(ST_2, d, i, t)] != 0.)) continue;
         double acc = 0.;
         for (int b = 1; d + b <= W && i - b >= 0; ++b)
@@ -1523,8 +1505,8 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
     }
     reorder(to, outside, true);
   }
-  if (inside_o) { auto h = fetch(d_ext_in_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) inside_o[(size_t)j * S + ref_id(s)] = conv(h[(size_t)j * S + s], cum[j]); }
-  if (outside_o) { auto h = fetch(d_ext_out_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) outside_o[(size_t)j * S + ref_id(s)] = conv(h[(size_t)j * S + s], cum[L] - cum[j]); }
+  if (inside_o) { auto h = fetch(d_ext_in_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) if (s != TL.shadow) inside_o[(size_t)j * Sref + ref_id(s)] = conv(h[(size_t)j * S + s], cum[j]); }
+  if (outside_o) { auto h = fetch(d_ext_out_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) if (s != TL.shadow) outside_o[(size_t)j * Sref + ref_id(s)] = conv(h[(size_t)j * S + s], cum[L] - cum[j]); }
   std::vector<double> o = fetch(d_seq_out_, out_stride_);
   const int nt = au_.n_theta();
   if (ENo) std::copy(o.begin() + 6, o.begin() + 6 + nt, ENo);

@@ -155,8 +155,6 @@ struct LinArgs {
   const double* xwi; size_t xwi_stride;   // exp(lambda_k * tsc) of the interior-loop items: [k][item]
   double* band_in; double* band_out; double* ext_in; double* ext_out;   // tables swept by this launch
   size_t band_stride, ext_stride;
-  double* band_in0; double* ext_in0;      // compact copies of state (0,0) written by the inside kernels (or null)
-  size_t band0_stride, ext0_stride;
   double* zs;                     // per slot: mantissas of Z(ari,nasi), Z(ari), Z(nasi), and log2 of the sequence's scale
   double* seq_out; int32_t out_stride;
   int32_t schedule, pass, d;
@@ -170,10 +168,9 @@ struct LinArgs {
   // scan, Viterbi pass on the batch pipeline: trace tables per slot (same indexing as the band / ext tables), outputs
   TraceRec* tr_band; TraceRec* tr_ext; int32_t* sc_psihat; char* sc_rss; int32_t* trace_stack; int32_t trace_stack_stride;
   long long* prof;                // optional [16] shader-clock sums per phase (thread 0 of every workgroup), or null
-  // rule 2, factorised (lin_rules.h): pair tables [d][i][p] per slot (a_stride doubles each), the compact copy of the pair
-  // ((0,0),(0,0)) for the no-motif pass, and the end-indexed pair mask (bits_base indexing, like okbits)
+  // rule 2, factorised (lin_rules.h): pair tables [d][i][p] per slot (a_stride doubles each) and the end-indexed pair mask
+  // (bits_base indexing, like okbits)
   double* a_in; double* a_out; size_t a_stride;
-  double* a_in0; size_t a0_stride;
   const uint32_t* okbits_end;
   int32_t lmax, nword_max;        // longest sequence of the launch / most pair-mask words of a sequence (LDS sizing)
   int32_t wmax;                   // largest span of the launch (sizes the position window staged in LDS)
@@ -196,8 +193,7 @@ hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st);
 hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax, int phase, hipStream_t st);
 // scan: Viterbi parse (max-plus CYK with trace records, then traceback) of a group; uses band_in / ext_in as the CYK table
 hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipStream_t st);
-hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, int Lmax, int Wmax, bool first_pass_only,
-                            hipStream_t st, hipStream_t st2 = nullptr, hipEvent_t ev_in = nullptr, hipEvent_t ev_p1 = nullptr);
+hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool first_pass_only, hipStream_t st);
 hipError_t launch_bpp_group(const TrArgs& base, const BppOut& o, int G, int Lmax, int Wmax, hipStream_t st);
 hipError_t launch_train_group(const TrArgs& base, int G, int Lmax, int Wmax, hipStream_t st);
 

@@ -49,6 +49,14 @@ namespace {
 struct LinSink {
   double* en_;
   double eh0, eh1;
+  // merged schedule: the lane works in world 1 (the shadow copy of (0,0) = the "no motif" pass) -- its statistics go to the
+  // second set of accumulators; ehs*: energy statistics of world 1 from a lane that serves both worlds (item phase)
+  int world = 0;
+  double ehm0 = 0., ehm1 = 0., ehs0 = 0., ehs1 = 0.;   // world 0 / world 1 sums of a phase whose lanes serve both worlds
+  __device__ __forceinline__ void eh_mixed(bool w1, int k, double w) {
+    if (w1) { if (k) ehs1 += w; else ehs0 += w; }
+    else { if (k) ehm1 += w; else ehm0 += w; }
+  }
   double* pos0 = nullptr;   // scan: per-sequence position posteriors (global memory, linear): start, inner, end
   double* pos1 = nullptr;
   double* pos2 = nullptr;
@@ -614,8 +622,6 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
         }
       }
       v.in.a(d, i, p) = av;
-      if (a.a_in0 != nullptr && s1 == A.s00 && t == A.s00)   // compact copy for the no-motif pass
-        a.a_in0[(size_t)by * a.a0_stride + (size_t)d * (v.in.L + 1) + i] = av;
       if (tgt >= 0 && av != 0.) atomicAdd(&hb[c * S + tgt], av);
     }
   }
@@ -668,14 +674,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     const int i = i0 + c;
     const double HB = hb[c * S + s];
     const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
-    const Cell7 r = lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, HB, he[c * S + s], con);
-    if (a.band_in0 != nullptr && s == A.s00) {   // compact copy of state (0,0) for the no-motif pass
-      TableView t0;
-      t0.band = a.band_in0 + (size_t)by * a.band0_stride;
-      t0.ext = nullptr; t0.L = v.in.L; t0.W = v.in.W; t0.S = 1;
-      t0.at(ST_P, d, i, 0) = r.vP; t0.at(ST_E, d, i, 0) = r.vE; t0.at(ST_M, d, i, 0) = r.vM; t0.at(ST_B, d, i, 0) = r.vB;
-      t0.at(ST_1, d, i, 0) = r.v1; t0.at(ST_2, d, i, 0) = r.v2; t0.at(ST_L, d, i, 0) = r.vL;
-    }
+    lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, HB, he[c * S + s], con);
   }
   pc.mark<4>();
   pc.finish();
@@ -739,9 +738,7 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   make_lviews(a, blockIdx.x, v);
   stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_ext), 0);
   const int S = a.lay.n_active, tid = threadIdx.x, L = v.q.L;
-  double* ext0 = a.ext_in0 ? a.ext_in0 + (size_t)blockIdx.x * a.ext0_stride : nullptr;
-  for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00) ? 1. : 0.;
-  if (ext0 && tid == 0) ext0[0] = 1.;
+  for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00 || s == a.lay.shadow) ? 1. : 0.;   // (the shadow of (0,0) starts like it)
   __syncthreads();
   // lanes = (part, state): the pairs ending at j are dealt to nparts lanes per state, the partial sums meet in LDS
   __shared__ double s_part[128];
@@ -756,13 +753,9 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
         double t = 0.;
         for (int k = 0; k < nparts; ++k) t += s_part[k * S + tid];
         v.in.o(j, tid) = t;
-        if (ext0 && tid == a.lay.s00) ext0[j] = t;
       }
     } else {
-      for (int s = tid; s < S; s += 128) {
-        lin_inside_ext_target<CON>(v.m, v.q, v.in, j, s, con);
-        if (ext0 && s == a.lay.s00) ext0[j] = v.in.o(j, s);
-      }
+      for (int s = tid; s < S; s += 128) lin_inside_ext_target<CON>(v.m, v.q, v.in, j, s, con);
     }
     __syncthreads();
   }
@@ -793,7 +786,7 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   }
 }
 
-struct LPass { double invZ; bool ari, nasi, skip; int en_off, eh_off; };
+struct LPass { double invZ; bool ari, nasi, skip; int en_off, eh_off; double invZs; bool merged; };
 // schedule 0 (reference): pass 0 = terminals (ari,nasi), pass 1 = the label's mask; schedule 1: ari only / nasi only
 __device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
   LPass pi;
@@ -811,6 +804,10 @@ __device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
     if (a.pass == 0) { Z = v.zs[1]; pi.ari = true; pi.nasi = false; }
     else { Z = v.zs[2]; pi.ari = false; pi.nasi = true; }
   }
+  // schedule 1 on an automaton with the shadow state: ONE sweep, "has motif" terminals for the pattern's states (world 0,
+  // Z(ari)), the "no motif" terminal for the shadow of (0,0) (world 1, Z(nasi))
+  pi.merged = a.schedule == 1 && a.lay.shadow >= 0;
+  pi.invZs = pi.merged ? 1. / v.zs[2] : 0.;
   pi.invZ = 1. / Z;
   pi.en_off = 6 + a.pass * nt;
   pi.eh_off = 6 + 2 * nt + 2 * a.pass;
@@ -819,18 +816,27 @@ __device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
 
 __device__ __forceinline__ void lflush(const LinArgs& a, const LViews& v, const LPass& pi, LinSink& sink, double* l_en, double* l_eh,
                                        int nthreads) {
-  const double e0 = wave_sum(sink.eh0), e1 = wave_sum(sink.eh1);
+  // l_en: [worlds][n_theta], l_eh: [worlds][2]
+  const int nw = pi.merged ? 2 : 1;
+  const double e0 = wave_sum((sink.world == 0 ? sink.eh0 : 0.) + sink.ehm0), e1 = wave_sum((sink.world == 0 ? sink.eh1 : 0.) + sink.ehm1);
   if ((threadIdx.x & 63) == 0) {
     if (e0 != 0.) atomicAdd(&l_eh[0], e0);
     if (e1 != 0.) atomicAdd(&l_eh[1], e1);
   }
+  if (pi.merged) {
+    const double f0 = wave_sum((sink.world == 1 ? sink.eh0 : 0.) + sink.ehs0), f1 = wave_sum((sink.world == 1 ? sink.eh1 : 0.) + sink.ehs1);
+    if ((threadIdx.x & 63) == 0) {
+      if (f0 != 0.) atomicAdd(&l_eh[2], f0);
+      if (f1 != 0.) atomicAdd(&l_eh[3], f1);
+    }
+  }
   __syncthreads();
   const int nt = a.lay.n_theta;
-  for (int t = threadIdx.x; t < nt; t += nthreads) {
+  for (int t = threadIdx.x; t < nw * nt; t += nthreads) {
     const double val = l_en[t];
-    if (val != 0.) atomicAdd(&v.row[pi.en_off + t], val);
+    if (val != 0.) atomicAdd(&v.row[pi.en_off + t], val);          // (world 1 lands on the second set: en_off + n_theta + .)
   }
-  if (threadIdx.x < 2 && l_eh[threadIdx.x] != 0.) atomicAdd(&v.row[pi.eh_off + threadIdx.x], l_eh[threadIdx.x]);
+  if (threadIdx.x < 2 * nw && l_eh[threadIdx.x] != 0.) atomicAdd(&v.row[pi.eh_off + threadIdx.x], l_eh[threadIdx.x]);
 }
 
 // position-posterior accumulators of the scan passes (linear, global memory, batch offsets)
@@ -872,33 +878,37 @@ __global__ __launch_bounds__(64) void k5_pick(LinArgs a, int G) {
 // ---- exterior chain of an outside pass
 template <int MODE, bool STAGE>
 __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
-  extern __shared__ double l_stat[];   // n_theta + 2, then the staged context
+  extern __shared__ double l_stat[];   // 2 * (n_theta + 2): statistics of the two worlds, then the staged context
   __shared__ AutomatonLayout s_lay;
   stage_layout(a, &s_lay, 128);
   LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
   const LPass pi = lpass(a, v);
   if (pi.skip) return;
-  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), a.lay.n_theta + 2);
+  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), 2 * a.lay.n_theta + 4);
   const int S = a.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
   double* l_en = l_stat;
-  double* l_eh = l_stat + nt;
-  for (int t = tid; t < nt + 2; t += 128) l_stat[t] = 0.;
+  double* l_eh = l_stat + 2 * nt;
+  for (int t = tid; t < 2 * nt + 4; t += 128) l_stat[t] = 0.;
+  __shared__ double s_part[128];
+  const int nparts = (S <= 128) ? 128 / S : 1;
+  const int part = tid / S, ps = tid - part * S;
+  // (merged schedule: the lane of the shadow state works in world 1 -- its own Z and statistics; S <= 128 there)
+  const bool shadow_lane = pi.merged && ps == a.lay.shadow;
   LinSink sink;
-  sink.en_ = l_en;
+  sink.world = shadow_lane ? 1 : 0;
+  sink.en_ = l_en + (shadow_lane ? nt : 0);
   sink.eh0 = sink.eh1 = 0.;
   scan_sink<MODE>(a, v, sink);
-  LinOutCtx<LinSink> x{v.m, v.q, v.in, v.out, pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
+  LinOutCtx<LinSink> x{v.m, v.q, v.in, v.out, shadow_lane ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
   for (int s = tid; s < S; s += 128) {
     double t = 0.;
     if (pi.nasi && s == a.lay.s00) t = 1.;
     if (pi.ari && (s == a.lay.s0m1 || s == a.lay.s0m2)) t = 1.;
+    if (pi.merged && s == a.lay.shadow) t = 1.;
     v.out.o(v.q.L, s) = t;
   }
   __syncthreads();
-  __shared__ double s_part[128];
-  const int nparts = (S <= 128) ? 128 / S : 1;
-  const int part = tid / S, ps = tid - part * S;
   for (int i = v.q.L - 1; i >= 0; --i) {
     if (S <= 128) {
       if (part < nparts) s_part[tid] = lin_outside_ext_part<MODE>(x, i, ps, part, nparts);
@@ -941,15 +951,15 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* h2 = h1 + CS;
   double* hp = h2 + CS;
   double* hl = hp + CS;
-  double* l_en = hl + CS;
-  double* l_eh = l_en + nt;
-  double* sOB1 = l_eh + 2;                     // item records of the three roles (kRecOut doubles)
-  const BlockLds BL = block_lds(4 * CS + nt + 2 + kRecOut, cpb, kLinEth + nt, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb);
+  double* l_en = hl + CS;                      // [2 worlds][n_theta]
+  double* l_eh = l_en + 2 * nt;                // [2 worlds][2]
+  double* sOB1 = l_eh + 4;                     // item records of the three roles (kRecOut doubles)
+  const BlockLds BL = block_lds(4 * CS + 2 * nt + 4 + kRecOut, cpb, kLinEth + nt, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb);
   const BlockCtx cx = stage_context<BIG, 1>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   if (pi.skip) return;   // (tested here: the loads behind `pi` travel with those of the context instead of before them)
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
-  for (int t = tid; t < 4 * CS + nt + 2; t += kThreads) lds[t] = 0.;
+  for (int t = tid; t < 4 * CS + 2 * nt + 4; t += kThreads) lds[t] = 0.;
   __syncthreads();
   pc.mark<5>();
   LinSink sink;
@@ -1116,7 +1126,10 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           const double term = x0[u] * (x1[u] * x2[u]) * xw[u];
           if (!ok[u] || aux[u] == 0. || term == 0.) continue;
           atomicAdd(&hp[hidx[u]], term);
-          if (MODE == OUT_TRAIN && par[u] >= 0) sink.eh(v.m.eh_index(par[u]), it[u].tsc * term * (aux[u] * pi.invZ));
+          if (MODE == OUT_TRAIN && par[u] >= 0) {
+            const bool w1 = pi.merged && par[u] == A.shadow;
+            sink.eh_mixed(w1, v.m.eh_index(par[u]), it[u].tsc * term * (aux[u] * (w1 ? pi.invZs : pi.invZ)));
+          }
         }
       }
       __syncthreads();
@@ -1126,7 +1139,10 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   pc.mark<10>();
   if (tid < nc * NA && !(a.dbg & 4)) {
     const int c = tid / NA, s = tid - c * NA;
-    LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
+    const bool w1 = pi.merged && s == A.shadow;      // the shadow state: world 1 (its own Z, second set of statistics)
+    sink.world = w1 ? 1 : 0;
+    sink.en_ = l_en + (w1 ? nt : 0);
+    LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
     HeavyOut H;
     H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
     H.ext_in_hp = true;
@@ -1137,12 +1153,16 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   // (i, d+1), with the statistics of the tail emissions
   if (!(a.dbg & 1) && !(a.dbg & 128)) {
     const int nA = A.n_ap;
-    LinOutCtx<LinSink> x{v.m, v.q, in, out, pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
+    double* const en_keep = sink.en_;
     for (int w = tid; w < nc * nA; w += kThreads) {
       const int c = w / nA, p = w - c * nA;
       const int tgt = v.m.ints[A.ap_tgt + p];
+      const bool w1 = pi.merged && v.m.ints[A.ap_t + p] == A.shadow;
+      sink.en_ = l_en + (w1 ? nt : 0);
+      LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
       lin_outside_apair<MODE>(x, d, i0 + c, p, tgt >= 0 ? h1[c * S + tgt] : 0.);
     }
+    sink.en_ = en_keep;
   }
   pc.mark<11>();
   if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, kThreads);
@@ -1468,11 +1488,11 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   a.pass = 0;
   a.scan = 1;
   const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
-  const size_t lds_out = block_lds(4 * a.cpb * S + nt + 2 + kRecOut, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
+  const size_t lds_out = block_lds(4 * a.cpb * S + 2 * nt + 4 + kRecOut, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
-  const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(nt + 2, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (nt + 2);
+  const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
 #define ELEMDP_SCAN_PASS(CON, MODE)                                                                                              \
   do {                                                                                                                           \
     for (int d = 0; d <= Wmax; ++d) {                                                                                            \
@@ -1507,8 +1527,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   return hipGetLastError();
 }
 
-hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, int Lmax, int Wmax, bool first_pass_only,
-                            hipStream_t st, hipStream_t st2, hipEvent_t ev_in, hipEvent_t ev_p1) {
+hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool first_pass_only, hipStream_t st) {
   if (G <= 0) return hipSuccess;
   LinArgs a = full;
   const int S = a.lay.S, nt = a.lay.n_theta;
@@ -1517,7 +1536,7 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   a.wmax = Wmax;
   const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
-  const size_t lds_stat = sizeof(double) * (nt + 2);
+  const size_t lds_stat = sizeof(double) * (2 * nt + 4);
   if (!a.no_rss)
     for (int d = 0; d <= Wmax; ++d) {
       const int ncell = Lmax - d + 1;
@@ -1531,45 +1550,25 @@ hipError_t launch_lin_group(const LinArgs& full, const LinArgs& compact, int G, 
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
   if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, false>), dim3(G), dim3(128), lds_ext_in, st, a);
   else hipLaunchKernelGGL((k4_in_ext<false, false>), dim3(G), dim3(128), 0, st, a);
-  // schedule 1: the two outside passes are independent (ari-only on the full tables, nasi-only on the compact ones; both
-  // only read the inside tables) -- with a second stream the small second pass runs beside the first (it fills the gaps
-  // of a launch-latency-bound small batch; a large batch gains nothing and loses nothing)
-  const bool two_streams = st2 != nullptr && a.schedule == 1 && !first_pass_only;
-  if (two_streams) {
-    hipError_t e = hipEventRecord(ev_in, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st2, ev_in, 0);
-    if (e != hipSuccess) return e;
-  }
-  const hipStream_t st_main = st;
-  for (int turn = 0; turn < 2; ++turn) {
-    const int pass = two_streams ? 1 - turn : turn;
-    if (pass == 1 && first_pass_only) continue;
-    st = (two_streams && pass == 1) ? st2 : st_main;
-    LinArgs b = (a.schedule == 1 && pass == 1) ? compact : a;
+  // schedule 1 (automaton with the shadow state): ONE outside sweep carries both passes -- the "has motif" terminals on the
+  // pattern's states, the "no motif" terminal on the shadow of (0,0), each with its own Z and statistics (lpass).
+  // schedule 0: the reference's two sweeps, (ari, nasi) then the label's mask.
+  const int n_pass = (a.schedule == 1 || first_pass_only) ? 1 : 2;
+  const size_t lds_b = block_lds(4 * a.cpb * S + 2 * nt + 4 + kRecOut, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    LinArgs b = a;
     b.pass = pass;
-    b.cpb = kThreads / b.lay.S;
-    if (b.cpb > ELEMDP_CPB_MAX) b.cpb = ELEMDP_CPB_MAX;
-    b.wmax = Wmax;
-    const size_t lds_b = block_lds(4 * b.cpb * b.lay.S + nt + 2 + kRecOut, b.cpb, kLinEth + nt, b.cpb + Wmax + 3, staged_ints(b.lay, b.n_stage, 1), 3 * b.cpb).total;
-    const bool big_b = b.n_stage >= b.lay.n_ints;
-    b.lmax = Lmax;
-    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(nt + 2, kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
+    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(2 * nt + 4, kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
     else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), lds_stat, st, b);
     if (!b.no_rss)
       for (int d = Wmax; d >= 0; --d) {
         const int ncell = Lmax - d + 1;
         if (ncell <= 0) continue;
         b.d = d;
-        if (big_b && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);   // (timing experiment: no statistics)
-        else if (big_b) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
+        if (big && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);   // (timing experiment: no statistics)
+        else if (big) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
       }
-  }
-  st = st_main;
-  if (two_streams) {
-    hipError_t e = hipEventRecord(ev_p1, st2);
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_p1, 0);
-    if (e != hipSuccess) return e;
   }
   if ((a.schedule == 1 || a.lik_ratio) && !first_pass_only) hipLaunchKernelGGL(k4_combine, dim3(G), dim3(kThreads), 0, st, a, G);
   return hipGetLastError();
