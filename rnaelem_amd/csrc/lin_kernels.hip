@@ -23,10 +23,10 @@
 #define ELEMDP_KCO 3
 #endif
 #ifndef ELEMDP_LB_IN
-#define ELEMDP_LB_IN 5
+#define ELEMDP_LB_IN 4
 #endif
 #ifndef ELEMDP_LB_OUT
-#define ELEMDP_LB_OUT 4
+#define ELEMDP_LB_OUT 3
 #endif
 #ifndef ELEMDP_CPB_MAX
 #define ELEMDP_CPB_MAX 64
@@ -493,7 +493,9 @@ __device__ __forceinline__ OuterRecs outer_recs(double* area, int n_doubles) {
   return r;
 }
 // ranges + prefix; returns the number of records of the workgroup
-__device__ __forceinline__ int outer_ranges(const LViews& v, int i0, int nc, int d, bool on, int tid, int* cnts, int* pre, int* base) {
+// (two halves: the CSR loads are issued before the pair phase of the kernel, whose own loads they travel with; the prefix
+// follows behind the barrier that ends the pair phase)
+__device__ __forceinline__ void outer_ranges_load(const LViews& v, int i0, int nc, int d, bool on, int tid, int* cnts, int* base) {
   for (int c = tid; c < nc; c += kThreads) {
     const int i = i0 + c;
     int n0 = 0, n1 = 0;
@@ -501,6 +503,18 @@ __device__ __forceinline__ int outer_ranges(const LViews& v, int i0, int nc, int
     base[c] = n0;
     cnts[c] = (n1 > n0) ? n1 - n0 : 0;
   }
+}
+__device__ __forceinline__ int outer_ranges_prefix(int nc, int tid, const int* cnts, int* pre) {
+  for (int c = tid; c <= nc; c += kThreads) {
+    int p = 0;
+    for (int k = 0; k < c; ++k) p += cnts[k];
+    pre[c] = p;
+  }
+  __syncthreads();
+  return pre[nc];
+}
+__device__ __forceinline__ int outer_ranges(const LViews& v, int i0, int nc, int d, bool on, int tid, int* cnts, int* pre, int* base) {
+  outer_ranges_load(v, i0, nc, d, on, tid, cnts, base);
   __syncthreads();
   for (int c = tid; c <= nc; c += kThreads) {
     int p = 0;
@@ -562,6 +576,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   __syncthreads();
   pc.mark<0>();
   const double* B = v.in.band;
+  const int nq = (a.dbg & 2) ? 0 : A.n_quad;
+  outer_ranges_load(v, i0, nc, d, nq > 0, tid, cnts, base);   // (CSR ranges of the item sums: in flight during the pair phase)
   // rule 2, factorised (lin_rules.h, lin_inside_apair): lane = (cell, pair p = (s1, t)).  A(i,j,p) = the tail step from
   // A(i,j-1,.) plus one term per stem (k, j) that ends at j and starts behind i; B(i,j,tgt(p)) += A(i,j,p).  The stems are
   // walked four at a time: their operand loads (1(i,k,s1), P(k,j,t), exp(lambda e_ml)) are in flight together.
@@ -629,9 +645,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   pc.mark<1>();
   // rule 6c: E(i,j,tgt) += sum_items P(k,l,s1) * L(i,k,s2) * L(l,j,s3) * exp(lambda * tsc): work item = (item, tuple), the
   // item records staged in the (now free) operand staging area, one round of table loads per work item
-  const int nq = (a.dbg & 2) ? 0 : A.n_quad;
   {
-    const int n_rec = outer_ranges(v, i0, nc, d, nq > 0, tid, cnts, pre, base);
+    const int n_rec = outer_ranges_prefix(nc, tid, cnts, pre);
     const OuterRecs R = outer_recs(st1, kRecIn);
     for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
       const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
@@ -698,7 +713,7 @@ __host__ __device__ inline ExtLds ext_lds(int nd, int n_lin, int Lmax, int nword
   return b;
 }
 template <bool STAGE>
-__device__ __forceinline__ void stage_ext_context(const LinArgs& a, LViews& v, unsigned char* raw, int nd) {
+__device__ __forceinline__ void stage_ext_context(const LinArgs& a, LViews& v, unsigned char* raw, int nd, int nthr = 128) {
   if (!STAGE) return;
   const int tid = threadIdx.x, L = v.q.L;
   const int nword = (int)((((long long)(L + 1) * (v.q.W + 1)) + 31) >> 5);
@@ -709,10 +724,10 @@ __device__ __forceinline__ void stage_ext_context(const LinArgs& a, LViews& v, u
   uint32_t* lbits = reinterpret_cast<uint32_t*>(raw + B.bits);
   uint8_t* lseq = raw + B.seq8;
   uint8_t* lunp = raw + B.unp8;
-  for (int t = tid; t < a.n_stage; t += 128) blob[t] = a.ints[t];
-  for (int t = tid; t < kLinEth + a.lay.n_theta; t += 128) llin[t] = a.lin[t];
-  for (int t = tid; t < nword; t += 128) lbits[t] = v.q.okbits[t];
-  for (int t = tid; t <= L; t += 128) {
+  for (int t = tid; t < a.n_stage; t += nthr) blob[t] = a.ints[t];
+  for (int t = tid; t < kLinEth + a.lay.n_theta; t += nthr) llin[t] = a.lin[t];
+  for (int t = tid; t < nword; t += nthr) lbits[t] = v.q.okbits[t];
+  for (int t = tid; t <= L; t += nthr) {
     lews[t] = v.q.ews[t];
     lunp[t] = v.q.unp[t];
     lseq[t] = (t < L) ? v.q.seq[t] : (uint8_t)0;
@@ -971,6 +986,17 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   const int nq = (a.dbg & 2) ? 0 : A.n_quad;
   const double* IB = in.band;
   const double* OB = out.band;
+  // CSR ranges of the item sums of the three roles (consumed behind the pair phase, whose loads they travel with)
+  for (int vc = tid; vc < 3 * nc; vc += kThreads) {
+    const int role = vc / nc, c = vc - role * nc;
+    const int i = i0 + c;
+    const int cell = v.q.cell(i, d);
+    const int32_t* off = role == 0 ? v.q.by_inner_off : role == 1 ? v.q.by_left_off : v.q.by_right_off;
+    int n0 = 0, n1 = 0;
+    if (nq > 0 && (role != 0 || v.q.pair_ok(i, d))) { n0 = off[cell]; n1 = off[cell + 1]; }
+    base[vc] = n0;
+    cnts[vc] = (n1 > n0) ? n1 - n0 : 0;
+  }
   // rule 2, factorised, outside direction (lin_rules.h: lheavy_o1 / lheavy_o2):
   //   h1[c][s1] = H1 = sum over the stems (j, l) that start at the cell's end j = i + d:  outA(i,l,p) * P(j,l,t) * xml(j,l)
   //   h2[c][t]  = HA = sum_{ii < i} outA(ii,j,p) * 1(ii,i,s1), only where the cell itself is a stem P(i,j)
@@ -1047,17 +1073,6 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   // then needs a single round of table loads, selected by role without branches.
   {
     const int nv = 3 * nc;
-    for (int vc = tid; vc < nv; vc += kThreads) {
-      const int role = vc / nc, c = vc - role * nc;
-      const int i = i0 + c;
-      const int cell = v.q.cell(i, d);
-      const int32_t* off = role == 0 ? v.q.by_inner_off : role == 1 ? v.q.by_left_off : v.q.by_right_off;
-      int n0 = 0, n1 = 0;
-      if (nq > 0 && (role != 0 || v.q.pair_ok(i, d))) { n0 = off[cell]; n1 = off[cell + 1]; }
-      base[vc] = n0;
-      cnts[vc] = (n1 > n0) ? n1 - n0 : 0;
-    }
-    __syncthreads();
     for (int vc = tid; vc <= nv; vc += kThreads) {
       int p = 0;
       for (int c = 0; c < vc; ++c) p += cnts[c];
