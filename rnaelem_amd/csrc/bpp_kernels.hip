@@ -10,7 +10,7 @@
 //     and the outside band values are divided by Z from the start (rule 7 enters as exp(ln O(i) + ln outO(j) - ln Z));
 //   * rule 2 is factorised as in lin_rules.h (A(i,j) = sum_k 1(i,k) 2(k,j) by a recurrence along the row + the stems that
 //     end at j);
-//   * the interior loops of rule 6c are enumerated in place from the pair mask, 16 lanes per cell, loop_energy evaluated on
+//   * the interior loops of rule 6c are enumerated in place from the pair mask, one lane per (cell, left end), loop_energy evaluated on
 //     the fly (the same energy_rules.h functions the plan builder calls) -- each candidate is needed once per direction, so
 //     materialising the list only cost bandwidth.
 // Same sums as k3_bpp_* (train_kernels.hip), which stay for spans beyond the linear range (W > kBppLinMaxSpan).
@@ -22,8 +22,6 @@
 namespace elemdp {
 namespace {
 
-constexpr int kLanes = 16;                  // lanes per cell
-constexpr int kCells = kThreads / kLanes;   // cells per workgroup
 enum { BP_P = 0, BP_E, BP_M, BP_B, BP_1, BP_2, BP_A, BP_IN_PLANES };   // inside planes
 enum { BO_P = 0, BO_E, BO_M, BO_2, BO_A, BO_OUT_PLANES };              // outside planes (divided by Z)
 enum { XW_STACK = 0, XW_EXT, XW_ML, XW_CLOSE, XW_HP };
@@ -68,12 +66,6 @@ __device__ __forceinline__ Seq make_seq(const BppLinArgs& a, int n) {
   q.tin = a.tin + p.cell_base; q.tout = a.tout + p.cell_base; q.t_stride = a.t_stride;
   q.lo_in = a.lo_in + p.dmin_base; q.lo_out = a.lo_out + p.dmin_base;
   return q;
-}
-
-__device__ __forceinline__ double group_sum(double v) {   // sum over the kLanes lanes of a cell
-#pragma unroll
-  for (int o = kLanes / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kLanes);
-  return v;
 }
 
 // set bits bit0 + n, n in [lo, hi], of a mask: calls f(n) (ascending)
@@ -126,42 +118,97 @@ __global__ __launch_bounds__(kThreads) void k6_terms(BppLinArgs a) {
   for (int k = 0; k < 5; ++k) xw[(size_t)k * a.xw_stride + c] = v[k];
 }
 
-// ---- inside, diagonal d: kCells cells per workgroup, kLanes lanes per cell
+// ---- the diagonal kernels: kC consecutive cells per workgroup.  The heavy sums are spread over the lanes as (cell, slot)
+// work items -- interior loops only for the cells that have them (a third of the cells; the list is compacted with a
+// ballot), slot = left end of the inner / outer pair -- and every partial sum has its own LDS word, added up in a fixed
+// order by the cell's lane: the filter is reproducible bit for bit from run to run.
+constexpr int kC = 32;        // cells per workgroup
+constexpr int kStem = 8;      // lanes per cell for the stem sums
+constexpr int kSlots = 32;    // partial sums per cell for the interior loops
+constexpr int kWin = 384;     // staged bases
+
+struct BppLds {
+  double stem[kC][kStem + 1];
+  double stem2[kC][kStem + 1];
+  double loop[kC][kSlots + 1];
+  int list[kC];
+  int n_list;
+  uint8_t seq[kWin];
+};
+
+// stage s[lo..hi] and return a pointer p with p[x] = s[x] for lo <= x <= hi (the plain pointer if the window is too long)
+__device__ __forceinline__ const uint8_t* stage_seq(const Seq& q, BppLds& sh, int lo, int hi) {
+  if (lo < 0) lo = 0;
+  if (hi > q.L - 1) hi = q.L - 1;
+  if (hi - lo + 1 > kWin) return q.seq;
+  for (int x = lo + (int)threadIdx.x; x <= hi; x += kThreads) sh.seq[x - lo] = q.seq[x];
+  return sh.seq - lo;
+}
+
 __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
+  __shared__ BppLds sh;
   const Seq q = make_seq(a, blockIdx.y);
-  const int d = a.d, lane = threadIdx.x % kLanes;
+  const int d = a.d, tid = threadIdx.x;
   if (d > q.W) return;
-  const int i = blockIdx.x * kCells + threadIdx.x / kLanes;
-  if (i > q.L - d) return;
-  const int j = i + d, L = q.L, W = q.W;
+  const int i0 = blockIdx.x * kC;
+  if (i0 > q.L - d) return;
+  const int W = q.W, L = q.L;
+  const int nc = (kC < L - d - i0 + 1) ? kC : L - d - i0 + 1;
+  const uint8_t* sq = stage_seq(q, sh, i0 - 1, i0 + nc - 1 + d);
+  if (tid < 64) {      // the cells with interior loops (E cells whose closing pair is allowed)
+    const int i = i0 + tid;
+    const bool e = tid < nc && i > 0 && d + 2 <= W && q.pair_ok(i - 1, d + 2);
+    const unsigned long long m = __ballot(e);
+    if (e) sh.list[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+    if (tid == 0) sh.n_list = __popcll(m);
+  }
+  __syncthreads();
+  // rule 2, factorised: the stems (k, j) that end at j and start behind i + dmin[i]
+  {
+    const int ci = tid / kStem, ln = tid % kStem;
+    double A = 0.;
+    if (ci < nc) {
+      const int i = i0 + ci, j = i + d, dmi = q.dmin[i];
+      if (dmi > 0 && dmi < d)
+        for (int sp = 1 + ln; sp <= d - dmi; sp += kStem)
+          if (q.pair_ok(j - sp, sp)) A = fma(q.in(BP_1, d - sp, i), q.in(BP_P, sp, j - sp) * q.x(XW_ML, q.cell(j - sp, sp)), A);
+      sh.stem[ci][ln] = A;
+    }
+  }
+  // rule 6c, inside set: inner pairs (k, l), i <= k, l <= j, (k-i) + (j-l) <= C, (k,l) != (i,j); slots take the left ends k
+  {
+    const EnergyTables& et = *a.et;
+    const int nE = sh.n_list, amax = (q.C < d - 2) ? q.C : d - 2;
+    for (int w = tid; w < nE * kSlots; w += kThreads) {
+      const int ci = sh.list[w / kSlots], slot = w % kSlots;
+      const int i = i0 + ci, j = i + d;
+      double HE = 0.;
+      for (int da = slot; da <= amax; da += kSlots) {
+        const int k = i + da;
+        const int lmin = (k + 2 > j - (q.C - da)) ? k + 2 : j - (q.C - da);
+        for_bits(q.ok, k * (W + 1), lmin - k, (j - k < W) ? j - k : W, [&](int sp) {
+          const int l = k + sp;
+          if (da == 0 && l == j) return;
+          const double tsc = a.no_ene ? 0. : loop_energy(et, sq, i - 1, j, k, l - 1);
+          if (tsc == ELEMDP_NEG_INF) return;
+          HE = fma(q.in(BP_P, sp, k), exp(tsc), HE);
+        });
+      }
+      sh.loop[ci][slot] = HE;
+    }
+  }
+  __syncthreads();
+  if (tid >= nc) return;
+  const int i = i0 + tid, j = i + d;
   const bool pok = q.pair_ok(i, d), lok = q.left_ok(i, d), mok = q.m_ok(i, d, a.m_min);
   const bool eok = i > 0 && d + 2 <= W && q.pair_ok(i - 1, d + 2);
   const int dmi = q.dmin[i];
-  // rule 2, factorised: the stems (k, j) that end at j and start behind i + dmin[i]
-  double A = 0.;
-  if (dmi > 0 && dmi < d)
-    for (int sp = 1 + lane; sp <= d - dmi; sp += kLanes)
-      if (q.pair_ok(j - sp, sp)) A = fma(q.in(BP_1, d - sp, i), q.in(BP_P, sp, j - sp) * q.x(XW_ML, q.cell(j - sp, sp)), A);
-  A = group_sum(A);
-  // rule 6c, inside set: inner pairs (k, l), i <= k, l <= j, (k-i) + (j-l) <= C, (k,l) != (i,j); lanes take the left ends k
-  double HE = 0.;
-  if (eok) {
-    const EnergyTables& et = *a.et;
-    const int amax = (q.C < d - 2) ? q.C : d - 2;
-    for (int da = lane; da <= amax; da += kLanes) {
-      const int k = i + da;
-      const int lmin = (k + 2 > j - (q.C - da)) ? k + 2 : j - (q.C - da);
-      for_bits(q.ok, k * (W + 1), lmin - k, (j - k < W) ? j - k : W, [&](int sp) {
-        const int l = k + sp;
-        if (da == 0 && l == j) return;
-        const double tsc = a.no_ene ? 0. : loop_energy(et, q.seq, i - 1, j, k, l - 1);
-        if (tsc == ELEMDP_NEG_INF) return;
-        HE = fma(q.in(BP_P, sp, k), exp(tsc), HE);
-      });
-    }
-  }
-  HE = group_sum(HE);
-  if (lane != 0) return;
+  double A = 0., HE = 0.;
+#pragma unroll
+  for (int k = 0; k < kStem; ++k) A += sh.stem[tid][k];
+  if (eok)
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) HE += sh.loop[tid][k];
   if (dmi > 0 && dmi < d) A += q.in(BP_A, d - 1, i);      // the tail grows by the unpaired base j-1
   const int c = q.cell(i, d), c_up = eok ? q.cell(i - 1, d + 2) : c;
   double vP = 0.;
@@ -175,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
   const double vE = eok ? fma(vM, q.x(XW_CLOSE, c_up), q.x(XW_HP, c_up) + HE) : 0.;                       // rules 6a, 6b (L = 1), 6c
   q.in(BP_P, d, i) = vP; q.in(BP_E, d, i) = vE; q.in(BP_M, d, i) = vM; q.in(BP_B, d, i) = vB;
   q.in(BP_1, d, i) = v1; q.in(BP_2, d, i) = v2; q.in(BP_A, d, i) = A;
-  (void)L;
+  (void)j;
 }
 
 // ---- exterior chains in log space, one wave per sequence: ln O(j) (rules 7, 8) and ln outO(i) - ln Z
@@ -240,45 +287,82 @@ __global__ __launch_bounds__(64) void k6_out_ext(BppLinArgs a) {
 
 // ---- outside, diagonal d (values divided by Z)
 __global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
+  __shared__ BppLds sh;
   const Seq q = make_seq(a, blockIdx.y);
-  const int d = a.d, lane = threadIdx.x % kLanes;
+  const int d = a.d, tid = threadIdx.x;
   if (d > q.W) return;
-  const int i = blockIdx.x * kCells + threadIdx.x / kLanes;
-  if (i > q.L - d) return;
-  const int j = i + d, L = q.L, W = q.W;
+  const int i0 = blockIdx.x * kC;
+  if (i0 > q.L - d) return;
+  const int W = q.W, L = q.L;
+  const int nc = (kC < L - d - i0 + 1) ? kC : L - d - i0 + 1;
+  const uint8_t* sq = stage_seq(q, sh, i0 - q.C - 2, i0 + nc + W);
+  if (tid < 64) {      // the stems P(i,j) that occur: they collect the interior loops around them
+    const int i = i0 + tid;
+    const bool e = tid < nc && q.pair_ok(i, d) && q.in(BP_P, d, i) != 0.;
+    const unsigned long long m = __ballot(e);
+    if (e) sh.list[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+    if (tid == 0) sh.n_list = __popcll(m);
+  }
+  __syncthreads();
+  {
+    const int ci = tid / kStem, ln = tid % kStem;
+    if (ci < nc) {
+      const int i = i0 + ci, j = i + d;
+      // H1: 1(i,j) under B(i,l) through a stem (j, l) that starts at j
+      double H1 = 0.;
+      if (q.left_ok(i, d) && q.in(BP_1, d, i) != 0.) {
+        const int hi = (W - d < L - j) ? W - d : L - j;
+        for (int sp = 1 + ln; sp <= hi; sp += kStem)
+          if (q.pair_ok(j, sp)) H1 = fma(q.out(BO_A, d + sp, i), q.in(BP_P, sp, j) * q.x(XW_ML, q.cell(j, sp)), H1);
+      }
+      sh.stem[ci][ln] = H1;
+      // HA: what reaches 2(i,j) through rule 2 (taken by the stem P(i,j) only)
+      double HA = 0.;
+      if (q.pair_ok(i, d)) {
+        const int bmax = (W - d < i) ? W - d : i;
+        for (int b = 1 + ln; b <= bmax; b += kStem) HA = fma(q.out(BO_A, d + b, i - b), q.in(BP_1, b, i - b), HA);
+      }
+      sh.stem2[ci][ln] = HA;
+    }
+  }
+  // HP: the interior loops around the stem; slots take the left ends of the outer cells
+  {
+    const EnergyTables& et = *a.et;
+    const int nP = sh.n_list;
+    for (int w = tid; w < nP * kSlots; w += kThreads) {
+      const int ci = sh.list[w / kSlots], slot = w % kSlots;
+      const int i = i0 + ci, j = i + d;
+      const int amax = (q.C < i - 1) ? q.C : i - 1;      // outside set: k - i' <= C; closing pair starts at i' - 1 >= 0
+      double HP = 0.;
+      for (int da = slot; da <= amax; da += kSlots) {
+        const int io = i - da;                            // outer E cell (io, jo), closing pair cell (io - 1, jo - io + 2)
+        const int hi = (W < L - io + 1) ? W : L - io + 1;   // (the reference's outside set does not bound jo - j)
+        for_bits(q.ok, (io - 1) * (W + 1), j - io + 2, hi, [&](int spc) {
+          const int jo = io + spc - 2;
+          if (da == 0 && jo == j) return;
+          const double tsc = a.no_ene ? 0. : loop_energy(et, sq, io - 1, jo, i, j - 1);
+          if (tsc == ELEMDP_NEG_INF) return;
+          HP = fma(q.out(BO_E, jo - io, io), exp(tsc), HP);
+        });
+      }
+      sh.loop[ci][slot] = HP;
+    }
+  }
+  __syncthreads();
+  if (tid >= nc) return;
+  const int i = i0 + tid, j = i + d;
   const bool pok = q.pair_ok(i, d), lok = q.left_ok(i, d), mok = q.m_ok(i, d, a.m_min);
   const bool up_ok = i > 0 && d + 2 <= W && q.pair_ok(i - 1, d + 2);
   const double inP = q.in(BP_P, d, i), inA = q.in(BP_A, d, i), in1 = q.in(BP_1, d, i);
-  // H1: 1(i,j) under B(i,l) through a stem (j, l) that starts at j
-  double H1 = 0.;
-  if (lok && in1 != 0.) {
-    const int hi = (W - d < L - j) ? W - d : L - j;
-    for (int sp = 1 + lane; sp <= hi; sp += kLanes)
-      if (q.pair_ok(j, sp)) H1 = fma(q.out(BO_A, d + sp, i), q.in(BP_P, sp, j) * q.x(XW_ML, q.cell(j, sp)), H1);
-  }
-  H1 = group_sum(H1);
-  // HA: what reaches 2(i,j) through rule 2 (taken by the stem P(i,j) only), and HP: the interior loops around the stem
-  double HA = 0., HP = 0.;
+  double H1 = 0., HA = 0., HP = 0.;
+#pragma unroll
+  for (int k = 0; k < kStem; ++k) H1 += sh.stem[tid][k];
   if (pok && inP != 0.) {
-    const int bmax = (W - d < i) ? W - d : i;
-    for (int b = 1 + lane; b <= bmax; b += kLanes) HA = fma(q.out(BO_A, d + b, i - b), q.in(BP_1, b, i - b), HA);
-    const EnergyTables& et = *a.et;
-    const int amax = (q.C < i - 1) ? q.C : i - 1;      // outside set: k - i' <= C; closing pair starts at i' - 1 >= 0
-    for (int da = lane; da <= amax; da += kLanes) {
-      const int io = i - da;                            // outer E cell (io, jo), closing pair cell (io - 1, jo - io + 2)
-      const int hi = (W < L - io + 1) ? W : L - io + 1;
-      for_bits(q.ok, (io - 1) * (W + 1), j - io + 2, hi, [&](int spc) {
-        const int jo = io + spc - 2;
-        if (da == 0 && jo == j) return;
-        const double tsc = a.no_ene ? 0. : loop_energy(et, q.seq, io - 1, jo, i, j - 1);
-        if (tsc == ELEMDP_NEG_INF) return;
-        HP = fma(q.out(BO_E, jo - io, io), exp(tsc), HP);
-      });
-    }
+#pragma unroll
+    for (int k = 0; k < kStem; ++k) HA += sh.stem2[tid][k];
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) HP += sh.loop[tid][k];
   }
-  HA = group_sum(HA);
-  HP = group_sum(HP);
-  if (lane != 0) return;
   const double inE = q.in(BP_E, d, i), inM = q.in(BP_M, d, i), inB = q.in(BP_B, d, i), in2 = q.in(BP_2, d, i);
   const int c = q.cell(i, d), c_up = up_ok ? q.cell(i - 1, d + 2) : c;
   const double opP = up_ok ? q.out(BO_P, d + 2, i - 1) : 0.;
@@ -346,7 +430,7 @@ hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hip
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) break;
     a.d = d;
-    hipLaunchKernelGGL(k6_in, dim3((ncell + kCells - 1) / kCells, G), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(k6_in, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), 0, st, a);
   }
   hipLaunchKernelGGL(k6_in_ext, dim3(G), dim3(64), 0, st, a);
   hipLaunchKernelGGL(k6_out_ext, dim3(G), dim3(64), 0, st, a);
@@ -354,7 +438,7 @@ hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hip
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) continue;
     a.d = d;
-    hipLaunchKernelGGL(k6_out, dim3((ncell + kCells - 1) / kCells, G), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(k6_out, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), 0, st, a);
   }
   hipLaunchKernelGGL(k6_threshold, dim3(G), dim3(kThreads), 0, st, a);
   return hipGetLastError();
