@@ -26,7 +26,7 @@ struct GpuSink {
   double* post_[3];  // LDS: log-space position posteriors (start, inner, end) or null
   double eh0, eh1;   // lane-private energy statistics
   __device__ __forceinline__ void en(int idx, double w) { atomicAdd(&en_[idx], w); }
-  __device__ __forceinline__ void eh(int k, double w) { if (k) eh1 += w; else eh0 += w; }
+  __device__ __forceinline__ void eh(int k, double w) { eh1 += k ? w : 0.; eh0 += k ? 0. : w; }   // (selects keep the sink in registers)
   __device__ __forceinline__ void pos(int which, int p, double z) { if (post_[which]) lse_atomic(&post_[which][p], z); }
 };
 
