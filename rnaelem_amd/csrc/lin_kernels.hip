@@ -26,7 +26,7 @@
 #define ELEMDP_LB_IN 4
 #endif
 #ifndef ELEMDP_LB_OUT
-#define ELEMDP_LB_OUT 3
+#define ELEMDP_LB_OUT 4
 #endif
 #ifndef ELEMDP_CPB_MAX
 #define ELEMDP_CPB_MAX 64
@@ -36,6 +36,12 @@
 #endif
 #ifndef ELEMDP_KIB
 #define ELEMDP_KIB 4
+#endif
+#ifndef ELEMDP_RECIN
+#define ELEMDP_RECIN 1024
+#endif
+#ifndef ELEMDP_RECOUT
+#define ELEMDP_RECOUT 2560
 #endif
 #include "kernels.h"
 #include "lin_rules.h"
@@ -50,21 +56,14 @@ struct LinSink {
   double* en_;
   double eh0, eh1;
   // merged schedule: the lane works in world 1 (the shadow copy of (0,0) = the "no motif" pass) -- its statistics go to the
-  // second set of accumulators; ehs*: energy statistics of world 1 from a lane that serves both worlds (item phase)
+  // second set of accumulators
   int world = 0;
-  double ehm0 = 0., ehm1 = 0., ehs0 = 0., ehs1 = 0.;   // world 0 / world 1 sums of a phase whose lanes serve both worlds
-  // (selects, not branches: a branch per accumulator becomes a pointer to one of the fields, and the whole sink then lives
-  // in scratch memory -- 96 B per lane, a memory round trip per statistic and 21 MB of HBM writes per sequence)
-  __device__ __forceinline__ void eh_mixed(bool w1, int k, double w) {
-    ehs1 += (w1 && k) ? w : 0.;
-    ehs0 += (w1 && !k) ? w : 0.;
-    ehm1 += (!w1 && k) ? w : 0.;
-    ehm0 += (!w1 && !k) ? w : 0.;
-  }
   double* pos0 = nullptr;   // scan: per-sequence position posteriors (global memory, linear): start, inner, end
   double* pos1 = nullptr;
   double* pos2 = nullptr;
   __device__ __forceinline__ void en(int idx, double w) { atomicAdd(&en_[idx], w); }
+  // (selects, not branches: a branch per accumulator becomes a pointer to one of the fields, and the whole sink then lives
+  // in scratch memory -- 96 B per lane, a memory round trip per statistic and 21 MB of HBM writes per sequence)
   __device__ __forceinline__ void eh(int k, double w) { eh1 += k ? w : 0.; eh0 += k ? 0. : w; }
   __device__ __forceinline__ void pos(int which, int p, double w) {
     double* a = (which == 0) ? pos0 : (which == 1) ? pos1 : pos2;
@@ -231,7 +230,7 @@ struct BlockLds {
   int lin, ews, ints, dm, cnts, pre, base, blob, bits, bits2, dmin16, seq8, unp8, total;   // byte offsets
 };
 // LDS doubles of the item-record area of k4_in / k5_cyk (one role) and of k4_out (three roles)
-constexpr int kRecIn = 1024, kRecOut = 2560;
+constexpr int kRecIn = ELEMDP_RECIN, kRecOut = ELEMDP_RECOUT;
 // Walks the set bits bit0 + n, n in [lo, hi], of a pair mask (ascending): next() returns n, or -1 at the end.
 struct BitIter {
   const uint32_t* m;
@@ -837,13 +836,13 @@ __device__ __forceinline__ void lflush(const LinArgs& a, const LViews& v, const 
                                        int nthreads) {
   // l_en: [worlds][n_theta], l_eh: [worlds][2]
   const int nw = pi.merged ? 2 : 1;
-  const double e0 = wave_sum((sink.world == 0 ? sink.eh0 : 0.) + sink.ehm0), e1 = wave_sum((sink.world == 0 ? sink.eh1 : 0.) + sink.ehm1);
+  const double e0 = wave_sum(sink.world == 0 ? sink.eh0 : 0.), e1 = wave_sum(sink.world == 0 ? sink.eh1 : 0.);
   if ((threadIdx.x & 63) == 0) {
     if (e0 != 0.) atomicAdd(&l_eh[0], e0);
     if (e1 != 0.) atomicAdd(&l_eh[1], e1);
   }
   if (pi.merged) {
-    const double f0 = wave_sum((sink.world == 1 ? sink.eh0 : 0.) + sink.ehs0), f1 = wave_sum((sink.world == 1 ? sink.eh1 : 0.) + sink.ehs1);
+    const double f0 = wave_sum(sink.world == 1 ? sink.eh0 : 0.), f1 = wave_sum(sink.world == 1 ? sink.eh1 : 0.);
     if ((threadIdx.x & 63) == 0) {
       if (f0 != 0.) atomicAdd(&l_eh[2], f0);
       if (f1 != 0.) atomicAdd(&l_eh[3], f1);
@@ -1089,6 +1088,9 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     LoopItem* r_it = reinterpret_cast<LoopItem*>(sOB1);
     double* r_xw = reinterpret_cast<double*>(r_it + cap);
     int* r_meta = reinterpret_cast<int*>(r_xw + 2 * cap);
+    // energy statistics of rule 6c: a lane serves both worlds here, so [world][stack / other] sums of their own, added to
+    // the workgroup's before the unary phase (four accumulators less across it)
+    double ew[4] = {0., 0., 0., 0.};
     for (int p0 = 0; p0 < n_rec; p0 += cap) {
       const int np = (cap < n_rec - p0) ? cap : n_rec - p0;
       for (int x = tid; x < np; x += kThreads) {
@@ -1147,12 +1149,24 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           atomicAdd(&hp[hidx[u]], term);
           if (MODE == OUT_TRAIN && par[u] >= 0) {
             const bool w1 = pi.merged && par[u] == A.shadow;
-            sink.eh_mixed(w1, v.m.eh_index(par[u]), it[u].tsc * term * (aux[u] * (w1 ? pi.invZs : pi.invZ)));
+            const int k = v.m.eh_index(par[u]);
+            const double w = it[u].tsc * term * (aux[u] * (w1 ? pi.invZs : pi.invZ));
+            ew[0] += (!w1 && !k) ? w : 0.;
+            ew[1] += (!w1 && k) ? w : 0.;
+            ew[2] += (w1 && !k) ? w : 0.;
+            ew[3] += (w1 && k) ? w : 0.;
           }
         }
       }
       __syncthreads();
       pc.mark<9>();
+    }
+    if (MODE == OUT_TRAIN && n_rec > 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double e = wave_sum(ew[k]);
+        if ((tid & 63) == 0 && e != 0.) atomicAdd(&l_eh[k], e);
+      }
     }
   }
   pc.mark<10>();
