@@ -366,7 +366,13 @@ ELEMDP_HD double heavy_loop(const ModelView& m, const SeqView& q, const TableVie
   return a.value();
 }
 
-constexpr int kUnary = 3;  // unary transition lists hold at most 3 entries (edges h, h-1, h-2); longer lists fall back to a loop
+#ifndef ELEMDP_KUNARY
+#define ELEMDP_KUNARY 2
+#endif
+// Parent values fetched ahead per unary transition list (complete lists hold up to 3 entries: edges h, h-1, h-2; the lists
+// pruned to complete parses rarely more than 2); longer lists continue in a loop.  2 instead of 3: k4_in needs 78 instead
+// of 94 vector registers = six workgroups per CU instead of five (+6 % on the whole evaluation).
+constexpr int kUnary = ELEMDP_KUNARY;
 
 // Computes and stores P,E,M,B,1,2,L of target (i, d, s) given the heavy sums HB (= B) and HE.
 // All short-range operands (diagonals d-1, d-2) are fetched first, with fixed unrolling, so that the
