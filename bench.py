@@ -127,7 +127,7 @@ class ScanSecondary:
                 "workload": "%d synthetic RNAs L=%d, pattern %s (S=%d), W=%d C=%d" % (n, self.L, self.pattern, eng.n_state, MAX_SPAN, MAX_ILOOP)}
 
 
-def minibatch_secondary(api, synth, device, n=2000, L=200, iters=12):
+def minibatch_secondary(api, synth, device, n=2000, L=200, iters=40):
     """The reference's default training mode (`elem train`: mini-batches of 64 records + their shuffled negatives, Adam):
     wall time per optimizer iteration, load_batch included (every iteration loads its batch)."""
     from rnaelem_amd import train
@@ -138,7 +138,7 @@ def minibatch_secondary(api, synth, device, n=2000, L=200, iters=12):
     ev = train.MiniBatches(seqs, quals, 64, None, kmer_shuf=2, engines=[eng, eng2])   # (as rnaelem_amd.cli does)
     x0 = eng.initial_params(0.0)
     rho = train.regularisation(len(x0), 0.1, 0.1)
-    train.minimize_adam(ev, x0, rho, max_iter=3)
+    train.minimize_adam(ev, x0, rho, max_iter=6)      # (buffers of both engines at their final sizes)
     t0 = time.perf_counter()
     train.minimize_adam(ev, x0, rho, max_iter=iters)
     dt = time.perf_counter() - t0
