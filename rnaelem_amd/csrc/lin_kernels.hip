@@ -278,6 +278,9 @@ __host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int wi
   return b;
 }
 struct BlockCtx { int* dm; int* cnts; int* pre; int* base; };
+// accumulator / staging doubles of k4_out: four heavy sums per (cell, state), the statistics of the two worlds, the position
+// posteriors of the scan over the window of positions the workgroup touches (start + inner, or end), the item records
+__host__ __device__ inline int out_doubles(int CS, int nt, int win) { return 4 * CS + 2 * nt + 4 + 2 * win + kRecOut; }
 // ints of the automaton blob a band kernel stages: everything (n_stage = n_ints) means the small part plus the run of
 // tuple lists of its direction (PART 0: inside, 1: outside); otherwise only the small part
 __host__ __device__ inline int staged_ints(const AutomatonLayout& L, int n_stage, int part) {
@@ -971,19 +974,26 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* hl = hp + CS;
   double* l_en = hl + CS;                      // [2 worlds][n_theta]
   double* l_eh = l_en + 2 * nt;                // [2 worlds][2]
-  double* sOB1 = l_eh + 4;                     // item records of the three roles (kRecOut doubles)
-  const BlockLds BL = block_lds(4 * CS + 2 * nt + 4 + kRecOut, cpb, kLinEth + nt, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb);
+  double* l_pos = l_eh + 4;                    // scan: [2][win] position posteriors of the window (start, inner | end, -)
+  const int win = cpb + a.wmax + 3;
+  double* sOB1 = l_pos + 2 * win;              // item records of the three roles (kRecOut doubles)
+  const BlockLds BL = block_lds(out_doubles(CS, nt, cpb + a.wmax + 3), cpb, kLinEth + nt, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb);
   const BlockCtx cx = stage_context<BIG, 1>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   if (pi.skip) return;   // (tested here: the loads behind `pi` travel with those of the context instead of before them)
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
-  for (int t = tid; t < 4 * CS + 2 * nt + 4; t += kThreads) lds[t] = 0.;
+  const int n_zero = 4 * CS + 2 * nt + 4 + ((MODE == OUT_SCAN || MODE == OUT_END) ? 2 * win : 0);
+  for (int t = tid; t < n_zero; t += kThreads) lds[t] = 0.;
   __syncthreads();
   pc.mark<5>();
   LinSink sink;
   sink.en_ = l_en;
   sink.eh0 = sink.eh1 = 0.;
-  scan_sink<MODE>(a, v, sink);
+  // scan: the position posteriors of this workgroup-diagonal are summed in LDS over the window of positions it touches
+  // ([p0, p0 + win): i0-1 .. i0+nc+d, the window of the staged context) and added to the sequence's arrays once at the end
+  const int pos_p0 = (i0 > 0) ? i0 - 1 : 0;
+  if (MODE == OUT_SCAN) { sink.pos0 = l_pos - pos_p0; sink.pos1 = l_pos + win - pos_p0; }
+  if (MODE == OUT_END) sink.pos2 = l_pos - pos_p0;
   const TableView& in = v.in;
   const TableView& out = v.out;
   const int nq = (a.dbg & 2) ? 0 : A.n_quad;
@@ -1198,6 +1208,19 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     sink.en_ = en_keep;
   }
   pc.mark<11>();
+  if (MODE == OUT_SCAN || MODE == OUT_END) {
+    __syncthreads();
+    const int p1 = (i0 + nc + d < L) ? i0 + nc + d : L;   // inclusive
+    for (int t = tid; t <= p1 - pos_p0; t += kThreads) {
+      const double v0 = l_pos[t], v1 = l_pos[win + t];
+      if (MODE == OUT_SCAN) {
+        if (v0 != 0. && pos_p0 + t < L) atomicAdd(&a.pos_start[v.seq_base + pos_p0 + t], v0);
+        if (v1 != 0. && pos_p0 + t < L) atomicAdd(&a.pos_inner[v.seq_base + pos_p0 + t], v1);
+      } else if (v0 != 0.) {
+        atomicAdd(&a.pos_end[v.pos_base + pos_p0 + t], v0);
+      }
+    }
+  }
   if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, kThreads);
   pc.mark<12>();
   pc.finish();
@@ -1521,7 +1544,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   a.pass = 0;
   a.scan = 1;
   const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
-  const size_t lds_out = block_lds(4 * a.cpb * S + 2 * nt + 4 + kRecOut, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
+  const size_t lds_out = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
@@ -1587,7 +1610,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   // pattern's states, the "no motif" terminal on the shadow of (0,0), each with its own Z and statistics (lpass).
   // schedule 0: the reference's two sweeps, (ari, nasi) then the label's mask.
   const int n_pass = (a.schedule == 1 || first_pass_only) ? 1 : 2;
-  const size_t lds_b = block_lds(4 * a.cpb * S + 2 * nt + 4 + kRecOut, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
+  const size_t lds_b = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
   for (int pass = 0; pass < n_pass; ++pass) {
     LinArgs b = a;
     b.pass = pass;
