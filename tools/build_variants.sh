@@ -1,10 +1,13 @@
 #!/bin/bash
-# builds library variants build/var/lib_<name>.so from "name:flags" arguments (timed on the GPU by tools/try_variants.sh)
+# builds library variants build/var/lib_<name>.so from "name:flags" arguments (timed on the GPU by tools/try_variants.sh);
+# a flag -O<x> replaces the default -O3
 cd "$(dirname "$0")/../rnaelem_amd/csrc"
 mkdir -p ../../build/var && rm -f ../../build/var/lib_*.so
 for v in "$@"; do
   n=${v%%:*}; f=${v#*:}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics $f kernels.hip train_kernels.hip lin_kernels.hip bpp_kernels.hip engine.cpp automaton.cpp energy_tables.cpp -o ../../build/var/lib_$n.so -ldl 2>/dev/null &
+  opt=-O3
+  case "$f" in *-O2*) opt=-O2; f=${f/-O2/};; *-Os*) opt=-Os; f=${f/-Os/};; esac
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 $opt -std=c++17 -fPIC -shared -munsafe-fp-atomics $f kernels.hip train_kernels.hip lin_kernels.hip bpp_kernels.hip engine.cpp automaton.cpp energy_tables.cpp -o ../../build/var/lib_$n.so -ldl 2>/dev/null &
 done
 wait
 ls ../../build/var
