@@ -284,12 +284,17 @@ class Engine {
   int device_ = -1, n_cu_ = 256;   // device_ < 0: no HIP device (host-only handle)
   hipStream_t st_ = nullptr;
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipStream_t st2_ = nullptr;                 // second outside pass of the linear pipeline (launch_lin_group)
   hipEvent_t ev2_[2] = {nullptr, nullptr};
   bool opt_two_streams_ = true;
   // groups evaluated concurrently (run_lin_batch, scan): stream k of gs_ (gs_[0] = st_) with its second-pass stream gs2_[k]
   static constexpr int kMaxGroupStreams = 4;
-  hipStream_t gs_[kMaxGroupStreams] = {nullptr, nullptr, nullptr, nullptr}, gs2_[kMaxGroupStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t gs_[kMaxGroupStreams] = {nullptr, nullptr, nullptr, nullptr};
+  // (created when first used: the runtime deals its few hardware queues to streams in the order they are made, and two
+  // handles that evaluate and load at the same time -- the mini-batch trainer -- must not end up sharing one)
+  void need_group_streams(int ns) {
+    for (int k = 1; k < ns && k < kMaxGroupStreams; ++k)
+      if (!gs_[k]) HIP_OK(hipStreamCreateWithFlags(&gs_[k], hipStreamNonBlocking));
+  }
   hipEvent_t gev_[kMaxGroupStreams][2] = {}, gdone_[kMaxGroupStreams] = {}, gstart_ = nullptr;
   int opt_group_streams_ = 2;
   DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_, d_lay_, d_lay0_, d_layr_, d_intsr_;
@@ -413,12 +418,7 @@ void Engine::init_device() {
   HIP_OK(hipGetDeviceProperties(&prop, device_));
   n_cu_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_OK(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
-  gs_[0] = st_; gs2_[0] = st2_;
-  for (int k = 1; k < kMaxGroupStreams; ++k) {
-    HIP_OK(hipStreamCreateWithFlags(&gs_[k], hipStreamNonBlocking));
-    HIP_OK(hipStreamCreateWithFlags(&gs2_[k], hipStreamNonBlocking));
-  }
+  gs_[0] = st_;
   for (int k = 0; k < kMaxGroupStreams; ++k) {
     if (k) for (auto& e : gev_[k]) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&gdone_[k], hipEventDisableTiming));
@@ -474,12 +474,10 @@ Engine::~Engine() {
   if (st_) (void)hipStreamSynchronize(st_);
   for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
   for (auto& e : ev2_) if (e) (void)hipEventDestroy(e);
-  if (st2_) (void)hipStreamDestroy(st2_);
   for (int k = 0; k < kMaxGroupStreams; ++k) {
     if (k) for (auto& e : gev_[k]) if (e) (void)hipEventDestroy(e);
     if (gdone_[k]) (void)hipEventDestroy(gdone_[k]);
     if (k && gs_[k]) (void)hipStreamDestroy(gs_[k]);
-    if (k && gs2_[k]) (void)hipStreamDestroy(gs2_[k]);
   }
   if (gstart_) (void)hipEventDestroy(gstart_);
   if (st_) (void)hipStreamDestroy(st_);
@@ -1304,6 +1302,7 @@ void Engine::run_lin_batch() {
     x.a_in += k * x.a_stride; x.a_out += k * x.a_stride;
     return x;
   };
+  need_group_streams(ns);
   if (ns > 1) {   // the other streams start behind the weights
     HIP_OK(hipEventRecord(gstart_, st_));
     for (int k = 1; k < ns; ++k) HIP_OK(hipStreamWaitEvent(gs_[k], gstart_, 0));
@@ -1606,6 +1605,7 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
     const int slots_each = n_slots_ / ns, tr_each = tr_slots / ns;
     const int n_groups = (n + slots_each - 1) / slots_each;
     const int gsz2 = (ns == 1) ? gsz : (n + n_groups - 1) / n_groups;
+    need_group_streams(ns);
     if (ns > 1) {
       HIP_OK(hipEventRecord(gstart_, st_));
       for (int k = 1; k < ns; ++k) HIP_OK(hipStreamWaitEvent(gs_[k], gstart_, 0));
