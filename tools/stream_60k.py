@@ -14,7 +14,7 @@ t0 = time.time()
 eng.load_batch(seqs, quals)
 print("load_batch %.2f s" % (time.time() - t0), flush=True)
 x = eng.initial_params(1.0)
-for rep in range(2):
+for rep in range(int(os.environ.get("STREAM_REPS", "2"))):
     t0 = time.time()
     fn, gr, eff, nsk = eng.train_eval(x)
     dt = time.time() - t0
