@@ -121,11 +121,14 @@ __global__ __launch_bounds__(kThreads) void k6_terms(BppLinArgs a) {
 // ---- the diagonal kernels: kC consecutive cells per workgroup.  The heavy sums are spread over the lanes as (cell, slot)
 // work items -- interior loops only for the cells that have them (a third of the cells; the list is compacted with a
 // ballot), slot = left end of the inner / outer pair -- and every partial sum has its own LDS word, added up in a fixed
-// order by the cell's lane: the filter is reproducible bit for bit from run to run.
+// order by the cell's lane: the filter is reproducible bit for bit from run to run.  The bases, the first-pair spans and the
+// rows of the pair mask the workgroup walks are staged in LDS with one round of loads (a pair test is then an LDS read, not
+// a dependent global load), and candidates are taken four at a time so that their table loads are in flight together.
 constexpr int kC = 32;        // cells per workgroup
 constexpr int kStem = 8;      // lanes per cell for the stem sums
 constexpr int kSlots = 32;    // partial sums per cell for the interior loops
 constexpr int kWin = 384;     // staged bases
+constexpr int kB = 4;         // candidates per batch of loads
 
 struct BppLds {
   double stem[kC][kStem + 1];
@@ -133,8 +136,13 @@ struct BppLds {
   double loop[kC][kSlots + 1];
   int list[kC];
   int n_list;
+  int dmin[kC];
   uint8_t seq[kWin];
 };
+extern __shared__ uint32_t s_bits[];   // mask rows of the workgroup (bpp_mask_words(W) words)
+
+__host__ __device__ inline int bpp_mask_rows(int W) { return kC + W + kMaxLoop + 6; }
+__host__ __device__ inline int bpp_mask_words(int W) { return (bpp_mask_rows(W) * (W + 1) + 31) / 32 + 3; }
 
 // stage s[lo..hi] and return a pointer p with p[x] = s[x] for lo <= x <= hi (the plain pointer if the window is too long)
 __device__ __forceinline__ const uint8_t* stage_seq(const Seq& q, BppLds& sh, int lo, int hi) {
@@ -144,6 +152,50 @@ __device__ __forceinline__ const uint8_t* stage_seq(const Seq& q, BppLds& sh, in
   for (int x = lo + (int)threadIdx.x; x <= hi; x += kThreads) sh.seq[x - lo] = q.seq[x];
   return sh.seq - lo;
 }
+// stage the mask rows [r_lo, r_hi] (clipped to the sequence) and return a pointer m with m[w] = ok[w] for their words
+__device__ __forceinline__ const uint32_t* stage_bits(const Seq& q, int r_lo, int r_hi) {
+  if (r_lo < 0) r_lo = 0;
+  if (r_hi > q.L) r_hi = q.L;
+  const int W1 = q.W + 1;
+  const int w0 = (r_lo * W1) >> 5, w1 = (((r_hi + 1) * W1 + 31) >> 5) + 1;     // [w0, w1)
+  const int wend = (int)((((long long)(q.L + 1) * W1) + 31) >> 5);
+  for (int t = threadIdx.x; t < w1 - w0; t += kThreads) s_bits[t] = (w0 + t < wend) ? q.ok[w0 + t] : 0u;
+  return s_bits - w0;
+}
+struct Mask {
+  const uint32_t* m;
+  int L, W;
+  __device__ __forceinline__ bool ok(int i, int d) const {
+    if (i < 0 || d < 0 || d > W || i + d > L) return false;
+    const int c = i * (W + 1) + d;
+    return (m[c >> 5] >> (c & 31)) & 1u;
+  }
+};
+// walks the set bits bit0 + n, n in [lo, hi], ascending: next() returns n, or -1 at the end
+struct Bits {
+  const uint32_t* m;
+  int bit0, e, w;
+  uint32_t word;
+  __device__ __forceinline__ void init(const uint32_t* mask, int b0, int lo, int hi) {
+    m = mask; bit0 = b0; e = b0 + hi;
+    const int b = b0 + (lo > 0 ? lo : 0);
+    w = b >> 5;
+    word = (hi >= lo && hi >= 0) ? (mask[w] & (~0u << (b & 31))) : 0u;
+    if (hi < lo || hi < 0) e = -1;
+  }
+  __device__ __forceinline__ int next() {
+    for (;;) {
+      if (word) {
+        const int bit = (w << 5) + __builtin_ctz(word);
+        word &= word - 1;
+        if (bit > e) { word = 0u; e = -1; return -1; }
+        return bit - bit0;
+      }
+      if (((w + 1) << 5) > e) return -1;
+      word = m[++w];
+    }
+  }
+};
 
 __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
   __shared__ BppLds sh;
@@ -155,26 +207,43 @@ __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
   const int W = q.W, L = q.L;
   const int nc = (kC < L - d - i0 + 1) ? kC : L - d - i0 + 1;
   const uint8_t* sq = stage_seq(q, sh, i0 - 1, i0 + nc - 1 + d);
+  const Mask mk{stage_bits(q, i0 - 1, i0 + nc - 1 + d), L, W};
+  if (tid < kC) sh.dmin[tid] = (tid < nc) ? q.dmin[i0 + tid] : 0;
+  __syncthreads();
   if (tid < 64) {      // the cells with interior loops (E cells whose closing pair is allowed)
     const int i = i0 + tid;
-    const bool e = tid < nc && i > 0 && d + 2 <= W && q.pair_ok(i - 1, d + 2);
+    const bool e = tid < nc && i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
     const unsigned long long m = __ballot(e);
     if (e) sh.list[__popcll(m & ((1ull << tid) - 1ull))] = tid;
     if (tid == 0) sh.n_list = __popcll(m);
   }
-  __syncthreads();
   // rule 2, factorised: the stems (k, j) that end at j and start behind i + dmin[i]
   {
     const int ci = tid / kStem, ln = tid % kStem;
     double A = 0.;
     if (ci < nc) {
-      const int i = i0 + ci, j = i + d, dmi = q.dmin[i];
-      if (dmi > 0 && dmi < d)
-        for (int sp = 1 + ln; sp <= d - dmi; sp += kStem)
-          if (q.pair_ok(j - sp, sp)) A = fma(q.in(BP_1, d - sp, i), q.in(BP_P, sp, j - sp) * q.x(XW_ML, q.cell(j - sp, sp)), A);
+      const int i = i0 + ci, j = i + d, dmi = sh.dmin[ci];
+      if (dmi > 0 && dmi < d) {
+        const int smax = d - dmi;
+        for (int sp0 = 1 + ln; sp0 <= smax; sp0 += kB * kStem) {
+          double x1[kB], xp[kB], xw[kB];
+          bool on[kB];
+#pragma unroll
+          for (int u = 0; u < kB; ++u) {
+            const int sp = sp0 + u * kStem;
+            on[u] = sp <= smax && mk.ok(j - sp, sp);
+            x1[u] = xp[u] = xw[u] = 0.;
+            if (on[u]) { x1[u] = q.in(BP_1, d - sp, i); xp[u] = q.in(BP_P, sp, j - sp); xw[u] = q.x(XW_ML, q.cell(j - sp, sp)); }
+          }
+#pragma unroll
+          for (int u = 0; u < kB; ++u)
+            if (on[u]) A = fma(x1[u], xp[u] * xw[u], A);
+        }
+      }
       sh.stem[ci][ln] = A;
     }
   }
+  __syncthreads();
   // rule 6c, inside set: inner pairs (k, l), i <= k, l <= j, (k-i) + (j-l) <= C, (k,l) != (i,j); slots take the left ends k
   {
     const EnergyTables& et = *a.et;
@@ -186,13 +255,29 @@ __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
       for (int da = slot; da <= amax; da += kSlots) {
         const int k = i + da;
         const int lmin = (k + 2 > j - (q.C - da)) ? k + 2 : j - (q.C - da);
-        for_bits(q.ok, k * (W + 1), lmin - k, (j - k < W) ? j - k : W, [&](int sp) {
-          const int l = k + sp;
-          if (da == 0 && l == j) return;
-          const double tsc = a.no_ene ? 0. : loop_energy(et, sq, i - 1, j, k, l - 1);
-          if (tsc == ELEMDP_NEG_INF) return;
-          HE = fma(q.in(BP_P, sp, k), exp(tsc), HE);
-        });
+        Bits it;
+        it.init(mk.m, k * (W + 1), lmin - k, (j - k < W) ? j - k : W);
+        for (;;) {
+          int sp[kB];
+          sp[0] = it.next();
+          if (sp[0] < 0) break;
+#pragma unroll
+          for (int u = 1; u < kB; ++u) sp[u] = (sp[u - 1] < 0) ? -1 : it.next();
+          double tsc[kB], pv[kB];
+#pragma unroll
+          for (int u = 0; u < kB; ++u) {
+            const bool on = sp[u] >= 0 && !(da == 0 && k + sp[u] == j);
+            tsc[u] = ELEMDP_NEG_INF; pv[u] = 0.;
+            if (on) {
+              tsc[u] = a.no_ene ? 0. : loop_energy(et, sq, i - 1, j, k, k + sp[u] - 1);
+              pv[u] = q.in(BP_P, sp[u], k);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kB; ++u)
+            if (tsc[u] != ELEMDP_NEG_INF) HE = fma(pv[u], exp(tsc[u]), HE);
+          if (sp[kB - 1] < 0) break;
+        }
       }
       sh.loop[ci][slot] = HE;
     }
@@ -200,9 +285,10 @@ __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
   __syncthreads();
   if (tid >= nc) return;
   const int i = i0 + tid, j = i + d;
-  const bool pok = q.pair_ok(i, d), lok = q.left_ok(i, d), mok = q.m_ok(i, d, a.m_min);
-  const bool eok = i > 0 && d + 2 <= W && q.pair_ok(i - 1, d + 2);
-  const int dmi = q.dmin[i];
+  const int dmi = sh.dmin[tid];
+  auto left_ok = [&](int dd) { return dd <= W && dd >= 0 && i + dd <= L && dmi > 0 && dd >= dmi; };
+  const bool pok = mk.ok(i, d), lok = left_ok(d), mok = q.m_ok(i, d, a.m_min);
+  const bool eok = i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
   double A = 0., HE = 0.;
 #pragma unroll
   for (int k = 0; k < kStem; ++k) A += sh.stem[tid][k];
@@ -214,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
   double vP = 0.;
   if (pok && d >= 2) vP = fma(q.in(BP_P, d - 2, i + 1), q.x(XW_STACK, c), q.in(BP_E, d - 2, i + 1));   // rules 1b, 1a
   const double vB = lok ? A : 0.;
-  const double s2 = (lok && q.left_ok(i, d - 1)) ? q.in(BP_2, d - 1, i) : 0.;                             // rule 3a
+  const double s2 = (lok && left_ok(d - 1)) ? q.in(BP_2, d - 1, i) : 0.;                                  // rule 3a
   const double v2 = lok ? fma(vP, pok ? q.x(XW_ML, c) : 0., s2) : 0.;                                     // rule 3b
   const double v1 = lok ? v2 + vB : 0.;                                                                   // rules 4a, 4b
   const double sM = (mok && q.m_ok(i + 1, d - 1, a.m_min)) ? q.in(BP_M, d - 1, i + 1) : 0.;               // rule 5a
@@ -296,35 +382,52 @@ __global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
   const int W = q.W, L = q.L;
   const int nc = (kC < L - d - i0 + 1) ? kC : L - d - i0 + 1;
   const uint8_t* sq = stage_seq(q, sh, i0 - q.C - 2, i0 + nc + W);
+  const int Cc = (q.C < kMaxLoop) ? q.C : kMaxLoop;
+  const Mask mk{stage_bits(q, i0 - Cc - 2, i0 + nc - 1 + d), L, W};
+  if (tid < kC) sh.dmin[tid] = (tid < nc) ? q.dmin[i0 + tid] : 0;
+  __syncthreads();
   if (tid < 64) {      // the stems P(i,j) that occur: they collect the interior loops around them
     const int i = i0 + tid;
-    const bool e = tid < nc && q.pair_ok(i, d) && q.in(BP_P, d, i) != 0.;
+    const bool e = tid < nc && mk.ok(i, d) && q.in(BP_P, d, i) != 0.;
     const unsigned long long m = __ballot(e);
     if (e) sh.list[__popcll(m & ((1ull << tid) - 1ull))] = tid;
     if (tid == 0) sh.n_list = __popcll(m);
   }
-  __syncthreads();
   {
     const int ci = tid / kStem, ln = tid % kStem;
     if (ci < nc) {
-      const int i = i0 + ci, j = i + d;
-      // H1: 1(i,j) under B(i,l) through a stem (j, l) that starts at j
-      double H1 = 0.;
-      if (q.left_ok(i, d) && q.in(BP_1, d, i) != 0.) {
-        const int hi = (W - d < L - j) ? W - d : L - j;
-        for (int sp = 1 + ln; sp <= hi; sp += kStem)
-          if (q.pair_ok(j, sp)) H1 = fma(q.out(BO_A, d + sp, i), q.in(BP_P, sp, j) * q.x(XW_ML, q.cell(j, sp)), H1);
+      const int i = i0 + ci, j = i + d, dmi = sh.dmin[ci];
+      const bool lok = d <= W && i + d <= L && dmi > 0 && d >= dmi;
+      const bool pok = mk.ok(i, d);
+      const double in1 = lok ? q.in(BP_1, d, i) : 0.;
+      // H1: 1(i,j) under B(i,l) through a stem (j, l) that starts at j;  HA: what reaches 2(i,j) through rule 2 (taken by
+      // the stem P(i,j) only) -- one round of loads for four candidates of each
+      double H1 = 0., HA = 0.;
+      const int hi = (in1 != 0.) ? ((W - d < L - j) ? W - d : L - j) : 0;
+      const int bmax = pok ? ((W - d < i) ? W - d : i) : 0;
+      const int nmax = (hi > bmax) ? hi : bmax;
+      for (int n0 = 1 + ln; n0 <= nmax; n0 += kB * kStem) {
+        double oa[kB], xp[kB], xw[kB], ob[kB], x1[kB];
+        bool on[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int n = n0 + u * kStem;
+          on[u] = n <= hi && mk.ok(j, n);
+          oa[u] = xp[u] = xw[u] = ob[u] = x1[u] = 0.;
+          if (on[u]) { oa[u] = q.out(BO_A, d + n, i); xp[u] = q.in(BP_P, n, j); xw[u] = q.x(XW_ML, q.cell(j, n)); }
+          if (n <= bmax) { ob[u] = q.out(BO_A, d + n, i - n); x1[u] = q.in(BP_1, n, i - n); }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          if (on[u]) H1 = fma(oa[u], xp[u] * xw[u], H1);
+          if (n0 + u * kStem <= bmax) HA = fma(ob[u], x1[u], HA);
+        }
       }
       sh.stem[ci][ln] = H1;
-      // HA: what reaches 2(i,j) through rule 2 (taken by the stem P(i,j) only)
-      double HA = 0.;
-      if (q.pair_ok(i, d)) {
-        const int bmax = (W - d < i) ? W - d : i;
-        for (int b = 1 + ln; b <= bmax; b += kStem) HA = fma(q.out(BO_A, d + b, i - b), q.in(BP_1, b, i - b), HA);
-      }
       sh.stem2[ci][ln] = HA;
     }
   }
+  __syncthreads();
   // HP: the interior loops around the stem; slots take the left ends of the outer cells
   {
     const EnergyTables& et = *a.et;
@@ -332,18 +435,35 @@ __global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
     for (int w = tid; w < nP * kSlots; w += kThreads) {
       const int ci = sh.list[w / kSlots], slot = w % kSlots;
       const int i = i0 + ci, j = i + d;
-      const int amax = (q.C < i - 1) ? q.C : i - 1;      // outside set: k - i' <= C; closing pair starts at i' - 1 >= 0
+      const int amax = (Cc < i - 1) ? Cc : i - 1;        // outside set: k - i' <= C (no loop beyond kMaxLoop); closing pair starts at i' - 1 >= 0
       double HP = 0.;
       for (int da = slot; da <= amax; da += kSlots) {
         const int io = i - da;                            // outer E cell (io, jo), closing pair cell (io - 1, jo - io + 2)
         const int hi = (W < L - io + 1) ? W : L - io + 1;   // (the reference's outside set does not bound jo - j)
-        for_bits(q.ok, (io - 1) * (W + 1), j - io + 2, hi, [&](int spc) {
-          const int jo = io + spc - 2;
-          if (da == 0 && jo == j) return;
-          const double tsc = a.no_ene ? 0. : loop_energy(et, sq, io - 1, jo, i, j - 1);
-          if (tsc == ELEMDP_NEG_INF) return;
-          HP = fma(q.out(BO_E, jo - io, io), exp(tsc), HP);
-        });
+        Bits it;
+        it.init(mk.m, (io - 1) * (W + 1), j - io + 2, hi);
+        for (;;) {
+          int sp[kB];
+          sp[0] = it.next();
+          if (sp[0] < 0) break;
+#pragma unroll
+          for (int u = 1; u < kB; ++u) sp[u] = (sp[u - 1] < 0) ? -1 : it.next();
+          double tsc[kB], ov[kB];
+#pragma unroll
+          for (int u = 0; u < kB; ++u) {
+            const int jo = io + sp[u] - 2;
+            const bool on = sp[u] >= 0 && !(da == 0 && jo == j);
+            tsc[u] = ELEMDP_NEG_INF; ov[u] = 0.;
+            if (on) {
+              tsc[u] = a.no_ene ? 0. : loop_energy(et, sq, io - 1, jo, i, j - 1);
+              ov[u] = q.out(BO_E, jo - io, io);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kB; ++u)
+            if (tsc[u] != ELEMDP_NEG_INF) HP = fma(ov[u], exp(tsc[u]), HP);
+          if (sp[kB - 1] < 0) break;
+        }
       }
       sh.loop[ci][slot] = HP;
     }
@@ -351,12 +471,15 @@ __global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
   __syncthreads();
   if (tid >= nc) return;
   const int i = i0 + tid, j = i + d;
-  const bool pok = q.pair_ok(i, d), lok = q.left_ok(i, d), mok = q.m_ok(i, d, a.m_min);
-  const bool up_ok = i > 0 && d + 2 <= W && q.pair_ok(i - 1, d + 2);
+  const int dmi = sh.dmin[tid];
+  auto left_ok = [&](int dd) { return dd <= W && dd >= 0 && i + dd <= L && dmi > 0 && dd >= dmi; };
+  const bool pok = mk.ok(i, d), lok = left_ok(d), mok = q.m_ok(i, d, a.m_min);
+  const bool up_ok = i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
   const double inP = q.in(BP_P, d, i), inA = q.in(BP_A, d, i), in1 = q.in(BP_1, d, i);
   double H1 = 0., HA = 0., HP = 0.;
+  if (lok && in1 != 0.)
 #pragma unroll
-  for (int k = 0; k < kStem; ++k) H1 += sh.stem[tid][k];
+    for (int k = 0; k < kStem; ++k) H1 += sh.stem[tid][k];
   if (pok && inP != 0.) {
 #pragma unroll
     for (int k = 0; k < kStem; ++k) HA += sh.stem2[tid][k];
@@ -373,7 +496,7 @@ __global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
   const double oM = (inM != 0.) ? fma(oE, up_ok ? q.x(XW_CLOSE, c_up) : 0., sM) : 0.;                        // rule 6a
   const double o1 = (in1 != 0.) ? H1 : 0.;
   const double oB = (inB != 0.) ? (mok ? oM : 0.) + o1 : 0.;                                                 // rules 5b, 4b
-  const bool do2 = lok && q.left_ok(i, d + 1) && j < L;
+  const bool do2 = lok && left_ok(d + 1) && j < L;
   const double s2 = (do2 && in2 != 0.) ? q.out(BO_2, d + 1, i) : 0.;                                         // rule 3a
   const double o2 = (in2 != 0.) ? o1 + s2 : 0.;                                                              // rule 4a (direct part)
   double oP = 0.;
@@ -425,12 +548,13 @@ hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hip
   if (G <= 0) return hipSuccess;
   BppLinArgs a = base;
   const int ncell_max = (Lmax + 1) * (Wmax + 1);
+  const size_t lds_bits = sizeof(uint32_t) * (size_t)bpp_mask_words(Wmax);
   hipLaunchKernelGGL(k6_terms, dim3((ncell_max + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
   for (int d = 0; d <= Wmax; ++d) {
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) break;
     a.d = d;
-    hipLaunchKernelGGL(k6_in, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(k6_in, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), lds_bits, st, a);
   }
   hipLaunchKernelGGL(k6_in_ext, dim3(G), dim3(64), 0, st, a);
   hipLaunchKernelGGL(k6_out_ext, dim3(G), dim3(64), 0, st, a);
@@ -438,7 +562,7 @@ hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hip
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) continue;
     a.d = d;
-    hipLaunchKernelGGL(k6_out, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL(k6_out, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), lds_bits, st, a);
   }
   hipLaunchKernelGGL(k6_threshold, dim3(G), dim3(kThreads), 0, st, a);
   return hipGetLastError();
