@@ -19,9 +19,6 @@
 #ifndef ELEMDP_KCI
 #define ELEMDP_KCI 4
 #endif
-#ifndef ELEMDP_KCO
-#define ELEMDP_KCO 3
-#endif
 #ifndef ELEMDP_LB_IN
 #define ELEMDP_LB_IN 4
 #endif
@@ -30,9 +27,6 @@
 #endif
 #ifndef ELEMDP_CPB_MAX
 #define ELEMDP_CPB_MAX 64
-#endif
-#ifndef ELEMDP_TILE
-#define ELEMDP_TILE 4
 #endif
 #ifndef ELEMDP_KIB
 #define ELEMDP_KIB 4
@@ -388,7 +382,6 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
 // multiplies out of LDS.  Global loads are thereby independent of the tuple structure (every element is fetched
 // once per workgroup, 2*kChunk loads in flight per lane) and the dependent chain per diagonal stays short.
 constexpr int kChunkIn = ELEMDP_KCI;    // split points per staging round, inside  (2 segments each)
-constexpr int kChunkOut = ELEMDP_KCO;   // split points per staging round, outside (4 segments each)
 
 // Which element of a staged operand row a lane copies.  Only the first NU = n_front states of a row can be non-zero in the
 // planes of the bifurcation rule (B, 1, 2) of a complete parse (Automaton::flatten puts them first), so a staged row is
