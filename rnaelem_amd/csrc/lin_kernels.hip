@@ -940,6 +940,36 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, 128);
 }
 
+// ---- rule 7, outside direction: P(i,j,tgt) as a child of the exterior chain = sum over the split entries of tgt of
+// out O(j,par) * in O(i,s2) * exp(lambda_par e_ext(i,j)).  Both chains are complete before the band sweep starts, so the
+// term of every pair cell goes into its (still unwritten) outside P entry by one throughput kernel -- all states, zeros
+// included: the table slot still holds another sequence's values -- and the unary phase of k4_out adds it to its sums
+// (it used to be gathered in k4_out's pair phase: 7 ms of the 145 ms evaluation of 4096 sequences).
+__global__ __launch_bounds__(kThreads) void k4_r7(LinArgs a) {
+  __shared__ AutomatonLayout s_lay;
+  stage_layout(a, &s_lay, kThreads);
+  LViews v(s_lay);
+  make_lviews(a, blockIdx.y, v);
+  __syncthreads();
+  const AutomatonLayout& A = s_lay;
+  const int L = v.q.L, W = v.q.W, S = A.S;
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c >= (L + 1) * (W + 1)) return;
+  const int i = c / (W + 1), d = c - i * (W + 1);
+  if (!v.q.pair_ok(i, d)) return;
+  const int j = i + d;
+  const int32_t* G = v.m.big;
+  const double x0 = xw_cell(v.q, 0, XT_EXT, v.q.cell(i, d)), x1 = xw_cell(v.q, 1, XT_EXT, v.q.cell(i, d));
+  for (int s = 0; s < S; ++s) {
+    double acc = 0.;
+    for (int u = G[A.split2_off + s]; u < G[A.split2_off + s + 1]; ++u) {
+      const int par = G[A.split2_ent + 2 * u], s2i = G[A.split2_ent + 2 * u + 1];
+      acc = fma(v.out.o(j, par), v.in.o(i, s2i) * (lamk(v.m, par) ? x1 : x0), acc);
+    }
+    v.out.at(ST_P, d, i, s) = acc;
+  }
+}
+
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
 template <int MODE, bool BIG>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
@@ -1041,24 +1071,16 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         if (acc != 0.) atomicAdd(&h1[c * S + s1], acc);
       }
     }
-    // HA: the few stem cells of the workgroup, work item = (stem cell, parent row ii = i - b, pair); and the rule-7 term
-    // of their P states (child of the exterior chain: out O(j,par) * in O(i,s2) * exp(lambda e_ext)), work item = (stem
-    // cell, split entry), added to the HP sums -- one round of loads for both
+    // HA: the few stem cells of the workgroup, work item = (stem cell, parent row ii = i - b, pair).  (The rule-7 term of
+    // their P states is already in the table: k4_r7.)
     int n_stem = 0;
     for (int c = 0; c < nc; ++c) n_stem += v.q.pair_ok(i0 + c, d) ? 1 : 0;
     if (n_stem > 0 && !(a.dbg & 1)) {
       const int nb = W - d;                   // b = 1 .. nb: parent span d + b <= W
       const int per = nb * nA;
-      const int nsp7 = A.n_split;
       for (int c = 0; c < nc; ++c) {
-        const int i = i0 + c, j = i + d;
+        const int i = i0 + c;
         if (!v.q.pair_ok(i, d)) continue;
-        if (!(a.dbg & 32))
-          for (int u = tid; u < nsp7; u += kThreads) {
-            const int par = G[A.split2_ent + 2 * u], s2i = G[A.split2_ent + 2 * u + 1], tg = G[A.split2_tgt + u];
-            const double term = out.o(j, par) * (in.o(i, s2i) * xw_cell(v.q, lamk(v.m, par), XT_EXT, v.q.cell(i, d)));
-            if (term != 0.) atomicAdd(&hp[c * S + tg], term);
-          }
         for (int w = tid; w < per; w += kThreads) {
           const int b = 1 + w / nA, p = w - (b - 1) * nA;
           const int ii = i - b;
@@ -1181,6 +1203,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
     HeavyOut H;
     H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
+    if (!(a.dbg & 32) && v.q.pair_ok(i0 + c, d)) H.HP += out.at(ST_P, d, i0 + c, s);   // rule-7 term (k4_r7)
     H.ext_in_hp = true;
     h1[c * S + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
   }
@@ -1556,6 +1579,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
     else hipLaunchKernelGGL((k4_in_ext<false, CON>), dim3(G), dim3(128), 0, st, a);                                              \
     if (stage_ext) hipLaunchKernelGGL((k4_out_ext<MODE, true>), dim3(G), dim3(128), lds_ext_out, st, a);                         \
     else hipLaunchKernelGGL((k4_out_ext<MODE, false>), dim3(G), dim3(128), lds_ext_out, st, a);                                  \
+    hipLaunchKernelGGL(k4_r7, dim3(((Lmax + 1) * (Wmax + 1) + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);           \
     for (int d = Wmax; d >= 0; --d) {                                                                                            \
       const int ncell = Lmax - d + 1;                                                                                            \
       if (ncell <= 0) continue;                                                                                                  \
@@ -1609,7 +1633,8 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
     b.pass = pass;
     if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(2 * nt + 4, kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
     else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), lds_stat, st, b);
-    if (!b.no_rss)
+    if (!b.no_rss) {
+      hipLaunchKernelGGL(k4_r7, dim3(((Lmax + 1) * (Wmax + 1) + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, b);
       for (int d = Wmax; d >= 0; --d) {
         const int ncell = Lmax - d + 1;
         if (ncell <= 0) continue;
@@ -1618,6 +1643,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
         else if (big) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
       }
+    }
   }
   if ((a.schedule == 1 || a.lik_ratio) && !first_pass_only) hipLaunchKernelGGL(k4_combine, dim3(G), dim3(kThreads), 0, st, a, G);
   return hipGetLastError();
