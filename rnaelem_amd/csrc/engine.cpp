@@ -258,6 +258,10 @@ class Engine {
   // (motif_trainer.hpp:124-153 over fastq_io.hpp:132-167) and recomputes the BPP filter in every evaluation, too.
   bool streaming_ = false;
   int st_chunk_ = 0, opt_max_resident_ = 0;
+  // an inner handle of a streamed batch: never streams itself, and its table slots stay inside the share of the device
+  // memory the outer handle left for them (two inner handles: plan + slots of each within 2/5 of the free memory)
+  bool inner_ = false;
+  size_t slot_budget_ = 0, st_slot_budget_ = 0;
   std::vector<uint8_t> st_seq_, st_qual_;
   std::vector<char> st_fix_;
   std::vector<double> st_rows_;                             // [Z(ari,nasi), Z(ari), Z(nasi), f, skipped] per sequence
@@ -269,6 +273,23 @@ class Engine {
   bool should_stream(const int32_t* off, int n);
   void stream_setup(const uint8_t* seq, const int32_t* off, const uint8_t* qual, const int32_t* qoff, const char* fix, int n);
   void stream_load_chunk(int k, Engine& e);
+  // The BPP filter does not depend on the parameters: a streamed batch keeps the filtered pair mask (1.3 KB per sequence of
+  // L = 200) and the kept fractions of every chunk on the host after its first load; later loads of the chunk hand them
+  // to the inner handle, which then skips K1 and only rebuilds the plan.
+  std::vector<std::vector<uint32_t>> st_mask_;
+  std::vector<std::vector<double>> st_eff_;
+  const uint32_t* preset_bits_ = nullptr;   // (consumed by the next load_batch)
+  const double* preset_eff_ = nullptr;
+  size_t preset_words_ = 0;
+  size_t bits_words_ = 0;                   // words of the pair mask of the loaded batch
+  void set_filter_preset(const uint32_t* bits, size_t words, const double* eff) { preset_bits_ = bits; preset_words_ = words; preset_eff_ = eff; }
+  void filter_result(std::vector<uint32_t>& bits, std::vector<double>& eff) {
+    bits.resize(bits_words_);
+    HIP_OK(hipMemcpyAsync(bits.data(), d_okbits1_.as<void>(), sizeof(uint32_t) * bits_words_, hipMemcpyDeviceToHost, st_));
+    HIP_OK(hipStreamSynchronize(st_));
+    eff.resize(h_plans_.size());
+    for (size_t k = 0; k < h_plans_.size(); ++k) eff[k] = h_plans_[k].bpp_eff;
+  }
   void stream_subs();
   template <class Work> void stream_chunks(Work work);
   void stream_train(const double* x, int n_param, void* partial, bool device_ptr, bool reduce);
@@ -502,6 +523,7 @@ void Engine::set_option(const std::string& key, double v) {
     if (has_device_) { DeviceGuard dg(device_); HIP_OK(hipStreamSynchronize(st_)); upload_automaton(); }
   }
   else throw ArgError("unknown option: " + key);
+  for (auto& m : st_mask_) m.clear();                  // (an option may change the filter: cached masks of a streamed batch go)
   opt_log_.emplace_back(key, v);                       // (replayed on the inner engines of a streamed batch)
   for (auto& e : sub_) if (e) e->set_option(key, v);
 }
@@ -652,7 +674,8 @@ void Engine::ensure_slots(int S, bool scan, int n_want) {
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   const size_t held_t = d_band_in_.bytes() + d_band_out_.bytes() + d_ext_in_.bytes() + d_ext_out_.bytes() + d_tmp_.bytes();
   const size_t held_tr = d_tr_band_.bytes() + d_tr_ext_.bytes() + d_tr_stack_.bytes();
-  const size_t budget = (size_t)((double)(free_b + held_t + held_tr) * 0.6);
+  size_t budget = (size_t)((double)(free_b + held_t + held_tr) * 0.6);
+  if (slot_budget_ > 0) budget = std::min(budget, slot_budget_);
   if (per_slot * (size_t)want > budget) want = (int)std::max<size_t>(1, budget / per_slot);
   if (!scan && per_slot * (size_t)want > free_b + held_t) { d_tr_band_.reset(); d_tr_ext_.reset(); d_tr_stack_.reset(); }
   if (per_slot * want > free_b + held_t + held_tr) throw HipError("not enough device memory for one table slot");
@@ -804,7 +827,18 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   h_lnbpp_base_.clear();
 
   const uint32_t* final_bits = d_okbits0_.as<uint32_t>();
-  if (no_rss) {
+  const uint32_t* preset_bits = preset_bits_;
+  const double* preset_eff = preset_eff_;
+  const bool preset = preset_bits && preset_words_ == (size_t)bits_b && !no_rss && !fixmode && min_bpp_ > 0 && !opt_keep_lnbpp_;
+  preset_bits_ = nullptr; preset_eff_ = nullptr; preset_words_ = 0;
+  bits_words_ = (size_t)bits_b;
+  if (preset) {          // the filter's result from an earlier load of the same records (streamed batch)
+    final_bits = d_okbits1_.as<uint32_t>();
+    HIP_OK(hipMemcpyAsync(d_okbits1_.as<void>(), preset_bits, sizeof(uint32_t) * bits_b, hipMemcpyHostToDevice, st_));
+    HIP_OK(hipStreamSynchronize(st_));
+    for (int k = 0; k < n; ++k) h_plans_[k].bpp_eff = preset_eff[k];
+    dbg_lap("load: filtered mask from the cache");
+  } else if (no_rss) {
     HIP_OK(hipMemsetAsync(d_okbits0_.as<void>(), 0, sizeof(uint32_t) * bits_b, st_));
     for (auto& p : h_plans_) p.bpp_eff = 0.;  // em.set_seq is never called in --no-rss mode (motif_model.hpp:57)
   } else if (fixmode) {
@@ -994,6 +1028,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
 
 // ---- streaming --------------------------------------------------------------------------------------------------------
 bool Engine::should_stream(const int32_t* off, int n) {
+  if (inner_) return false;
   if (opt_max_resident_ > 0) return n > opt_max_resident_;
   // resident needs per sequence: plan (terms, CSR offsets, items in four orders, their weights) + its share of the table
   // slots; a batch whose plan alone would take more than half of the free device memory is streamed
@@ -1026,14 +1061,21 @@ void Engine::stream_setup(const uint8_t* seq, const int32_t* off, const uint8_t*
   st_seq_.assign(seq + off[0], seq + off[n]);
   st_qual_.assign(qual + qoff[0], qual + qoff[n]);
   if (fix) st_fix_.assign(fix + off[0], fix + off[n]); else st_fix_.clear();
+  st_slot_budget_ = 0;
   if (opt_max_resident_ > 0) st_chunk_ = opt_max_resident_;
   else {   // two inner engines, each with a fifth of the free memory for its plan
     size_t free_b = 0, total_b = 0;
     HIP_OK(hipMemGetInfo(&free_b, &total_b));
     const double per_seq = cells / n * 600.0;
     st_chunk_ = (int)std::max(256.0, std::min((double)n, 0.2 * (double)free_b / per_seq));
+    st_slot_budget_ = (size_t)(0.2 * (double)free_b);
   }
   st_rows_.clear();
+  {
+    const int nchunks = (n + st_chunk_ - 1) / st_chunk_;
+    st_mask_.assign(nchunks, {});
+    st_eff_.assign(nchunks, {});
+  }
   // (the buffers of an earlier resident batch would only stand in the way of the inner engines)
   for (DevBuf* b : {&d_band_in_, &d_band_out_, &d_ext_in_, &d_ext_out_, &d_tmp_, &d_xwc_, &d_xwi_, &d_a_in_, &d_a_out_, &d_tr_band_, &d_tr_ext_})
     b->reset();
@@ -1044,12 +1086,14 @@ void Engine::stream_setup(const uint8_t* seq, const int32_t* off, const uint8_t*
 
 void Engine::stream_subs() {
   for (auto& e : sub_) {
-    if (e) continue;
+    if (e) { e->slot_budget_ = st_slot_budget_; continue; }
     elemdp_model_desc d = desc_;
     d.pattern = desc_pattern_.c_str();
     d.energy_param = desc_has_par_ ? desc_par_.c_str() : nullptr;
     d.device = device_;
     e.reset(new Engine(d));
+    e->inner_ = true;
+    e->slot_budget_ = st_slot_budget_;
     for (auto const& kv : opt_log_) e->set_option(kv.first, kv.second);
   }
 }
@@ -1059,7 +1103,10 @@ void Engine::stream_load_chunk(int k, Engine& e) {
   std::vector<int32_t> off(c1 - c0 + 1), qoff(c1 - c0 + 1);
   for (int t = c0; t <= c1; ++t) { off[t - c0] = h_seq_off_[t] - h_seq_off_[c0]; qoff[t - c0] = h_qual_off_[t] - h_qual_off_[c0]; }
   const size_t s0 = (size_t)(h_seq_off_[c0] - h_seq_off_[0]), q0 = (size_t)(h_qual_off_[c0] - h_qual_off_[0]);
+  const bool cached = k < (int)st_mask_.size() && !st_mask_[k].empty();
+  if (cached) e.set_filter_preset(st_mask_[k].data(), st_mask_[k].size(), st_eff_[k].data());
   e.load_batch(st_seq_.data() + s0, off.data(), st_qual_.data() + q0, qoff.data(), st_fix_.empty() ? nullptr : st_fix_.data() + s0, c1 - c0);
+  if (!cached && k < (int)st_mask_.size() && st_fix_.empty() && !(flags_ & ELEMDP_NO_RSS) && min_bpp_ > 0) e.filter_result(st_mask_[k], st_eff_[k]);
 }
 
 // work(k, c0, c1, engine): chunk k = sequences [c0, c1) is resident on `engine`; the next chunk loads meanwhile
@@ -1143,7 +1190,8 @@ int Engine::balanced_group(size_t per_slot_bytes) {
   size_t free_b = 0, total_b = 0;
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   const size_t held = d_band_in_.bytes() + d_band_out_.bytes() + d_ext_in_.bytes() + d_ext_out_.bytes();
-  const size_t budget = (size_t)((double)(free_b + held) * 0.55);
+  size_t budget = (size_t)((double)(free_b + held) * 0.55);
+  if (slot_budget_ > 0) budget = std::min(budget, slot_budget_);
   long cap = (long)(budget / std::max<size_t>(per_slot_bytes, 1));
   cap = std::max(1L, std::min(cap, (long)group_cap_));
   const long n_groups = (n_seq_ + cap - 1) / cap;

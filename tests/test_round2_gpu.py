@@ -306,6 +306,8 @@ def test_streamed_batch_gives_the_resident_numbers():
     part = eng.train_partial(x)                  # the partial / finish pair of the multi-GPU path streams, too
     fin = eng.train_finish(part)
     assert fin[0] == pytest.approx(ref[0], rel=1e-11)
+    np.testing.assert_allclose(fin[1], ref[1], rtol=1e-11, atol=1e-11)     # (second pass over the chunks: the filter's masks
+    np.testing.assert_array_equal(eng.bpp_eff(), ref_eff)                  #  and kept fractions come from the cache)
     recs, en = eng.scan(x)
     for a, b in zip(recs, ref_recs):
         assert (a["Ys"], a["Ye"], a["rss"]) == (b["Ys"], b["Ye"], b["rss"]) and list(a["psihat"]) == list(b["psihat"])
