@@ -1071,23 +1071,38 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         if (acc != 0.) atomicAdd(&h1[c * S + s1], acc);
       }
     }
-    // HA: the few stem cells of the workgroup, work item = (stem cell, parent row ii = i - b, pair).  (The rule-7 term of
-    // their P states is already in the table: k4_r7.)
-    int n_stem = 0;
-    for (int c = 0; c < nc; ++c) n_stem += v.q.pair_ok(i0 + c, d) ? 1 : 0;
-    if (n_stem > 0 && !(a.dbg & 1)) {
+    // HA: the few stem cells of the workgroup, work item = (stem cell, parent row ii = i - b, pair) over ALL of them as one
+    // flat list, four work items' loads in flight per lane (a loop per stem cell was three to four dependent round trips for
+    // each of them).  (The rule-7 term of their P states is already in the table: k4_r7.)
+    unsigned long long stems = 0;             // bit c: cell c of the workgroup is a pair (cpb <= 64)
+    for (int c = 0; c < nc; ++c) stems |= v.q.pair_ok(i0 + c, d) ? (1ull << c) : 0ull;
+    if (stems && !(a.dbg & 1)) {
       const int nb = W - d;                   // b = 1 .. nb: parent span d + b <= W
-      const int per = nb * nA;
-      for (int c = 0; c < nc; ++c) {
-        const int i = i0 + c;
-        if (!v.q.pair_ok(i, d)) continue;
-        for (int w = tid; w < per; w += kThreads) {
-          const int b = 1 + w / nA, p = w - (b - 1) * nA;
-          const int ii = i - b;
-          if (ii < 0) continue;
+      const int per = nb * nA, total = __popcll(stems) * per;
+      constexpr int kHA = 4;
+      for (int w0 = tid; w0 < total; w0 += kHA * kThreads) {
+        double oa[kHA], x1[kHA];
+        int hidx[kHA];
+#pragma unroll
+        for (int u = 0; u < kHA; ++u) {
+          const int w = w0 + u * kThreads;
+          const bool valid = w < total;
+          const int sc = valid ? w / per : 0, r = valid ? w - sc * per : 0;
+          unsigned long long m = stems;
+          for (int k = 0; k < sc; ++k) m &= m - 1;          // the sc-th stem cell
+          const int c = __builtin_ctzll(m);
+          const int b = 1 + r / nA, p = r - (b - 1) * nA;
+          const int ii = i0 + c - b;
+          const bool ok = valid && ii >= 0;
           const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];   // (1(ii, i, .) is 0 where it is not parsable)
-          const double term = out.a(d + b, ii, p) * IB[in.idx(ST_1, b, ii, s1)];
-          if (term != 0.) atomicAdd(&h2[c * S + t], term);
+          oa[u] = ok ? out.a(d + b, ii, p) : 0.;
+          x1[u] = ok ? IB[in.idx(ST_1, b, ii, s1)] : 0.;
+          hidx[u] = c * S + t;
+        }
+#pragma unroll
+        for (int u = 0; u < kHA; ++u) {
+          const double term = oa[u] * x1[u];
+          if (term != 0.) atomicAdd(&h2[hidx[u]], term);
         }
       }
     }
