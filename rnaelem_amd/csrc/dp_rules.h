@@ -373,6 +373,11 @@ ELEMDP_HD double heavy_loop(const ModelView& m, const SeqView& q, const TableVie
 // pruned to complete parses rarely more than 2); longer lists continue in a loop.  2 instead of 3: k4_in needs 78 instead
 // of 94 vector registers = six workgroups per CU instead of five (+6 % on the whole evaluation).
 constexpr int kUnary = ELEMDP_KUNARY;
+#ifndef ELEMDP_KUNARYR
+#define ELEMDP_KUNARYR ELEMDP_KUNARY
+#endif
+// (the right-unpaired lists are the ones that keep a third entry after pruning: their own prefetch depth, scaled-linear rules)
+constexpr int kUnaryR = ELEMDP_KUNARYR;
 
 // Computes and stores P,E,M,B,1,2,L of target (i, d, s) given the heavy sums HB (= B) and HE.
 // All short-range operands (diagonals d-1, d-2) are fetched first, with fixed unrolling, so that the

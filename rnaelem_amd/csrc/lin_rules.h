@@ -164,28 +164,30 @@ ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const 
   const int pr = j > 0 ? j - 1 : 0;   // position emitted on the right
   double sL = 0., s2 = 0., sP = 0., sM = 0.;
 #pragma unroll
-  for (int u = 0; u < kUnary; ++u) {
+  for (int u = 0; u < kUnaryR; ++u) {
     const bool vr = u < nR;
     const int s1 = vr ? I[A.right_ent + 2 * (r0 + u)] : 0, tfr = vr ? I[A.right_ent + 2 * (r0 + u) + 1] : 0;
-    const bool vp = u < nP;
-    const int sp = vp ? I[A.pair_ent + 2 * (p0 + u)] : 0, tfp = vp ? I[A.pair_ent + 2 * (p0 + u) + 1] : 0;
-    const bool vl = u < nL;
-    const int sl = vl ? I[A.left_ent + 2 * (l0 + u)] : 0, tfl = vl ? I[A.left_ent + 2 * (l0 + u) + 1] : 0;
     const double tL = T.at(ST_L, d1, i, s1), t2 = T.at(ST_2, d1, i, s1);
-    const double tE = T.at(ST_E, d2, i1, sp), tP = T.at(ST_P, d2, i1, sp);
-    const double tM = T.at(ST_M, d1, i1, sl);
     const bool okr = vr && (!CON || allow_right(m, con, q.L, j, s, s1));
-    const bool okp = vp && pok && (!CON || allow_pair(m, con, q.L, i, j, s, sp));
-    const bool okl = vl && doM && (!CON || allow_left(m, con, i, s, sl));
     const double wr = (okr && d > 0) ? lw_right(m, q, s, tfr, pr) : 0.;
-    const double wp = okp ? lw_pair(m, q, s, sp, tfp, i, pr) : 0.;
-    const double wl = okl ? lw_left(m, q, sl, tfl, i) : 0.;
     sL += (doL && okr) ? tL * wr : 0.;
     s2 += (do2 && okr) ? t2 * wr : 0.;
-    sP += okp ? wp * fma(tP, xst, tE) : 0.;
-    sM += okl ? tM * wl : 0.;
+    if (u < kUnary) {
+      const bool vp = u < nP;
+      const int sp = vp ? I[A.pair_ent + 2 * (p0 + u)] : 0, tfp = vp ? I[A.pair_ent + 2 * (p0 + u) + 1] : 0;
+      const bool vl = u < nL;
+      const int sl = vl ? I[A.left_ent + 2 * (l0 + u)] : 0, tfl = vl ? I[A.left_ent + 2 * (l0 + u) + 1] : 0;
+      const double tE = T.at(ST_E, d2, i1, sp), tP = T.at(ST_P, d2, i1, sp);
+      const double tM = T.at(ST_M, d1, i1, sl);
+      const bool okp = vp && pok && (!CON || allow_pair(m, con, q.L, i, j, s, sp));
+      const bool okl = vl && doM && (!CON || allow_left(m, con, i, s, sl));
+      const double wp = okp ? lw_pair(m, q, s, sp, tfp, i, pr) : 0.;
+      const double wl = okl ? lw_left(m, q, sl, tfl, i) : 0.;
+      sP += okp ? wp * fma(tP, xst, tE) : 0.;
+      sM += okl ? tM * wl : 0.;
+    }
   }
-  for (int u = kUnary; u < nR; ++u) {
+  for (int u = kUnaryR; u < nR; ++u) {
     const int s1 = I[A.right_ent + 2 * (r0 + u)], tf = I[A.right_ent + 2 * (r0 + u) + 1];
     if (CON && !allow_right(m, con, q.L, j, s, s1)) continue;
     const double wr = lw_right(m, q, s, tf, pr);
@@ -617,15 +619,18 @@ ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, c
     sL += tL;
   };
 #pragma unroll
-  for (int u = 0; u < kUnary; ++u) {
-    const bool vp = u < nRP, vl = u < nRL, vr = u < nRR;
-    const int par_p = vp ? I[A.rpair_ent + 2 * (rp0 + u)] : 0, tf_p = vp ? I[A.rpair_ent + 2 * (rp0 + u) + 1] : 0;
-    const int par_l = vl ? I[A.rleft_ent + 2 * (rl0 + u)] : 0, tf_l = vl ? I[A.rleft_ent + 2 * (rl0 + u) + 1] : 0;
+  for (int u = 0; u < kUnaryR; ++u) {
+    const bool vr = u < nRR;
     const int par_r = vr ? I[A.rright_ent + 2 * (rr0 + u)] : 0, tf_r = vr ? I[A.rright_ent + 2 * (rr0 + u) + 1] : 0;
-    const double opP = out.at(ST_P, dp2, im1, par_p), opM = out.at(ST_M, dp1, im1, par_l);
     const double op2 = out.at(ST_2, dp1, i, par_r), opL = out.at(ST_L, dp1, i, par_r);
-    if (vp && (aE || aP)) step_pair(par_p, tf_p, opP);
-    if (vl && aM) step_left(par_l, tf_l, opM);
+    if (u < kUnary) {
+      const bool vp = u < nRP, vl = u < nRL;
+      const int par_p = vp ? I[A.rpair_ent + 2 * (rp0 + u)] : 0, tf_p = vp ? I[A.rpair_ent + 2 * (rp0 + u) + 1] : 0;
+      const int par_l = vl ? I[A.rleft_ent + 2 * (rl0 + u)] : 0, tf_l = vl ? I[A.rleft_ent + 2 * (rl0 + u) + 1] : 0;
+      const double opP = out.at(ST_P, dp2, im1, par_p), opM = out.at(ST_M, dp1, im1, par_l);
+      if (vp && (aE || aP)) step_pair(par_p, tf_p, opP);
+      if (vl && aM) step_left(par_l, tf_l, opM);
+    }
     if (vr && (a2 || aL)) step_right(par_r, tf_r, op2, opL);
   }
   if (aE || aP)
@@ -639,7 +644,7 @@ ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, c
       step_left(par, I[A.rleft_ent + 2 * (rl0 + u) + 1], out.at(ST_M, d + 1, i - 1, par));
     }
   if (a2 || aL)
-    for (int u = kUnary; u < nRR; ++u) {
+    for (int u = kUnaryR; u < nRR; ++u) {
       const int par = I[A.rright_ent + 2 * (rr0 + u)];
       step_right(par, I[A.rright_ent + 2 * (rr0 + u) + 1], out.at(ST_2, d + 1, i, par), out.at(ST_L, d + 1, i, par));
     }
