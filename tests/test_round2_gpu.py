@@ -352,3 +352,31 @@ def test_linear_bpp_filter_equals_the_log_space_filter_and_the_oracle():
     kept, ln = eng.pairs(0, with_lnbpp=True)
     assert np.array_equal(kept, kept_o) and eng.bpp_eff()[0] == eff_o
     assert_log_close(ln, ln_o, rtol=1e-9, atol=1e-9, what="lnbpp, L = 1500")
+
+
+@pytest.mark.parametrize("W,C", [(20, 5), (50, 12), (100, 30), (255, 30), (33, 0)])
+def test_bpp_filter_kernels_on_odd_shapes_against_the_oracle(W, C):
+    """The filter kernels stage mask rows / bases / first-pair spans of a workgroup in LDS and take candidates four at a time:
+    band widths from 20 to 255 (the linear range), interior loops capped at 0 .. 30, lengths around the workgroup's 32 cells
+    and the band width, N bases, one batch -- kept sets and kept fractions exact, ln BPP to 1e-9 against the oracle."""
+    rng = np.random.default_rng(1000 * W + C)
+    lens = [1, 2, 6, 31, 32, 33, 64, 65, W - 1, W, W + 1, W + 34, 2 * W + 7, 180]
+    seqs, quals = [], []
+    for k, L in enumerate(lens):
+        (s_,), (q_,) = synth.synth_batch(1, max(1, L), seed=int(rng.integers(1 << 30)))
+        if k % 3 == 0 and L > 8:
+            s_ = s_.copy()
+            s_[rng.integers(0, L, size=max(1, L // 15))] = 0          # N
+        seqs.append(s_)
+        quals.append(q_)
+    eng = api.Engine("(.)", "~T2004~", W, C, 1e-4)
+    eng.set_option("keep_lnbpp", 1)
+    eng.load_batch(seqs, quals)
+    o = po.make_oracle("(.)", W, C, min_bpp=1e-4)
+    eff = eng.bpp_eff()
+    for k, s_ in enumerate(seqs):
+        ln_o, kept_o, eff_o, _ = o.bpp(s_)
+        kept, ln = eng.pairs(k, with_lnbpp=True)
+        assert np.array_equal(kept, kept_o), (k, len(s_))
+        assert eff[k] == eff_o or (np.isnan(eff[k]) and np.isnan(eff_o))     # (no canonical pair at all: 0 / 0 in both)
+        assert_log_close(ln, ln_o, rtol=1e-9, atol=1e-9, what="lnbpp L=%d" % len(s_))
