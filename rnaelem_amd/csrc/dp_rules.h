@@ -188,7 +188,9 @@ struct TableView {
     return (((uint32_t)e * (uint32_t)(W + 1) + (uint32_t)d) * (uint32_t)(L + 1) + (uint32_t)i) * (uint32_t)S + (uint32_t)s;
   }
   ELEMDP_HD double& at(int e, int d, int i, int s) const { return band[idx(e, d, i, s)]; }
-  ELEMDP_HD double& o(int j, int s) const { return ext[(uint32_t)j * (uint32_t)S + (uint32_t)s]; }
+  // (omask: the exterior-chain kernels keep the last rows of the chain in an LDS ring of a power-of-two number of rows)
+  uint32_t omask = 0xffffffffu;
+  ELEMDP_HD double& o(int j, int s) const { return ext[((uint32_t)j & omask) * (uint32_t)S + (uint32_t)s]; }
   // pair table of the factorised rule 2 (scaled-linear pipeline, lin_rules.h): [d][i][p], p < nA pairs (s1, t)
   double* ap = nullptr;
   int32_t nA = 0;

@@ -711,6 +711,16 @@ __host__ __device__ inline ExtLds ext_lds(int nd, int n_lin, int Lmax, int nword
   b.total = o + 8;
   return b;
 }
+// The exterior-chain kernels read the chain's own last W+1 rows at every step: those live in an LDS ring of a power-of-two
+// number of rows (TableView::omask) beside the global table -- a step then waits for the band rows of its pairs only, not
+// for the row the previous step has just stored.  0: the ring would not fit beside the staged context (wide bands, long
+// sequences), the chain is read from global.  nd0: the kernel's own doubles in front (statistics).
+__host__ __device__ inline int ext_ring_rows(int Wmax) { int r = 2; while (r < Wmax + 2) r <<= 1; return r; }
+__host__ __device__ inline int ext_ring_doubles(int nd0, int Wmax, int S, int n_lin, int Lmax, int nword, int n_stage) {
+  const long long n = (long long)ext_ring_rows(Wmax) * S;
+  if (S > 128 || n * 8 > 48 * 1024) return 0;
+  return ext_lds(nd0 + (int)n, n_lin, Lmax, nword, n_stage).total <= 64 * 1024 ? (int)n : 0;
+}
 template <bool STAGE>
 __device__ __forceinline__ void stage_ext_context(const LinArgs& a, LViews& v, unsigned char* raw, int nd, int nthr = 128) {
   if (!STAGE) return;
@@ -750,9 +760,16 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   stage_layout(a, &s_lay, 128);
   LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
-  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_ext), 0);
+  const int n_ring = STAGE ? ext_ring_doubles(0, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
+  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_ext), n_ring);
   const int S = a.lay.n_active, tid = threadIdx.x, L = v.q.L;
-  for (int s = tid; s < S; s += 128) v.in.o(0, s) = (s == a.lay.s00 || s == a.lay.shadow) ? 1. : 0.;   // (the shadow of (0,0) starts like it)
+  TableView Tr = v.in;      // the chain's rows through the LDS ring
+  if (n_ring > 0) { Tr.ext = l_ext; Tr.omask = (uint32_t)ext_ring_rows(a.wmax) - 1u; }
+  for (int s = tid; s < S; s += 128) {
+    const double o0 = (s == a.lay.s00 || s == a.lay.shadow) ? 1. : 0.;   // (the shadow of (0,0) starts like it)
+    v.in.o(0, s) = o0;
+    if (n_ring > 0) Tr.o(0, s) = o0;
+  }
   __syncthreads();
   // lanes = (part, state): the pairs ending at j are dealt to nparts lanes per state, the partial sums meet in LDS
   __shared__ double s_part[128];
@@ -761,12 +778,13 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
   for (int j = 1; j <= L; ++j) {
     if (S <= 128) {
-      if (part < nparts) s_part[tid] = lin_inside_ext_part<CON>(v.m, v.q, v.in, j, ps, con, part, nparts);
+      if (part < nparts) s_part[tid] = lin_inside_ext_part<CON>(v.m, v.q, Tr, j, ps, con, part, nparts);
       __syncthreads();
       if (tid < S) {
         double t = 0.;
         for (int k = 0; k < nparts; ++k) t += s_part[k * S + tid];
         v.in.o(j, tid) = t;
+        if (n_ring > 0) Tr.o(j, tid) = t;
       }
     } else {
       for (int s = tid; s < S; s += 128) lin_inside_ext_target<CON>(v.m, v.q, v.in, j, s, con);
@@ -899,8 +917,11 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   make_lviews(a, blockIdx.x, v);
   const LPass pi = lpass(a, v);
   if (pi.skip) return;
-  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), 2 * a.lay.n_theta + 4);
+  const int n_ring = STAGE ? ext_ring_doubles(2 * a.lay.n_theta + 4, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
+  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), 2 * a.lay.n_theta + 4 + n_ring);
   const int S = a.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
+  TableView Or = v.out;     // the chain's rows through the LDS ring
+  if (n_ring > 0) { Or.ext = l_stat + 2 * nt + 4; Or.omask = (uint32_t)ext_ring_rows(a.wmax) - 1u; }
   double* l_en = l_stat;
   double* l_eh = l_stat + 2 * nt;
   for (int t = tid; t < 2 * nt + 4; t += 128) l_stat[t] = 0.;
@@ -914,13 +935,14 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   sink.en_ = l_en + (shadow_lane ? nt : 0);
   sink.eh0 = sink.eh1 = 0.;
   scan_sink<MODE>(a, v, sink);
-  LinOutCtx<LinSink> x{v.m, v.q, v.in, v.out, shadow_lane ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
+  LinOutCtx<LinSink> x{v.m, v.q, v.in, Or, shadow_lane ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
   for (int s = tid; s < S; s += 128) {
     double t = 0.;
     if (pi.nasi && s == a.lay.s00) t = 1.;
     if (pi.ari && (s == a.lay.s0m1 || s == a.lay.s0m2)) t = 1.;
     if (pi.merged && s == a.lay.shadow) t = 1.;
     v.out.o(v.q.L, s) = t;
+    if (n_ring > 0) Or.o(v.q.L, s) = t;
   }
   __syncthreads();
   for (int i = v.q.L - 1; i >= 0; --i) {
@@ -931,6 +953,7 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
         double t = 0.;
         for (int k = 0; k < nparts; ++k) t += s_part[k * S + tid];
         v.out.o(i, tid) = t;
+        if (n_ring > 0) Or.o(i, tid) = t;
       }
     } else {
       for (int s = tid; s < S; s += 128) lin_outside_ext_target<MODE>(x, i, s);
@@ -1578,8 +1601,8 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   const size_t lds_out = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
-  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
-  const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
+  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
+  const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4 + ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
 #define ELEMDP_SCAN_PASS(CON, MODE)                                                                                              \
   do {                                                                                                                           \
     for (int d = 0; d <= Wmax; ++d) {                                                                                            \
@@ -1635,7 +1658,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
     }
   a.lmax = Lmax;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
-  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
+  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
   if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, false>), dim3(G), dim3(128), lds_ext_in, st, a);
   else hipLaunchKernelGGL((k4_in_ext<false, false>), dim3(G), dim3(128), 0, st, a);
   // schedule 1 (automaton with the shadow state): ONE outside sweep carries both passes -- the "has motif" terminals on the
@@ -1646,7 +1669,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   for (int pass = 0; pass < n_pass; ++pass) {
     LinArgs b = a;
     b.pass = pass;
-    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(2 * nt + 4, kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
+    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(2 * nt + 4 + ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, b.nword_max, b.n_stage), kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
     else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), lds_stat, st, b);
     if (!b.no_rss) {
       hipLaunchKernelGGL(k4_r7, dim3(((Lmax + 1) * (Wmax + 1) + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, b);

@@ -245,8 +245,7 @@ ELEMDP_HD double lin_inside_ext_part(const ModelView& m, const SeqView& q, const
   for (int i = j - 1 - part; i >= i0; i -= nparts) {
     const int d = j - i;
     if (!q.pair_ok(i, d)) continue;
-    const double xe = xw_cell(q, kl, XT_EXT, q.cell(i, d));
-    if (xe == 0.) continue;
+    const double xe = xw_cell(q, kl, XT_EXT, q.cell(i, d));   // (0 where the term is log 0; travels with the rows below)
     double b = 0.;
     for (int u = G[A.split_off + s]; u < G[A.split_off + s + 1]; ++u)
       b = fma(T.o(i, G[A.split_ent + 2 * u]), T.at(ST_P, d, i, G[A.split_ent + 2 * u + 1]), b);
@@ -393,8 +392,7 @@ template <int MODE, class Sink> ELEMDP_HD double lin_outside_ext_part(LinOutCtx<
     const int d = j - i;
     if (!q.pair_ok(i, d)) continue;
     const int c = q.cell(i, d);
-    const double t = q.e_ext[c];
-    if (t == ELEMDP_NEG_INF) continue;
+    const double t = q.e_ext[c];      // (log 0: both weights below are 0, the terms vanish and take no statistic)
     const double x0 = xw_cell(q, 0, XT_EXT, c), x1 = xw_cell(q, 1, XT_EXT, c);
     for (int u = G[A.split1_off + s]; u < G[A.split1_off + s + 1]; ++u) {
       const int par = G[A.split1_ent + 2 * u], s1 = G[A.split1_ent + 2 * u + 1];
