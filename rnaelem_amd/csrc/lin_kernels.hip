@@ -714,7 +714,9 @@ __host__ __device__ inline ExtLds ext_lds(int nd, int n_lin, int Lmax, int nword
 // The exterior-chain kernels read the chain's own last W+1 rows at every step: those live in an LDS ring of a power-of-two
 // number of rows (TableView::omask) beside the global table -- a step then waits for the band rows of its pairs only, not
 // for the row the previous step has just stored.  0: the ring would not fit beside the staged context (wide bands, long
-// sequences), the chain is read from global.  nd0: the kernel's own doubles in front (statistics).
+// sequences), the chain is read from global.  nd0: the kernel's own doubles in front (statistics).  Only for groups whose
+// workgroups are all resident anyway (LinArgs::ext_ring): the ring halves the workgroups a CU holds, and a large group
+// then takes two rounds of them (k4_in_ext +46 % at 3 333 sequences per launch, -7 % at 64).
 __host__ __device__ inline int ext_ring_rows(int Wmax) { int r = 2; while (r < Wmax + 2) r <<= 1; return r; }
 __host__ __device__ inline int ext_ring_doubles(int nd0, int Wmax, int S, int n_lin, int Lmax, int nword, int n_stage) {
   const long long n = (long long)ext_ring_rows(Wmax) * S;
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   stage_layout(a, &s_lay, 128);
   LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
-  const int n_ring = STAGE ? ext_ring_doubles(0, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
+  const int n_ring = (STAGE && a.ext_ring) ? ext_ring_doubles(0, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
   stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_ext), n_ring);
   const int S = a.lay.n_active, tid = threadIdx.x, L = v.q.L;
   TableView Tr = v.in;      // the chain's rows through the LDS ring
@@ -917,7 +919,7 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   make_lviews(a, blockIdx.x, v);
   const LPass pi = lpass(a, v);
   if (pi.skip) return;
-  const int n_ring = STAGE ? ext_ring_doubles(2 * a.lay.n_theta + 4, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
+  const int n_ring = (STAGE && a.ext_ring) ? ext_ring_doubles(2 * a.lay.n_theta + 4, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
   stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), 2 * a.lay.n_theta + 4 + n_ring);
   const int S = a.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
   TableView Or = v.out;     // the chain's rows through the LDS ring
@@ -1566,6 +1568,7 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   a.cpb = kThreads / S;
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
+  a.ext_ring = G <= 1024 ? 1 : 0;
   a.lmax = Lmax;
   const size_t lds = block_lds(3 * a.cpb * S + 2 * kChunkIn * kThreads, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
@@ -1593,6 +1596,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   a.cpb = kThreads / S;
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
+  a.ext_ring = G <= 1024 ? 1 : 0;
   a.lmax = Lmax;
   a.schedule = 0;   // terminals (ari, nasi), Z = Z(ari,nasi): pass 0 of the reference schedule
   a.pass = 0;
@@ -1601,8 +1605,8 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   const size_t lds_out = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
-  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
-  const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4 + ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
+  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds((a.ext_ring ? ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
+  const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4 + (a.ext_ring ? ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
 #define ELEMDP_SCAN_PASS(CON, MODE)                                                                                              \
   do {                                                                                                                           \
     for (int d = 0; d <= Wmax; ++d) {                                                                                            \
@@ -1645,6 +1649,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   a.cpb = kThreads / S;
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
+  a.ext_ring = G <= 1024 ? 1 : 0;
   const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const size_t lds_stat = sizeof(double) * (2 * nt + 4);
@@ -1658,7 +1663,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
     }
   a.lmax = Lmax;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
-  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds(ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
+  const size_t lds_ext_in = stage_ext ? (size_t)ext_lds((a.ext_ring ? ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
   if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, false>), dim3(G), dim3(128), lds_ext_in, st, a);
   else hipLaunchKernelGGL((k4_in_ext<false, false>), dim3(G), dim3(128), 0, st, a);
   // schedule 1 (automaton with the shadow state): ONE outside sweep carries both passes -- the "has motif" terminals on the
@@ -1669,7 +1674,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   for (int pass = 0; pass < n_pass; ++pass) {
     LinArgs b = a;
     b.pass = pass;
-    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(2 * nt + 4 + ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, b.nword_max, b.n_stage), kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
+    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(2 * nt + 4 + (b.ext_ring ? ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, b.nword_max, b.n_stage) : 0), kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
     else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), lds_stat, st, b);
     if (!b.no_rss) {
       hipLaunchKernelGGL(k4_r7, dim3(((Lmax + 1) * (Wmax + 1) + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, b);
