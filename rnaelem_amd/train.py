@@ -176,21 +176,24 @@ class MiniBatches:
         return s1 + negs, q1 + [np.r_[np.zeros(len(s), dtype=np.uint8), np.uint8(1)] for s in negs]
 
     def _prefetch(self, slot):
+        """the next evaluation's batch: reader, negatives and load_batch, all on a thread of their own (the reader and the
+        shuffles draw from the process-global rand() of the reference: one thread at a time, in the reference's order)"""
         import threading
-        s1, q1, c = self._next_batch()
-        sa, qa = self._with_negatives(s1, q1, c) if self.k is not None else (s1, q1)
         eng = self.engines[slot]
         box = {}
 
         def work():
             try:
+                s1, q1, c = self._next_batch()
+                sa, qa = self._with_negatives(s1, q1, c) if self.k is not None else (s1, q1)
+                box.update(s1=s1, q1=q1, c=c)
                 eng.load_batch(sa, qa)
             except Exception as e:      # re-raised by the evaluation that needs the batch
                 box["error"] = e
 
         th = threading.Thread(target=work)
         th.start()
-        return dict(thread=th, box=box, s1=s1, q1=q1, c=c, slot=slot)
+        return dict(thread=th, box=box, slot=slot)
 
     def finish(self):
         """waits for the batch that was prefetched for an evaluation that never came (call before the engines go away)"""
@@ -205,6 +208,7 @@ class MiniBatches:
         cur["thread"].join()
         if "error" in cur["box"]:
             raise cur["box"]["error"]
+        cur.update(cur["box"])
         self._pending = self._prefetch(1 - cur["slot"])       # the next batch loads while this one is evaluated
         eng, n_rec = self.engines[cur["slot"]], len(cur["s1"])
         fn, gr, eff, nsk = eng.train_eval(x)
@@ -214,6 +218,7 @@ class MiniBatches:
         if not np.any(skipped[:n_rec]):
             return fn, gr, float(eng.bpp_eff()[:n_rec].sum()), nsk
         # a record was skipped: its negative must be left out -- the two-step evaluation on the same engine
+        self._pending["thread"].join()       # (the shuffles below and the prefetch thread's share one rand())
         eng.load_batch(cur["s1"], cur["q1"])
         fn, gr, eff, nsk = eng.train_eval(x)
         sk = eng.seq_stats()[:, 4] != 0
