@@ -380,3 +380,19 @@ def test_bpp_filter_kernels_on_odd_shapes_against_the_oracle(W, C):
         assert np.array_equal(kept, kept_o), (k, len(s_))
         assert eff[k] == eff_o or (np.isnan(eff[k]) and np.isnan(eff_o))     # (no canonical pair at all: 0 / 0 in both)
         assert_log_close(ln, ln_o, rtol=1e-9, atol=1e-9, what="lnbpp L=%d" % len(s_))
+
+
+def test_wide_band_against_the_oracle():
+    """max_span = 300 (six times the default band): the LDS windows of the band kernels, the pair-mask rows of the filter
+    and the exterior-chain staging all scale with the span.  fn / gr of two sequences of L = 330 against the oracle."""
+    W = 300
+    eng = api.Engine("((.*.))", "~T2004~", W, 30, 1e-4, 0.1, 0, 0)
+    seqs, quals = synth.synth_batch(2, 330, seed=11)
+    quals[1][-1] = 5
+    eng.load_batch(seqs, quals)
+    x = eng.initial_params(1.0)
+    fn, gr, eff, nsk = eng.train_eval(x)
+    o = po.make_oracle("((.*.))", W, 30, min_bpp=1e-4, tau=0.1)
+    fo, go, eo, no = o.train_eval(x, seqs, quals)
+    assert nsk == no and fn == pytest.approx(fo, rel=1e-9) and eff == pytest.approx(eo, rel=1e-12)
+    np.testing.assert_allclose(gr, go, rtol=1e-7, atol=1e-7)
