@@ -674,7 +674,7 @@ void Engine::ensure_slots(int S, bool scan, int n_want) {
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   const size_t held_t = d_band_in_.bytes() + d_band_out_.bytes() + d_ext_in_.bytes() + d_ext_out_.bytes() + d_tmp_.bytes();
   const size_t held_tr = d_tr_band_.bytes() + d_tr_ext_.bytes() + d_tr_stack_.bytes();
-  size_t budget = (size_t)((double)(free_b + held_t + held_tr) * 0.6);
+  size_t budget = (size_t)((double)(free_b + held_t + held_tr) * 0.72);
   if (slot_budget_ > 0) budget = std::min(budget, slot_budget_);
   if (per_slot * (size_t)want > budget) want = (int)std::max<size_t>(1, budget / per_slot);
   if (!scan && per_slot * (size_t)want > free_b + held_t) { d_tr_band_.reset(); d_tr_ext_.reset(); d_tr_stack_.reset(); }
@@ -1190,7 +1190,7 @@ int Engine::balanced_group(size_t per_slot_bytes) {
   size_t free_b = 0, total_b = 0;
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   const size_t held = d_band_in_.bytes() + d_band_out_.bytes() + d_ext_in_.bytes() + d_ext_out_.bytes();
-  size_t budget = (size_t)((double)(free_b + held) * 0.55);
+  size_t budget = (size_t)((double)(free_b + held) * 0.68);
   if (slot_budget_ > 0) budget = std::min(budget, slot_budget_);
   long cap = (long)(budget / std::max<size_t>(per_slot_bytes, 1));
   cap = std::max(1L, std::min(cap, (long)group_cap_));
@@ -1341,7 +1341,8 @@ void Engine::run_lin_batch() {
   // whose tables debug_tables reads, nor under the phase profile.)
   const int ns = (opt_group_streams_ >= 2 && n_seq_ >= 64 && n_slots_ >= 64 && !opt_profile_) ? std::min(opt_group_streams_, kMaxGroupStreams) : 1;
   const int slots_each = n_slots_ / ns;
-  const int n_groups = (n_seq_ + slots_each - 1) / slots_each;
+  int n_groups = (n_seq_ + slots_each - 1) / slots_each;
+  if (ns > 1) n_groups = ((n_groups + ns - 1) / ns) * ns;      // (every stream the same number of groups)
   const int gsz2 = (ns == 1) ? gsz : (n_seq_ + n_groups - 1) / n_groups;
   auto shifted = [&](LinArgs x, size_t k) {   // the arguments of a group that uses the slots from k on
     x.band_in += k * x.band_stride; x.band_out += k * x.band_stride;
@@ -1651,7 +1652,8 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
     // five exterior chains of a group run under the band kernels of the other
     const int ns = (opt_group_streams_ >= 2 && n >= 128 && n_slots_ >= 128 && tr_slots >= kMaxGroupStreams) ? std::min(opt_group_streams_, kMaxGroupStreams) : 1;
     const int slots_each = n_slots_ / ns, tr_each = tr_slots / ns;
-    const int n_groups = (n + slots_each - 1) / slots_each;
+    int n_groups = (n + slots_each - 1) / slots_each;
+    if (ns > 1) n_groups = ((n_groups + ns - 1) / ns) * ns;    // (every stream the same number of groups)
     const int gsz2 = (ns == 1) ? gsz : (n + n_groups - 1) / n_groups;
     need_group_streams(ns);
     if (ns > 1) {
