@@ -1015,7 +1015,6 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   n_cells_total_ = 0;
   for (auto const& pl : h_plans_) n_cells_total_ += (int64_t)(pl.L + 1) * (pl.W + 1);
   d_xwc_.alloc(sizeof(double) * 10 * (size_t)n_cells_total_);
-  d_xwi_.alloc(sizeof(double) * (8 * (size_t)plan_.n_items + 1), true);   // 4 orders x 2 lambda classes
   d_flagged_.alloc(sizeof(int32_t) * ((size_t)n + 1));
   lin_slots_ = 0;
   out_stride_ = 6 + 2 * au_.n_theta() + 4;
@@ -1258,7 +1257,7 @@ void Engine::lin_weights() {
   w.items_inner = pa.items_inner; w.items_left = pa.items_left; w.items_right = pa.items_right;
   w.n_cells = (size_t)n_cells_total_; w.n_items = (size_t)plan_.n_items;
   w.params = d_params_.as<double>();
-  w.xwc = d_xwc_.as<double>(); w.xwi = d_xwi_.as<double>();
+  w.xwc = d_xwc_.as<double>(); w.xwi = nullptr;   // (item weights: computed where the records are staged)
   HIP_OK(launch_lin_weights(w, st_));
 }
 
@@ -1301,7 +1300,7 @@ int Engine::prepare_lin(LinArgs& a, bool sched1) {
   a.okbits = d_okbits1_.as<uint32_t>();
   a.p = plan_.arrays();
   a.xwc = d_xwc_.as<double>(); a.xwc_stride = (size_t)n_cells_total_;
-  a.xwi = d_xwi_.as<double>(); a.xwi_stride = (size_t)plan_.n_items;
+  a.xwi = nullptr; a.xwi_stride = 0;
   a.band_in = d_band_in_.as<double>(); a.band_out = d_band_out_.as<double>();
   a.ext_in = d_ext_in_.as<double>(); a.ext_out = d_ext_out_.as<double>();
   a.band_stride = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;

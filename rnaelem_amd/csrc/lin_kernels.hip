@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
     a.xwc[3 * a.n_cells + c] = lin_weight(l0, e3); a.xwc[8 * a.n_cells + c] = lin_weight(l1, e3);
     a.xwc[4 * a.n_cells + c] = lin_weight(l0, e4); a.xwc[9 * a.n_cells + c] = lin_weight(l1, e4);
   }
+  if (a.xwi)   // (the band kernels exponentiate the item terms themselves; an array only for callers that ask for one)
   for (size_t n = (size_t)blockIdx.x * kThreads + threadIdx.x; n < a.n_items; n += stride) {
     const double t = a.items[n].tsc;
     a.xwi[n] = lin_weight(l0, t);
@@ -536,10 +537,10 @@ __device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r,
     const int n = base[lo] + (p - pre[lo]);
     const bool in = v.q.item_in[n] != 0;
     r.it[x] = v.q.items[n];
-    if (WEIGHTS) {
-      const double w0 = v.q.xwi[n], w1 = v.q.xwi[v.q.xwi_stride + n];
-      r.xw[x] = in ? w0 : 0.;
-      r.xw[r.cap + x] = in ? w1 : 0.;
+    if (WEIGHTS) {   // exp(lambda_k * tsc) on the spot: two exps per staged record are cheaper than an array of them in HBM
+      const double tsc = r.it[x].tsc;
+      r.xw[x] = in ? lin_weight(v.m.lambda[0], tsc) : 0.;
+      r.xw[r.cap + x] = in ? lin_weight(v.m.lambda[1], tsc) : 0.;
     }
     r.meta[x] = (in ? 0 : (int)0x80000000) | (lo << 16) | (p - pre[lo]);
   }
@@ -1169,8 +1170,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         const int n = base[lo] + (p - pre[lo]);
         const LoopItem* src = role == 0 ? v.q.items_inner : role == 1 ? v.q.items_left : v.q.items_right;
         r_it[x] = src[n];
-        r_xw[x] = v.q.xwi[(size_t)(2 + 2 * role) * v.q.xwi_stride + n];
-        r_xw[cap + x] = v.q.xwi[(size_t)(3 + 2 * role) * v.q.xwi_stride + n];
+        r_xw[x] = lin_weight(v.m.lambda[0], r_it[x].tsc);          // (exp(lambda_k * tsc), as in outer_stage)
+        r_xw[cap + x] = lin_weight(v.m.lambda[1], r_it[x].tsc);
         r_meta[x] = (role << 16) | c;
       }
       __syncthreads();
