@@ -3,16 +3,19 @@
 // Same diagonal-synchronous batch pipeline as train_kernels.hip (a group of G sequences swept in
 // lockstep, kernel boundaries = dependencies), but a term of the O(L W^2) rules is one FMA on two
 // table loads instead of an exp, so the pipeline is bound by the table traffic, not by the VALU:
-//   k4_weights   once per evaluation: exp(lambda_k * structural term) of every pair cell / loop item
-//   k4_in(d)     ONE launch per diagonal: workgroup = cpb = 256/S consecutive cells of one sequence;
-//                heavy sums (rules 2, 6c) with one lane per (cell, state tuple) accumulated into LDS,
-//                then one lane per (cell, state) finishes P,E,M,B,1,2,L (heavy and unary phase fused:
-//                the heavy sums never touch HBM)
+//   k4_weights   once per evaluation: exp(lambda_k * structural term) of every cell (the loop items' terms are
+//                exponentiated where their records are staged)
+//   k4_in(d)     ONE launch per diagonal: workgroup = cpb = 256/S consecutive cells of one sequence; set-up (context of the
+//                workgroup staged in LDS), pair phase (rule 2 factorised: lane = (cell, pair)), item sums (rule 6c: lane =
+//                (record, tuple), records staged in LDS), then one lane per (cell, state) finishes P,E,M,B,1,2,L -- the heavy
+//                sums never touch HBM
 //   k4_in_ext    exterior chain, partition functions, objective, range check (flags the sequence)
-//   k4_out_ext / k4_out(d)   outside pass with expected counts; pass 0 sweeps the pattern automaton with
-//                the "has motif" terminals, pass 1 the one-state automaton over COMPACT (S = 1) tables
-//                that k4_in / k4_in_ext fill on the side (coalesced instead of 1-in-S strided)
+//   k4_out_ext   exterior chain of the outside pass;  k4_r7: its contribution to every pair cell (rule 7)
+//   k4_out(d)    outside sweep with the expected counts; train schedule 1 = ONE sweep for both passes of the reference: the
+//                "has motif" terminals on the pattern's states, the "no motif" terminal on a shadow copy of state (0,0),
+//                each world with its own Z and statistics
 //   k4_combine   statistics of the reference's two passes (motif_trainer.hpp:209-225) from those two
+//   k5_*         scan: position arg-max, Viterbi pass (max-plus, reference tie order), traceback
 // Reference path: RNAelemTrainDP::operator(), RNAelem/motif_trainer.hpp:124-272.
 #include <hip/hip_runtime.h>
 
