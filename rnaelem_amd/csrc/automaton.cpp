@@ -304,7 +304,8 @@ Automaton::Liveness Automaton::liveness() const {
   return lv;
 }
 
-void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0, bool prune, bool shadow) const {
+void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0, bool prune, bool shadow,
+                        int row_pad) const {
   const int S_ = S(), m = M();
   const int ST = S_ + (shadow ? 1 : 0);   // states of the flattened automaton (the shadow of (0,0) is the last one)
   Liveness lv;
@@ -487,6 +488,26 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     put(by_s1, &A.ap_by_s1_off, &A.ap_by_s1_ent);
     put(by_t, &A.ap_by_t_off, &A.ap_by_t_ent);
   }
+  // compact tables of the scaled-linear pipeline: one column per state that is useful in the plane (all states without pruning;
+  // the shadow state has the liveness of (0,0)); strides padded to a multiple of `row_pad` doubles
+  {
+    const int pad = row_pad > 0 ? row_pad : 1;
+    A.tab_cmap = (int32_t)ints->size();
+    int cs = 0;
+    for (int e = 0; e < 7; ++e) {
+      int n = 0;
+      for (int k = 0; k < ST; ++k) {
+        const int r = k < S_ ? ref_of[k] : 0;
+        const bool live = !prune || only_state0 || U[e][r];
+        ints->push_back(live ? n++ : -1);
+      }
+      A.tab_rs[e] = std::max(pad, ((n + pad - 1) / pad) * pad);
+      A.tab_cs[e] = cs;
+      cs += A.tab_rs[e];
+    }
+    A.tab_row = cs;
+    A.ap_rs = std::max(pad, ((A.n_ap + pad - 1) / pad) * pad);
+  }
   A.n_small = (int32_t)ints->size();
   // big part: tuple lists of the bifurcation and interior-loop rules -- first the ones the inside direction reads (by
   // parent), then the ones of the outside direction (by child): a kernel stages the small part and its own run
@@ -532,6 +553,9 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   A.ap_s1 = one(0); A.ap_t = one(0); A.ap_tgt = one(0);
   csr(2, &A.ap_chain_off, &A.ap_chain_ent); csr(2, &A.ap_rchain_off, &A.ap_rchain_ent);
   csr(1, &A.ap_by_s1_off, &A.ap_by_s1_ent); csr(1, &A.ap_by_t_off, &A.ap_by_t_ent);
+  A.tab_cmap = (int32_t)ints->size();
+  for (int e = 0; e < 7; ++e) { ints->push_back(0); A.tab_rs[e] = 1; A.tab_cs[e] = e; }
+  A.tab_row = 7; A.ap_rs = 1;
   A.n_small = (int32_t)ints->size();
   csr(2, &A.split_off, &A.split_ent); csr(3, &A.quad_off, &A.quad_ent);
   A.split_tgt = A.quad_tgt = one(0);

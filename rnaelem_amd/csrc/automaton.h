@@ -56,8 +56,10 @@ class Automaton {
   // shadow: append a copy of state 0 = (0,0) as state S, closed under the same transitions but isolated from every other
   // state (requires that state 0 is closed, Engine::linear_ok_).  One outside sweep with the "has motif" terminals on the
   // states of the pattern and the "no motif" terminal on the shadow then yields both outside passes of the train schedule.
+  // row_pad: the rows of the compact tables of the scaled-linear pipeline (AutomatonLayout::tab_*) are padded to a multiple of
+  // row_pad doubles (8 = every row starts on a 64-byte line).
   void flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0 = false, bool prune = false,
-               bool shadow = false) const;
+               bool shadow = false, int row_pad = 8) const;
 
   // Static liveness of the (structural state, interval state) pairs, from the rule table alone in the
   // boolean semiring: inside_live[e][s] = some sequence gives inside(., ., e, s) a non-zero weight; useful[e][s] = inside-live

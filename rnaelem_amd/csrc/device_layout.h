@@ -71,6 +71,15 @@ struct AutomatonLayout {
   int32_t ap_s1, ap_t, ap_tgt;
   int32_t ap_chain_off, ap_chain_ent, ap_rchain_off, ap_rchain_ent;
   int32_t ap_by_s1_off, ap_by_s1_ent, ap_by_t_off, ap_by_t_ent;
+  // Compact band tables of the scaled-linear pipeline (lin_rules.h): plane e keeps one row of tab_rs[e] doubles per cell with
+  // one column per interval state that is USEFUL in that plane (Automaton::liveness; every state without pruning):
+  // ints[tab_cmap + e * S + s] = column of state s in plane e, or -1 (the entry is 0 in every complete parse and is neither
+  // stored nor read).  tab_cs[e] = sum of the strides of the planes before e, tab_row = sum of all seven; the plane of a
+  // sequence starts at tab_cs[e] * (W+1) * (L+1).  Strides are padded (multiples of 8 doubles) so that rows start on 64-byte
+  // lines.  ap_rs: row stride of the pair tables of the factorised rule 2 (>= n_ap).
+  int32_t tab_cmap;
+  int32_t tab_rs[7], tab_cs[7], tab_row;
+  int32_t ap_rs;
   int32_t n_small;  // the first n_small ints (per-state attributes, unary lists) are staged in LDS;
                     // the tuple lists behind them are read from global memory (ModelView::big)
   int32_t big_in_end;  // the tuple lists behind n_small come in two runs: [n_small, big_in_end) = lists of the inside

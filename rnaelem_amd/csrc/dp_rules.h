@@ -191,11 +191,47 @@ struct TableView {
   // (omask: the exterior-chain kernels keep the last rows of the chain in an LDS ring of a power-of-two number of rows)
   uint32_t omask = 0xffffffffu;
   ELEMDP_HD double& o(int j, int s) const { return ext[((uint32_t)j & omask) * (uint32_t)S + (uint32_t)s]; }
-  // pair table of the factorised rule 2 (scaled-linear pipeline, lin_rules.h): [d][i][p], p < nA pairs (s1, t)
+  // pair table of the factorised rule 2 (scaled-linear pipeline, lin_rules.h): [d][i][p], p < nA pairs (s1, t), rows of
+  // nAs >= nA doubles
   double* ap = nullptr;
-  int32_t nA = 0;
-  ELEMDP_HD uint32_t aidx(int d, int i, int p) const { return ((uint32_t)d * (uint32_t)(L + 1) + (uint32_t)i) * (uint32_t)nA + (uint32_t)p; }
+  int32_t nA = 0, nAs = 0;
+  ELEMDP_HD uint32_t aidx(int d, int i, int p) const { return ((uint32_t)d * (uint32_t)(L + 1) + (uint32_t)i) * (uint32_t)nAs + (uint32_t)p; }
   ELEMDP_HD double& a(int d, int i, int p) const { return ap[aidx(d, i, p)]; }
+  // ---- compact layout (scaled-linear pipeline only; the accessors above are the dense layout of the log-space pipelines and
+  // the Viterbi pass).  Plane e keeps one row of rs[e] doubles per cell, a column per interval state that is useful in the
+  // plane (AutomatonLayout::tab_cmap); entries that are structurally 0 -- a state without a column, or a cell that is not
+  // parsable in that plane (is_parsable, energy_model.hpp:289-338) -- are neither stored nor read: the table holds garbage
+  // there, so every reader decides liveness from the pair mask / dmin first (`live`) and never multiplies a loaded value by 0.
+  uint32_t pb[7] = {0, 0, 0, 0, 0, 0, 0};   // first entry of plane e: tab_cs[e] * (W+1) * (L+1)
+  int32_t rs[7] = {0, 0, 0, 0, 0, 0, 0};    // row stride of plane e
+  const int32_t* cm = nullptr;              // [7][S] column of (plane, state) or -1 (LDS on the GPU)
+  ELEMDP_HD void set_compact(const AutomatonLayout& A, const int32_t* ints) {
+    const uint32_t cells = (uint32_t)(W + 1) * (uint32_t)(L + 1);
+#pragma unroll
+    for (int e = 0; e < 7; ++e) { pb[e] = (uint32_t)A.tab_cs[e] * cells; rs[e] = A.tab_rs[e]; }
+    cm = ints + A.tab_cmap;
+    nAs = A.ap_rs;
+  }
+  ELEMDP_HD int col(int e, int s) const { return cm[e * S + s]; }
+  ELEMDP_HD uint32_t cidx(int e, int d, int i, int c) const {
+    return pb[e] + ((uint32_t)d * (uint32_t)(L + 1) + (uint32_t)i) * (uint32_t)rs[e] + (uint32_t)c;
+  }
+  // load by column (c < 0 or !live: 0, from an address that is valid anyway -- a select, not a branch)
+  ELEMDP_HD double ldc(int e, int d, int i, int c, bool live = true) const {
+    const bool ok = live && c >= 0;
+    const double v = band[ok ? cidx(e, d, i, c) : 0u];
+    return ok ? v : 0.;
+  }
+  ELEMDP_HD double ld(int e, int d, int i, int s, bool live = true) const { return ldc(e, d, i, col(e, s), live); }
+  ELEMDP_HD void st(int e, int d, int i, int s, double v, bool live = true) const {
+    const int c = col(e, s);
+    if (live && c >= 0) band[cidx(e, d, i, c)] = v;
+  }
+  // pair table: an entry (d, i, .) exists iff 0 < dmin[i] < d
+  ELEMDP_HD double lda(int d, int i, int p, bool live = true) const {
+    const double v = ap[live ? aidx(d, i, p) : 0u];
+    return live ? v : 0.;
+  }
 };
 
 // calls fn(n) for every set bit bit0 + n of a pair mask with n in [lo, hi], ascending (walks the 32-bit words)

@@ -233,19 +233,25 @@ class Engine {
   LdsLayout lds_layout(const AutomatonLayout& lay, int Lmax, int nword_max, bool scan) const;
   DpArgs base_args(const AutomatonLayout& lay, const int32_t* d_ints, const double* d_params, const PlanSet& ps,
                    const uint32_t* d_okbits, int S);
-  void ensure_slots(int S, bool scan, int n_want);
+  // row: doubles per cell of a band table slot (0: the dense layout, 7 * S; the compact tables of the scaled-linear pipeline
+  // pass AutomatonLayout::tab_row)
+  void ensure_slots(int S, bool scan, int n_want, int row = 0);
   void run_train(bool first_pass_only);
   void run_train_batch();
   void run_lin_batch();
-  int prepare_lin(LinArgs& a, bool sched1);
+  int prepare_lin(LinArgs& a, bool sched1, bool dense_too = false);
   void lin_weights();
   int balanced_group(size_t per_slot_bytes);
   int group_cap_ = 8192;   // most sequences swept in lockstep (a first scan uses fewer: fresh table memory costs ~20 ms / GB)
   TrArgs log_pipeline_args();
   void init_device();
   void flatten_automaton();
+  void poison_tables();
   void upload_automaton();
   bool opt_prune_ = true;   // transition lists pruned to the transitions of complete parses (Automaton::flatten)
+  int opt_row_pad_ = 8;     // rows of the compact tables padded to a multiple of this many doubles (8 = 64-byte lines)
+  bool opt_poison_ = false; // tests: the table slots are filled with NaN before every evaluation of the scaled-linear pipeline, so
+                            // that a read of an entry nobody stored shows up in the results (the compact tables hold garbage there)
   void require_device() const;
   bool has_device_ = false;
   int want_device_ = -1;
@@ -373,7 +379,8 @@ class Engine {
 
 Engine::Engine(const elemdp_model_desc& d)
     : au_(d.pattern ? d.pattern : ""), flags_(d.flags), max_span_(d.max_span), max_iloop_(d.max_iloop), min_bpp_(d.min_bpp),
-      tau_(d.tau), desc_(d) {
+      tau_(d.tau) {
+  desc_ = d;
   desc_pattern_ = d.pattern ? d.pattern : "";
   desc_has_par_ = d.energy_param != nullptr;
   if (desc_has_par_) desc_par_ = d.energy_param;
@@ -387,15 +394,17 @@ Engine::Engine(const elemdp_model_desc& d)
   if (par == "~T2004~") par = read_file(default_data_dir() + "/turner2004.elempar");
   else if (par == "~A2007~") par = read_file(default_data_dir() + "/andronescu2007.elempar");
   parse_energy_text(par, &et_);
+  if (const char* e = getenv("ELEMDP_POISON")) opt_poison_ = e[0] == '1';   // (the test-suite sets it: see poison_tables)
   flatten_trivial(&lay0_, &ints0_);
-  flatten_automaton();
-  // the linear schedule needs state 0 = (0,0) to be closed under every transition family
+  // the linear schedule needs state 0 = (0,0) to be closed under every transition family (decided before the automaton is
+  // flattened: the shadow copy of (0,0) is only built for a closed state)
   linear_ok_ = au_.state(0).l == 0 && au_.state(0).r == 0;
   for (int c : au_.right(0)) linear_ok_ = linear_ok_ && c == 0;
   for (int c : au_.left(0)) linear_ok_ = linear_ok_ && c == 0;
   for (int c : au_.pair(0)) linear_ok_ = linear_ok_ && c == 0;
   for (auto const& sp : au_.splits(0)) linear_ok_ = linear_ok_ && sp[0] == 0 && sp[1] == 0;
   for (auto const& q : au_.quads()) if (q[0] == 0) linear_ok_ = linear_ok_ && q[1] == 0 && q[2] == 0 && q[3] == 0;
+  flatten_automaton();
 
   int ndev = 0;
   has_device_ = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
@@ -408,9 +417,9 @@ Engine::Engine(const elemdp_model_desc& d)
 // the flat transition lists of the pattern automaton (pruned to the transitions that can occur in a complete parse unless
 // option "prune" = 0) and of its restriction to state (0,0)
 void Engine::flatten_automaton() {
-  au_.flatten(&lay_, &ints_, false, opt_prune_);
-  au_.flatten(&layr_, &intsr_, true, opt_prune_);
-  if (linear_ok_ && au_.S() < 127) au_.flatten(&lays_, &intss_, false, opt_prune_, true);
+  au_.flatten(&lay_, &ints_, false, opt_prune_, false, opt_row_pad_);
+  au_.flatten(&layr_, &intsr_, true, opt_prune_, false, opt_row_pad_);
+  if (linear_ok_ && au_.S() < 127) au_.flatten(&lays_, &intss_, false, opt_prune_, true, opt_row_pad_);
   else { lays_ = lay_; lays_.shadow = -1; intss_ = ints_; }
   lin_slots_ = 0;   // (the pair tables of the linear pipeline are sized by the automaton's pair list)
 }
@@ -517,8 +526,11 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "schedule") opt_schedule_ = (int)v;
   else if (key == "dbg") opt_dbg_ = (int)v;
   else if (key == "bpp_log") opt_bpp_log_ = v != 0;
-  else if (key == "prune") {
-    opt_prune_ = v != 0;
+  else if (key == "poison") opt_poison_ = v != 0;
+  else if (key == "prune" || key == "row_pad") {
+    if (key == "prune") opt_prune_ = v != 0;
+    else opt_row_pad_ = std::max(1, (int)v);
+    n_slots_ = 0;
     flatten_automaton();
     if (has_device_) { DeviceGuard dg(device_); HIP_OK(hipStreamSynchronize(st_)); upload_automaton(); }
   }
@@ -659,8 +671,11 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   HIP_OK(hipStreamSynchronize(st_));
 }
 
-void Engine::ensure_slots(int S, bool scan, int n_want) {
-  const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;
+void Engine::ensure_slots(int S, bool scan, int n_want, int row) {
+  if (row <= 0) row = kNumBandStates * S;
+  const size_t band = (size_t)(Wmax_ + 1) * (Lmax_ + 1) * row;
+  // (the log-space fallback of the scaled-linear pipeline sweeps dense tables over the same buffers: at least one fits)
+  const size_t dense1 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * au_.S();
   const size_t ext = (size_t)(Lmax_ + 1) * S;
   int want = opt_slots_ > 0 ? opt_slots_ : 2 * n_cu_;
   if (slot_override_ > 0) want = slot_override_;
@@ -681,8 +696,8 @@ void Engine::ensure_slots(int S, bool scan, int n_want) {
   if (per_slot * want > free_b + held_t + held_tr) throw HipError("not enough device memory for one table slot");
   n_slots_ = want; slots_S_ = S; slots_scan_ = scan;
   band_stride_ = band; ext_stride_ = ext;
-  d_band_in_.alloc(band * want * sizeof(double));
-  d_band_out_.alloc(band * want * sizeof(double));
+  d_band_in_.alloc(std::max(band * want, dense1) * sizeof(double));
+  d_band_out_.alloc(std::max(band * want, dense1) * sizeof(double));
   d_ext_in_.alloc(ext * want * sizeof(double));
   d_ext_out_.alloc(ext * want * sizeof(double));
   d_tmp_.alloc(ext * 3 * want * sizeof(double));
@@ -1249,6 +1264,12 @@ void Engine::run_train_batch() {
 // The scaled-linear pipeline (lin_kernels.hip); sequences it flags (partition function outside the double range, or a
 // structurally empty component) are re-evaluated by the log-space pipeline, which applies the reference's skip rule.
 // slots, side buffers and the argument record of the scaled-linear pipeline; returns the balanced group size
+void Engine::poison_tables() {
+  if (!opt_poison_) return;
+  for (DevBuf* b : {&d_band_in_, &d_band_out_, &d_a_in_, &d_a_out_})
+    if (b->bytes()) HIP_OK(hipMemsetAsync(b->as<void>(), 0xff, b->bytes(), st_));   // (all-ones bytes: NaN)
+}
+
 void Engine::lin_weights() {
   LinWeightArgs w;
   const PlanArrays pa = plan_.arrays();
@@ -1261,18 +1282,21 @@ void Engine::lin_weights() {
   HIP_OK(launch_lin_weights(w, st_));
 }
 
-int Engine::prepare_lin(LinArgs& a, bool sched1) {
+int Engine::prepare_lin(LinArgs& a, bool sched1, bool dense_too) {
   // schedule 1 sweeps the automaton with the shadow copy of (0,0) (one state more per table row); the scan and schedule 0
   // the plain one.  The slots are sized for the wider row.
   const bool shadow = sched1 && lays_.shadow >= 0;
   const AutomatonLayout& L = shadow ? lays_ : lay_;
-  const int S = L.S, Sa = std::max(lay_.S, lays_.S), nap = std::max(lay_.n_ap, lays_.n_ap);
+  const int S = L.S, Sa = std::max(lay_.S, lays_.S), nap = std::max(lay_.ap_rs, lays_.ap_rs);
+  // compact band tables (AutomatonLayout::tab_row doubles per cell); the scan's Viterbi pass sweeps dense tables over the
+  // same slots (dense_too)
+  const int row = std::max(std::max(lay_.tab_row, lays_.tab_row), dense_too ? kNumBandStates * lay_.S : 0);
   {
-    const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext = (size_t)(Lmax_ + 1);
-    slot_override_ = balanced_group((band + ext) * Sa * 2 * sizeof(double) + ext * Sa * 3 * sizeof(double) +
-                                    (size_t)(Wmax_ + 1) * (Lmax_ + 1) * nap * 2 * sizeof(double));
+    const size_t cells = (size_t)(Wmax_ + 1) * (Lmax_ + 1), ext = (size_t)(Lmax_ + 1);
+    slot_override_ = balanced_group((cells * row + ext * Sa) * 2 * sizeof(double) + ext * Sa * 3 * sizeof(double) +
+                                    cells * nap * 2 * sizeof(double));
   }
-  ensure_slots(Sa, false, n_seq_);
+  ensure_slots(Sa, false, n_seq_, row);
   slot_override_ = 0;
   // (if the allocation had to shrink, rebalance for the slots we got)
   const int n_groups = (n_seq_ + n_slots_ - 1) / n_slots_;
@@ -1303,11 +1327,11 @@ int Engine::prepare_lin(LinArgs& a, bool sched1) {
   a.xwi = nullptr; a.xwi_stride = 0;
   a.band_in = d_band_in_.as<double>(); a.band_out = d_band_out_.as<double>();
   a.ext_in = d_ext_in_.as<double>(); a.ext_out = d_ext_out_.as<double>();
-  a.band_stride = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S;
+  a.band_stride = band_stride_;
   a.ext_stride = (size_t)(Lmax_ + 1) * S;
   a.zs = d_zs_.as<double>();
   a.a_in = d_a_in_.as<double>(); a.a_out = d_a_out_.as<double>();
-  a.a_stride = (size_t)(Wmax_ + 1) * (Lmax_ + 1) * L.n_ap;
+  a.a_stride = (size_t)(Wmax_ + 1) * (Lmax_ + 1) * L.ap_rs;
   a.okbits_end = d_okbits_end_.as<uint32_t>();
   a.lmax = Lmax_;
   a.nword_max = nword_max_;
@@ -1335,6 +1359,7 @@ void Engine::run_lin_batch() {
   HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
   HIP_OK(hipEventRecord(ev_[1], st_));
   lin_weights();
+  poison_tables();
   // Two groups at a time, each on its own stream and its own half of the table slots: the serial parts of a
   // group (exterior chains, launch tails) run under the band kernels of the other.  (Not for a handful of sequences,
   // whose tables debug_tables reads, nor under the phase profile.)
@@ -1382,8 +1407,10 @@ void Engine::run_lin_batch() {
   tables_linear_ = n_flagged == 0;
   if (n_flagged > 0) {
     TrArgs t = log_pipeline_args();
-    for (int g0 = 0; g0 < n_flagged; g0 += n_slots_) {
-      const int G = std::min(n_slots_, n_flagged - g0);
+    // (dense tables over the buffers of the compact ones: as many slots as fit, at least one -- ensure_slots)
+    const int n_dense = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_slots_, (band_stride_ * (size_t)n_slots_) / t.band_stride));
+    for (int g0 = 0; g0 < n_flagged; g0 += n_dense) {
+      const int G = std::min(n_dense, n_flagged - g0);
       t.grp = d_flagged_.as<int32_t>() + 1 + g0;
       HIP_OK(launch_train_group(t, G, Lmax_, Wmax_, st_));
     }
@@ -1510,47 +1537,82 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
   const int S = (tables_linear_ && tables_S_ > 0) ? tables_S_ : Sref;
   const AutomatonLayout& TL = (S == lays_.S && lays_.shadow >= 0 && S != Sref) ? lays_ : lay_;
   const std::vector<int32_t>& TI = (&TL == &lays_) ? intss_ : ints_;
-  const size_t band = (size_t)7 * (W + 1) * (L + 1) * S, ext = (size_t)(L + 1) * S;
+  const size_t cells = (size_t)(W + 1) * (L + 1);
+  // the scaled-linear pipeline keeps Boltzmann weights times a power-of-two scale (lin_rules.h) in COMPACT tables
+  // (TableView::ld / st, dp_rules.h): columns only for the states that are useful in a plane, nothing for cells that are not
+  // parsable in it -- the export reads those as 0 -> log 0
+  const bool lin = tables_linear_;
+  const size_t band = lin ? cells * TL.tab_row : (size_t)7 * cells * S, ext = (size_t)(L + 1) * S;
   auto fetch = [&](const DevBuf& src, size_t cnt) {
     std::vector<double> h(cnt);
     HIP_OK(hipMemcpy(h.data(), src.as<void>(), sizeof(double) * cnt, hipMemcpyDeviceToHost));
     return h;
   };
-  // the scaled-linear pipeline keeps Boltzmann weights times a power-of-two scale (lin_rules.h): export logs
-  const bool lin = tables_linear_;
   std::vector<double> cum(L + 1, 0.);   // log2 of prod_{p<j} psb[base(p)]
   if (lin) for (int t = 0; t < L; ++t) cum[t + 1] = cum[t] + h_lin_[kLinPl2 + h_seq_[p.seq_base + t]];
   const double ln2 = 0.69314718055994530942, NEGINF = -std::numeric_limits<double>::infinity();
   auto ref_id = [&](int s) { return TI[TL.st_ref + s]; };   // tables are exported in the reference's state order
   auto conv = [&](double v, double scale_log2) { return !lin ? v : (v > 0. ? std::log(v) - scale_log2 * ln2 : NEGINF); };
-  auto reorder = [&](const std::vector<double>& t, double* dst, bool outside_tab) {  // [e][d][i][s] -> [i][d][e][s]
+  // liveness of a cell in a plane (is_parsable, energy_model.hpp:289-338) from the pair mask and dmin of the sequence
+  std::vector<uint32_t> bits((cells + 31) / 32 + 1, 0u);
+  std::vector<int16_t> dmin(L + 1, 0);
+  if (lin) {
+    HIP_OK(hipMemcpy(bits.data(), d_okbits1_.as<uint32_t>() + p.bits_base, sizeof(uint32_t) * ((cells + 31) / 32), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(dmin.data(), plan_.arrays().dmin + p.dmin_base, sizeof(int16_t) * (L + 1), hipMemcpyDeviceToHost));
+  }
+  const int m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
+  auto pair_ok = [&](int i, int d) {
+    if (i < 0 || d < 0 || d > W || i + d > L) return false;
+    const size_t c = (size_t)i * (W + 1) + d;
+    return ((bits[c >> 5] >> (c & 31)) & 1u) != 0;
+  };
+  auto left_ok = [&](int i, int d) { return i >= 0 && d >= 0 && d <= W && i + d <= L && dmin[i] > 0 && d >= dmin[i]; };
+  auto cell_live = [&](int e, int d, int i) {
+    switch (e) {
+      case ST_P: return pair_ok(i, d);
+      case ST_E: return i > 0 && d + 2 <= W && pair_ok(i - 1, d + 2);
+      case ST_M: return 0 < i && i + d < L && d <= W && m_min <= d;
+      case ST_B: case ST_1: case ST_2: return left_ok(i, d);
+      default: return true;
+    }
+  };
+  // value of entry (e, d, i, s) of a fetched table in either layout
+  auto tab = [&](const std::vector<double>& t, int e, int d, int i, int s2) {
+    if (!lin) return t[(((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s2];
+    const int c = TI[TL.tab_cmap + e * S + s2];
+    if (c < 0 || !cell_live(e, d, i)) return 0.;
+    return t[(size_t)TL.tab_cs[e] * cells + ((size_t)d * (L + 1) + i) * TL.tab_rs[e] + c];
+  };
+  auto reorder = [&](const std::vector<double>& t, const std::vector<double>* plus2, double* dst, bool outside_tab) {  // -> [i][d][e][s]
     for (int i = 0; i <= L; ++i) for (int d = 0; d <= W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s) {
       if (s == TL.shadow) continue;
       double sc = (i + d <= L) ? cum[i + d] - cum[i] : 0.;
       if (outside_tab) sc = cum[L] - sc;
-      dst[(((size_t)i * (W + 1) + d) * 7 + e) * Sref + ref_id(s)] =
-          (i + d <= L) ? conv(t[(((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s], sc) : NEGINF;
+      double v = (i + d <= L) ? tab(t, e, d, i, s) : 0.;
+      if (plus2 && e == ST_2 && i + d <= L) v += (*plus2)[((size_t)d * (L + 1) + i) * S + s];
+      dst[(((size_t)i * (W + 1) + d) * 7 + e) * Sref + ref_id(s)] = (i + d <= L) ? conv(v, sc) : NEGINF;
     }
   };
-  if (inside) reorder(fetch(d_band_in_, band), inside, false);
+  if (inside) reorder(fetch(d_band_in_, band), nullptr, inside, false);
   if (outside) {
-    std::vector<double> to = fetch(d_band_out_, band);
-    if (lin && TL.n_ap > 0 && d_a_out_.bytes() >= sizeof(double) * (size_t)(W + 1) * (L + 1) * TL.n_ap) {
+    std::vector<double> to = fetch(d_band_out_, band), ha;
+    if (lin && TL.n_ap > 0 && d_a_out_.bytes() >= sizeof(double) * cells * TL.ap_rs) {
       // the linear pipeline keeps only the direct part (rules 4a, 3a) of the plane-2 outside values; what arrives through
       // rule 2 is HA(k,l,t) = sum_i sum_{p=(s1,t)} outA(i,l,p) 1(i,k,s1) (lin_rules.h) -- added here for the export
-      const int nA = TL.n_ap;
-      const std::vector<double> ti = fetch(d_band_in_, band), ao = fetch(d_a_out_, (size_t)(W + 1) * (L + 1) * nA);
-      auto at = [&](int e, int d, int i, int s2) { return (((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s2; };
-      for (int d = 0; d <= W; ++d) for (int i = 0; i + d <= L; ++i) for (int p = 0; p < nA; ++p) {
-        const int s1 = TI[TL.ap_s1 + p], t = TI[TL.ap_t + p];
-        if (!(ti[at(ST_2, d, i, t)] != 0.)) continue;
+      const int nA = TL.n_ap, nAs = TL.ap_rs;
+      const std::vector<double> ti = fetch(d_band_in_, band), ao = fetch(d_a_out_, cells * nAs);
+      ha.assign(cells * S, 0.);
+      for (int d = 0; d <= W; ++d) for (int i = 0; i + d <= L; ++i) for (int q = 0; q < nA; ++q) {
+        const int s1 = TI[TL.ap_s1 + q], t = TI[TL.ap_t + q];
+        if (!(tab(ti, ST_2, d, i, t) != 0.)) continue;
         double acc = 0.;
         for (int b = 1; d + b <= W && i - b >= 0; ++b)
-          acc += ao[((size_t)(d + b) * (L + 1) + (i - b)) * nA + p] * ti[at(ST_1, b, i - b, s1)];
-        to[at(ST_2, d, i, t)] += acc;
+          if (left_ok(i - b, b))   // 1(i-b, i, .) is parsable; the pair entries of (i-b, d+b) then exist
+            acc += ao[((size_t)(d + b) * (L + 1) + (i - b)) * nAs + q] * tab(ti, ST_1, b, i - b, s1);
+        ha[((size_t)d * (L + 1) + i) * S + t] += acc;
       }
     }
-    reorder(to, outside, true);
+    reorder(to, ha.empty() ? nullptr : &ha, outside, true);
   }
   if (inside_o) { auto h = fetch(d_ext_in_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) if (s != TL.shadow) inside_o[(size_t)j * Sref + ref_id(s)] = conv(h[(size_t)j * S + s], cum[j]); }
   if (outside_o) { auto h = fetch(d_ext_out_, ext); for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) if (s != TL.shadow) outside_o[(size_t)j * Sref + ref_id(s)] = conv(h[(size_t)j * S + s], cum[L] - cum[j]); }
@@ -1609,7 +1671,7 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
     // a scan is one pass: 1 024 sequences per group run within 4 % of the largest groups and need a third of the table
     // memory (an evaluation loop that already holds larger groups keeps them)
     group_cap_ = std::max(1024, n_slots_);
-    const int gsz = prepare_lin(a, false);
+    const int gsz = prepare_lin(a, false, true);
     group_cap_ = 8192;
     dbg_lap("scan: prepare_lin (table slots)");
     a.scan = 1;
@@ -1624,8 +1686,9 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
     HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n, st_));
     HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
     lin_weights();
-    // trace tables of the Viterbi pass: one per slot of a CYK sub-batch (as large as one band table each)
-    const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S, ext = (size_t)(Lmax_ + 1) * S;
+    poison_tables();
+    // trace tables of the Viterbi pass: one per slot of a CYK sub-batch (as large as one band table slot each)
+    const size_t band = a.band_stride, ext = (size_t)(Lmax_ + 1) * S;
     const int stack_stride = 4 * (4 * (Lmax_ + 2));
     int tr_slots;
     {

@@ -169,6 +169,8 @@ __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) 
   v.in.ap = a.a_in ? a.a_in + (size_t)g * a.a_stride : nullptr;
   v.out.ap = a.a_out ? a.a_out + (size_t)g * a.a_stride : nullptr;
   v.in.nA = v.out.nA = a.lay.n_ap;
+  v.in.set_compact(a.lay, a.ints);      // (the column map moves to LDS with the automaton blob: stage_context)
+  v.out.set_compact(a.lay, a.ints);
   q.okbits_end = a.okbits_end ? a.okbits_end + p.bits_base : nullptr;
   v.row = a.seq_out + (size_t)n * a.out_stride;
   v.zs = a.zs + (size_t)g * 4;
@@ -292,7 +294,9 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
                                                   int d, int cpb) {
   const int tid = threadIdx.x;
   const int L = v.q.L;
-  const int p0 = (i0 > 0) ? i0 - 1 : 0;
+  // (the outside kernel also needs dmin of the rows i - b, b <= W - d, whose pair entries feed HA: lheavy_o2)
+  const int back = (PART == 1 && v.q.W - d > 1) ? v.q.W - d : 1;
+  const int p0 = (i0 > back) ? i0 - back : 0;
   const int p1 = (i0 + nc + d < L) ? i0 + nc + d : L;   // inclusive
   const int len = p1 - p0 + 1;
   double* llin = reinterpret_cast<double*>(raw + B.lin);
@@ -309,7 +313,8 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   // stems that START at the ends j = i + d of its cells (rule 2, factorised): rows up to i0+nc-1+d.  The inside kernel
   // walks the stems that END there: rows i0+d .. i0+nc-1+d of the end-indexed mask (second window).
   const int W1 = v.q.W + 1;
-  const int last_row = (PART == 1) ? ((i0 + nc + d <= L + 1) ? i0 + nc + d : L + 1) : i0 + nc;
+  // (the inside kernel tests the inner pair (i+1, d-2) of its last cell: one row more)
+  const int last_row = (PART == 1) ? ((i0 + nc + d <= L + 1) ? i0 + nc + d : L + 1) : ((i0 + nc + 1 <= L + 1) ? i0 + nc + 1 : L + 1);
   const int bit0 = ((i0 > 0) ? i0 - 1 : 0) * W1, bit1 = last_row * W1;   // [bit0, bit1)
   const int w0 = bit0 >> 5, w1 = ((bit1 + 31) >> 5) + 1;
   const int wend = (int)((((long long)(L + 1) * W1) + 31) >> 5);
@@ -369,6 +374,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   c.base = reinterpret_cast<int*>(raw + B.base);
   if (tid < cpb) c.dm[tid] = (tid < nc) ? (int)r_dm : 0;
   v.m.ints = blob;
+  v.in.cm = v.out.cm = blob + a.lay.tab_cmap;
   if (BIG) v.m.big = blob + a.lay.n_small - big_lo;   // (indices of the staged run keep their global values)
   v.m.lin = llin;
   v.q.ews = lews - p0;
@@ -594,17 +600,19 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
       const int c = w / nA, p = w - c * nA;
       const int i = i0 + c, j = i + d;
       const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p], tgt = I[A.ap_tgt + p];
+      const int c1 = v.in.col(ST_1, s1), cP = v.in.col(ST_P, t);
       const int dmi = dm[c];
       double av = 0.;
-      if (dmi > 0 && dmi < d) {          // 1(i,k,.) != 0 needs k - i >= dmin[i], and k < j
+      if (dmi > 0 && dmi < d) {          // 1(i,k,.) != 0 needs k - i >= dmin[i], and k < j: otherwise no entry (i, d, .) exists
         const double* xml = v.q.xwc + (size_t)(lamk(v.m, t) * 5 + XT_ML) * v.q.xwc_stride;
         BitIter it;
         it.init(v.q.okbits_end, j * W1, 1, d - dmi);      // spans of the stems: k = j - sp >= i + dmin[i]
         // tail step: the (at most kUnary, else looped) predecessors' values are in flight with the first stems
         const int e0 = I[A.ap_chain_off + p], ne = v.q.unp[j - 1] ? I[A.ap_chain_off + p + 1] - e0 : 0;
         double pv[kUnary];
+        const bool tail = dmi < d - 1;   // (the entries of (i, d-1) exist)
 #pragma unroll
-        for (int u = 0; u < kUnary; ++u) pv[u] = v.in.a(d - 1, i, u < ne ? I[A.ap_chain_ent + 2 * (e0 + u)] : p);
+        for (int u = 0; u < kUnary; ++u) pv[u] = v.in.lda(d - 1, i, u < ne ? I[A.ap_chain_ent + 2 * (e0 + u)] : p, tail);
         bool first = true;
         for (;;) {
           const int sp0 = it.next();
@@ -623,24 +631,25 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
             for (int u = kUnary; u < ne; ++u) {
               const int pc2 = I[A.ap_chain_ent + 2 * (e0 + u)], tf = I[A.ap_chain_ent + 2 * (e0 + u) + 1];
               if (CON && !allow_right(v.m, con, v.q.L, j, t, I[A.ap_t + pc2])) continue;
-              av = fma(v.in.a(d - 1, i, pc2), lw_right(v.m, v.q, t, tf, j - 1), av);
+              av = fma(v.in.lda(d - 1, i, pc2, tail), lw_right(v.m, v.q, t, tf, j - 1), av);
             }
             if (sp0 < 0) break;
           }
           const int sp1 = it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
           const int q1 = sp1 < 0 ? sp0 : sp1, q2 = sp2 < 0 ? sp0 : sp2, q3 = sp3 < 0 ? sp0 : sp3;
-          const double a0 = B[v.in.idx(ST_1, d - sp0, i, s1)], b0 = B[v.in.idx(ST_P, sp0, j - sp0, t)], c0 = xml[v.q.cell(j - sp0, sp0)];
-          const double a1 = B[v.in.idx(ST_1, d - q1, i, s1)], b1 = B[v.in.idx(ST_P, q1, j - q1, t)], c1 = xml[v.q.cell(j - q1, q1)];
-          const double a2 = B[v.in.idx(ST_1, d - q2, i, s1)], b2 = B[v.in.idx(ST_P, q2, j - q2, t)], c2 = xml[v.q.cell(j - q2, q2)];
-          const double a3 = B[v.in.idx(ST_1, d - q3, i, s1)], b3 = B[v.in.idx(ST_P, q3, j - q3, t)], c3 = xml[v.q.cell(j - q3, q3)];
-          av = fma(a0, b0 * c0, av);
-          if (sp1 >= 0) av = fma(a1, b1 * c1, av);
-          if (sp2 >= 0) av = fma(a2, b2 * c2, av);
-          if (sp3 >= 0) av = fma(a3, b3 * c3, av);
+          // (1(i,k,.) and the stem P(k,j,.) are parsable by construction of the walk)
+          const double a0 = v.in.ldc(ST_1, d - sp0, i, c1), b0 = v.in.ldc(ST_P, sp0, j - sp0, cP), w0 = xml[v.q.cell(j - sp0, sp0)];
+          const double a1 = v.in.ldc(ST_1, d - q1, i, c1), b1 = v.in.ldc(ST_P, q1, j - q1, cP), w1 = xml[v.q.cell(j - q1, q1)];
+          const double a2 = v.in.ldc(ST_1, d - q2, i, c1), b2 = v.in.ldc(ST_P, q2, j - q2, cP), w2 = xml[v.q.cell(j - q2, q2)];
+          const double a3 = v.in.ldc(ST_1, d - q3, i, c1), b3 = v.in.ldc(ST_P, q3, j - q3, cP), w3 = xml[v.q.cell(j - q3, q3)];
+          av = fma(a0, b0 * w0, av);
+          if (sp1 >= 0) av = fma(a1, b1 * w1, av);
+          if (sp2 >= 0) av = fma(a2, b2 * w2, av);
+          if (sp3 >= 0) av = fma(a3, b3 * w3, av);
           if (sp3 < 0) break;
         }
+        v.in.a(d, i, p) = av;
       }
-      v.in.a(d, i, p) = av;
       if (tgt >= 0 && av != 0.) atomicAdd(&hb[c * S + tgt], av);
     }
   }
@@ -671,9 +680,9 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
           const int c = (R.meta[x] >> 16) & 0x7fff;
           const int i = i0 + c, j = i + d;
           const int tgt = G[A.quad_tgt + t];
-          x0[u] = B[v.in.idx(ST_P, it.l - it.k, it.k, G[A.quad_ent + 3 * t])];
-          x1[u] = B[v.in.idx(ST_L, it.k - i, i, G[A.quad_ent + 3 * t + 1])];
-          x2[u] = B[v.in.idx(ST_L, j - it.l, it.l, G[A.quad_ent + 3 * t + 2])];
+          x0[u] = v.in.ld(ST_P, it.l - it.k, it.k, G[A.quad_ent + 3 * t]);       // (the inner pair of an item is a kept pair)
+          x1[u] = v.in.ld(ST_L, it.k - i, i, G[A.quad_ent + 3 * t + 1]);
+          x2[u] = v.in.ld(ST_L, j - it.l, it.l, G[A.quad_ent + 3 * t + 2]);
           xw[u] = R.xw[lamk(v.m, tgt) * R.cap + x];
           hidx[u] = c * S + tgt;
         }
@@ -748,6 +757,7 @@ __device__ __forceinline__ void stage_ext_context(const LinArgs& a, LViews& v, u
     lseq[t] = (t < L) ? v.q.seq[t] : (uint8_t)0;
   }
   v.m.ints = blob;
+  v.in.cm = v.out.cm = blob + a.lay.tab_cmap;
   if (a.n_stage >= a.lay.n_ints) v.m.big = blob;
   v.m.lin = llin;
   v.q.ews = lews;
@@ -995,7 +1005,7 @@ __global__ __launch_bounds__(kThreads) void k4_r7(LinArgs a) {
       const int par = G[A.split2_ent + 2 * u], s2i = G[A.split2_ent + 2 * u + 1];
       acc = fma(v.out.o(j, par), v.in.o(i, s2i) * (lamk(v.m, par) ? x1 : x0), acc);
     }
-    v.out.at(ST_P, d, i, s) = acc;
+    v.out.st(ST_P, d, i, s, acc);
   }
 }
 
@@ -1075,6 +1085,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       const int c = w / nA, p = w - c * nA;
       const int i = i0 + c, j = i + d;
       const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
+      const int cP = in.col(ST_P, t);
       const int dmi = dm[c];
       if (dmi > 0 && dmi <= d) {     // left_ok(i, d)  (a dead child 1(i,j,s1) drops the sum in the unary phase)
         const int hi = (W - d < L - j) ? W - d : L - j;
@@ -1087,10 +1098,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           if (sp0 < 0) break;
           const int sp1 = it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
           const int q1 = sp1 < 0 ? sp0 : sp1, q2 = sp2 < 0 ? sp0 : sp2, q3 = sp3 < 0 ? sp0 : sp3;
-          const double a0 = out.a(d + sp0, i, p), b0 = IB[in.idx(ST_P, sp0, j, t)], c0 = xml[v.q.cell(j, sp0)];
-          const double a1 = out.a(d + q1, i, p), b1 = IB[in.idx(ST_P, q1, j, t)], c1 = xml[v.q.cell(j, q1)];
-          const double a2 = out.a(d + q2, i, p), b2 = IB[in.idx(ST_P, q2, j, t)], c2 = xml[v.q.cell(j, q2)];
-          const double a3 = out.a(d + q3, i, p), b3 = IB[in.idx(ST_P, q3, j, t)], c3 = xml[v.q.cell(j, q3)];
+          // (the pair entries of (i, d + sp) exist: dmin[i] <= d < d + sp; the stems are kept pairs)
+          const double a0 = out.a(d + sp0, i, p), b0 = in.ldc(ST_P, sp0, j, cP), c0 = xml[v.q.cell(j, sp0)];
+          const double a1 = out.a(d + q1, i, p), b1 = in.ldc(ST_P, q1, j, cP), c1 = xml[v.q.cell(j, q1)];
+          const double a2 = out.a(d + q2, i, p), b2 = in.ldc(ST_P, q2, j, cP), c2 = xml[v.q.cell(j, q2)];
+          const double a3 = out.a(d + q3, i, p), b3 = in.ldc(ST_P, q3, j, cP), c3 = xml[v.q.cell(j, q3)];
           acc = fma(a0, b0 * c0, acc);
           if (sp1 >= 0) acc = fma(a1, b1 * c1, acc);
           if (sp2 >= 0) acc = fma(a2, b2 * c2, acc);
@@ -1122,10 +1134,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           const int c = __builtin_ctzll(m);
           const int b = 1 + r / nA, p = r - (b - 1) * nA;
           const int ii = i0 + c - b;
-          const bool ok = valid && ii >= 0;
-          const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];   // (1(ii, i, .) is 0 where it is not parsable)
-          oa[u] = ok ? out.a(d + b, ii, p) : 0.;
-          x1[u] = ok ? IB[in.idx(ST_1, b, ii, s1)] : 0.;
+          const int dmii = (valid && ii >= 0) ? (int)v.q.dmin[ii] : 0;
+          const bool ok = dmii > 0 && b >= dmii;              // 1(ii, i, .) is parsable (then the pair entries of (ii, d + b) exist)
+          const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
+          oa[u] = out.lda(d + b, ii, p, ok);
+          x1[u] = in.ld(ST_1, b, ii, s1, ok);
           hidx[u] = c * S + t;
         }
 #pragma unroll
@@ -1203,10 +1216,18 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           const int d1 = role == 0 ? i - it[u].i : it[u].l - it[u].k, p1 = role == 0 ? it[u].i : it[u].k;
           const int d2 = role == 0 ? it[u].j - j : role == 1 ? it[u].j - it[u].l : it[u].k - it[u].i;
           const int p2 = role == 0 ? j : role == 1 ? it[u].l : it[u].i;
-          x0[u] = OB[out.idx(ST_E, it[u].j - it[u].i, it[u].i, q0)];
-          x1[u] = IB[in.idx(e1, d1, p1, q1)];
-          x2[u] = IB[in.idx(ST_L, d2, p2, q2)];
-          aux[u] = IB[in.idx(role == 0 ? ST_P : ST_L, d, i, tgt)];
+          // (operand liveness by construction: the outer cell of an item is a parsable E cell, its inner pair a kept pair, the
+          // loops L are stored everywhere; role 0 only runs for pair cells).  The plane that depends on the role is chosen by
+          // selecting between the two constant-plane addresses.
+          const int cL1 = in.col(ST_L, q1), cP1 = in.col(ST_P, q1), cLt = in.col(ST_L, tgt), cPt = in.col(ST_P, tgt);
+          const int c1 = role == 0 ? cL1 : cP1, ct = role == 0 ? cPt : cLt;
+          const uint32_t a1 = role == 0 ? in.cidx(ST_L, d1, p1, c1) : in.cidx(ST_P, d1, p1, c1);
+          const uint32_t at = role == 0 ? in.cidx(ST_P, d, i, ct) : in.cidx(ST_L, d, i, ct);
+          x0[u] = out.ld(ST_E, it[u].j - it[u].i, it[u].i, q0);
+          const double r1 = IB[c1 >= 0 ? a1 : 0u], rt = IB[ct >= 0 ? at : 0u];
+          x1[u] = c1 >= 0 ? r1 : 0.;
+          x2[u] = in.ld(ST_L, d2, p2, q2);
+          aux[u] = ct >= 0 ? rt : 0.;
           xw[u] = r_xw[lamk(v.m, q0) * cap + x];
           hidx[u] = (role == 0 ? 0 : CS) + c * S + tgt;   // hp, or hl = hp + CS
           par[u] = role == 0 ? q0 : -1;
@@ -1247,7 +1268,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
     HeavyOut H;
     H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
-    if (!(a.dbg & 32) && v.q.pair_ok(i0 + c, d)) H.HP += out.at(ST_P, d, i0 + c, s);   // rule-7 term (k4_r7)
+    if (!(a.dbg & 32)) H.HP += out.ld(ST_P, d, i0 + c, s, v.q.pair_ok(i0 + c, d));   // rule-7 term (k4_r7)
     H.ext_in_hp = true;
     h1[c * S + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
   }

@@ -15,6 +15,12 @@
 // reference's skip rule (motif_trainer.hpp:211-215) for it.
 //
 // Guards mirror dp_rules.h: "x == log 0" becomes "x == 0".
+//
+// Tables are COMPACT (TableView::ld / st / lda, dp_rules.h): a plane keeps columns only for the interval states that are
+// useful in it, and nothing is stored for a cell that is not parsable in the plane (is_parsable<e>, energy_model.hpp:289-338:
+// P, E at kept pairs; B, 1, 2 where left_ok; M where m_ok; pair tables where 0 < dmin[i] < d).  Every load therefore
+// names the liveness of its operand (`live`), known from the pair mask and dmin alone; a dead operand reads as 0 without
+// touching the table.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -82,18 +88,21 @@ ELEMDP_HD double lin_inside_apair(const ModelView& m, const SeqView& q, const Ta
   const int32_t* I = m.ints;
   const int j = i + d;
   const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
+  const int dmi = q.dmin[i];
+  if (!(dmi > 0 && dmi < d)) return 0.;    // no k with 1(i,k,.) != 0 in front of j: the entry does not exist
   double a = 0.;
-  if (d >= 1 && q.unp[j - 1])
+  if (d - 1 > dmi && q.unp[j - 1])         // (the entry of (i, j-1) exists iff dmin[i] < d - 1)
     for (int e = I[A.ap_chain_off + p]; e < I[A.ap_chain_off + p + 1]; ++e) {
       const int pc = I[A.ap_chain_ent + 2 * e], tf = I[A.ap_chain_ent + 2 * e + 1];
       if (CON && !allow_right(m, con, q.L, j, t, I[A.ap_t + pc])) continue;
       a = fma(T.a(d - 1, i, pc), lw_right(m, q, t, tf, j - 1), a);
     }
   const int kl = lamk(m, t);
-  // stems (k, j) that end at j and start behind i: spans 1 .. d-1 of row j of the end-indexed pair mask
-  for_mask_bits(q.okbits_end, j * (q.W + 1), 1, d - 1, [&](int sp) {
+  // stems (k, j) that end at j and start at k >= i + dmin[i] (1(i,k,.) is parsable): spans 1 .. d-dmin[i] of row j of the
+  // end-indexed pair mask
+  for_mask_bits(q.okbits_end, j * (q.W + 1), 1, d - dmi, [&](int sp) {
     const int k = j - sp;
-    a = fma(T.at(ST_1, k - i, i, s1), T.at(ST_P, sp, k, t) * xw_cell(q, kl, XT_ML, q.cell(k, sp)), a);
+    a = fma(T.ld(ST_1, k - i, i, s1), T.ld(ST_P, sp, k, t) * xw_cell(q, kl, XT_ML, q.cell(k, sp)), a);
   });
   T.a(d, i, p) = a;
   return a;
@@ -109,12 +118,14 @@ ELEMDP_HD double lheavy_bif(const ModelView& m, const SeqView& q, const TableVie
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
   double a = 0.;
+  const int dmi = q.dmin[i];
+  if (!(dmi > 0 && dmi < d)) return 0.;
   for (int p = 0; p < A.n_ap; ++p)
     if (I[A.ap_tgt + p] == s) a += T.a(d, i, p);
   return a;
 }
 ELEMDP_HD double lloop_term(const TableView& T, int i, int j, const LoopItem& x, int s1, int s2, int s3) {
-  return T.at(ST_P, x.l - x.k, x.k, s1) * (T.at(ST_L, x.k - i, i, s2) * T.at(ST_L, j - x.l, x.l, s3));
+  return T.ld(ST_P, x.l - x.k, x.k, s1) * (T.ld(ST_L, x.k - i, i, s2) * T.ld(ST_L, j - x.l, x.l, s3));
 }
 ELEMDP_HD double lheavy_loop(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, int s) {
   const AutomatonLayout& A = m.lay;
@@ -130,6 +141,22 @@ ELEMDP_HD double lheavy_loop(const ModelView& m, const SeqView& q, const TableVi
       a = fma(lloop_term(T, i, j, x, G[A.quad_ent + 3 * t], G[A.quad_ent + 3 * t + 1], G[A.quad_ent + 3 * t + 2]), xw, a);
   }
   return a;
+}
+
+// does the compact table keep a row for plane e at cell (i, d)?  (is_parsable<e>, energy_model.hpp:289-338)
+ELEMDP_HD bool lin_cell_live(const ModelView& m, const SeqView& q, int e, int d, int i) {
+  if (d < 0 || d > q.W || i < 0 || i + d > q.L) return false;
+  switch (e) {
+    case ST_P: return q.pair_ok(i, d);
+    case ST_E: return q.e_ok(i, d);
+    case ST_M: return m_ok(m, q, i, d);
+    case ST_B: case ST_1: case ST_2: return q.left_ok(i, d);
+    default: return true;
+  }
+}
+// value of an entry for exports and tests: 0 where nothing is stored
+ELEMDP_HD double lin_get(const ModelView& m, const SeqView& q, const TableView& T, int e, int d, int i, int s) {
+  return T.ld(e, d, i, s, lin_cell_live(m, q, e, d, i));
 }
 
 struct Cell7 { double vP, vE, vM, vB, v1, v2, vL; };
@@ -162,12 +189,16 @@ ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const 
   const double xst = pok ? l_st : 0., xml = pok ? l_ml : 0., xcl = eok ? l_cl : 0., xhp = eok ? l_hp : 0.;
   const int d1 = d > 0 ? d - 1 : 0, d2 = d > 1 ? d - 2 : 0, i1 = i < q.L ? i + 1 : i;
   const int pr = j > 0 ? j - 1 : 0;   // position emitted on the right
+  // liveness of the operand cells: L(i,j-1) exists for d > 0; 2(i,j-1) where left_ok; E(i+1,j-1) where its closing pair (i,j)
+  // is kept; P(i+1,j-1) where that inner pair is kept; M(i+1,j) where m_ok
+  const bool inner_ok = d >= 2 && q.pair_ok(i + 1, d - 2);
+  const bool cE = pok && d >= 2, cP = pok && inner_ok;
   double sL = 0., s2 = 0., sP = 0., sM = 0.;
 #pragma unroll
   for (int u = 0; u < kUnaryR; ++u) {
     const bool vr = u < nR;
     const int s1 = vr ? I[A.right_ent + 2 * (r0 + u)] : 0, tfr = vr ? I[A.right_ent + 2 * (r0 + u) + 1] : 0;
-    const double tL = T.at(ST_L, d1, i, s1), t2 = T.at(ST_2, d1, i, s1);
+    const double tL = T.ld(ST_L, d1, i, s1, vr && doL), t2 = T.ld(ST_2, d1, i, s1, vr && do2);
     const bool okr = vr && (!CON || allow_right(m, con, q.L, j, s, s1));
     const double wr = (okr && d > 0) ? lw_right(m, q, s, tfr, pr) : 0.;
     sL += (doL && okr) ? tL * wr : 0.;
@@ -177,8 +208,8 @@ ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const 
       const int sp = vp ? I[A.pair_ent + 2 * (p0 + u)] : 0, tfp = vp ? I[A.pair_ent + 2 * (p0 + u) + 1] : 0;
       const bool vl = u < nL;
       const int sl = vl ? I[A.left_ent + 2 * (l0 + u)] : 0, tfl = vl ? I[A.left_ent + 2 * (l0 + u) + 1] : 0;
-      const double tE = T.at(ST_E, d2, i1, sp), tP = T.at(ST_P, d2, i1, sp);
-      const double tM = T.at(ST_M, d1, i1, sl);
+      const double tE = T.ld(ST_E, d2, i1, sp, vp && cE), tP = T.ld(ST_P, d2, i1, sp, vp && cP);
+      const double tM = T.ld(ST_M, d1, i1, sl, vl && doM);
       const bool okp = vp && pok && (!CON || allow_pair(m, con, q.L, i, j, s, sp));
       const bool okl = vl && doM && (!CON || allow_left(m, con, i, s, sl));
       const double wp = okp ? lw_pair(m, q, s, sp, tfp, i, pr) : 0.;
@@ -191,20 +222,20 @@ ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const 
     const int s1 = I[A.right_ent + 2 * (r0 + u)], tf = I[A.right_ent + 2 * (r0 + u) + 1];
     if (CON && !allow_right(m, con, q.L, j, s, s1)) continue;
     const double wr = lw_right(m, q, s, tf, pr);
-    if (doL) sL += T.at(ST_L, d - 1, i, s1) * wr;
-    if (do2) s2 += T.at(ST_2, d - 1, i, s1) * wr;
+    if (doL) sL += T.ld(ST_L, d - 1, i, s1) * wr;
+    if (do2) s2 += T.ld(ST_2, d - 1, i, s1) * wr;
   }
   for (int u = kUnary; u < nP; ++u) {
     if (!pok) break;
     const int s1 = I[A.pair_ent + 2 * (p0 + u)], tf = I[A.pair_ent + 2 * (p0 + u) + 1];
     if (CON && !allow_pair(m, con, q.L, i, j, s, s1)) continue;
-    sP += lw_pair(m, q, s, s1, tf, i, j - 1) * fma(T.at(ST_P, d - 2, i + 1, s1), xst, T.at(ST_E, d - 2, i + 1, s1));
+    sP += lw_pair(m, q, s, s1, tf, i, j - 1) * fma(T.ld(ST_P, d - 2, i + 1, s1, cP), xst, T.ld(ST_E, d - 2, i + 1, s1, cE));
   }
   for (int u = kUnary; u < nL; ++u) {
     if (!doM) break;
     const int s1 = I[A.left_ent + 2 * (l0 + u)], tf = I[A.left_ent + 2 * (l0 + u) + 1];
     if (CON && !allow_left(m, con, i, s, s1)) continue;
-    sM += T.at(ST_M, d - 1, i + 1, s1) * lw_left(m, q, s1, tf, i);
+    sM += T.ld(ST_M, d - 1, i + 1, s1) * lw_left(m, q, s1, tf, i);
   }
   Cell7 c;
   c.vL = isloop ? (d == 0 ? ((m.st_l(s) == m.st_r(s)) ? 1. : 0.) : sL) : 0.;   // motif_trainer.hpp:89-95
@@ -214,13 +245,13 @@ ELEMDP_HD Cell7 lin_inside_target_u(const ModelView& m, const SeqView& q, const 
   c.v1 = lok ? c.v2 + c.vB : 0.;                                                 // rules 4a, 4b
   c.vM = mok ? sM + c.vB : 0.;                                                   // rules 5a, 5b
   c.vE = eok ? fma(c.vM, xcl, fma(c.vL, xhp, HE)) : 0.;                          // rules 6a, 6b, 6c
-  T.at(ST_L, d, i, s) = c.vL;
-  T.at(ST_P, d, i, s) = c.vP;
-  T.at(ST_B, d, i, s) = c.vB;
-  T.at(ST_2, d, i, s) = c.v2;
-  T.at(ST_1, d, i, s) = c.v1;
-  T.at(ST_M, d, i, s) = c.vM;
-  T.at(ST_E, d, i, s) = c.vE;
+  T.st(ST_L, d, i, s, c.vL);
+  T.st(ST_P, d, i, s, c.vP, pok);
+  T.st(ST_B, d, i, s, c.vB, lok);
+  T.st(ST_2, d, i, s, c.v2, lok);
+  T.st(ST_1, d, i, s, c.v1, lok);
+  T.st(ST_M, d, i, s, c.vM, mok);
+  T.st(ST_E, d, i, s, c.vE, eok);
   return c;
 }
 template <bool CON = false>
@@ -248,7 +279,7 @@ ELEMDP_HD double lin_inside_ext_part(const ModelView& m, const SeqView& q, const
     const double xe = xw_cell(q, kl, XT_EXT, q.cell(i, d));   // (0 where the term is log 0; travels with the rows below)
     double b = 0.;
     for (int u = G[A.split_off + s]; u < G[A.split_off + s + 1]; ++u)
-      b = fma(T.o(i, G[A.split_ent + 2 * u]), T.at(ST_P, d, i, G[A.split_ent + 2 * u + 1]), b);
+      b = fma(T.o(i, G[A.split_ent + 2 * u]), T.ld(ST_P, d, i, G[A.split_ent + 2 * u + 1]), b);
     a = fma(b, xe, a);
   }
   if (part == 0 && q.unp[j - 1])
@@ -396,7 +427,7 @@ template <int MODE, class Sink> ELEMDP_HD double lin_outside_ext_part(LinOutCtx<
     const double x0 = xw_cell(q, 0, XT_EXT, c), x1 = xw_cell(q, 1, XT_EXT, c);
     for (int u = G[A.split1_off + s]; u < G[A.split1_off + s + 1]; ++u) {
       const int par = G[A.split1_ent + 2 * u], s1 = G[A.split1_ent + 2 * u + 1];
-      const double term = x.out.o(j, par) * (x.in.at(ST_P, d, i, s1) * (lamk(m, par) ? x1 : x0));
+      const double term = x.out.o(j, par) * (x.in.ld(ST_P, d, i, s1) * (lamk(m, par) ? x1 : x0));
       lstat_energy<MODE>(x, par, t, term * inz);
       a += term;
     }
@@ -425,7 +456,7 @@ template <class Sink> ELEMDP_HD double lheavy_o1(LinOutCtx<Sink>& x, int d, int 
     const int c = q.cell(k, sp);
     for (int e = I[A.ap_by_s1_off + s]; e < I[A.ap_by_s1_off + s + 1]; ++e) {
       const int p = I[A.ap_by_s1_ent + e], t = I[A.ap_t + p];
-      a = fma(x.out.a(d + sp, i, p), x.in.at(ST_P, sp, k, t) * xw_cell(q, lamk(m, t), XT_ML, c), a);
+      a = fma(x.out.a(d + sp, i, p), x.in.ld(ST_P, sp, k, t) * xw_cell(q, lamk(m, t), XT_ML, c), a);
     }
   });
   return a;
@@ -441,7 +472,7 @@ template <class Sink> ELEMDP_HD double lheavy_o2(LinOutCtx<Sink>& x, int d, int 
     if (!o2_valid(q, i, ii)) continue;          // 1(ii, i, .) is log 0
     for (int e = I[A.ap_by_t_off + t]; e < I[A.ap_by_t_off + t + 1]; ++e) {
       const int p = I[A.ap_by_t_ent + e];
-      a = fma(x.out.a(j - ii, ii, p), x.in.at(ST_1, i - ii, ii, I[A.ap_s1 + p]), a);
+      a = fma(x.out.a(j - ii, ii, p), x.in.ld(ST_1, i - ii, ii, I[A.ap_s1 + p]), a);
     }
   }
   return a;
@@ -453,14 +484,16 @@ template <int MODE, class Sink> ELEMDP_HD void lin_outside_apair(LinOutCtx<Sink>
   const AutomatonLayout& A = m.lay; const int32_t* I = m.ints;
   const int j = i + d;
   const int t = I[A.ap_t + p], tgt = I[A.ap_tgt + p];
+  const int dmi = q.dmin[i];
+  if (!(dmi > 0 && dmi < d)) return;        // the entry does not exist (lin_inside_apair)
   const bool step = d + 1 <= q.W && j < q.L && q.unp[j];
   const int e0 = I[A.ap_rchain_off + p], ne = step ? I[A.ap_rchain_off + p + 1] - e0 : 0;
   // (the parents' values are fetched together with the inside value: one round trip; lists longer than kUnary follow)
   const double a_in = x.in.a(d, i, p);
   double op[kUnary];
 #pragma unroll
-  for (int u = 0; u < kUnary; ++u) op[u] = x.out.a(step ? d + 1 : d, i, u < ne ? I[A.ap_rchain_ent + 2 * (e0 + u)] : p);
-  double a = (tgt >= 0 && q.left_ok(i, d)) ? oB_tgt : 0.;
+  for (int u = 0; u < kUnary; ++u) op[u] = x.out.lda(d + 1, i, u < ne ? I[A.ap_rchain_ent + 2 * (e0 + u)] : p, step);
+  double a = (tgt >= 0) ? oB_tgt : 0.;
   if (a_in != 0.) {
     const double inz = a_in * x.invZ;
     for (int u = 0; u < ne; ++u) {
@@ -485,7 +518,7 @@ template <int MODE, class Sink> ELEMDP_HD void lin_outside_apair(LinOutCtx<Sink>
 template <int MODE, class Sink> ELEMDP_HD void lin_outside_cell_pairs(LinOutCtx<Sink>& x, int d, int i) {
   for (int p = 0; p < x.m.lay.n_ap; ++p) {
     const int tgt = x.m.ints[x.m.lay.ap_tgt + p];
-    lin_outside_apair<MODE>(x, d, i, p, tgt >= 0 ? x.out.at(ST_B, d, i, tgt) : 0.);
+    lin_outside_apair<MODE>(x, d, i, p, tgt >= 0 ? x.out.ld(ST_B, d, i, tgt, x.q.left_ok(i, d)) : 0.);
   }
 }
 // HP and the energy statistic of rule 6c: the posterior of (item, tuple) is term * inside P(i,j,s) / Z
@@ -493,7 +526,7 @@ template <int MODE, class Sink> ELEMDP_HD double lheavy_oP(LinOutCtx<Sink>& x, i
   const ModelView& m = x.m; const SeqView& q = x.q;
   const AutomatonLayout& A = m.lay; const int32_t* G = m.big;
   const int j = i + d;
-  const double in_c = x.in.at(ST_P, d, i, s);
+  const double in_c = x.in.ld(ST_P, d, i, s);     // (the caller has checked pair_ok(i, d))
   if (in_c == 0.) return 0.;
   const double inz = in_c * x.invZ;
   double a = 0.;
@@ -504,9 +537,9 @@ template <int MODE, class Sink> ELEMDP_HD double lheavy_oP(LinOutCtx<Sink>& x, i
     const double x0 = xw_item(q, 0, idx), x1 = xw_item(q, 1, idx);
     for (int u = G[A.quad1_off + s]; u < G[A.quad1_off + s + 1]; ++u) {
       const int par = G[A.quad1_ent + 3 * u];
-      const double term = x.out.at(ST_E, it.j - it.i, it.i, par) *
-                          (x.in.at(ST_L, i - it.i, it.i, G[A.quad1_ent + 3 * u + 1]) *
-                           (x.in.at(ST_L, it.j - j, j, G[A.quad1_ent + 3 * u + 2]) * (lamk(m, par) ? x1 : x0)));
+      const double term = x.out.ld(ST_E, it.j - it.i, it.i, par) *
+                          (x.in.ld(ST_L, i - it.i, it.i, G[A.quad1_ent + 3 * u + 1]) *
+                           (x.in.ld(ST_L, it.j - j, j, G[A.quad1_ent + 3 * u + 2]) * (lamk(m, par) ? x1 : x0)));
       lstat_energy<MODE>(x, par, it.tsc, term * inz);
       a += term;
     }
@@ -524,9 +557,9 @@ template <class Sink> ELEMDP_HD double lheavy_oL(LinOutCtx<Sink>& x, int d, int 
     const double x0 = xw_item(q, 0, idx), x1 = xw_item(q, 1, idx);
     for (int u = G[A.quad2_off + s]; u < G[A.quad2_off + s + 1]; ++u) {
       const int par = G[A.quad2_ent + 3 * u];
-      a = fma(x.out.at(ST_E, it.j - it.i, it.i, par),
-              x.in.at(ST_P, it.l - it.k, it.k, G[A.quad2_ent + 3 * u + 1]) *
-                  (x.in.at(ST_L, it.j - it.l, it.l, G[A.quad2_ent + 3 * u + 2]) * (lamk(m, par) ? x1 : x0)), a);
+      a = fma(x.out.ld(ST_E, it.j - it.i, it.i, par),
+              x.in.ld(ST_P, it.l - it.k, it.k, G[A.quad2_ent + 3 * u + 1]) *
+                  (x.in.ld(ST_L, it.j - it.l, it.l, G[A.quad2_ent + 3 * u + 2]) * (lamk(m, par) ? x1 : x0)), a);
     }
   }
   for (int n = q.by_right_off[lc]; n < q.by_right_off[lc + 1]; ++n) {
@@ -535,9 +568,9 @@ template <class Sink> ELEMDP_HD double lheavy_oL(LinOutCtx<Sink>& x, int d, int 
     const double x0 = xw_item(q, 0, idx), x1 = xw_item(q, 1, idx);
     for (int u = G[A.quad3_off + s]; u < G[A.quad3_off + s + 1]; ++u) {
       const int par = G[A.quad3_ent + 3 * u];
-      a = fma(x.out.at(ST_E, it.j - it.i, it.i, par),
-              x.in.at(ST_P, it.l - it.k, it.k, G[A.quad3_ent + 3 * u + 1]) *
-                  (x.in.at(ST_L, it.k - it.i, it.i, G[A.quad3_ent + 3 * u + 2]) * (lamk(m, par) ? x1 : x0)), a);
+      a = fma(x.out.ld(ST_E, it.j - it.i, it.i, par),
+              x.in.ld(ST_P, it.l - it.k, it.k, G[A.quad3_ent + 3 * u + 1]) *
+                  (x.in.ld(ST_L, it.k - it.i, it.i, G[A.quad3_ent + 3 * u + 2]) * (lamk(m, par) ? x1 : x0)), a);
     }
   }
   return a;
@@ -566,10 +599,9 @@ ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, c
   const bool do2 = lok && q.left_ok(i, d + 1) && q.unp[j];
   const bool doL = isloop && j < q.L && d + 1 <= q.W;
 
-  const double rE = in.at(ST_E, d, i, s), rM = in.at(ST_M, d, i, s), r1 = in.at(ST_1, d, i, s), rB = in.at(ST_B, d, i, s);
-  const double r2 = in.at(ST_2, d, i, s), rP = in.at(ST_P, d, i, s), rL = in.at(ST_L, d, i, s);
-  const double inE = eok ? rE : 0., inM = mok ? rM : 0., in1 = lok ? r1 : 0., inB = lok ? rB : 0., in2 = lok ? r2 : 0.;
-  const double inP = pok ? rP : 0., inL = isloop ? rL : 0.;
+  const double inE = in.ld(ST_E, d, i, s, eok), inM = in.ld(ST_M, d, i, s, mok), in1 = in.ld(ST_1, d, i, s, lok);
+  const double inB = in.ld(ST_B, d, i, s, lok), in2 = in.ld(ST_2, d, i, s, lok), inP = in.ld(ST_P, d, i, s, pok);
+  const double inL = in.ld(ST_L, d, i, s, isloop);
   const int c_here = q.cell(i, d), c_up = (i > 0 && d + 2 <= q.W && i + d < q.L) ? q.cell(i - 1, d + 2) : c_here;
   // raw terms (for the energy statistic) and their exponentials for both lambda classes
   const double e_cl = q.e_close[c_up], e_hp = q.e_hp[c_up], e_su = q.e_stack[c_up], e_ml = q.e_ml[c_here];
@@ -620,12 +652,12 @@ ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, c
   for (int u = 0; u < kUnaryR; ++u) {
     const bool vr = u < nRR;
     const int par_r = vr ? I[A.rright_ent + 2 * (rr0 + u)] : 0, tf_r = vr ? I[A.rright_ent + 2 * (rr0 + u) + 1] : 0;
-    const double op2 = out.at(ST_2, dp1, i, par_r), opL = out.at(ST_L, dp1, i, par_r);
+    const double op2 = out.ld(ST_2, dp1, i, par_r, vr && do2), opL = out.ld(ST_L, dp1, i, par_r, vr && doL);
     if (u < kUnary) {
       const bool vp = u < nRP, vl = u < nRL;
       const int par_p = vp ? I[A.rpair_ent + 2 * (rp0 + u)] : 0, tf_p = vp ? I[A.rpair_ent + 2 * (rp0 + u) + 1] : 0;
       const int par_l = vl ? I[A.rleft_ent + 2 * (rl0 + u)] : 0, tf_l = vl ? I[A.rleft_ent + 2 * (rl0 + u) + 1] : 0;
-      const double opP = out.at(ST_P, dp2, im1, par_p), opM = out.at(ST_M, dp1, im1, par_l);
+      const double opP = out.ld(ST_P, dp2, im1, par_p, vp && up_ok), opM = out.ld(ST_M, dp1, im1, par_l, vl && doM);
       if (vp && (aE || aP)) step_pair(par_p, tf_p, opP);
       if (vl && aM) step_left(par_l, tf_l, opM);
     }
@@ -634,19 +666,19 @@ ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, c
   if (aE || aP)
     for (int u = kUnary; u < nRP; ++u) {
       const int par = I[A.rpair_ent + 2 * (rp0 + u)];
-      step_pair(par, I[A.rpair_ent + 2 * (rp0 + u) + 1], out.at(ST_P, d + 2, i - 1, par));
+      step_pair(par, I[A.rpair_ent + 2 * (rp0 + u) + 1], out.ld(ST_P, d + 2, i - 1, par));
     }
   if (aM)
     for (int u = kUnary; u < nRL; ++u) {
       const int par = I[A.rleft_ent + 2 * (rl0 + u)];
-      step_left(par, I[A.rleft_ent + 2 * (rl0 + u) + 1], out.at(ST_M, d + 1, i - 1, par));
+      step_left(par, I[A.rleft_ent + 2 * (rl0 + u) + 1], out.ld(ST_M, d + 1, i - 1, par));
     }
   if (a2 || aL)
     for (int u = kUnaryR; u < nRR; ++u) {
       const int par = I[A.rright_ent + 2 * (rr0 + u)];
-      step_right(par, I[A.rright_ent + 2 * (rr0 + u) + 1], out.at(ST_2, d + 1, i, par), out.at(ST_L, d + 1, i, par));
+      step_right(par, I[A.rright_ent + 2 * (rr0 + u) + 1], out.ld(ST_2, d + 1, i, par, a2), out.ld(ST_L, d + 1, i, par, aL));
     }
-  out.at(ST_E, d, i, s) = oE;
+  out.st(ST_E, d, i, s, oE, eok);
 
   // M: child of E (6a) and of M(i-1,j,par) (5a)
   double oM = 0.;
@@ -655,15 +687,15 @@ ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, c
     lstat_energy<MODE>(x, s, e_cl, t6a * inMz);
     oM = t6a + sM;
   }
-  out.at(ST_M, d, i, s) = oM;
+  out.st(ST_M, d, i, s, oM, mok);
 
   // 1: heavy sum H1 ; B: child of M (5b) and 1 (4b) ; 2: child of 1 (4a), 2(i,j+1,par) (3a), heavy sum H2
   const double o1 = (in1 != 0.) ? H.H1 : 0.;
   const double oB = (inB != 0.) ? (mok ? oM : 0.) + o1 : 0.;
   const double o2 = (in2 != 0.) ? o1 + s2 : 0.;   // direct part (rules 4a, 3a); the rule-2 part reaches P as H.H2 = HA
-  out.at(ST_1, d, i, s) = o1;
-  out.at(ST_B, d, i, s) = oB;
-  out.at(ST_2, d, i, s) = o2;
+  out.st(ST_1, d, i, s, o1, lok);
+  out.st(ST_B, d, i, s, oB, lok);
+  out.st(ST_2, d, i, s, o2, lok);
 
   // P: child of O (7), of P(i-1,j+1,par) (1b), of 2 (3b), inner pair of interior loops (6c: HP)
   double oP = 0.;
@@ -678,7 +710,7 @@ ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, c
     lstat_energy<MODE>(x, s, e_ml, t3b * inPz);
     oP = a + oP1b + t3b + H.HP;
   }
-  out.at(ST_P, d, i, s) = oP;
+  out.st(ST_P, d, i, s, oP, pok);
 
   // L: child of E (6b), of L(i,j+1,par), loops of interior loops (6c: HL)
   double oL = 0.;
@@ -687,7 +719,7 @@ ELEMDP_HD double lin_outside_target_u(LinOutCtx<Sink>& x, int d, int i, int s, c
     lstat_energy<MODE>(x, s, e_hp, t6b * inLz);
     oL = t6b + sL + H.HL;
   }
-  out.at(ST_L, d, i, s) = oL;
+  out.st(ST_L, d, i, s, oL);
   return oB;
 }
 
@@ -695,10 +727,11 @@ template <int MODE, class Sink> ELEMDP_HD void lin_outside_target(LinOutCtx<Sink
   const SeqView& q = x.q;
   HeavyOut H;
   const bool lok = q.left_ok(i, d);
-  H.H1 = (lok && x.in.at(ST_1, d, i, s) != 0.) ? lheavy_o1(x, d, i, s) : 0.;
-  H.H2 = (q.pair_ok(i, d) && x.in.at(ST_P, d, i, s) != 0.) ? lheavy_o2(x, d, i, s) : 0.;
-  H.HP = q.pair_ok(i, d) ? lheavy_oP<MODE>(x, d, i, s) : 0.;
-  H.HL = (x.m.ints[x.m.lay.st_is_loop + s] && x.in.at(ST_L, d, i, s) != 0.) ? lheavy_oL(x, d, i, s) : 0.;
+  const bool pok = q.pair_ok(i, d);
+  H.H1 = (lok && x.in.ld(ST_1, d, i, s) != 0.) ? lheavy_o1(x, d, i, s) : 0.;
+  H.H2 = (pok && x.in.ld(ST_P, d, i, s) != 0.) ? lheavy_o2(x, d, i, s) : 0.;
+  H.HP = pok ? lheavy_oP<MODE>(x, d, i, s) : 0.;
+  H.HL = (x.m.ints[x.m.lay.st_is_loop + s] && x.in.ld(ST_L, d, i, s) != 0.) ? lheavy_oL(x, d, i, s) : 0.;
   lin_outside_target_u<MODE>(x, d, i, s, H);
 }
 

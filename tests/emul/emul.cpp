@@ -18,6 +18,7 @@
 #include "../../rnaelem_amd/csrc/energy_rules.h"
 #include "../../rnaelem_amd/csrc/energy_tables.h"
 #include "../../rnaelem_amd/csrc/host_prep.h"
+#include <limits>
 #include "../../rnaelem_amd/csrc/lin_rules.h"
 #include "../../rnaelem_amd/csrc/plan_rules.h"
 #include "../../rnaelem_amd/csrc/scan_rules.h"
@@ -207,6 +208,25 @@ struct Tab {
                                          ap((size_t)(W + 1) * (L + 1) * nA + 1, 0.) {
     v.band = band.data(); v.ext = ext.data(); v.L = L; v.W = W; v.S = S;
     v.ap = ap.data(); v.nA = nA;
+  }
+};
+
+// compact tables of the scaled-linear rules (TableView::ld / st): every entry starts as NaN, so that a read of an entry
+// nobody stored -- a dead cell or a state without a column -- poisons the result instead of passing as a structural zero
+struct LinTab {
+  std::vector<double> band, ext, ap;
+  TableView v;
+  LinTab(int L, int W, const AutomatonLayout& A, const int32_t* ints)
+      : band((size_t)(W + 1) * (L + 1) * A.tab_row + 1), ext((size_t)(L + 1) * A.S, 0.), ap((size_t)(W + 1) * (L + 1) * A.ap_rs + 1) {
+    v.band = band.data(); v.ext = ext.data(); v.L = L; v.W = W; v.S = A.S;
+    v.ap = ap.data(); v.nA = A.n_ap;
+    v.set_compact(A, ints);
+    poison();
+  }
+  void poison() {
+    std::fill(band.begin(), band.end(), std::numeric_limits<double>::quiet_NaN());
+    std::fill(ap.begin(), ap.end(), std::numeric_limits<double>::quiet_NaN());
+    std::fill(ext.begin(), ext.end(), 0.);
   }
 };
 
@@ -459,9 +479,7 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
     std::vector<double> cum(L + 1, 0.);   // log2 of prod_{p<j} psb
     for (int p = 0; p < L; ++p) cum[p + 1] = cum[p] + lin[kLinPl2 + seq[p]];
     const double ln2 = 0.69314718055994530942;
-    Tab in(L, P.W, S, m.lay.n_ap), out(L, P.W, S, m.lay.n_ap);
-    std::fill(in.band.begin(), in.band.end(), 0.); std::fill(in.ext.begin(), in.ext.end(), 0.);
-    std::fill(out.band.begin(), out.band.end(), 0.); std::fill(out.ext.begin(), out.ext.end(), 0.);
+    LinTab in(L, P.W, m.lay, E.ints.data()), out(L, P.W, m.lay, E.ints.data());
     for (int d = 0; d <= q.W; ++d)
       for (int i = 0; i + d <= q.L; ++i) {
         lin_inside_cell_pairs(m, q, in.v, d, i);     // rule 2, factorised: the pair table of the cell first
@@ -474,11 +492,11 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
     auto tolog = [&](double v, double sc) { return v > 0. ? std::log(v) - sc * ln2 : NEG; };
     out9[0] = tolog(Zo, cum[L]); out9[1] = tolog(Za, cum[L]); out9[2] = tolog(Zn, cum[L]);
     out9[3] = 0; out9[4] = eff; out9[5] = 0; out9[6] = L; out9[7] = P.W; out9[8] = (double)P.items.size();
-    auto copy_tab = [&](Tab& T, double* dst, bool outside_tab) {
+    auto copy_tab = [&](LinTab& T, double* dst, bool outside_tab) {
       for (int i = 0; i <= L; ++i) for (int d = 0; d <= P.W; ++d) for (int e = 0; e < 7; ++e) for (int s = 0; s < S; ++s) {
         double sc = (i + d <= L) ? cum[i + d] - cum[i] : 0.;
         if (outside_tab) sc = cum[L] - sc;
-        dst[(((size_t)i * (P.W + 1) + d) * 7 + e) * S + E.ints[E.lay.st_ref + s]] = (i + d <= L) ? tolog(T.v.at(e, d, i, s), sc) : NEG;
+        dst[(((size_t)i * (P.W + 1) + d) * 7 + e) * S + E.ints[E.lay.st_ref + s]] = (i + d <= L) ? tolog(lin_get(m, q, T.v, e, d, i, s), sc) : NEG;
       }
     };
     if (inside_o) for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) inside_o[(size_t)j * S + E.ints[E.lay.st_ref + s]] = tolog(in.v.o(j, s), cum[j]);
@@ -497,7 +515,6 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
       if (ari) { out.v.o(L, mm.lay.s0m1) = 1.; out.v.o(L, mm.lay.s0m2) = 1.; }
       for (int i = L - 1; i >= 0; --i)
         for (int s = 0; s < NA; ++s) lin_outside_ext_target<OUT_TRAIN>(xo, i, s);
-      std::fill(out.ap.begin(), out.ap.end(), 0.);
       for (int d = q.W; d >= 0; --d)
         for (int i = 0; i + d <= L; ++i) {
           for (int s = 0; s < NA; ++s) lin_outside_target<OUT_TRAIN>(xo, d, i, s);
@@ -514,7 +531,7 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
       for (int d = 0; d <= q.W; ++d)
         for (int i = 0; i + d <= L; ++i)
           for (int t = 0; t < S; ++t)
-            if (q.left_ok(i, d) && in.v.at(ST_2, d, i, t) != 0.) out.v.at(ST_2, d, i, t) += lheavy_o2(xo, d, i, t);
+            if (q.left_ok(i, d) && in.v.ld(ST_2, d, i, t) != 0.) out.v.st(ST_2, d, i, t, out.v.ld(ST_2, d, i, t) + lheavy_o2(xo, d, i, t));
     };
     if (schedule == 0) {
       run_out(m, Zo, true, true, enA, ehA);
@@ -524,7 +541,7 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
     } else {
       run_out(m, Za, true, false, enA, ehA);
       if (outside) { complete_plane2(); copy_tab(out, outside, true); }
-      std::fill(out.band.begin(), out.band.end(), 0.); std::fill(out.ext.begin(), out.ext.end(), 0.);
+      out.poison();
       run_out(mr, Zn, false, true, enB, ehB);
       const double pa = Za / Zo, pn = Zn / Zo;
       for (int t = 0; t < nt; ++t) { const double a = enA[t], b = enB[t]; enA[t] = pa * a + pn * b; enB[t] = positive ? a : b; }
@@ -644,8 +661,8 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
       for (size_t n = 0; n < ni; ++n) xwi[(size_t)k * ni + n] = lin_weight(m.lambda[k], P.items[n].tsc);
     }
     q.ews = ews.data(); q.xwc = xwc.data(); q.xwc_stride = nc; q.xwi = xwi.data(); q.xwi_stride = ni;
-    Tab in(L, P.W, S, m.lay.n_ap), out(L, P.W, S, m.lay.n_ap);
-    auto zero = [](Tab& T) { std::fill(T.band.begin(), T.band.end(), 0.); std::fill(T.ext.begin(), T.ext.end(), 0.); std::fill(T.ap.begin(), T.ap.end(), 0.); };
+    LinTab in(L, P.W, m.lay, E.ints.data()), out(L, P.W, m.lay, E.ints.data());
+    auto zero = [](LinTab& T) { T.poison(); };
     auto run_in = [&](const Constraint& c, bool con) {
       zero(in);
       for (int d = 0; d <= q.W; ++d)
