@@ -508,6 +508,95 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     A.tab_row = cs;
     A.ap_rs = std::max(pad, ((A.n_ap + pad - 1) / pad) * pad);
   }
+  // table-driven unary phases (device_layout.h: fp_*): programs per state, static attributes per forward transition.  They
+  // travel with the tuple lists of their direction (the "big" runs below), not with the small part every kernel stages.
+  std::vector<int32_t> prog_in, prog_out, attr_r, attr_p;
+  {
+    auto colof = [&](int e, int k) { return (*ints)[A.tab_cmap + e * ST + k] & 0xff; };   // (-1 -> 0xff)
+    auto base_of = [&](const Csr& c) {   // first transition id of every row
+      std::vector<int> b(ST + 1, 0);
+      for (int k = 0; k < ST; ++k) b[k + 1] = b[k] + (int)c.rows[k].size() / c.width;
+      return b;
+    };
+    const std::vector<int> br = base_of(right), bp = base_of(pair), bl = base_of(left);
+    A.n_wr = br[ST]; A.n_wp = bp[ST]; A.n_wl = bl[ST];
+    auto fwd_id = [&](const Csr& c, const std::vector<int>& b, int par, int child) {   // id of the transition par -> child
+      for (size_t e = 0; e + 1 < c.rows[par].size(); e += 2) if (c.rows[par][e] == child) return b[par] + (int)e / 2;
+      throw std::runtime_error("flatten: reverse transition without its forward entry");
+    };
+    auto attr = [&](int32_t pos, int k) { return (*ints)[pos + k]; };
+    bool ok = A.n_wr < 32768 && A.n_wp < 32768 && A.n_wl < 32768 && A.tab_row < 250;
+    for (int k = 0; k < ST; ++k) {
+      for (const Csr* c : {&right, &rright}) ok = ok && (int)c->rows[k].size() / 2 <= kFastR;
+      for (const Csr* c : {&pair, &rpair}) ok = ok && (int)c->rows[k].size() / 2 <= kFastP;
+      for (const Csr* c : {&left, &rleft}) ok = ok && (int)c->rows[k].size() / 2 <= kFastL;
+    }
+    A.fp_ok = ok ? 1 : 0;
+    for (int k = 0; k < ST; ++k) {
+      int32_t w[kFastW] = {0};
+      const int nR = ok ? (int)right.rows[k].size() / 2 : 0, nP = ok ? (int)pair.rows[k].size() / 2 : 0, nL = ok ? (int)left.rows[k].size() / 2 : 0;
+      w[0] = (attr(A.st_is_loop, k) ? 1 : 0) | (attr(A.st_l, k) == attr(A.st_r, k) ? 2 : 0) | (attr(A.st_lam, k) ? 4 : 0) |
+             (attr(A.st_w_r, k) ? 8 : 0) | (nR << 8) | (nP << 12) | (nL << 16);
+      w[1] = colof(ST_P, k) | (colof(ST_E, k) << 8) | (colof(ST_M, k) << 16) | (colof(ST_B, k) << 24);
+      w[2] = colof(ST_1, k) | (colof(ST_2, k) << 8) | (colof(ST_L, k) << 16);
+      for (int u = 0; u < nR; ++u) {
+        const int ch = right.rows[k][2 * u];
+        w[4 + u] = colof(ST_L, ch) | (colof(ST_2, ch) << 8) | ((br[k] + u) << 16);
+      }
+      for (int u = 0; u < nP; ++u) {
+        const int ch = pair.rows[k][2 * u];
+        w[8 + u] = colof(ST_E, ch) | (colof(ST_P, ch) << 8) | ((bp[k] + u) << 16) | (attr(A.st_w_l, ch) ? (int32_t)0x80000000 : 0);
+      }
+      for (int u = 0; u < nL; ++u) {
+        const int ch = left.rows[k][2 * u];
+        w[12 + u] = colof(ST_M, ch) | ((bl[k] + u) << 16) | (attr(A.st_w_l, ch) ? (int32_t)0x80000000 : 0);
+      }
+      prog_in.insert(prog_in.end(), w, w + kFastW);
+    }
+    auto rowoff1 = [&](int row) { return row >= 0 ? (*ints)[A.row_off + row] - 1 : -1000000; };   // index of base b: + b
+    for (int k = 0; k < ST; ++k) {
+      int32_t w[kFastW] = {0};
+      const int nR = ok ? (int)rright.rows[k].size() / 2 : 0, nP = ok ? (int)rpair.rows[k].size() / 2 : 0, nL = ok ? (int)rleft.rows[k].size() / 2 : 0;
+      w[0] = (attr(A.st_is_loop, k) ? 1 : 0) | (attr(A.st_lam, k) ? 4 : 0) | (attr(A.st_w_l, k) ? 16 : 0) | (k == A.shadow ? 32 : 0) |
+             (nR << 8) | (nP << 12) | (nL << 16);
+      w[1] = colof(ST_P, k) | (colof(ST_E, k) << 8) | (colof(ST_M, k) << 16) | (colof(ST_B, k) << 24);
+      w[2] = colof(ST_1, k) | (colof(ST_2, k) << 8) | (colof(ST_L, k) << 16);
+      w[3] = rowoff1(attr(A.st_row_l, k));
+      for (int u = 0; u < nR; ++u) {
+        const int par = rright.rows[k][2 * u];
+        w[4 + u] = colof(ST_2, par) | (colof(ST_L, par) << 8) | (fwd_id(right, br, par, k) << 16) | (attr(A.st_is_loop, par) ? (int32_t)0x80000000 : 0);
+      }
+      for (int u = 0; u < nP; ++u) {
+        const int par = rpair.rows[k][2 * u];
+        w[8 + u] = colof(ST_P, par) | (fwd_id(pair, bp, par, k) << 16);
+      }
+      for (int u = 0; u < nL; ++u) {
+        const int par = rleft.rows[k][2 * u];
+        w[12 + u] = colof(ST_M, par) | (fwd_id(left, bl, par, k) << 16);
+      }
+      prog_out.insert(prog_out.end(), w, w + kFastW);
+    }
+    // static attributes per forward transition.  right: {index of base b of the parent's r-row minus b, flags: bit 0 the
+    // position weight applies (parent's r-node), bit 1 lambda class of the parent}; pair: {flags: bit 0 the parent's r-node
+    // emits the pair as a pair type, 1 position weight of the child's l-node, 2 of the parent's r-node, 3 lambda class of the
+    // parent; r-row of the parent; l-row of the child (same convention)}
+    for (int k = 0; k < ST; ++k)
+      for (size_t e = 0; e + 1 < right.rows[k].size(); e += 2) {
+        attr_r.push_back(rowoff1(attr(A.st_row_r, k)));
+        attr_r.push_back((attr(A.st_w_r, k) ? 1 : 0) | (attr(A.st_lam, k) ? 2 : 0));
+      }
+    for (int k = 0; k < ST; ++k)
+      for (size_t e = 0; e + 1 < pair.rows[k].size(); e += 2) {
+        const int ch = pair.rows[k][e];
+        attr_p.push_back((attr(A.st_pair_r, k) ? 1 : 0) | (attr(A.st_w_l, ch) ? 2 : 0) | (attr(A.st_w_r, k) ? 4 : 0) | (attr(A.st_lam, k) ? 8 : 0));
+        attr_p.push_back(rowoff1(attr(A.st_row_r, k)));
+        attr_p.push_back(rowoff1(attr(A.st_row_l, ch)));
+      }
+    A.lin_wr = 11 + A.n_theta;            // (kLinEth + n_theta, lin_params.h)
+    A.lin_wl = A.lin_wr + 5 * A.n_wr;
+    A.lin_wp = A.lin_wl + 5 * A.n_wl;
+    A.lin_total = A.lin_wp + 8 * A.n_wp;
+  }
   A.n_small = (int32_t)ints->size();
   // big part: tuple lists of the bifurcation and interior-loop rules -- first the ones the inside direction reads (by
   // parent), then the ones of the outside direction (by child): a kernel stages the small part and its own run
@@ -515,6 +604,8 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   put(quad, &A.quad_off, &A.quad_ent);
   A.split_tgt = split.emit_targets(ints);
   A.quad_tgt = quad.emit_targets(ints);
+  A.fp_in = (int32_t)ints->size();
+  ints->insert(ints->end(), prog_in.begin(), prog_in.end());
   A.big_in_end = (int32_t)ints->size();
   put(split1, &A.split1_off, &A.split1_ent);
   put(split2, &A.split2_off, &A.split2_ent);
@@ -526,6 +617,12 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   A.quad1_tgt = quad1.emit_targets(ints);
   A.quad2_tgt = quad2.emit_targets(ints);
   A.quad3_tgt = quad3.emit_targets(ints);
+  A.fp_out = (int32_t)ints->size();
+  ints->insert(ints->end(), prog_out.begin(), prog_out.end());
+  A.fe_r = (int32_t)ints->size();
+  ints->insert(ints->end(), attr_r.begin(), attr_r.end());
+  A.fe_p = (int32_t)ints->size();
+  ints->insert(ints->end(), attr_p.begin(), attr_p.end());
   A.n_split = split.count();
   A.n_quad = quad.count();
   A.n_ints = (int32_t)ints->size();
@@ -556,6 +653,8 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   A.tab_cmap = (int32_t)ints->size();
   for (int e = 0; e < 7; ++e) { ints->push_back(0); A.tab_rs[e] = 1; A.tab_cs[e] = e; }
   A.tab_row = 7; A.ap_rs = 1;
+  A.fp_ok = 0; A.fp_in = A.fp_out = A.fe_r = A.fe_p = 0; A.n_wr = A.n_wp = A.n_wl = 0;
+  A.lin_wr = A.lin_wl = A.lin_wp = A.lin_total = 11;
   A.n_small = (int32_t)ints->size();
   csr(2, &A.split_off, &A.split_ent); csr(3, &A.quad_off, &A.quad_ent);
   A.split_tgt = A.quad_tgt = one(0);

@@ -80,12 +80,24 @@ struct AutomatonLayout {
   int32_t tab_cmap;
   int32_t tab_rs[7], tab_cs[7], tab_row;
   int32_t ap_rs;
+  // Table-driven unary phases of the train kernels (lin_fast.h).  One PROGRAM of kFastW ints per interval state and direction
+  // lists everything a (cell, state) lane needs: its own columns, and per unary transition the operand columns and the id of
+  // the transition = its position in the forward list (right / pair / left), which indexes the per-evaluation weight tables
+  // WR[id][base], WL[id][base], WP[id][pair type] behind the linear parameter block (lin_params.h) and the static attribute
+  // tables fe_r (2 ints per right transition) / fe_p (3 ints per pair transition).  fp_ok = 0: a list is longer than
+  // kFastR / kFastP / kFastL, the kernels then run the generic rule code.
+  int32_t fp_ok, fp_in, fp_out, fe_r, fe_p;
+  int32_t n_wr, n_wp, n_wl;                     // transitions per forward list = rows of the weight tables
+  int32_t lin_wr, lin_wl, lin_wp, lin_total;    // offsets (doubles) of the weight tables in the linear block; its length
   int32_t n_small;  // the first n_small ints (per-state attributes, unary lists) are staged in LDS;
                     // the tuple lists behind them are read from global memory (ModelView::big)
   int32_t big_in_end;  // the tuple lists behind n_small come in two runs: [n_small, big_in_end) = lists of the inside
                        // direction (split, quad + targets), [big_in_end, n_ints) = lists of the outside direction
   int32_t n_ints;   // total length of the int blob
 };
+
+constexpr int kFastW = 16;                        // ints per unary program
+constexpr int kFastR = 3, kFastP = 3, kFastL = 2;  // most right / pair / left transitions of a state the programs (and the kernels) hold
 
 // Per-evaluation parameters (changes every optimizer step)
 struct ParamBlock {

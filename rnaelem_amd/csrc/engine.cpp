@@ -250,6 +250,7 @@ class Engine {
   void upload_automaton();
   bool opt_prune_ = true;   // transition lists pruned to the transitions of complete parses (Automaton::flatten)
   int opt_row_pad_ = 8;     // rows of the compact tables padded to a multiple of this many doubles (8 = 64-byte lines)
+  bool opt_fast_ = true;    // table-driven unary phases of the train kernels (lin_fast.h); 0 = the generic rule code
   bool opt_poison_ = false; // tests: the table slots are filled with NaN before every evaluation of the scaled-linear pipeline, so
                             // that a read of an entry nobody stored shows up in the results (the compact tables hold garbage there)
   void require_device() const;
@@ -354,14 +355,14 @@ class Engine {
   std::vector<int32_t> intss_;
   DevBuf d_lays_, d_intss_;
   int tables_S_ = 0;                     // state stride of the tables of the last linear evaluation (debug_tables)
-  std::vector<double> h_lin_;            // linear parameter block of the last evaluation
+  std::vector<double> h_lin_, h_lins_;   // linear parameter block of the last evaluation (plain automaton / with the shadow state)
   std::vector<uint8_t> h_seq_;           // base codes of the batch (table export)
   int64_t n_cells_total_ = 0;
   bool tables_linear_ = false;           // the resident tables hold scaled linear values (debug_tables converts)
   int n_flagged_last_ = 0;
   DevBuf d_a_in_, d_a_out_;   // pair tables of the factorised rule 2 (lin_rules.h), per slot [W+1][Lmax+1][n_ap]
   DevBuf d_plans_sorted_;   // plan records in processing (h_order_) order
-  DevBuf d_ews_, d_xwc_, d_xwi_, d_lin_, d_zs_, d_flagged_;
+  DevBuf d_ews_, d_xwc_, d_xwi_, d_lin_, d_lins_, d_zs_, d_flagged_;
   int lin_slots_ = 0;
   int opt_schedule_ = 1;   // 1 = linear (ari pass + one-state nasi pass), 0 = the reference's two full passes
   int opt_dbg_ = 0;        // timing experiments (LinArgs::dbg); results are wrong when set
@@ -527,6 +528,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "dbg") opt_dbg_ = (int)v;
   else if (key == "bpp_log") opt_bpp_log_ = v != 0;
   else if (key == "poison") opt_poison_ = v != 0;
+  else if (key == "fast") opt_fast_ = v != 0;
   else if (key == "prune" || key == "row_pad") {
     if (key == "prune") opt_prune_ = v != 0;
     else opt_row_pad_ = std::max(1, (int)v);
@@ -569,8 +571,14 @@ void Engine::upload_params(const double* x, const AutomatonLayout& lay, bool) {
   std::memcpy(blob.data(), &pb, sizeof(pb));
   std::copy(theta_.begin(), theta_.end(), blob.begin() + sizeof(ParamBlock) / sizeof(double));
   HIP_OK(hipMemcpyAsync(d_params_.as<void>(), blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+  // linear parameter block (+ the weight tables of the table-driven unary phases) for the plain automaton and for the one
+  // with the shadow state (their transition ids differ)
   make_lin_params(lay_, ints_.data(), theta_.data(), tau_, (flags_ & ELEMDP_NO_PROFILE) != 0, &h_lin_);
+  d_lin_.alloc(sizeof(double) * (h_lin_.size() + 1));
   HIP_OK(hipMemcpyAsync(d_lin_.as<void>(), h_lin_.data(), h_lin_.size() * sizeof(double), hipMemcpyHostToDevice, st_));
+  make_lin_params(lays_, intss_.data(), theta_.data(), tau_, (flags_ & ELEMDP_NO_PROFILE) != 0, &h_lins_);
+  d_lins_.alloc(sizeof(double) * (h_lins_.size() + 1));
+  HIP_OK(hipMemcpyAsync(d_lins_.as<void>(), h_lins_.data(), h_lins_.size() * sizeof(double), hipMemcpyHostToDevice, st_));
   HIP_OK(hipStreamSynchronize(st_));  // blob is a local
   (void)lay;
 }
@@ -1313,7 +1321,10 @@ int Engine::prepare_lin(LinArgs& a, bool sched1, bool dense_too) {
   a.layp = shadow ? d_lays_.as<AutomatonLayout>() : d_lay_.as<AutomatonLayout>();
   a.ints = shadow ? d_intss_.as<int32_t>() : d_ints_.as<int32_t>();
   a.params = d_params_.as<double>();
-  a.lin = d_lin_.as<double>();
+  a.lin = shadow ? d_lins_.as<double>() : d_lin_.as<double>();
+  // (table-driven unary phases: not under FIX_RSS, whose fixed pairs need not be canonical -- the weight tables are indexed
+  // by the pair type)
+  a.fast = (opt_fast_ && !(flags_ & ELEMDP_DBG_FIX_RSS)) ? 1 : 0;
   a.no_prf = (flags_ & ELEMDP_NO_PROFILE) ? 1 : 0;
   a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
   a.no_rss = (flags_ & ELEMDP_NO_RSS) ? 1 : 0;

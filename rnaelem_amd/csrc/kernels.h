@@ -177,6 +177,8 @@ struct LinArgs {
   int32_t n_stage;                // ints of the automaton blob staged in LDS: n_ints (whole blob) or n_small
   int32_t dbg;                    // timing experiments only: bit 0 skip split sums, 1 skip item sums, 2 skip the unary phase
   int32_t ext_ring;               // exterior-chain kernels keep the chain's last rows in an LDS ring (small groups only)
+  int32_t n_lin;                  // doubles of the linear parameter block the band kernels stage (with or without the weight tables)
+  int32_t fast;                   // train: table-driven unary phases (lin_fast.h); the host clears it where they do not apply
 };
 struct LinWeightArgs {
   const LoopItem* items_inner; const LoopItem* items_left; const LoopItem* items_right;   // (may be null)

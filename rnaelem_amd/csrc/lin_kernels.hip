@@ -38,10 +38,11 @@
 #define ELEMDP_RECIN 1024
 #endif
 #ifndef ELEMDP_RECOUT
-#define ELEMDP_RECOUT 2560
+#define ELEMDP_RECOUT 1536
 #endif
 #include "kernels.h"
 #include "lin_rules.h"
+#include "lin_fast.h"
 #include "scan_rules.h"
 #include "wave_gather.h"
 
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
 // window of positions the workgroup touches, small int arrays, the automaton blob, and the dmin / base / unpaired
 // windows.  With the context in LDS the unary phase has a single level of global loads (the tables themselves).
 struct BlockLds {
-  int lin, ews, ints, dm, cnts, pre, base, blob, bits, bits2, dmin16, seq8, unp8, total;   // byte offsets
+  int lin, ews, ints, dm, cnts, pre, base, blob, bits, bits2, dmin16, seq8, unp8, crec, crfl, total;   // byte offsets
 };
 // LDS doubles of the item-record area of k4_in / k5_cyk (one role) and of k4_out (three roles)
 constexpr int kRecIn = ELEMDP_RECIN, kRecOut = ELEMDP_RECOUT;
@@ -256,12 +257,15 @@ struct BitIter {
     }
   }
 };
-__host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int win, int n_stage, int nv = 0) {
+// crd: doubles per cell record of the table-driven unary phase (lin_fast.h), 0 = none
+__host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int win, int n_stage, int nv = 0, int crd = 0) {
   BlockLds b;
   if (nv < cpb) nv = cpb;   // CSR ranges of the item sums: one per cell, or one per (role, cell) in k4_out
   int o = nd * 8;
   b.lin = o; o += n_lin * 8;
   b.ews = o; o += win * 8;
+  b.crec = o; o += cpb * crd * 8;
+  b.crfl = o; o += crd ? ((cpb + 1) / 2) * 8 : 0;
   b.ints = o;
   b.dm = o; o += cpb * 4;
   b.cnts = o; o += nv * 4;
@@ -305,7 +309,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   int16_t* ldmin = reinterpret_cast<int16_t*>(raw + B.dmin16);
   uint8_t* lseq = raw + B.seq8;
   uint8_t* lunp = raw + B.unp8;
-  const int n_lin = kLinEth + a.lay.n_theta;
+  const int n_lin = a.n_lin;
   const int big_lo = (PART == 0) ? a.lay.n_small : a.lay.big_in_end, big_hi = (PART == 0) ? a.lay.big_in_end : a.lay.n_ints;
   uint32_t* lbits = reinterpret_cast<uint32_t*>(raw + B.bits);
   uint32_t* lbits2 = reinterpret_cast<uint32_t*>(raw + B.bits2);
@@ -556,7 +560,8 @@ __device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r,
   __syncthreads();
 }
 
-template <bool BIG, bool CON>
+// FAST: table-driven unary phase (lin_fast.h; train schedule, whole blob staged)
+template <bool BIG, bool CON, bool FAST = false>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
@@ -577,13 +582,42 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   double* hb = lds;
   double* he = hb + CS;
   double* st1 = he + CS;                     // item records (kRecIn doubles)
-  const BlockLds BL = block_lds(2 * CS + kRecIn, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
+  const BlockLds BL = block_lds(2 * CS + kRecIn, cpb, a.n_lin, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0), 0, FAST ? kCellInD : 0);
+  // cell records of the table-driven unary phase: the exponentiated structural terms of the cells are fetched with the context
+  // (lane = (cell, value); the addresses depend on the plan record only), the flags follow once the context is in LDS
+  constexpr int kCRin = (ELEMDP_CPB_MAX * 8 + kThreads - 1) / kThreads;
+  double crx[kCRin];
+  if (FAST) {
+#pragma unroll
+    for (int r = 0; r < kCRin; ++r) {
+      const int t = tid + r * kThreads, c = (t >> 3) < nc ? (t >> 3) : 0;
+      crx[r] = cell_in_fetch(v.q, d, i0 + c, t & 7);
+    }
+  }
   const BlockCtx cx = stage_context<BIG, 0>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
+  double* crec = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
+  int* crfl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
   for (int t = tid; t < 2 * CS; t += kThreads) lds[t] = 0.;
   __syncthreads();
   pc.mark<0>();
+  if (FAST) {   // (read by the unary phase, behind the barriers of the heavy sums)
+#pragma unroll
+    for (int r = 0; r < kCRin; ++r) {
+      const int t = tid + r * kThreads, c = t >> 3, k = t & 7;
+      if (c < nc) {
+        const bool on = k < 4 ? v.q.pair_ok(i0 + c, d) : v.q.e_ok(i0 + c, d);
+        crec[c * kCellInD + 2 + k] = on ? crx[r] : 0.;
+      }
+    }
+    for (int c = tid; c < nc; c += kThreads) {
+      const int i = i0 + c, j = i + d;
+      crfl[c] = cell_in_flags(v.m, v.q, d, i);
+      crec[c * kCellInD] = v.q.ews[i];
+      crec[c * kCellInD + 1] = v.q.ews[j > 0 ? j - 1 : 0];
+    }
+  }
   const double* B = v.in.band;
   const int nq = (a.dbg & 2) ? 0 : A.n_quad;
   outer_ranges_load(v, i0, nc, d, nq > 0, tid, cnts, base);   // (CSR ranges of the item sums: in flight during the pair phase)
@@ -700,8 +734,12 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     const int c = tid / NA, s = tid - c * NA;
     const int i = i0 + c;
     const double HB = hb[c * S + s];
-    const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
-    lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, HB, he[c * S + s], con);
+    if (FAST) {
+      fast_inside_unary(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, HB, he[c * S + s]);
+    } else {
+      const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
+      lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, HB, he[c * S + s], con);
+    }
   }
   pc.mark<4>();
   pc.finish();
@@ -1010,7 +1048,7 @@ __global__ __launch_bounds__(kThreads) void k4_r7(LinArgs a) {
 }
 
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
-template <int MODE, bool BIG>
+template <int MODE, bool BIG, bool FAST = false>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
@@ -1039,15 +1077,44 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* l_pos = l_eh + 4;                    // scan: [2][win] position posteriors of the window (start, inner | end, -)
   const int win = cpb + a.wmax + 3;
   double* sOB1 = l_pos + 2 * win;              // item records of the three roles (kRecOut doubles)
-  const BlockLds BL = block_lds(out_doubles(CS, nt, cpb + a.wmax + 3), cpb, kLinEth + nt, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb);
+  const BlockLds BL = block_lds(out_doubles(CS, nt, cpb + a.wmax + 3), cpb, a.n_lin, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb, FAST ? kCellOutD : 0);
+  // cell records of the table-driven unary phase (see k4_in): twelve global values per cell, fetched with the context
+  constexpr int kCRout = (ELEMDP_CPB_MAX * 12 + kThreads - 1) / kThreads;
+  double crx[kCRout];
+  if (FAST) {
+#pragma unroll
+    for (int r = 0; r < kCRout; ++r) {
+      const int t = tid + r * kThreads, c0 = t / 12, c = c0 < nc ? c0 : 0;
+      crx[r] = cell_out_fetch(v.q, d, i0 + c, t - c0 * 12);
+    }
+  }
   const BlockCtx cx = stage_context<BIG, 1>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   if (pi.skip) return;   // (tested here: the loads behind `pi` travel with those of the context instead of before them)
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
+  double* crec = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
+  int* crfl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
   const int n_zero = 4 * CS + 2 * nt + 4 + ((MODE == OUT_SCAN || MODE == OUT_END) ? 2 * win : 0);
   for (int t = tid; t < n_zero; t += kThreads) lds[t] = 0.;
   __syncthreads();
   pc.mark<5>();
+  if (FAST) {   // (read by the unary phase, behind the barriers of the heavy sums)
+#pragma unroll
+    for (int r = 0; r < kCRout; ++r) {
+      const int t = tid + r * kThreads, c = t / 12, k = t - c * 12;
+      if (c < nc) {
+        const int i = i0 + c;
+        const bool on = k < 4 ? v.q.e_ok(i, d) : k < 6 ? v.q.pair_ok(i, d) : k < 8 ? (v.q.pair_ok(i - 1, d + 2) && v.q.pair_ok(i, d)) : true;
+        crec[c * kCellOutD + 2 + k] = on ? crx[r] : 0.;
+      }
+    }
+    for (int c = tid; c < nc; c += kThreads) {
+      const int i = i0 + c, j = i + d;
+      crfl[c] = cell_out_flags(v.m, v.q, d, i);
+      crec[c * kCellOutD] = v.q.ews[i > 0 ? i - 1 : 0];
+      crec[c * kCellOutD + 1] = v.q.ews[j < L ? j : L];
+    }
+  }
   LinSink sink;
   sink.en_ = l_en;
   sink.eh0 = sink.eh1 = 0.;
@@ -1265,12 +1332,18 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     const bool w1 = pi.merged && s == A.shadow;      // the shadow state: world 1 (its own Z, second set of statistics)
     sink.world = w1 ? 1 : 0;
     sink.en_ = l_en + (w1 ? nt : 0);
-    LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
-    HeavyOut H;
-    H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
-    if (!(a.dbg & 32)) H.HP += out.ld(ST_P, d, i0 + c, s, v.q.pair_ok(i0 + c, d));   // rule-7 term (k4_r7)
-    H.ext_in_hp = true;
-    h1[c * S + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
+    if (FAST) {
+      h1[c * S + s] = fast_outside_unary(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c], d, i0 + c,
+                                         w1 ? pi.invZs : pi.invZ, v.m.lam_same != 0, v.m.no_prf != 0, sink, h1[c * S + s], h2[c * S + s],
+                                         hp[c * S + s], hl[c * S + s]);
+    } else {
+      LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
+      HeavyOut H;
+      H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
+      if (!(a.dbg & 32)) H.HP += out.ld(ST_P, d, i0 + c, s, v.q.pair_ok(i0 + c, d));   // rule-7 term (k4_r7)
+      H.ext_in_hp = true;
+      h1[c * S + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
+    }
   }
   __syncthreads();
   // outside values of the pair entries of the cells (lin_outside_apair): out B of the target + the tail step from
@@ -1595,6 +1668,7 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   a.wmax = Wmax;
   a.ext_ring = G <= 1024 ? 1 : 0;
   a.lmax = Lmax;
+  a.n_lin = kLinEth + nt; a.fast = 0;
   const size_t lds = block_lds(3 * a.cpb * S + 2 * kChunkIn * kThreads, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const long long products = (long long)a.cpb * a.lay.n_split;   // (cell, tuple) products of a workgroup
@@ -1626,6 +1700,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   a.schedule = 0;   // terminals (ari, nasi), Z = Z(ari,nasi): pass 0 of the reference schedule
   a.pass = 0;
   a.scan = 1;
+  a.n_lin = kLinEth + nt; a.fast = 0;
   const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const size_t lds_out = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
   const bool big = a.n_stage >= a.lay.n_ints;
@@ -1675,15 +1750,21 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
   a.ext_ring = G <= 1024 ? 1 : 0;
-  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
+  // table-driven unary phases (lin_fast.h): the train schedule on an automaton whose lists fit the programs, the whole blob
+  // and the weight tables staged
+  const bool fast = a.fast && big && a.lay.fp_ok && !(a.dbg & 16) && a.lay.lin_total <= 2048;
+  a.fast = fast ? 1 : 0;
+  a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
+  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
   const size_t lds_stat = sizeof(double) * (2 * nt + 4);
   if (!a.no_rss)
     for (int d = 0; d <= Wmax; ++d) {
       const int ncell = Lmax - d + 1;
       if (ncell <= 0) break;
       a.d = d;
-      if (big) hipLaunchKernelGGL((k4_in<true, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
+      if (fast) hipLaunchKernelGGL((k4_in<true, false, true>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
+      else if (big) hipLaunchKernelGGL((k4_in<true, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
       else hipLaunchKernelGGL((k4_in<false, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
     }
   a.lmax = Lmax;
@@ -1695,7 +1776,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   // pattern's states, the "no motif" terminal on the shadow of (0,0), each with its own Z and statistics (lpass).
   // schedule 0: the reference's two sweeps, (ari, nasi) then the label's mask.
   const int n_pass = (a.schedule == 1 || first_pass_only) ? 1 : 2;
-  const size_t lds_b = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
+  const size_t lds_b = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
   for (int pass = 0; pass < n_pass; ++pass) {
     LinArgs b = a;
     b.pass = pass;
@@ -1708,6 +1789,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
         if (ncell <= 0) continue;
         b.d = d;
         if (big && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);   // (timing experiment: no statistics)
+        else if (fast) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else if (big) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
       }
