@@ -606,6 +606,25 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   A.quad_tgt = quad.emit_targets(ints);
   A.fp_in = (int32_t)ints->size();
   ints->insert(ints->end(), prog_in.begin(), prog_in.end());
+  // column records of the interior-loop tuples (device_layout.h: qc_*)
+  auto col_of = [&](int e, int k) { return (*ints)[A.tab_cmap + e * ST + k]; };
+  auto emit_qc = [&](const Csr& c, int which) {
+    const int32_t pos = (int32_t)ints->size();
+    for (int k = 0; k < ST; ++k)
+      for (size_t e = 0; e + 2 < c.rows[k].size(); e += 3) {
+        const int a = c.rows[k][e], b = c.rows[k][e + 1], d3 = c.rows[k][e + 2];
+        int c0, c1, c2, ca, par;
+        if (which == 0) { c0 = col_of(ST_P, a); c1 = col_of(ST_L, b); c2 = col_of(ST_L, d3); ca = 0; par = k; }
+        else if (which == 1) { c0 = col_of(ST_E, a); c1 = col_of(ST_L, b); c2 = col_of(ST_L, d3); ca = col_of(ST_P, k); par = a; }
+        else { c0 = col_of(ST_E, a); c1 = col_of(ST_P, b); c2 = col_of(ST_L, d3); ca = col_of(ST_L, k); par = a; }
+        const bool dead = c0 < 0 || c1 < 0 || c2 < 0 || ca < 0 || c0 > 254 || c1 > 254 || c2 > 254 || ca > 254;
+        const int fl = ((*ints)[A.st_lam + par] ? 1 : 0) | (par == A.shadow ? 2 : 0) | (dead ? 4 : 0);
+        ints->push_back(dead ? 0 : (c0 | (c1 << 8) | (c2 << 16) | (ca << 24)));
+        ints->push_back(k | (fl << 16));
+      }
+    return pos;
+  };
+  A.qc_in = emit_qc(quad, 0);
   A.big_in_end = (int32_t)ints->size();
   put(split1, &A.split1_off, &A.split1_ent);
   put(split2, &A.split2_off, &A.split2_ent);
@@ -623,6 +642,9 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   ints->insert(ints->end(), attr_r.begin(), attr_r.end());
   A.fe_p = (int32_t)ints->size();
   ints->insert(ints->end(), attr_p.begin(), attr_p.end());
+  A.qc_out1 = emit_qc(quad1, 1);
+  A.qc_out2 = emit_qc(quad2, 2);
+  A.qc_out3 = emit_qc(quad3, 2);
   A.n_split = split.count();
   A.n_quad = quad.count();
   A.n_ints = (int32_t)ints->size();
@@ -655,6 +677,7 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   A.tab_row = 7; A.ap_rs = 1;
   A.fp_ok = 0; A.fp_in = A.fp_out = A.fe_r = A.fe_p = 0; A.n_wr = A.n_wp = A.n_wl = 0;
   A.lin_wr = A.lin_wl = A.lin_wp = A.lin_total = 11;
+  A.qc_in = A.qc_out1 = A.qc_out2 = A.qc_out3 = 0;
   A.n_small = (int32_t)ints->size();
   csr(2, &A.split_off, &A.split_ent); csr(3, &A.quad_off, &A.quad_ent);
   A.split_tgt = A.quad_tgt = one(0);

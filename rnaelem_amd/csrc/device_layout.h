@@ -89,6 +89,14 @@ struct AutomatonLayout {
   int32_t fp_ok, fp_in, fp_out, fe_r, fe_p;
   int32_t n_wr, n_wp, n_wl;                     // transitions per forward list = rows of the weight tables
   int32_t lin_wr, lin_wl, lin_wp, lin_total;    // offsets (doubles) of the weight tables in the linear block; its length
+  // Column records of the interior-loop tuples (rule 6c), 2 ints each, in the tuple-list runs of the blob: the item sums hold
+  // one item record per lane and read the tuples' operand columns from here instead of deriving them from the state ids.
+  // {columns of the first, second, third operand and of the target's own entry, one byte each; target state | flags << 16
+  // (bit 0 lambda class of the rule's parent, 1 the parent is the shadow state, 2 a column is missing: the tuple is dead)}
+  //   qc_in  (quad order):  P(inner) [s1], L(left) [s2], L(right) [s3], -; target = parent E state
+  //   qc_out1 (quad1 order, target = the inner pair's P state): out E [par], L [s2], L [s3], own = P [target]
+  //   qc_out2 / qc_out3 (quad2 / quad3 order, target = a loop's L state): out E [par], P [s1], L [other loop], own = L [target]
+  int32_t qc_in, qc_out1, qc_out2, qc_out3;
   int32_t n_small;  // the first n_small ints (per-state attributes, unary lists) are staged in LDS;
                     // the tuple lists behind them are read from global memory (ModelView::big)
   int32_t big_in_end;  // the tuple lists behind n_small come in two runs: [n_small, big_in_end) = lists of the inside

@@ -19,6 +19,9 @@
 // Reference path: RNAelemTrainDP::operator(), RNAelem/motif_trainer.hpp:124-272.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #ifndef ELEMDP_KCI
 #define ELEMDP_KCI 4
 #endif
@@ -492,6 +495,16 @@ struct WorkIdx {
   }
 };
 
+// Item sums (rule 6c): a lane holds ONE item record and walks the tuples of the rule through their column records
+// (AutomatonLayout::qc_*, staged with the tuple lists); the four waves share the tuples (wave w takes t = w, w + 4, ..), kTU of
+// them per pass with all their table operands in flight together -- one round trip per 64 records.  Everything that depends
+// on the record (row addresses, weights) is computed once per lane, a tuple then costs its four loads and a handful of
+// instructions.
+#ifndef ELEMDP_KTU
+#define ELEMDP_KTU 3
+#endif
+constexpr int kTU = ELEMDP_KTU;
+
 // Item records of the workgroup's cells in LDS (k4_in, k5_cyk: the by_outer order; k4_out stages its three roles the same
 // way inline): CSR range per cell -> prefix in LDS, then all lanes fetch the records of [p0, p0 + cap) with one round of
 // loads.  meta = cell << 16 | position of the item in its cell; xw = exp(lambda_k tsc) for k = 0, 1 (0 when the item is
@@ -697,33 +710,35 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
       const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
       outer_stage<true>(v, R, p0, np, nc, tid, pre, base);
-      const int total = np * nq;
-      const int nqd = nq > 0 ? nq : 1, q256 = kThreads / nqd, r256 = kThreads % nqd;
-      WorkIdx wi{tid / nqd, tid % nqd};
-      for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
-        double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], xw[kItemBatch];
-        int hidx[kItemBatch];
-        bool ok[kItemBatch];
+      const int wv = tid >> 6, lane = tid & 63;
+      for (int xb = 0; xb < np; xb += 64) {
+        const int x = xb + lane;
+        const int xc = x < np ? x : np - 1;
+        const LoopItem it = R.it[xc];
+        const int meta = R.meta[xc];
+        const int c = (meta >> 16) & 0x7fff;
+        const int i = i0 + c, j = i + d;
+        const bool in_set = x < np && meta >= 0;   // (sign bit: not in the inside enumeration)
+        // (the inner pair of an item is a kept pair, the loops L are stored everywhere)
+        const uint32_t rP = v.in.cidx(ST_P, it.l - it.k, it.k, 0), rL1 = v.in.cidx(ST_L, it.k - i, i, 0), rL2 = v.in.cidx(ST_L, j - it.l, it.l, 0);
+        const double xw0 = R.xw[xc], xw1 = R.xw[R.cap + xc];
+        double* hrow = he + c * S;
+        for (int t0 = wv; t0 < nq; t0 += 4 * kTU) {
+          int qa[kTU], qb[kTU];
+          double x0[kTU], x1[kTU], x2[kTU];
 #pragma unroll
-        for (int u = 0; u < kItemBatch; ++u) {
-          const int w = w0 + u * kThreads;
-          ok[u] = w < total;
-          const int x = ok[u] ? wi.x : np - 1, t = ok[u] ? wi.t : nq - 1;
-          wi.step(q256, r256, nqd);
-          const LoopItem it = R.it[x];
-          const int c = (R.meta[x] >> 16) & 0x7fff;
-          const int i = i0 + c, j = i + d;
-          const int tgt = G[A.quad_tgt + t];
-          x0[u] = v.in.ld(ST_P, it.l - it.k, it.k, G[A.quad_ent + 3 * t]);       // (the inner pair of an item is a kept pair)
-          x1[u] = v.in.ld(ST_L, it.k - i, i, G[A.quad_ent + 3 * t + 1]);
-          x2[u] = v.in.ld(ST_L, j - it.l, it.l, G[A.quad_ent + 3 * t + 2]);
-          xw[u] = R.xw[lamk(v.m, tgt) * R.cap + x];
-          hidx[u] = c * S + tgt;
-        }
+          for (int u = 0; u < kTU; ++u) {
+            const int t = t0 + 4 * u;
+            const bool on = t < nq;
+            qa[u] = G[A.qc_in + 2 * (on ? t : t0)];
+            qb[u] = on ? G[A.qc_in + 2 * (on ? t : t0) + 1] : (4 << 16);
+            x0[u] = B[rP + (qa[u] & 0xff)]; x1[u] = B[rL1 + ((qa[u] >> 8) & 0xff)]; x2[u] = B[rL2 + ((qa[u] >> 16) & 0xff)];
+          }
 #pragma unroll
-        for (int u = 0; u < kItemBatch; ++u) {
-          const double term = x0[u] * (x1[u] * x2[u]) * xw[u];
-          if (ok[u] && term != 0.) atomicAdd(&he[hidx[u]], term);
+          for (int u = 0; u < kTU; ++u) {
+            const double term = x0[u] * (x1[u] * x2[u]) * ((qb[u] & (1 << 16)) ? xw1 : xw0);
+            if (!(qb[u] & (4 << 16)) && in_set && term != 0.) atomicAdd(&hrow[qb[u] & 0xffff], term);
+          }
         }
       }
       __syncthreads();
@@ -1259,59 +1274,51 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       }
       __syncthreads();
       pc.mark<8>();
-      const int total = np * nq;
-      const int nqd = nq > 0 ? nq : 1, q256 = kThreads / nqd, r256 = kThreads % nqd;
-      WorkIdx wi{tid / nqd, tid % nqd};
-      for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
-        LoopItem it[kItemBatch];
-        double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], xw[kItemBatch], aux[kItemBatch];
-        int hidx[kItemBatch], par[kItemBatch];
-        bool ok[kItemBatch];
+      // lane = item record of any role (the column records of the three roles' tuple lists lie at qc_out1 + role * 2 * nq).
+      // Operand liveness by construction: the outer cell of an item is a parsable E cell, its inner pair a kept pair, the loops L
+      // are stored everywhere; role 0 only has records at pair cells.
+      const int wv = tid >> 6, lane = tid & 63;
+      for (int xb = 0; xb < np; xb += 64) {
+        const int x = xb + lane;
+        const bool valid = x < np;
+        const int xc = valid ? x : np - 1;
+        const LoopItem it = r_it[xc];
+        const int role = r_meta[xc] >> 16, c = r_meta[xc] & 0xffff;
+        const int i = i0 + c, j = i + d;
+        const uint32_t rE = out.cidx(ST_E, it.j - it.i, it.i, 0);
+        const uint32_t rPi = in.cidx(ST_P, it.l - it.k, it.k, 0);
+        const uint32_t r1 = role == 0 ? in.cidx(ST_L, i - it.i, it.i, 0) : rPi;
+        const uint32_t r2 = role == 0 ? in.cidx(ST_L, it.j - j, j, 0) : role == 1 ? in.cidx(ST_L, it.j - it.l, it.l, 0) : in.cidx(ST_L, it.k - it.i, it.i, 0);
+        const uint32_t rA = role == 0 ? in.cidx(ST_P, d, i, 0) : in.cidx(ST_L, d, i, 0);
+        const double xw0 = r_xw[xc], xw1 = r_xw[cap + xc];
+        double* hrow = hp + (role == 0 ? 0 : CS) + c * S;   // hp, or hl = hp + CS
+        const int qc0 = A.qc_out1 + role * 2 * nq;
+        for (int t0 = wv; t0 < nq; t0 += 4 * kTU) {
+          int qa[kTU], qb[kTU];
+          double x0[kTU], x1[kTU], x2[kTU], aux[kTU];
 #pragma unroll
-        for (int u = 0; u < kItemBatch; ++u) {
-          const int w = w0 + u * kThreads;
-          ok[u] = w < total;
-          const int x = ok[u] ? wi.x : np - 1, t = ok[u] ? wi.t : nq - 1;
-          wi.step(q256, r256, nqd);
-          const int role = r_meta[x] >> 16, c = r_meta[x] & 0xffff;
-          it[u] = r_it[x];
-          const int ent = (role == 0 ? A.quad1_ent : role == 1 ? A.quad2_ent : A.quad3_ent) + 3 * t;
-          const int tgt = G[(role == 0 ? A.quad1_tgt : role == 1 ? A.quad2_tgt : A.quad3_tgt) + t];
-          const int q0 = G[ent], q1 = G[ent + 1], q2 = G[ent + 2];
-          const int i = i0 + c, j = i + d;
-          const int e1 = role == 0 ? ST_L : ST_P;
-          const int d1 = role == 0 ? i - it[u].i : it[u].l - it[u].k, p1 = role == 0 ? it[u].i : it[u].k;
-          const int d2 = role == 0 ? it[u].j - j : role == 1 ? it[u].j - it[u].l : it[u].k - it[u].i;
-          const int p2 = role == 0 ? j : role == 1 ? it[u].l : it[u].i;
-          // (operand liveness by construction: the outer cell of an item is a parsable E cell, its inner pair a kept pair, the
-          // loops L are stored everywhere; role 0 only runs for pair cells).  The plane that depends on the role is chosen by
-          // selecting between the two constant-plane addresses.
-          const int cL1 = in.col(ST_L, q1), cP1 = in.col(ST_P, q1), cLt = in.col(ST_L, tgt), cPt = in.col(ST_P, tgt);
-          const int c1 = role == 0 ? cL1 : cP1, ct = role == 0 ? cPt : cLt;
-          const uint32_t a1 = role == 0 ? in.cidx(ST_L, d1, p1, c1) : in.cidx(ST_P, d1, p1, c1);
-          const uint32_t at = role == 0 ? in.cidx(ST_P, d, i, ct) : in.cidx(ST_L, d, i, ct);
-          x0[u] = out.ld(ST_E, it[u].j - it[u].i, it[u].i, q0);
-          const double r1 = IB[c1 >= 0 ? a1 : 0u], rt = IB[ct >= 0 ? at : 0u];
-          x1[u] = c1 >= 0 ? r1 : 0.;
-          x2[u] = in.ld(ST_L, d2, p2, q2);
-          aux[u] = ct >= 0 ? rt : 0.;
-          xw[u] = r_xw[lamk(v.m, q0) * cap + x];
-          hidx[u] = (role == 0 ? 0 : CS) + c * S + tgt;   // hp, or hl = hp + CS
-          par[u] = role == 0 ? q0 : -1;
-        }
+          for (int u = 0; u < kTU; ++u) {
+            const int t = t0 + 4 * u;
+            const bool on = t < nq;
+            qa[u] = G[qc0 + 2 * (on ? t : t0)];
+            qb[u] = on ? G[qc0 + 2 * (on ? t : t0) + 1] : (4 << 16);
+            x0[u] = OB[rE + (qa[u] & 0xff)]; x1[u] = IB[r1 + ((qa[u] >> 8) & 0xff)]; x2[u] = IB[r2 + ((qa[u] >> 16) & 0xff)];
+            aux[u] = IB[rA + ((qa[u] >> 24) & 0xff)];
+          }
 #pragma unroll
-        for (int u = 0; u < kItemBatch; ++u) {
-          const double term = x0[u] * (x1[u] * x2[u]) * xw[u];
-          if (!ok[u] || aux[u] == 0. || term == 0.) continue;
-          atomicAdd(&hp[hidx[u]], term);
-          if (MODE == OUT_TRAIN && par[u] >= 0) {
-            const bool w1 = pi.merged && par[u] == A.shadow;
-            const int k = v.m.eh_index(par[u]);
-            const double w = it[u].tsc * term * (aux[u] * (w1 ? pi.invZs : pi.invZ));
-            ew[0] += (!w1 && !k) ? w : 0.;
-            ew[1] += (!w1 && k) ? w : 0.;
-            ew[2] += (w1 && !k) ? w : 0.;
-            ew[3] += (w1 && k) ? w : 0.;
+          for (int u = 0; u < kTU; ++u) {
+            const double term = x0[u] * (x1[u] * x2[u]) * ((qb[u] & (1 << 16)) ? xw1 : xw0);
+            if ((qb[u] & (4 << 16)) || !valid || aux[u] == 0. || term == 0.) continue;
+            atomicAdd(&hrow[qb[u] & 0xffff], term);
+            if (MODE == OUT_TRAIN && role == 0) {   // energy statistic of the rule (world and lambda class of the tuple's parent)
+              const bool w1 = pi.merged && (qb[u] & (2 << 16));
+              const bool k1 = !v.m.lam_same && (qb[u] & (1 << 16));
+              const double w = it.tsc * term * (aux[u] * (w1 ? pi.invZs : pi.invZ));
+              ew[0] += (!w1 && !k1) ? w : 0.;
+              ew[1] += (!w1 && k1) ? w : 0.;
+              ew[2] += (w1 && !k1) ? w : 0.;
+              ew[3] += (w1 && k1) ? w : 0.;
+            }
           }
         }
       }
@@ -1777,6 +1784,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   // schedule 0: the reference's two sweeps, (ari, nasi) then the label's mask.
   const int n_pass = (a.schedule == 1 || first_pass_only) ? 1 : 2;
   const size_t lds_b = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
+  if (getenv("ELEMDP_LDS_DEBUG")) fprintf(stderr, "lin group: G %d cpb %d fast %d n_lin %d staged ints in/out %d/%d lds k4_in %zu k4_out %zu\n", G, a.cpb, (int)fast, a.n_lin, staged_ints(a.lay, a.n_stage, 0), staged_ints(a.lay, a.n_stage, 1), lds_in, lds_b);
   for (int pass = 0; pass < n_pass; ++pass) {
     LinArgs b = a;
     b.pass = pass;
