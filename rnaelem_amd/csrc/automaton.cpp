@@ -447,6 +447,8 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   put(rpair, &A.rpair_off, &A.rpair_ent);
   // pairs (s1, t) of the factorised rule 2: the kept splits (s; s1, t), closed under t' in right(t) (the tail of unpaired
   // bases behind the last stem of a multiloop part grows by right emissions); internal ids, split order
+  std::vector<std::array<int, 3>> ap_keep;
+  Csr chain_keep(1, 2), rchain_keep(1, 2);
   {
     std::vector<std::array<int, 3>> ap;   // (s1, t, tgt)
     auto find = [&](int s1, int t) { for (size_t k = 0; k < ap.size(); ++k) if (ap[k][0] == s1 && ap[k][1] == t) return (int)k; return -1; };
@@ -487,6 +489,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     put(rchain, &A.ap_rchain_off, &A.ap_rchain_ent);
     put(by_s1, &A.ap_by_s1_off, &A.ap_by_s1_ent);
     put(by_t, &A.ap_by_t_off, &A.ap_by_t_ent);
+    ap_keep = ap; chain_keep = chain; rchain_keep = rchain;
   }
   // compact tables of the scaled-linear pipeline: one column per state that is useful in the plane (all states without pruning;
   // the shadow state has the liveness of (0,0)); strides padded to a multiple of `row_pad` doubles
@@ -510,7 +513,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   }
   // table-driven unary phases (device_layout.h: fp_*): programs per state, static attributes per forward transition.  They
   // travel with the tuple lists of their direction (the "big" runs below), not with the small part every kernel stages.
-  std::vector<int32_t> prog_in, prog_out, attr_r, attr_p;
+  std::vector<int32_t> prog_in, prog_out, attr_r, attr_p, pair_rec;
   {
     auto colof = [&](int e, int k) { return (*ints)[A.tab_cmap + e * ST + k] & 0xff; };   // (-1 -> 0xff)
     auto base_of = [&](const Csr& c) {   // first transition id of every row
@@ -592,6 +595,26 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
         attr_p.push_back(rowoff1(attr(A.st_row_r, k)));
         attr_p.push_back(rowoff1(attr(A.st_row_l, ch)));
       }
+    // pair records of the factorised rule 2 (device_layout.h)
+    for (int k = 0; k < A.n_ap && ok; ++k) {
+      const int s1 = ap_keep[k][0], t = ap_keep[k][1], tgt = ap_keep[k][2];
+      const int nch = (int)chain_keep.rows[k].size() / 2, nrch = (int)rchain_keep.rows[k].size() / 2;
+      if (nch > kFastR || nrch > kFastR || A.n_ap > 254 || ST > 254) { ok = false; break; }
+      int32_t w[8] = {0};
+      w[0] = colof(ST_1, s1) | (colof(ST_P, t) << 8) | ((tgt >= 0 ? tgt : 0xff) << 16) |
+             (((attr(A.st_lam, t) ? 1 : 0) | (attr(A.st_w_r, t) ? 2 : 0) | (t == A.shadow ? 4 : 0)) << 24);
+      w[1] = s1 | (t << 8) | (nch << 16) | (nrch << 20);
+      for (int u = 0; u < nch; ++u) {
+        const int pc = chain_keep.rows[k][2 * u];
+        w[2 + u] = pc | (fwd_id(right, br, t, ap_keep[pc][1]) << 8);
+      }
+      for (int u = 0; u < nrch; ++u) {
+        const int pp = rchain_keep.rows[k][2 * u];
+        w[5 + u] = pp | (fwd_id(right, br, ap_keep[pp][1], t) << 8);
+      }
+      pair_rec.insert(pair_rec.end(), w, w + 8);
+    }
+    A.fp_ok = ok ? 1 : 0;
     A.lin_wr = 11 + A.n_theta;            // (kLinEth + n_theta, lin_params.h)
     A.lin_wl = A.lin_wr + 5 * A.n_wr;
     A.lin_wp = A.lin_wl + 5 * A.n_wl;
@@ -604,8 +627,6 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   put(quad, &A.quad_off, &A.quad_ent);
   A.split_tgt = split.emit_targets(ints);
   A.quad_tgt = quad.emit_targets(ints);
-  A.fp_in = (int32_t)ints->size();
-  ints->insert(ints->end(), prog_in.begin(), prog_in.end());
   // column records of the interior-loop tuples (device_layout.h: qc_*)
   auto col_of = [&](int e, int k) { return (*ints)[A.tab_cmap + e * ST + k]; };
   auto emit_qc = [&](const Csr& c, int which) {
@@ -636,18 +657,28 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   A.quad1_tgt = quad1.emit_targets(ints);
   A.quad2_tgt = quad2.emit_targets(ints);
   A.quad3_tgt = quad3.emit_targets(ints);
-  A.fp_out = (int32_t)ints->size();
-  ints->insert(ints->end(), prog_out.begin(), prog_out.end());
-  A.fe_r = (int32_t)ints->size();
-  ints->insert(ints->end(), attr_r.begin(), attr_r.end());
-  A.fe_p = (int32_t)ints->size();
-  ints->insert(ints->end(), attr_p.begin(), attr_p.end());
   A.qc_out1 = emit_qc(quad1, 1);
   A.qc_out2 = emit_qc(quad2, 2);
   A.qc_out3 = emit_qc(quad3, 2);
   A.n_split = split.count();
   A.n_quad = quad.count();
   A.n_ints = (int32_t)ints->size();
+  // fast blobs of the table-driven train kernels (behind n_ints: the generic kernels never stage them)
+  auto append = [&](const std::vector<int32_t>& v) { const int32_t pos = (int32_t)ints->size(); ints->insert(ints->end(), v.begin(), v.end()); return pos; };
+  auto copy_of = [&](int32_t from, int n) { return std::vector<int32_t>(ints->begin() + from, ints->begin() + from + n); };
+  const std::vector<int32_t> qci = copy_of(A.qc_in, 2 * A.n_quad), qco = copy_of(A.qc_out1, 6 * A.n_quad);
+  A.fb_in = (int32_t)ints->size();
+  A.fp_in = append(prog_in);
+  A.fqc_in = append(qci);
+  A.fpr_in = append(pair_rec);
+  A.fb_in_n = (int32_t)ints->size() - A.fb_in;
+  A.fb_out = (int32_t)ints->size();
+  A.fp_out = append(prog_out);
+  A.fe_r = append(attr_r);
+  A.fe_p = append(attr_p);
+  A.fqc_out = append(qco);
+  A.fpr_out = append(pair_rec);
+  A.fb_out_n = (int32_t)ints->size() - A.fb_out;
 }
 
 void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
@@ -676,6 +707,7 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   for (int e = 0; e < 7; ++e) { ints->push_back(0); A.tab_rs[e] = 1; A.tab_cs[e] = e; }
   A.tab_row = 7; A.ap_rs = 1;
   A.fp_ok = 0; A.fp_in = A.fp_out = A.fe_r = A.fe_p = 0; A.n_wr = A.n_wp = A.n_wl = 0;
+  A.fb_in = A.fb_in_n = A.fb_out = A.fb_out_n = A.fqc_in = A.fpr_in = A.fqc_out = A.fpr_out = 0;
   A.lin_wr = A.lin_wl = A.lin_wp = A.lin_total = 11;
   A.qc_in = A.qc_out1 = A.qc_out2 = A.qc_out3 = 0;
   A.n_small = (int32_t)ints->size();

@@ -80,13 +80,21 @@ struct AutomatonLayout {
   int32_t tab_cmap;
   int32_t tab_rs[7], tab_cs[7], tab_row;
   int32_t ap_rs;
-  // Table-driven unary phases of the train kernels (lin_fast.h).  One PROGRAM of kFastW ints per interval state and direction
-  // lists everything a (cell, state) lane needs: its own columns, and per unary transition the operand columns and the id of
-  // the transition = its position in the forward list (right / pair / left), which indexes the per-evaluation weight tables
-  // WR[id][base], WL[id][base], WP[id][pair type] behind the linear parameter block (lin_params.h) and the static attribute
-  // tables fe_r (2 ints per right transition) / fe_p (3 ints per pair transition).  fp_ok = 0: a list is longer than
-  // kFastR / kFastP / kFastL, the kernels then run the generic rule code.
-  int32_t fp_ok, fp_in, fp_out, fe_r, fe_p;
+  // ---- Table-driven train kernels (lin_fast.h, k4_in / k4_out with FAST).  They stage only their own FAST BLOB -- ints
+  // [fb_in, fb_in + fb_in_n) resp. [fb_out, fb_out + fb_out_n) behind n_ints -- instead of the generic lists:
+  //   * one PROGRAM of kFastW ints per interval state (fp_in / fp_out): the state's own columns, and per unary transition the
+  //     operand columns and the id of the transition = its position in the forward list (right / pair / left), which indexes
+  //     the per-evaluation weight tables WR[id][base], WL[id][base], WP[id][pair type] behind the linear parameter block
+  //     (lin_params.h) and the static attribute tables fe_r (2 ints per right transition) / fe_p (3 per pair transition);
+  //   * one PAIR RECORD of 8 ints per pair (s1, t) of the factorised rule 2 (fpr_in / fpr_out): {c1 | cP << 8 | tgt << 16 |
+  //     flags << 24 (bit 0 lambda class of t, 1 position weight of t's r-node, 2 t is the shadow state); s1 | t << 8 |
+  //     n_chain << 16 | n_rchain << 20; 3 chain entries pc | id << 8 (tail step from pair pc, right transition id); 3 rchain
+  //     entries pp | id << 8} with c1 / cP = column of s1 in plane 1 / of t in plane P, tgt = 0xff for none;
+  //   * the column records of the interior-loop tuples (fqc_in; fqc_out = three lists of n_quad, see qc_* below).
+  // fp_ok = 0: a list is longer than kFastR / kFastP / kFastL (or a column index does not fit a byte); the kernels then
+  // run the generic rule code.
+  int32_t fp_ok, fb_in, fb_in_n, fb_out, fb_out_n;
+  int32_t fp_in, fqc_in, fpr_in, fp_out, fe_r, fe_p, fqc_out, fpr_out;
   int32_t n_wr, n_wp, n_wl;                     // transitions per forward list = rows of the weight tables
   int32_t lin_wr, lin_wl, lin_wp, lin_total;    // offsets (doubles) of the weight tables in the linear block; its length
   // Column records of the interior-loop tuples (rule 6c), 2 ints each, in the tuple-list runs of the blob: the item sums hold

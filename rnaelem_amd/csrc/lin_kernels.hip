@@ -52,6 +52,11 @@
 namespace elemdp {
 namespace {
 
+// q / n for small non-negative q (< 2^20) and n > 0 through the single-precision reciprocal: (q + 1/2) * rcp(n) is off by less than
+// 1 / (2 n) from the true quotient plus 1/(2n), so the truncation is exact.  An integer division by a run-time divisor costs ~30
+// instructions, and the band kernels are bound by instruction issue.
+__device__ __forceinline__ int div_small(int q, int n) { return (int)(((float)q + 0.5f) * __frcp_rn((float)n)); }
+
 // statistics sink of the linear pipeline: emission counts into LDS, energy statistics lane-private
 struct LinSink {
   double* en_;
@@ -295,8 +300,9 @@ __host__ __device__ inline int staged_ints(const AutomatonLayout& L, int n_stage
   return L.n_small + (part == 0 ? L.big_in_end - L.n_small : L.n_ints - L.big_in_end);
 }
 
-// stages the context and redirects the views to it; positions [p0, p0+len) = [i0-1, i0+nc+d] clipped to [0, L]
-template <bool BIG, int PART>
+// stages the context and redirects the views to it; positions [p0, p0+len) = [i0-1, i0+nc+d] clipped to [0, L].
+// FAST: only the fast blob of the direction is staged (AutomatonLayout::fb_*); the generic lists stay in global memory.
+template <bool BIG, int PART, bool FAST = false>
 __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, unsigned char* raw, const BlockLds& B, int i0, int nc,
                                                   int d, int cpb) {
   const int tid = threadIdx.x;
@@ -313,7 +319,9 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   uint8_t* lseq = raw + B.seq8;
   uint8_t* lunp = raw + B.unp8;
   const int n_lin = a.n_lin;
-  const int big_lo = (PART == 0) ? a.lay.n_small : a.lay.big_in_end, big_hi = (PART == 0) ? a.lay.big_in_end : a.lay.n_ints;
+  const int big_lo = FAST ? (PART == 0 ? a.lay.fb_in : a.lay.fb_out) : (PART == 0) ? a.lay.n_small : a.lay.big_in_end;
+  const int big_hi = FAST ? big_lo + (PART == 0 ? a.lay.fb_in_n : a.lay.fb_out_n) : (PART == 0) ? a.lay.big_in_end : a.lay.n_ints;
+  const int big_at = FAST ? 0 : a.lay.n_small;      // where the run lands in the LDS blob
   uint32_t* lbits = reinterpret_cast<uint32_t*>(raw + B.bits);
   uint32_t* lbits2 = reinterpret_cast<uint32_t*>(raw + B.bits2);
   // pair mask: bits of the cells (i0-1, .) .. (i0+nc-1, .)  (bit index = i * (W+1) + d); the outside kernel also walks the
@@ -329,7 +337,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   // ALL loads of the context are issued before the first LDS store (clamped addresses, fixed unrolling): one round trip
   // for the whole context instead of one per array (a plain copy loop waits for its loads before it stores)
   constexpr int kU = 4;
-  const int n_sm = BIG ? a.lay.n_small : a.n_stage, n_bg = BIG ? big_hi - big_lo : 0;
+  const int n_sm = FAST ? 0 : BIG ? a.lay.n_small : a.n_stage, n_bg = BIG ? big_hi - big_lo : 0;
   int r_sm[kU], r_bg[kU];
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
@@ -350,7 +358,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   for (int u = 0; u < kU; ++u) {
     const int t = tid + u * kThreads;
     if (t < n_sm) blob[t] = r_sm[u];
-    if (t < n_bg) blob[a.lay.n_small + t] = r_bg[u];
+    if (t < n_bg) blob[big_at + t] = r_bg[u];
   }
   if (tid < n_lin) llin[tid] = r_lin;
   if (tid < w1 - w0) lbits[tid] = (w0 + tid < wend) ? r_bits : 0u;
@@ -363,7 +371,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   }
   // (larger automata / windows than the unrolled part covers)
   for (int t = tid + kU * kThreads; t < n_sm; t += kThreads) blob[t] = a.ints[t];
-  for (int t = tid + kU * kThreads; t < n_bg; t += kThreads) blob[a.lay.n_small + t] = a.ints[big_lo + t];
+  for (int t = tid + kU * kThreads; t < n_bg; t += kThreads) blob[big_at + t] = a.ints[big_lo + t];
   for (int t = tid + kThreads; t < n_lin; t += kThreads) llin[t] = a.lin[t];
   for (int t = tid + kThreads; t < w1 - w0; t += kThreads) lbits[t] = (w0 + t < wend) ? v.q.okbits[w0 + t] : 0u;
   if (PART == 0) for (int t = tid + kThreads; t < e1 - e0; t += kThreads) lbits2[t] = (e0 + t < wend) ? v.q.okbits_end[e0 + t] : 0u;
@@ -380,9 +388,11 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   c.pre = reinterpret_cast<int*>(raw + B.pre);
   c.base = reinterpret_cast<int*>(raw + B.base);
   if (tid < cpb) c.dm[tid] = (tid < nc) ? (int)r_dm : 0;
-  v.m.ints = blob;
-  v.in.cm = v.out.cm = blob + a.lay.tab_cmap;
-  if (BIG) v.m.big = blob + a.lay.n_small - big_lo;   // (indices of the staged run keep their global values)
+  if (!FAST) {
+    v.m.ints = blob;
+    v.in.cm = v.out.cm = blob + a.lay.tab_cmap;
+  }
+  if (BIG) v.m.big = blob + big_at - big_lo;   // (indices of the staged run keep their global values)
   v.m.lin = llin;
   v.q.ews = lews - p0;
   v.q.dmin = ldmin - p0;
@@ -595,7 +605,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   double* hb = lds;
   double* he = hb + CS;
   double* st1 = he + CS;                     // item records (kRecIn doubles)
-  const BlockLds BL = block_lds(2 * CS + kRecIn, cpb, a.n_lin, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0), 0, FAST ? kCellInD : 0);
+  const BlockLds BL = block_lds(2 * CS + kRecIn, cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, FAST ? kCellInD : 0);
   // cell records of the table-driven unary phase: the exponentiated structural terms of the cells are fetched with the context
   // (lane = (cell, value); the addresses depend on the plan record only), the flags follow once the context is in LDS
   constexpr int kCRin = (ELEMDP_CPB_MAX * 8 + kThreads - 1) / kThreads;
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
       crx[r] = cell_in_fetch(v.q, d, i0 + c, t & 7);
     }
   }
-  const BlockCtx cx = stage_context<BIG, 0>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  const BlockCtx cx = stage_context<BIG, 0, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   double* crec = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
@@ -644,8 +654,56 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     const int W1 = v.q.W + 1;
     const int nwork = (a.dbg & 1) ? 0 : nc * nA;
     for (int w = tid; w < nwork; w += kThreads) {
-      const int c = w / nA, p = w - c * nA;
+      const int c = div_small(w, nA), p = w - c * nA;
       const int i = i0 + c, j = i + d;
+      if (FAST) {   // the same sums from the pair record (AutomatonLayout::fpr_in): columns, chain entries with their weight ids
+        const int32_t* PR = G + A.fpr_in + 8 * p;
+        const int r0 = PR[0], r1 = PR[1];
+        const int c1 = fcol(r0, 0), cP = fcol(r0, 1), tg = (r0 >> 16) & 0xff;
+        const int dmi = dm[c];
+        double av = 0.;
+        if (dmi > 0 && dmi < d) {
+          const double* xml = v.q.xwc + (size_t)(((r0 >> 24) & 1) * 5 + XT_ML) * v.q.xwc_stride;
+          BitIter it;
+          it.init(v.q.okbits_end, j * W1, 1, d - dmi);
+          const int nch = (dmi < d - 1 && v.q.unp[j - 1]) ? (r1 >> 16) & 15 : 0;   // (the entries of (i, d-1) exist iff dmin[i] < d - 1)
+          int ce[kFastR];
+          double pv[kFastR];
+#pragma unroll
+          for (int u = 0; u < kFastR; ++u) {
+            ce[u] = PR[2 + u];
+            pv[u] = v.in.lda(d - 1, i, u < nch ? ce[u] & 0xff : p, u < nch);
+          }
+          bool first = true;
+          for (;;) {
+            const int sp0 = it.next();
+            if (sp0 < 0 && !first) break;
+            const int sp1 = sp0 < 0 ? -1 : it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
+            const int q0 = sp0 < 0 ? 1 : sp0, q1 = sp1 < 0 ? q0 : sp1, q2 = sp2 < 0 ? q0 : sp2, q3 = sp3 < 0 ? q0 : sp3;
+            const bool g0 = sp0 >= 0;
+            const double a0 = v.in.ldc(ST_1, d - q0, i, c1, g0), b0 = v.in.ldc(ST_P, q0, j - q0, cP, g0), w0 = xml[v.q.cell(j - q0, q0)];
+            const double a1 = v.in.ldc(ST_1, d - q1, i, c1, g0), b1 = v.in.ldc(ST_P, q1, j - q1, cP, g0), w1 = xml[v.q.cell(j - q1, q1)];
+            const double a2 = v.in.ldc(ST_1, d - q2, i, c1, g0), b2 = v.in.ldc(ST_P, q2, j - q2, cP, g0), w2 = xml[v.q.cell(j - q2, q2)];
+            const double a3 = v.in.ldc(ST_1, d - q3, i, c1, g0), b3 = v.in.ldc(ST_P, q3, j - q3, cP, g0), w3 = xml[v.q.cell(j - q3, q3)];
+            if (first) {   // tail step (its operands travelled with the first stems')
+              first = false;
+              const double wt = (r0 & (2 << 24)) ? v.q.ews[j - 1] : 1.;
+              const int bj = v.q.seq[j - 1];
+#pragma unroll
+              for (int u = 0; u < kFastR; ++u)
+                if (u < nch) av = fma(pv[u], v.m.lin[A.lin_wr + 5 * ((ce[u] >> 8) & 0x7fff) + bj] * wt, av);
+            }
+            if (sp0 >= 0) av = fma(a0, b0 * w0, av);
+            if (sp1 >= 0) av = fma(a1, b1 * w1, av);
+            if (sp2 >= 0) av = fma(a2, b2 * w2, av);
+            if (sp3 >= 0) av = fma(a3, b3 * w3, av);
+            if (sp3 < 0) break;
+          }
+          v.in.a(d, i, p) = av;
+        }
+        if (tg != 0xff && av != 0.) atomicAdd(&hb[c * S + tg], av);
+        continue;
+      }
       const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p], tgt = I[A.ap_tgt + p];
       const int c1 = v.in.col(ST_1, s1), cP = v.in.col(ST_P, t);
       const int dmi = dm[c];
@@ -711,6 +769,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
       const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
       outer_stage<true>(v, R, p0, np, nc, tid, pre, base);
       const int wv = tid >> 6, lane = tid & 63;
+      const int qc_in = FAST ? A.fqc_in : A.qc_in;
       for (int xb = 0; xb < np; xb += 64) {
         const int x = xb + lane;
         const int xc = x < np ? x : np - 1;
@@ -730,8 +789,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
           for (int u = 0; u < kTU; ++u) {
             const int t = t0 + 4 * u;
             const bool on = t < nq;
-            qa[u] = G[A.qc_in + 2 * (on ? t : t0)];
-            qb[u] = on ? G[A.qc_in + 2 * (on ? t : t0) + 1] : (4 << 16);
+            qa[u] = G[qc_in + 2 * (on ? t : t0)];
+            qb[u] = on ? G[qc_in + 2 * (on ? t : t0) + 1] : (4 << 16);
             x0[u] = B[rP + (qa[u] & 0xff)]; x1[u] = B[rL1 + ((qa[u] >> 8) & 0xff)]; x2[u] = B[rL2 + ((qa[u] >> 16) & 0xff)];
           }
 #pragma unroll
@@ -746,7 +805,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   }
   pc.mark<3>();
   if (tid < nc * NA && !(a.dbg & 4)) {
-    const int c = tid / NA, s = tid - c * NA;
+    const int c = div_small(tid, NA), s = tid - c * NA;
     const int i = i0 + c;
     const double HB = hb[c * S + s];
     if (FAST) {
@@ -1092,7 +1151,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* l_pos = l_eh + 4;                    // scan: [2][win] position posteriors of the window (start, inner | end, -)
   const int win = cpb + a.wmax + 3;
   double* sOB1 = l_pos + 2 * win;              // item records of the three roles (kRecOut doubles)
-  const BlockLds BL = block_lds(out_doubles(CS, nt, cpb + a.wmax + 3), cpb, a.n_lin, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * cpb, FAST ? kCellOutD : 0);
+  const BlockLds BL = block_lds(out_doubles(CS, nt, cpb + a.wmax + 3), cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * cpb, FAST ? kCellOutD : 0);
   // cell records of the table-driven unary phase (see k4_in): twelve global values per cell, fetched with the context
   constexpr int kCRout = (ELEMDP_CPB_MAX * 12 + kThreads - 1) / kThreads;
   double crx[kCRout];
@@ -1103,7 +1162,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       crx[r] = cell_out_fetch(v.q, d, i0 + c, t - c0 * 12);
     }
   }
-  const BlockCtx cx = stage_context<BIG, 1>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  const BlockCtx cx = stage_context<BIG, 1, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   if (pi.skip) return;   // (tested here: the loads behind `pi` travel with those of the context instead of before them)
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
@@ -1145,7 +1204,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   const double* OB = out.band;
   // CSR ranges of the item sums of the three roles (consumed behind the pair phase, whose loads they travel with)
   for (int vc = tid; vc < 3 * nc; vc += kThreads) {
-    const int role = vc / nc, c = vc - role * nc;
+    const int role = (vc >= nc) + (vc >= 2 * nc), c = vc - role * nc;
     const int i = i0 + c;
     const int cell = v.q.cell(i, d);
     const int32_t* off = role == 0 ? v.q.by_inner_off : role == 1 ? v.q.by_left_off : v.q.by_right_off;
@@ -1163,15 +1222,21 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     const int32_t* I = v.m.ints;
     const int W1 = W + 1;
     const int nwork = (a.dbg & 1) ? 0 : nc * nA;
+    // attributes of pair p: from its record in the fast blob (AutomatonLayout::fpr_out), or from the generic lists
+    auto pr_s1 = [&](int p) { return FAST ? (G[A.fpr_out + 8 * p + 1] & 0xff) : I[A.ap_s1 + p]; };
+    auto pr_t = [&](int p) { return FAST ? ((G[A.fpr_out + 8 * p + 1] >> 8) & 0xff) : I[A.ap_t + p]; };
+    auto pr_c1 = [&](int p) { return FAST ? fcol(G[A.fpr_out + 8 * p], 0) : in.col(ST_1, I[A.ap_s1 + p]); };
+    auto pr_cP = [&](int p) { return FAST ? fcol(G[A.fpr_out + 8 * p], 1) : in.col(ST_P, I[A.ap_t + p]); };
+    auto pr_kl = [&](int p) { return FAST ? ((G[A.fpr_out + 8 * p] >> 24) & 1) : lamk(v.m, I[A.ap_t + p]); };
     for (int w = tid; w < nwork; w += kThreads) {
-      const int c = w / nA, p = w - c * nA;
+      const int c = div_small(w, nA), p = w - c * nA;
       const int i = i0 + c, j = i + d;
-      const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
-      const int cP = in.col(ST_P, t);
+      const int s1 = pr_s1(p);
+      const int cP = pr_cP(p);
       const int dmi = dm[c];
       if (dmi > 0 && dmi <= d) {     // left_ok(i, d)  (a dead child 1(i,j,s1) drops the sum in the unary phase)
         const int hi = (W - d < L - j) ? W - d : L - j;
-        const double* xml = v.q.xwc + (size_t)(lamk(v.m, t) * 5 + XT_ML) * v.q.xwc_stride;
+        const double* xml = v.q.xwc + (size_t)(pr_kl(p) * 5 + XT_ML) * v.q.xwc_stride;
         double acc = 0.;
         BitIter it;
         it.init(v.q.okbits, j * W1, 1, hi);
@@ -1210,18 +1275,17 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         for (int u = 0; u < kHA; ++u) {
           const int w = w0 + u * kThreads;
           const bool valid = w < total;
-          const int sc = valid ? w / per : 0, r = valid ? w - sc * per : 0;
+          const int sc = valid ? div_small(w, per) : 0, r = valid ? w - sc * per : 0;
           unsigned long long m = stems;
           for (int k = 0; k < sc; ++k) m &= m - 1;          // the sc-th stem cell
           const int c = __builtin_ctzll(m);
-          const int b = 1 + r / nA, p = r - (b - 1) * nA;
+          const int b = 1 + div_small(r, nA), p = r - (b - 1) * nA;
           const int ii = i0 + c - b;
           const int dmii = (valid && ii >= 0) ? (int)v.q.dmin[ii] : 0;
           const bool ok = dmii > 0 && b >= dmii;              // 1(ii, i, .) is parsable (then the pair entries of (ii, d + b) exist)
-          const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p];
           oa[u] = out.lda(d + b, ii, p, ok);
-          x1[u] = in.ld(ST_1, b, ii, s1, ok);
-          hidx[u] = c * S + t;
+          x1[u] = in.ldc(ST_1, b, ii, pr_c1(p), ok);
+          hidx[u] = c * S + pr_t(p);
         }
 #pragma unroll
         for (int u = 0; u < kHA; ++u) {
@@ -1264,7 +1328,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           const int mid = (lo + hi + 1) >> 1;
           if (pre[mid] <= p) lo = mid; else hi = mid - 1;
         }
-        const int role = lo / nc, c = lo - role * nc;
+        const int role = (lo >= nc) + (lo >= 2 * nc), c = lo - role * nc;
         const int n = base[lo] + (p - pre[lo]);
         const LoopItem* src = role == 0 ? v.q.items_inner : role == 1 ? v.q.items_left : v.q.items_right;
         r_it[x] = src[n];
@@ -1292,7 +1356,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         const uint32_t rA = role == 0 ? in.cidx(ST_P, d, i, 0) : in.cidx(ST_L, d, i, 0);
         const double xw0 = r_xw[xc], xw1 = r_xw[cap + xc];
         double* hrow = hp + (role == 0 ? 0 : CS) + c * S;   // hp, or hl = hp + CS
-        const int qc0 = A.qc_out1 + role * 2 * nq;
+        const int qc0 = (FAST ? A.fqc_out : A.qc_out1) + role * 2 * nq;
         for (int t0 = wv; t0 < nq; t0 += 4 * kTU) {
           int qa[kTU], qb[kTU];
           double x0[kTU], x1[kTU], x2[kTU], aux[kTU];
@@ -1335,7 +1399,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   }
   pc.mark<10>();
   if (tid < nc * NA && !(a.dbg & 4)) {
-    const int c = tid / NA, s = tid - c * NA;
+    const int c = div_small(tid, NA), s = tid - c * NA;
     const bool w1 = pi.merged && s == A.shadow;      // the shadow state: world 1 (its own Z, second set of statistics)
     sink.world = w1 ? 1 : 0;
     sink.en_ = l_en + (w1 ? nt : 0);
@@ -1359,7 +1423,45 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     const int nA = A.n_ap;
     double* const en_keep = sink.en_;
     for (int w = tid; w < nc * nA; w += kThreads) {
-      const int c = w / nA, p = w - c * nA;
+      const int c = div_small(w, nA), p = w - c * nA;
+      if (FAST) {   // lin_outside_apair from the pair record (AutomatonLayout::fpr_out) and the weight tables
+        const int32_t* PR = G + A.fpr_out + 8 * p;
+        const int r0 = PR[0], r1 = PR[1];
+        const int tg = (r0 >> 16) & 0xff;
+        const bool w1 = pi.merged && (r0 & (4 << 24));
+        const int i = i0 + c, j = i + d, dmi = dm[c];
+        if (dmi > 0 && dmi < d) {      // (otherwise the entry does not exist)
+          const bool step = d + 1 <= W && j < L && v.q.unp[j];
+          const int nr = step ? (r1 >> 20) & 15 : 0;
+          const double a_in = in.a(d, i, p);
+          int ce[kFastR];
+          double op[kFastR];
+#pragma unroll
+          for (int u = 0; u < kFastR; ++u) {
+            ce[u] = PR[5 + u];
+            op[u] = out.lda(d + 1, i, u < nr ? ce[u] & 0xff : p, u < nr);
+          }
+          double acc = 0.;
+          if (a_in != 0.) {
+            acc = tg != 0xff ? h1[c * S + tg] : 0.;
+            const double inz = a_in * (w1 ? pi.invZs : pi.invZ);
+            const int bj = step ? (int)v.q.seq[j] : 0;
+            const double ewj = step ? v.q.ews[j] : 1.;
+            double* en = l_en + (w1 ? nt : 0);
+#pragma unroll
+            for (int u = 0; u < kFastR; ++u)
+              if (u < nr) {
+                const int id = (ce[u] >> 8) & 0x7fff;
+                const double term = op[u] * (v.m.lin[A.lin_wr + 5 * id + bj] * ((G[A.fe_r + 2 * id + 1] & 1) ? ewj : 1.));
+                const double z = term * inz;
+                if (!v.m.no_prf && z != 0. && bj) atomicAdd(&en[G[A.fe_r + 2 * id] + bj], z);
+                acc += term;
+              }
+          }
+          out.a(d, i, p) = acc;
+        }
+        continue;
+      }
       const int tgt = v.m.ints[A.ap_tgt + p];
       const bool w1 = pi.merged && v.m.ints[A.ap_t + p] == A.shadow;
       sink.en_ = l_en + (w1 ? nt : 0);
@@ -1763,7 +1865,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   const bool fast = a.fast && big && a.lay.fp_ok && !(a.dbg & 16) && a.lay.lin_total <= 2048;
   a.fast = fast ? 1 : 0;
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
-  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
+  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
   const size_t lds_stat = sizeof(double) * (2 * nt + 4);
   if (!a.no_rss)
     for (int d = 0; d <= Wmax; ++d) {
@@ -1783,7 +1885,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   // pattern's states, the "no motif" terminal on the shadow of (0,0), each with its own Z and statistics (lpass).
   // schedule 0: the reference's two sweeps, (ari, nasi) then the label's mask.
   const int n_pass = (a.schedule == 1 || first_pass_only) ? 1 : 2;
-  const size_t lds_b = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
+  const size_t lds_b = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
   if (getenv("ELEMDP_LDS_DEBUG")) fprintf(stderr, "lin group: G %d cpb %d fast %d n_lin %d staged ints in/out %d/%d lds k4_in %zu k4_out %zu\n", G, a.cpb, (int)fast, a.n_lin, staged_ints(a.lay, a.n_stage, 0), staged_ints(a.lay, a.n_stage, 1), lds_in, lds_b);
   for (int pass = 0; pass < n_pass; ++pass) {
     LinArgs b = a;
