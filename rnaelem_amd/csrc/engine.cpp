@@ -355,6 +355,7 @@ class Engine {
   std::vector<int32_t> intss_;
   DevBuf d_lays_, d_intss_;
   int tables_S_ = 0;                     // state stride of the tables of the last linear evaluation (debug_tables)
+  std::vector<double> last_x_;           // parameters of the last train evaluation (debug_tables repeats it with the generic kernels)
   std::vector<double> h_lin_, h_lins_;   // linear parameter block of the last evaluation (plain automaton / with the shadow state)
   std::vector<uint8_t> h_seq_;           // base codes of the batch (table export)
   int64_t n_cells_total_ = 0;
@@ -1469,6 +1470,7 @@ void Engine::train_partial(const double* x, int n_param_in, void* partial, bool 
   if (n_seq_ <= 0 && !(comm_ && reduce)) throw StateError("train_eval before load_batch");
   if (n_param_in != n_param()) throw ArgError("n_param mismatch");
   HIP_OK(hipEventRecord(ev_[0], st_));
+  last_x_.assign(x, x + n_param_in);
   upload_params(x, lay_, false);
   if (n_seq_ > 0) {
     run_train(false);
@@ -1542,6 +1544,14 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
   DeviceGuard dg(device_);
   if (n_seq_ != 1 || streaming_) throw StateError("debug_tables needs a resident batch of exactly one sequence");
   if (n_slots_ < 1) throw StateError("debug_tables before train_eval");
+  if (tables_linear_ && opt_fast_ && !last_x_.empty()) {
+    // the table-driven train kernels do not store the planes nothing reads (inside B, outside B and 1): the export repeats the
+    // evaluation of the one sequence with the generic kernels, which store every plane
+    std::vector<double> part(partial_len());
+    opt_fast_ = false;
+    try { train_partial(last_x_.data(), n_param(), part.data(), false, false); } catch (...) { opt_fast_ = true; throw; }
+    opt_fast_ = true;
+  }
   const SeqPlan& p = h_plans_[0];
   const int Sref = au_.S(), L = p.L, W = p.W;
   // (a schedule-1 evaluation of the linear pipeline leaves tables with one more state per row: the shadow of (0,0))

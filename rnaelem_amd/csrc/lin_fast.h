@@ -18,6 +18,9 @@
 
 namespace elemdp {
 
+#ifndef ELEMDP_UNARY2
+#define ELEMDP_UNARY2 1
+#endif
 constexpr int kFR = kFastR, kFP = kFastP, kFL = kFastL;   // unary transitions per list a program holds (device_layout.h)
 
 // ---- cell records ---------------------------------------------------------------------------------------------------------
@@ -107,10 +110,10 @@ __device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, cons
   const double v1 = lok ? v2 + vB : 0.;                                     // rules 4a, 4b
   const double vM = mok ? sM + vB : 0.;                                     // rules 5a, 5b
   const double vE = eok ? fma(vM, xcl, fma(vL, xhp, HE)) : 0.;              // rules 6a, 6b, 6c
-  const int cLo = fcol(w2, 2), cPo = fcol(w1, 0), cBo = fcol(w1, 3), c2o = fcol(w2, 1), c1o = fcol(w2, 0), cMo = fcol(w1, 2), cEo = fcol(w1, 1);
+  // (the B plane is not stored: nothing reads it -- the outside pass of the train kernels decides liveness from the pair entries)
+  const int cLo = fcol(w2, 2), cPo = fcol(w1, 0), c2o = fcol(w2, 1), c1o = fcol(w2, 0), cMo = fcol(w1, 2), cEo = fcol(w1, 1);
   if (cLo >= 0) T.band[T.cidx(ST_L, d, i, cLo)] = vL;
   if (pok && cPo >= 0) T.band[T.cidx(ST_P, d, i, cPo)] = vP;
-  if (lok && cBo >= 0) T.band[T.cidx(ST_B, d, i, cBo)] = vB;
   if (lok && c2o >= 0) T.band[T.cidx(ST_2, d, i, c2o)] = v2;
   if (lok && c1o >= 0) T.band[T.cidx(ST_1, d, i, c1o)] = v1;
   if (mok && cMo >= 0) T.band[T.cidx(ST_M, d, i, cMo)] = vM;
@@ -163,21 +166,17 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
   const bool pok = fl & CF_POK, lok = fl & CF_LOK, mok = fl & CF_MOK, eok = fl & CF_EOK, do2 = fl & CF_DO2, doM = fl & CF_DOM;
   const bool up_ok = fl & CF_UP, doL = isloop && (fl & CF_DOL);
   const int bl = (fl >> 8) & 7, br = (fl >> 11) & 7, ty = (fl >> 14) & 7;
-  const int cLo = fcol(w2, 2), cPo = fcol(w1, 0), cBo = fcol(w1, 3), c2o = fcol(w2, 1), c1o = fcol(w2, 0), cMo = fcol(w1, 2), cEo = fcol(w1, 1);
+  const int cLo = fcol(w2, 2), cPo = fcol(w1, 0), c2o = fcol(w2, 1), c1o = fcol(w2, 0), cMo = fcol(w1, 2), cEo = fcol(w1, 1);
   const int dp1 = d + 1, dp2 = d + 2, im1 = i - 1;   // (only dereferenced where the parent cell exists: do2 / doL / up_ok / doM)
-  // all table operands first: the cell's own inside values, the rule-7 term k4_r7 left in the outside P entry, the parents
-  const double inE = in.ldc(ST_E, d, i, cEo, eok), inM = in.ldc(ST_M, d, i, cMo, mok), in1 = in.ldc(ST_1, d, i, c1o, lok);
-  const double inB = in.ldc(ST_B, d, i, cBo, lok), in2 = in.ldc(ST_2, d, i, c2o, lok), inP = in.ldc(ST_P, d, i, cPo, pok);
-  const double inL = in.ldc(ST_L, d, i, cLo, isloop);
-  const double r7 = out.ldc(ST_P, d, i, cPo, pok);
-  double op2[kFR], opL[kFR], opP[kFP], opM[kFL];
-  int eR[kFR], eP[kFP], eL[kFL];
-#pragma unroll
-  for (int u = 0; u < kFR; ++u) {
-    eR[u] = P[4 + u];
-    op2[u] = out.ldc(ST_2, dp1, i, fcol(eR[u], 0), u < nRR && do2);
-    opL[u] = out.ldc(ST_L, dp1, i, fcol(eR[u], 1), u < nRR && doL && eR[u] < 0);   // (sign bit: the parent is a loop state)
-  }
+  // Two batches of table operands: (A) what the pair and left parents need -- E, P, M of the cell, the parents' P and M --, then
+  // (B) the rest.  One batch (everything in flight together) costs ~30 more vector registers than the rest of the kernel and
+  // so a workgroup per CU; ELEMDP_UNARY2 = 0 keeps it for comparison.  The B planes and the outside plane 1 are not stored
+  // here: nothing reads them (the generic kernels, which debug_tables uses, store every plane).
+  const double ews_l = cr[0], ews_r = cr[1];
+  const int ehs = lam_same ? 0 : kl;
+  const double inE = in.ldc(ST_E, d, i, cEo, eok), inM = in.ldc(ST_M, d, i, cMo, mok), inP = in.ldc(ST_P, d, i, cPo, pok);
+  double opP[kFP], opM[kFL];
+  int eP[kFP], eL[kFL];
 #pragma unroll
   for (int u = 0; u < kFP; ++u) {
     eP[u] = P[8 + u];
@@ -188,31 +187,42 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
     eL[u] = P[12 + u];
     opM[u] = out.ldc(ST_M, dp1, im1, fcol(eL[u], 0), u < nRL && doM);
   }
-  const double ews_l = cr[0], ews_r = cr[1];
-  const double xcl = cr[2 + kl], xhp = cr[4 + kl], xml = cr[6 + kl], xsu0 = cr[8], xsu1 = cr[9];
-  const double e_cl = cr[10], e_hp = cr[11], e_su = cr[12], e_ml = cr[13];
-  const double inEz = inE * invZ, inPz = inP * invZ, inMz = inM * invZ, in2z = in2 * invZ, inLz = inL * invZ;
-  const bool aE = up_ok && inE != 0., aP = up_ok && pok && inP != 0., aM = doM && inM != 0., a2 = do2 && in2 != 0., aL = doL && inL != 0.;
-  const int ehs = lam_same ? 0 : kl;
-  double oE = 0., oP1b = 0., sM = 0., s2 = 0., sL = 0.;
-  // E as child of P(i-1,j+1,par) (rule 1a) and P as child of it (rule 1b): same parents, same emission
+#if !ELEMDP_UNARY2
+  const double in1 = in.ldc(ST_1, d, i, c1o, lok), in2 = in.ldc(ST_2, d, i, c2o, lok), inL = in.ldc(ST_L, d, i, cLo, isloop);
+  const double r7 = out.ldc(ST_P, d, i, cPo, pok);
+  double op2[kFR], opL[kFR];
+  int eR[kFR];
 #pragma unroll
-  for (int u = 0; u < kFP; ++u)
-    if (u < nRP && (aE || aP)) {
-      const int id = (eP[u] >> 16) & 0x7fff;
-      const int f = G[A.fe_p + 3 * id], offR = G[A.fe_p + 3 * id + 1], offL = G[A.fe_p + 3 * id + 2];
-      const double w = lin[A.lin_wp + 8 * id + ty] * (((f & 2) ? ews_l : 1.) * ((f & 4) ? ews_r : 1.));
-      const double tE = aE ? opP[u] * w : 0.;
-      const double tP = aP ? opP[u] * (w * ((f & 8) ? xsu1 : xsu0)) : 0.;
-      const double zP = tP * inPz, z = fma(tE, inEz, zP);
-      if (!no_prf && z != 0.) {   // expected emission counts (motif_trainer.hpp:384-388 / profile_hmm.hpp:144-179)
-        if (f & 1) { if (ty) sink.en(offR + ty, z); }
-        else { if (bl) sink.en(offL + bl, z); if (br) sink.en(offR + br, z); }
+  for (int u = 0; u < kFR; ++u) {
+    eR[u] = P[4 + u];
+    op2[u] = out.ldc(ST_2, dp1, i, fcol(eR[u], 0), u < nRR && do2);
+    opL[u] = out.ldc(ST_L, dp1, i, fcol(eR[u], 1), u < nRR && doL && eR[u] < 0);   // (sign bit: the parent is a loop state)
+  }
+#endif
+  const double inEz = inE * invZ, inPz = inP * invZ, inMz = inM * invZ;
+  const bool aE = up_ok && inE != 0., aP = up_ok && pok && inP != 0., aM = doM && inM != 0.;
+  double oE = 0., oP1b = 0., sM = 0., s2 = 0., sL = 0.;
+  {
+    const double xsu0 = cr[8], xsu1 = cr[9], e_su = cr[12];
+    // E as child of P(i-1,j+1,par) (rule 1a) and P as child of it (rule 1b): same parents, same emission
+#pragma unroll
+    for (int u = 0; u < kFP; ++u)
+      if (u < nRP && (aE || aP)) {
+        const int id = (eP[u] >> 16) & 0x7fff;
+        const int f = G[A.fe_p + 3 * id], offR = G[A.fe_p + 3 * id + 1], offL = G[A.fe_p + 3 * id + 2];
+        const double w = lin[A.lin_wp + 8 * id + ty] * (((f & 2) ? ews_l : 1.) * ((f & 4) ? ews_r : 1.));
+        const double tE = aE ? opP[u] * w : 0.;
+        const double tP = aP ? opP[u] * (w * ((f & 8) ? xsu1 : xsu0)) : 0.;
+        const double zP = tP * inPz, z = fma(tE, inEz, zP);
+        if (!no_prf && z != 0.) {   // expected emission counts (motif_trainer.hpp:384-388 / profile_hmm.hpp:144-179)
+          if (f & 1) { if (ty) sink.en(offR + ty, z); }
+          else { if (bl) sink.en(offL + bl, z); if (br) sink.en(offR + br, z); }
+        }
+        if (zP != 0.) sink.eh(lam_same ? 0 : ((f >> 3) & 1), e_su * zP);   // motif_trainer.hpp:380-381
+        oE += tE;
+        oP1b += tP;
       }
-      if (zP != 0.) sink.eh(lam_same ? 0 : ((f >> 3) & 1), e_su * zP);   // motif_trainer.hpp:380-381
-      oE += tE;
-      oP1b += tP;
-    }
+  }
   // M as child of M(i-1,j,par) (rule 5a): left emission by the l-node of this state
 #pragma unroll
   for (int u = 0; u < kFL; ++u)
@@ -222,6 +232,29 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
       if (!no_prf && z != 0. && bl) sink.en(enl + bl, z);
       sM += term;
     }
+  if (eok && cEo >= 0) out.band[out.cidx(ST_E, d, i, cEo)] = oE;
+  double oM = 0.;
+  if (inM != 0.) {   // child of E (6a) and of M(i-1,j,par) (5a)
+    const double t6a = oE * cr[2 + kl], z = t6a * inMz;
+    if (z != 0.) sink.eh(ehs, cr[10] * z);
+    oM = t6a + sM;
+  }
+  if (mok && cMo >= 0) out.band[out.cidx(ST_M, d, i, cMo)] = oM;
+#if ELEMDP_UNARY2
+  __builtin_amdgcn_sched_barrier(0);
+  const double in1 = in.ldc(ST_1, d, i, c1o, lok), in2 = in.ldc(ST_2, d, i, c2o, lok), inL = in.ldc(ST_L, d, i, cLo, isloop);
+  const double r7 = out.ldc(ST_P, d, i, cPo, pok);
+  double op2[kFR], opL[kFR];
+  int eR[kFR];
+#pragma unroll
+  for (int u = 0; u < kFR; ++u) {
+    eR[u] = P[4 + u];
+    op2[u] = out.ldc(ST_2, dp1, i, fcol(eR[u], 0), u < nRR && do2);
+    opL[u] = out.ldc(ST_L, dp1, i, fcol(eR[u], 1), u < nRR && doL && eR[u] < 0);   // (sign bit: the parent is a loop state)
+  }
+#endif
+  const double in2z = in2 * invZ, inLz = inL * invZ;
+  const bool a2 = do2 && in2 != 0., aL = doL && inL != 0.;
   // 2 and L as children of 2 / L (i,j+1,par) (rules 3a, L <- L): right emission by the parent's r-node
 #pragma unroll
   for (int u = 0; u < kFR; ++u)
@@ -235,31 +268,23 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
       s2 += t2;
       sL += tL;
     }
-  if (eok && cEo >= 0) out.band[out.cidx(ST_E, d, i, cEo)] = oE;
-  double oM = 0.;
-  if (inM != 0.) {   // child of E (6a) and of M(i-1,j,par) (5a)
-    const double t6a = oE * xcl, z = t6a * inMz;
-    if (z != 0.) sink.eh(ehs, e_cl * z);
-    oM = t6a + sM;
-  }
-  if (mok && cMo >= 0) out.band[out.cidx(ST_M, d, i, cMo)] = oM;
+  // 1 (heavy sum H1), B (child of M (5b) and of 1 (4b): its inside value is non-zero wherever a pair entry that takes it is),
+  // 2 (child of 1 (4a), of 2(i,j+1,par) (3a); the rule-2 part reaches P as H2 = HA)
   const double o1 = (in1 != 0.) ? H1 : 0.;
-  const double oB = (inB != 0.) ? (mok ? oM : 0.) + o1 : 0.;
-  const double o2 = (in2 != 0.) ? o1 + s2 : 0.;   // direct part (rules 4a, 3a); the rule-2 part reaches P as H2 = HA
-  if (lok && c1o >= 0) out.band[out.cidx(ST_1, d, i, c1o)] = o1;
-  if (lok && cBo >= 0) out.band[out.cidx(ST_B, d, i, cBo)] = oB;
+  const double oB = lok ? (mok ? oM : 0.) + o1 : 0.;
+  const double o2 = (in2 != 0.) ? o1 + s2 : 0.;
   if (lok && c2o >= 0) out.band[out.cidx(ST_2, d, i, c2o)] = o2;
   double oP = 0.;
   if (inP != 0.) {   // child of O (7: r7), of P(i-1,j+1,par) (1b), of 2 (3b), inner pair of interior loops (6c: HP)
-    const double t3b = (o2 + H2) * xml, z = t3b * inPz;
-    if (z != 0.) sink.eh(ehs, e_ml * z);
+    const double t3b = (o2 + H2) * cr[6 + kl], z = t3b * inPz;
+    if (z != 0.) sink.eh(ehs, cr[13] * z);
     oP = oP1b + t3b + (HP + r7);
   }
   if (pok && cPo >= 0) out.band[out.cidx(ST_P, d, i, cPo)] = oP;
   double oL = 0.;
   if (inL != 0.) {   // child of E (6b), of L(i,j+1,par), loops of interior loops (6c: HL)
-    const double t6b = oE * xhp, z = t6b * inLz;
-    if (z != 0.) sink.eh(ehs, e_hp * z);
+    const double t6b = oE * cr[4 + kl], z = t6b * inLz;
+    if (z != 0.) sink.eh(ehs, cr[11] * z);
     oL = t6b + sL + HL;
   }
   if (cLo >= 0) out.band[out.cidx(ST_L, d, i, cLo)] = oL;

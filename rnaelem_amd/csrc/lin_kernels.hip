@@ -507,13 +507,23 @@ struct WorkIdx {
 
 // Item sums (rule 6c): a lane holds ONE item record and walks the tuples of the rule through their column records
 // (AutomatonLayout::qc_*, staged with the tuple lists); the four waves share the tuples (wave w takes t = w, w + 4, ..), kTU of
-// them per pass with all their table operands in flight together -- one round trip per 64 records.  Everything that depends
+// them per pass with all their table operands in flight together.  (Two lanes per record -- every tuple of the usual lists in
+// one pass -- computes the record's row addresses twice and measured 2 % slower.)  Everything that depends
 // on the record (row addresses, weights) is computed once per lane, a tuple then costs its four loads and a handful of
 // instructions.
-#ifndef ELEMDP_KTU
-#define ELEMDP_KTU 3
+#ifndef ELEMDP_AHEAD_IN
+#define ELEMDP_AHEAD_IN 0
 #endif
-constexpr int kTU = ELEMDP_KTU;
+#ifndef ELEMDP_AHEAD_OUT
+#define ELEMDP_AHEAD_OUT 0
+#endif
+#ifndef ELEMDP_KTU_IN
+#define ELEMDP_KTU_IN 3
+#endif
+#ifndef ELEMDP_KTU_OUT
+#define ELEMDP_KTU_OUT 3
+#endif
+constexpr int kTUin = ELEMDP_KTU_IN, kTUout = ELEMDP_KTU_OUT;
 
 // Item records of the workgroup's cells in LDS (k4_in, k5_cyk: the by_outer order; k4_out stages its three roles the same
 // way inline): CSR range per cell -> prefix in LDS, then all lanes fetch the records of [p0, p0 + cap) with one round of
@@ -560,25 +570,54 @@ __device__ __forceinline__ int outer_ranges(const LViews& v, int i0, int nc, int
   __syncthreads();
   return pre[nc];
 }
-template <bool WEIGHTS>
+// record p of the workgroup (prefix `pre` over its nc cells): its cell and its index in the item arrays
+__device__ __forceinline__ void outer_locate(int p, int nc, const int* pre, const int* base, int& lo, int& n) {
+  lo = 0;
+  int hi = nc - 1;   // the cell owning record p: largest c with pre[c] <= p
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (pre[mid] <= p) lo = mid; else hi = mid - 1;
+  }
+  n = base[lo] + (p - pre[lo]);
+}
+// A record fetched ahead of the heavy sums (its loads travel with theirs): record `tid` of the workgroup
+struct RecAhead { LoopItem it; int meta; bool have; };
+__device__ __forceinline__ RecAhead outer_fetch_ahead(const LViews& v, int n_rec, int nc, int tid, const int* pre, const int* base) {
+  RecAhead r;
+  r.have = tid < n_rec;
+  r.meta = 0;
+  r.it = LoopItem{0., 0, 0, 0, 0};
+  if (r.have) {
+    int lo, n;
+    outer_locate(tid, nc, pre, base, lo, n);
+    const bool in = v.q.item_in[n] != 0;
+    r.it = v.q.items[n];
+    r.meta = (in ? 0 : (int)0x80000000) | (lo << 16) | (tid - pre[lo]);
+  }
+  return r;
+}
+template <bool WEIGHTS, bool AHEAD = false>
 __device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r, int p0, int np, int nc, int tid, const int* pre,
-                                            const int* base) {
+                                            const int* base, const RecAhead ahead = RecAhead{LoopItem{0., 0, 0, 0, 0}, 0, false}) {
   for (int x = tid; x < np; x += kThreads) {
     const int p = p0 + x;
-    int lo = 0, hi = nc - 1;   // the cell owning record p: largest c with pre[c] <= p
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (pre[mid] <= p) lo = mid; else hi = mid - 1;
+    LoopItem itv;
+    int meta;
+    if (AHEAD && p == tid && ahead.have) { itv = ahead.it; meta = ahead.meta; }
+    else {
+      int lo, n;
+      outer_locate(p, nc, pre, base, lo, n);
+      const bool in = v.q.item_in[n] != 0;
+      itv = v.q.items[n];
+      meta = (in ? 0 : (int)0x80000000) | (lo << 16) | (p - pre[lo]);
     }
-    const int n = base[lo] + (p - pre[lo]);
-    const bool in = v.q.item_in[n] != 0;
-    r.it[x] = v.q.items[n];
+    r.it[x] = itv;
     if (WEIGHTS) {   // exp(lambda_k * tsc) on the spot: two exps per staged record are cheaper than an array of them in HBM
-      const double tsc = r.it[x].tsc;
-      r.xw[x] = in ? lin_weight(v.m.lambda[0], tsc) : 0.;
-      r.xw[r.cap + x] = in ? lin_weight(v.m.lambda[1], tsc) : 0.;
+      const double tsc = itv.tsc;
+      r.xw[x] = meta >= 0 ? lin_weight(v.m.lambda[0], tsc) : 0.;
+      r.xw[r.cap + x] = meta >= 0 ? lin_weight(v.m.lambda[1], tsc) : 0.;
     }
-    r.meta[x] = (in ? 0 : (int)0x80000000) | (lo << 16) | (p - pre[lo]);
+    r.meta[x] = meta;
   }
   __syncthreads();
 }
@@ -643,7 +682,12 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   }
   const double* B = v.in.band;
   const int nq = (a.dbg & 2) ? 0 : A.n_quad;
-  outer_ranges_load(v, i0, nc, d, nq > 0, tid, cnts, base);   // (CSR ranges of the item sums: in flight during the pair phase)
+  // CSR ranges of the item sums, their prefix, and the first 256 item records: fetched ahead, so that the records arrive while
+  // the pair phase runs (one round trip less on the workgroup's chain)
+  outer_ranges_load(v, i0, nc, d, nq > 0, tid, cnts, base);
+  __syncthreads();
+  const int n_rec = outer_ranges_prefix(nc, tid, cnts, pre);
+  const RecAhead ahead = outer_fetch_ahead(v, ELEMDP_AHEAD_IN ? n_rec : 0, nc, tid, pre, base);
   // rule 2, factorised (lin_rules.h, lin_inside_apair): lane = (cell, pair p = (s1, t)).  A(i,j,p) = the tail step from
   // A(i,j-1,.) plus one term per stem (k, j) that ends at j and starts behind i; B(i,j,tgt(p)) += A(i,j,p).  The stems are
   // walked four at a time: their operand loads (1(i,k,s1), P(k,j,t), exp(lambda e_ml)) are in flight together.
@@ -763,13 +807,13 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   // rule 6c: E(i,j,tgt) += sum_items P(k,l,s1) * L(i,k,s2) * L(l,j,s3) * exp(lambda * tsc): work item = (item, tuple), the
   // item records staged in the (now free) operand staging area, one round of table loads per work item
   {
-    const int n_rec = outer_ranges_prefix(nc, tid, cnts, pre);
     const OuterRecs R = outer_recs(st1, kRecIn);
     for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
       const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
-      outer_stage<true>(v, R, p0, np, nc, tid, pre, base);
+      outer_stage<true, true>(v, R, p0, np, nc, tid, pre, base, ahead);
       const int wv = tid >> 6, lane = tid & 63;
       const int qc_in = FAST ? A.fqc_in : A.qc_in;
+      constexpr int kTU = kTUin;
       for (int xb = 0; xb < np; xb += 64) {
         const int x = xb + lane;
         const int xc = x < np ? x : np - 1;
@@ -789,8 +833,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
           for (int u = 0; u < kTU; ++u) {
             const int t = t0 + 4 * u;
             const bool on = t < nq;
-            qa[u] = G[qc_in + 2 * (on ? t : t0)];
-            qb[u] = on ? G[qc_in + 2 * (on ? t : t0) + 1] : (4 << 16);
+            qa[u] = G[qc_in + 2 * (on ? t : wv)];
+            qb[u] = on ? G[qc_in + 2 * (on ? t : wv) + 1] : (4 << 16);
             x0[u] = B[rP + (qa[u] & 0xff)]; x1[u] = B[rL1 + ((qa[u] >> 8) & 0xff)]; x2[u] = B[rL2 + ((qa[u] >> 16) & 0xff)];
           }
 #pragma unroll
@@ -1213,6 +1257,26 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     base[vc] = n0;
     cnts[vc] = (n1 > n0) ? n1 - n0 : 0;
   }
+  // ... their prefix, and the first 256 item records fetched ahead: they arrive while the pair phases run
+  __syncthreads();
+  const int nv = 3 * nc;
+  for (int vc = tid; vc <= nv; vc += kThreads) {
+    int p = 0;
+    for (int c = 0; c < vc; ++c) p += cnts[c];
+    pre[vc] = p;
+  }
+  __syncthreads();
+  const int n_rec = pre[nv];
+  LoopItem ah_it = LoopItem{0., 0, 0, 0, 0};
+  int ah_meta = -1;
+  if (ELEMDP_AHEAD_OUT && tid < n_rec) {
+    int lo, n;
+    outer_locate(tid, nv, pre, base, lo, n);
+    const int role = (lo >= nc) + (lo >= 2 * nc);
+    const LoopItem* src = role == 0 ? v.q.items_inner : role == 1 ? v.q.items_left : v.q.items_right;
+    ah_it = src[n];
+    ah_meta = (role << 16) | (lo - role * nc);
+  }
   // rule 2, factorised, outside direction (lin_rules.h: lheavy_o1 / lheavy_o2):
   //   h1[c][s1] = H1 = sum over the stems (j, l) that start at the cell's end j = i + d:  outA(i,l,p) * P(j,l,t) * xml(j,l)
   //   h2[c][t]  = HA = sum_{ii < i} outA(ii,j,p) * 1(ii,i,s1), only where the cell itself is a stem P(i,j)
@@ -1303,14 +1367,6 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   // their weights are staged into the (now free) operand staging area by all lanes with one round of loads; a work item
   // then needs a single round of table loads, selected by role without branches.
   {
-    const int nv = 3 * nc;
-    for (int vc = tid; vc <= nv; vc += kThreads) {
-      int p = 0;
-      for (int c = 0; c < vc; ++c) p += cnts[c];
-      pre[vc] = p;
-    }
-    __syncthreads();
-    const int n_rec = pre[nv];
     // record area: LoopItem it[cap], double xw[2][cap], int meta[cap] (role << 16 | cell)
     const int cap = (kRecOut * 8) / 40;
     LoopItem* r_it = reinterpret_cast<LoopItem*>(sOB1);
@@ -1323,18 +1379,20 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       const int np = (cap < n_rec - p0) ? cap : n_rec - p0;
       for (int x = tid; x < np; x += kThreads) {
         const int p = p0 + x;
-        int lo = 0, hi = nv - 1;   // the (role, cell) owning record p: largest vc with pre[vc] <= p
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (pre[mid] <= p) lo = mid; else hi = mid - 1;
+        LoopItem itv = ah_it;
+        int meta = ah_meta;
+        if (!ELEMDP_AHEAD_OUT || p != tid) {   // (record `tid` came ahead)
+          int lo, n;
+          outer_locate(p, nv, pre, base, lo, n);   // the (role, cell) owning record p
+          const int role = (lo >= nc) + (lo >= 2 * nc);
+          const LoopItem* src = role == 0 ? v.q.items_inner : role == 1 ? v.q.items_left : v.q.items_right;
+          itv = src[n];
+          meta = (role << 16) | (lo - role * nc);
         }
-        const int role = (lo >= nc) + (lo >= 2 * nc), c = lo - role * nc;
-        const int n = base[lo] + (p - pre[lo]);
-        const LoopItem* src = role == 0 ? v.q.items_inner : role == 1 ? v.q.items_left : v.q.items_right;
-        r_it[x] = src[n];
-        r_xw[x] = lin_weight(v.m.lambda[0], r_it[x].tsc);          // (exp(lambda_k * tsc), as in outer_stage)
-        r_xw[cap + x] = lin_weight(v.m.lambda[1], r_it[x].tsc);
-        r_meta[x] = (role << 16) | c;
+        r_it[x] = itv;
+        r_xw[x] = lin_weight(v.m.lambda[0], itv.tsc);          // (exp(lambda_k * tsc), as in outer_stage)
+        r_xw[cap + x] = lin_weight(v.m.lambda[1], itv.tsc);
+        r_meta[x] = meta;
       }
       __syncthreads();
       pc.mark<8>();
@@ -1342,6 +1400,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       // Operand liveness by construction: the outer cell of an item is a parsable E cell, its inner pair a kept pair, the loops L
       // are stored everywhere; role 0 only has records at pair cells.
       const int wv = tid >> 6, lane = tid & 63;
+      constexpr int kTU = kTUout;
       for (int xb = 0; xb < np; xb += 64) {
         const int x = xb + lane;
         const bool valid = x < np;
@@ -1364,8 +1423,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           for (int u = 0; u < kTU; ++u) {
             const int t = t0 + 4 * u;
             const bool on = t < nq;
-            qa[u] = G[qc0 + 2 * (on ? t : t0)];
-            qb[u] = on ? G[qc0 + 2 * (on ? t : t0) + 1] : (4 << 16);
+            qa[u] = G[qc0 + 2 * (on ? t : wv)];
+            qb[u] = on ? G[qc0 + 2 * (on ? t : wv) + 1] : (4 << 16);
             x0[u] = OB[rE + (qa[u] & 0xff)]; x1[u] = IB[r1 + ((qa[u] >> 8) & 0xff)]; x2[u] = IB[r2 + ((qa[u] >> 16) & 0xff)];
             aux[u] = IB[rA + ((qa[u] >> 24) & 0xff)];
           }
