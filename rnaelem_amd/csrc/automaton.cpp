@@ -529,6 +529,9 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     };
     auto attr = [&](int32_t pos, int k) { return (*ints)[pos + k]; };
     bool ok = A.n_wr < 32768 && A.n_wp < 32768 && A.n_wl < 32768 && A.tab_row < 250;
+    A.fp_max_p = 0;
+    for (int k = 0; k < ST; ++k)
+      for (const Csr* c : {&pair, &rpair}) A.fp_max_p = std::max(A.fp_max_p, (int32_t)c->rows[k].size() / 2);
     for (int k = 0; k < ST; ++k) {
       for (const Csr* c : {&right, &rright}) ok = ok && (int)c->rows[k].size() / 2 <= kFastR;
       for (const Csr* c : {&pair, &rpair}) ok = ok && (int)c->rows[k].size() / 2 <= kFastP;
@@ -708,6 +711,7 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   A.tab_row = 7; A.ap_rs = 1;
   A.fp_ok = 0; A.fp_in = A.fp_out = A.fe_r = A.fe_p = 0; A.n_wr = A.n_wp = A.n_wl = 0;
   A.fb_in = A.fb_in_n = A.fb_out = A.fb_out_n = A.fqc_in = A.fpr_in = A.fqc_out = A.fpr_out = 0;
+  A.fp_max_p = kFastP;
   A.lin_wr = A.lin_wl = A.lin_wp = A.lin_total = 11;
   A.qc_in = A.qc_out1 = A.qc_out2 = A.qc_out3 = 0;
   A.n_small = (int32_t)ints->size();

@@ -94,6 +94,7 @@ struct AutomatonLayout {
   // fp_ok = 0: a list is longer than kFastR / kFastP / kFastL (or a column index does not fit a byte); the kernels then
   // run the generic rule code.
   int32_t fp_ok, fb_in, fb_in_n, fb_out, fb_out_n;
+  int32_t fp_max_p;   // longest pair list (forward or reverse) of a state: the kernels unroll 2 or kFastP slots
   int32_t fp_in, fqc_in, fpr_in, fp_out, fe_r, fe_p, fqc_out, fpr_out;
   int32_t n_wr, n_wp, n_wl;                     // transitions per forward list = rows of the weight tables
   int32_t lin_wr, lin_wl, lin_wp, lin_total;    // offsets (doubles) of the weight tables in the linear block; its length

@@ -21,7 +21,8 @@ namespace elemdp {
 #ifndef ELEMDP_UNARY2
 #define ELEMDP_UNARY2 1
 #endif
-constexpr int kFR = kFastR, kFP = kFastP, kFL = kFastL;   // unary transitions per list a program holds (device_layout.h)
+// kFR / kFP / kFL (template parameters below): unary transitions per list the code unrolls -- the longest lists of the automaton
+// (AutomatonLayout::fp_max), at most kFastR / kFastP / kFastL.  Every unrolled slot is a load instruction, used or not.
 
 // ---- cell records ---------------------------------------------------------------------------------------------------------
 constexpr int kCellInD = 10;    // doubles per cell, inside:  ews(i), ews(j-1), xst[2], xml[2], xcl[2], xhp[2]
@@ -49,9 +50,11 @@ __device__ __forceinline__ int cell_in_flags(const ModelView& m, const SeqView& 
          ((pok && d >= 2) ? CF_CE : 0) | ((pok && inner) ? CF_CP : 0) | (bi << 8) | (bj << 11) | (bp_type(bi, bj) << 14);
 }
 
-// P,E,M,B,1,2,L of target (i, d, state of program P) from the heavy sums HB (rule 2) and HE (rule 6c); stores them
+// P,E,M,B,1,2,L of target (i, d, state of program P) from the heavy sums *pHB (rule 2) and *pHE (rule 6c, both in LDS: read
+// where they are used); stores them
+template <int kFR, int kFP, int kFL>
 __device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, const int32_t* P, const double* lin, const TableView& T,
-                                                  const double* cr, int fl, int d, int i, double HB, double HE) {
+                                                  const double* cr, int fl, int d, int i, const double* pHB, const double* pHE) {
   const int w0 = P[0], w1 = P[1], w2 = P[2];
   const bool isloop = w0 & 1, wr_pos = w0 & 8;
   const int kl = (w0 >> 2) & 1, nR = (w0 >> 8) & 15, nP = (w0 >> 12) & 15, nL = (w0 >> 16) & 15;
@@ -103,6 +106,7 @@ __device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, cons
       const double w = lin[A.lin_wl + 5 * ((eL[u] >> 16) & 0x7fff) + bi] * (eL[u] < 0 ? ews_i : 1.);
       sM = fma(tM[u], w, sM);
     }
+  const double HB = *pHB, HE = *pHE;
   const double vL = isloop ? (d == 0 ? ((w0 & 2) ? 1. : 0.) : sL) : 0.;   // motif_trainer.hpp:89-95
   const double vP = pok ? sP : 0.;                                          // rules 1a, 1b
   const double vB = lok ? HB : 0.;                                          // rule 2
@@ -155,11 +159,11 @@ __device__ __forceinline__ bool cell_out_mask(int fl, int k) {
 }
 
 // band target (i, d, state of program P) of the train schedule's outside sweep; returns out B.  invZ: of the lane's world.
-template <class Sink>
+// (heavy sums H1, H2, HP, HL of the target at ph[0], ph[CS], ph[2 CS], ph[3 CS] in LDS: read where they are used)
+template <int kFR, int kFP, int kFL, class Sink>
 __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, const int32_t* P, const int32_t* G, const double* lin,
                                                      const TableView& in, const TableView& out, const double* cr, int fl, int d, int i,
-                                                     double invZ, bool lam_same, bool no_prf, Sink& sink, double H1, double H2,
-                                                     double HP, double HL) {
+                                                     double invZ, bool lam_same, bool no_prf, Sink& sink, const double* ph, int CS) {
   const int w0 = P[0], w1 = P[1], w2 = P[2], enl = P[3];
   const bool isloop = w0 & 1, wl_s = w0 & 16;
   const int kl = (w0 >> 2) & 1, nRR = (w0 >> 8) & 15, nRP = (w0 >> 12) & 15, nRL = (w0 >> 16) & 15;
@@ -270,6 +274,7 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
     }
   // 1 (heavy sum H1), B (child of M (5b) and of 1 (4b): its inside value is non-zero wherever a pair entry that takes it is),
   // 2 (child of 1 (4a), of 2(i,j+1,par) (3a); the rule-2 part reaches P as H2 = HA)
+  const double H1 = ph[0], H2 = ph[CS], HP = ph[2 * CS], HL = ph[3 * CS];
   const double o1 = (in1 != 0.) ? H1 : 0.;
   const double oB = lok ? (mok ? oM : 0.) + o1 : 0.;
   const double o2 = (in2 != 0.) ? o1 + s2 : 0.;

@@ -511,6 +511,11 @@ struct WorkIdx {
 // one pass -- computes the record's row addresses twice and measured 2 % slower.)  Everything that depends
 // on the record (row addresses, weights) is computed once per lane, a tuple then costs its four loads and a handful of
 // instructions.
+// Register-pressure analysis only (tools/kmeta.py ... -DELEMDP_KO=<bits>): phases compiled out of k4_in / k4_out.
+// bit 0 pair phases, 1 item sums, 2 unary phase, 3 pair entries behind the unary phase (k4_out).  Results are invalid.
+#ifndef ELEMDP_KO
+#define ELEMDP_KO 0
+#endif
 #ifndef ELEMDP_AHEAD_IN
 #define ELEMDP_AHEAD_IN 0
 #endif
@@ -622,8 +627,8 @@ __device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r,
   __syncthreads();
 }
 
-// FAST: table-driven unary phase (lin_fast.h; train schedule, whole blob staged)
-template <bool BIG, bool CON, bool FAST = false>
+// FAST: table-driven phases (lin_fast.h; train schedule, the fast blob staged); FP: longest pair list of a state (2 or 3)
+template <bool BIG, bool CON, bool FAST = false, int FP = kFastP>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     }
   }
   const double* B = v.in.band;
-  const int nq = (a.dbg & 2) ? 0 : A.n_quad;
+  const int nq = ((a.dbg & 2) || (ELEMDP_KO & 2)) ? 0 : A.n_quad;
   // CSR ranges of the item sums, their prefix, and the first 256 item records: fetched ahead, so that the records arrive while
   // the pair phase runs (one round trip less on the workgroup's chain)
   outer_ranges_load(v, i0, nc, d, nq > 0, tid, cnts, base);
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     const int32_t* I = v.m.ints;
     const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
     const int W1 = v.q.W + 1;
-    const int nwork = (a.dbg & 1) ? 0 : nc * nA;
+    const int nwork = ((a.dbg & 1) || (ELEMDP_KO & 1)) ? 0 : nc * nA;
     for (int w = tid; w < nwork; w += kThreads) {
       const int c = div_small(w, nA), p = w - c * nA;
       const int i = i0 + c, j = i + d;
@@ -848,15 +853,14 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     }
   }
   pc.mark<3>();
-  if (tid < nc * NA && !(a.dbg & 4)) {
+  if (tid < nc * NA && !(a.dbg & 4) && !(ELEMDP_KO & 4)) {
     const int c = div_small(tid, NA), s = tid - c * NA;
     const int i = i0 + c;
-    const double HB = hb[c * S + s];
     if (FAST) {
-      fast_inside_unary(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, HB, he[c * S + s]);
+      fast_inside_unary<kFastR, FP, kFastL>(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, hb + c * S + s, he + c * S + s);
     } else {
       const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
-      lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, HB, he[c * S + s], con);
+      lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, hb[c * S + s], he[c * S + s], con);
     }
   }
   pc.mark<4>();
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(kThreads) void k4_r7(LinArgs a) {
 }
 
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
-template <int MODE, bool BIG, bool FAST = false>
+template <int MODE, bool BIG, bool FAST = false, int FP = kFastP>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
@@ -1243,7 +1247,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   if (MODE == OUT_END) sink.pos2 = l_pos - pos_p0;
   const TableView& in = v.in;
   const TableView& out = v.out;
-  const int nq = (a.dbg & 2) ? 0 : A.n_quad;
+  const int nq = ((a.dbg & 2) || (ELEMDP_KO & 2)) ? 0 : A.n_quad;
   const double* IB = in.band;
   const double* OB = out.band;
   // CSR ranges of the item sums of the three roles (consumed behind the pair phase, whose loads they travel with)
@@ -1285,7 +1289,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     const int nA = A.n_ap;
     const int32_t* I = v.m.ints;
     const int W1 = W + 1;
-    const int nwork = (a.dbg & 1) ? 0 : nc * nA;
+    const int nwork = ((a.dbg & 1) || (ELEMDP_KO & 1)) ? 0 : nc * nA;
     // attributes of pair p: from its record in the fast blob (AutomatonLayout::fpr_out), or from the generic lists
     auto pr_s1 = [&](int p) { return FAST ? (G[A.fpr_out + 8 * p + 1] & 0xff) : I[A.ap_s1 + p]; };
     auto pr_t = [&](int p) { return FAST ? ((G[A.fpr_out + 8 * p + 1] >> 8) & 0xff) : I[A.ap_t + p]; };
@@ -1328,7 +1332,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     // each of them).  (The rule-7 term of their P states is already in the table: k4_r7.)
     unsigned long long stems = 0;             // bit c: cell c of the workgroup is a pair (cpb <= 64)
     for (int c = 0; c < nc; ++c) stems |= v.q.pair_ok(i0 + c, d) ? (1ull << c) : 0ull;
-    if (stems && !(a.dbg & 1)) {
+    if (stems && !(a.dbg & 1) && !(ELEMDP_KO & 1)) {
       const int nb = W - d;                   // b = 1 .. nb: parent span d + b <= W
       const int per = nb * nA, total = __popcll(stems) * per;
       constexpr int kHA = 4;
@@ -1457,15 +1461,15 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     }
   }
   pc.mark<10>();
-  if (tid < nc * NA && !(a.dbg & 4)) {
+  if (tid < nc * NA && !(a.dbg & 4) && !(ELEMDP_KO & 4)) {
     const int c = div_small(tid, NA), s = tid - c * NA;
     const bool w1 = pi.merged && s == A.shadow;      // the shadow state: world 1 (its own Z, second set of statistics)
     sink.world = w1 ? 1 : 0;
     sink.en_ = l_en + (w1 ? nt : 0);
     if (FAST) {
-      h1[c * S + s] = fast_outside_unary(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c], d, i0 + c,
-                                         w1 ? pi.invZs : pi.invZ, v.m.lam_same != 0, v.m.no_prf != 0, sink, h1[c * S + s], h2[c * S + s],
-                                         hp[c * S + s], hl[c * S + s]);
+      h1[c * S + s] = fast_outside_unary<kFastR, FP, kFastL>(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c], d,
+                                                             i0 + c, w1 ? pi.invZs : pi.invZ, v.m.lam_same != 0, v.m.no_prf != 0, sink,
+                                                             h1 + c * S + s, CS);
     } else {
       LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
       HeavyOut H;
@@ -1478,7 +1482,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   __syncthreads();
   // outside values of the pair entries of the cells (lin_outside_apair): out B of the target + the tail step from
   // (i, d+1), with the statistics of the tail emissions
-  if (!(a.dbg & 1) && !(a.dbg & 128)) {
+  if (!(a.dbg & 1) && !(a.dbg & 128) && !(ELEMDP_KO & 8)) {
     const int nA = A.n_ap;
     double* const en_keep = sink.en_;
     for (int w = tid; w < nc * nA; w += kThreads) {
@@ -1931,7 +1935,8 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
       const int ncell = Lmax - d + 1;
       if (ncell <= 0) break;
       a.d = d;
-      if (fast) hipLaunchKernelGGL((k4_in<true, false, true>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
+      if (fast && a.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_in<true, false, true, 2>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
+      else if (fast) hipLaunchKernelGGL((k4_in<true, false, true>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
       else if (big) hipLaunchKernelGGL((k4_in<true, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
       else hipLaunchKernelGGL((k4_in<false, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
     }
@@ -1958,6 +1963,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
         if (ncell <= 0) continue;
         b.d = d;
         if (big && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);   // (timing experiment: no statistics)
+        else if (fast && b.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else if (fast) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else if (big) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
         else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
