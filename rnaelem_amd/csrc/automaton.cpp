@@ -670,12 +670,21 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   auto append = [&](const std::vector<int32_t>& v) { const int32_t pos = (int32_t)ints->size(); ints->insert(ints->end(), v.begin(), v.end()); return pos; };
   auto copy_of = [&](int32_t from, int n) { return std::vector<int32_t>(ints->begin() + from, ints->begin() + from + n); };
   const std::vector<int32_t> qci = copy_of(A.qc_in, 2 * A.n_quad), qco = copy_of(A.qc_out1, 6 * A.n_quad);
+  std::vector<int32_t> live_states;
+  for (int k = 0; k < ST; ++k) {
+    bool any = false;
+    for (int e = 0; e < 7; ++e) any = any || (*ints)[A.tab_cmap + e * ST + k] >= 0;
+    if (any) live_states.push_back(k);
+  }
+  A.n_lane = (int32_t)live_states.size();
   A.fb_in = (int32_t)ints->size();
+  A.f_live_in = append(live_states);
   A.fp_in = append(prog_in);
   A.fqc_in = append(qci);
   A.fpr_in = append(pair_rec);
   A.fb_in_n = (int32_t)ints->size() - A.fb_in;
   A.fb_out = (int32_t)ints->size();
+  A.f_live_out = append(live_states);
   A.fp_out = append(prog_out);
   A.fe_r = append(attr_r);
   A.fe_p = append(attr_p);
@@ -711,7 +720,7 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   A.tab_row = 7; A.ap_rs = 1;
   A.fp_ok = 0; A.fp_in = A.fp_out = A.fe_r = A.fe_p = 0; A.n_wr = A.n_wp = A.n_wl = 0;
   A.fb_in = A.fb_in_n = A.fb_out = A.fb_out_n = A.fqc_in = A.fpr_in = A.fqc_out = A.fpr_out = 0;
-  A.fp_max_p = kFastP;
+  A.fp_max_p = kFastP; A.n_lane = 1; A.f_live_in = A.f_live_out = 0;
   A.lin_wr = A.lin_wl = A.lin_wp = A.lin_total = 11;
   A.qc_in = A.qc_out1 = A.qc_out2 = A.qc_out3 = 0;
   A.n_small = (int32_t)ints->size();

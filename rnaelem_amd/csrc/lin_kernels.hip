@@ -19,6 +19,7 @@
 // Reference path: RNAelemTrainDP::operator(), RNAelem/motif_trainer.hpp:124-272.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -853,8 +854,10 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     }
   }
   pc.mark<3>();
-  if (tid < nc * NA && !(a.dbg & 4) && !(ELEMDP_KO & 4)) {
-    const int c = div_small(tid, NA), s = tid - c * NA;
+  const int NL = FAST ? A.n_lane : NA;   // lanes per cell of the unary phase: the states that have a column at all
+  if (tid < nc * NL && !(a.dbg & 4) && !(ELEMDP_KO & 4)) {
+    const int c = div_small(tid, NL);
+    const int s = FAST ? G[A.f_live_in + tid - c * NL] : tid - c * NL;
     const int i = i0 + c;
     if (FAST) {
       fast_inside_unary<kFastR, FP, kFastL>(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, hb + c * S + s, he + c * S + s);
@@ -1461,8 +1464,10 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     }
   }
   pc.mark<10>();
-  if (tid < nc * NA && !(a.dbg & 4) && !(ELEMDP_KO & 4)) {
-    const int c = div_small(tid, NA), s = tid - c * NA;
+  const int NL = FAST ? A.n_lane : NA;   // lanes per cell of the unary phase: the states that have a column at all
+  if (tid < nc * NL && !(a.dbg & 4) && !(ELEMDP_KO & 4)) {
+    const int c = div_small(tid, NL);
+    const int s = FAST ? G[A.f_live_out + tid - c * NL] : tid - c * NL;
     const bool w1 = pi.merged && s == A.shadow;      // the shadow state: world 1 (its own Z, second set of statistics)
     sink.world = w1 ? 1 : 0;
     sink.en_ = l_en + (w1 ? nt : 0);
@@ -1927,6 +1932,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   // and the weight tables staged
   const bool fast = a.fast && big && a.lay.fp_ok && !(a.dbg & 16) && a.lay.lin_total <= 2048;
   a.fast = fast ? 1 : 0;
+  if (fast) a.cpb = std::min(kThreads / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);   // (states without any column take no lane)
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
   const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
   const size_t lds_stat = sizeof(double) * (2 * nt + 4);
