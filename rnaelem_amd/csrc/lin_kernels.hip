@@ -691,9 +691,13 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   // CSR ranges of the item sums, their prefix, and the first 256 item records: fetched ahead, so that the records arrive while
   // the pair phase runs (one round trip less on the workgroup's chain)
   outer_ranges_load(v, i0, nc, d, nq > 0, tid, cnts, base);
+#if ELEMDP_AHEAD_IN
   __syncthreads();
   const int n_rec = outer_ranges_prefix(nc, tid, cnts, pre);
-  const RecAhead ahead = outer_fetch_ahead(v, ELEMDP_AHEAD_IN ? n_rec : 0, nc, tid, pre, base);
+  const RecAhead ahead = outer_fetch_ahead(v, n_rec, nc, tid, pre, base);
+#else
+  const RecAhead ahead{LoopItem{0., 0, 0, 0, 0}, 0, false};   // (off: two barriers more than the round trip saved, measured)
+#endif
   // rule 2, factorised (lin_rules.h, lin_inside_apair): lane = (cell, pair p = (s1, t)).  A(i,j,p) = the tail step from
   // A(i,j-1,.) plus one term per stem (k, j) that ends at j and starts behind i; B(i,j,tgt(p)) += A(i,j,p).  The stems are
   // walked four at a time: their operand loads (1(i,k,s1), P(k,j,t), exp(lambda e_ml)) are in flight together.
@@ -813,10 +817,13 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   // rule 6c: E(i,j,tgt) += sum_items P(k,l,s1) * L(i,k,s2) * L(l,j,s3) * exp(lambda * tsc): work item = (item, tuple), the
   // item records staged in the (now free) operand staging area, one round of table loads per work item
   {
+#if !ELEMDP_AHEAD_IN
+    const int n_rec = outer_ranges_prefix(nc, tid, cnts, pre);
+#endif
     const OuterRecs R = outer_recs(st1, kRecIn);
     for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
       const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
-      outer_stage<true, true>(v, R, p0, np, nc, tid, pre, base, ahead);
+      outer_stage<true, ELEMDP_AHEAD_IN != 0>(v, R, p0, np, nc, tid, pre, base, ahead);
       const int wv = tid >> 6, lane = tid & 63;
       const int qc_in = FAST ? A.fqc_in : A.qc_in;
       constexpr int kTU = kTUin;
@@ -1264,9 +1271,13 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     base[vc] = n0;
     cnts[vc] = (n1 > n0) ? n1 - n0 : 0;
   }
-  // ... their prefix, and the first 256 item records fetched ahead: they arrive while the pair phases run
-  __syncthreads();
   const int nv = 3 * nc;
+  LoopItem ah_it = LoopItem{0., 0, 0, 0, 0};
+  int ah_meta = -1;
+#if ELEMDP_AHEAD_OUT
+  // ... their prefix, and the first 256 item records fetched ahead: they arrive while the pair phases run
+  // (off by default: two barriers more than the round trip saved, measured)
+  __syncthreads();
   for (int vc = tid; vc <= nv; vc += kThreads) {
     int p = 0;
     for (int c = 0; c < vc; ++c) p += cnts[c];
@@ -1274,9 +1285,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   }
   __syncthreads();
   const int n_rec = pre[nv];
-  LoopItem ah_it = LoopItem{0., 0, 0, 0, 0};
-  int ah_meta = -1;
-  if (ELEMDP_AHEAD_OUT && tid < n_rec) {
+  if (tid < n_rec) {
     int lo, n;
     outer_locate(tid, nv, pre, base, lo, n);
     const int role = (lo >= nc) + (lo >= 2 * nc);
@@ -1284,6 +1293,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     ah_it = src[n];
     ah_meta = (role << 16) | (lo - role * nc);
   }
+#endif
   // rule 2, factorised, outside direction (lin_rules.h: lheavy_o1 / lheavy_o2):
   //   h1[c][s1] = H1 = sum over the stems (j, l) that start at the cell's end j = i + d:  outA(i,l,p) * P(j,l,t) * xml(j,l)
   //   h2[c][t]  = HA = sum_{ii < i} outA(ii,j,p) * 1(ii,i,s1), only where the cell itself is a stem P(i,j)
@@ -1299,6 +1309,44 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     auto pr_c1 = [&](int p) { return FAST ? fcol(G[A.fpr_out + 8 * p], 0) : in.col(ST_1, I[A.ap_s1 + p]); };
     auto pr_cP = [&](int p) { return FAST ? fcol(G[A.fpr_out + 8 * p], 1) : in.col(ST_P, I[A.ap_t + p]); };
     auto pr_kl = [&](int p) { return FAST ? ((G[A.fpr_out + 8 * p] >> 24) & 1) : lamk(v.m, I[A.ap_t + p]); };
+    // HA: the few stem cells of the workgroup, work item = (stem cell, parent row ii = i - b, pair) over ALL of them as one
+    // flat list, four work items' loads in flight per lane.  The loads of the first round are issued here, ahead of the H1
+    // sums: both read outA of larger spans only, so one round trip serves both.  (The rule-7 term of the stem cells' P states
+    // is already in the table: k4_r7.)
+    unsigned long long stems = 0;             // bit c: cell c of the workgroup is a pair (cpb <= 64)
+    for (int c = 0; c < nc; ++c) stems |= v.q.pair_ok(i0 + c, d) ? (1ull << c) : 0ull;
+    if ((a.dbg & 1) || (ELEMDP_KO & 1)) stems = 0;
+    const int nb = W - d;                     // b = 1 .. nb: parent span d + b <= W
+    const int per = nb * nA, total = __popcll(stems) * per;
+    constexpr int kHA = 4;
+    double ha_oa[kHA], ha_x1[kHA];
+    int ha_idx[kHA];
+    auto ha_load = [&](int w0) {
+#pragma unroll
+      for (int u = 0; u < kHA; ++u) {
+        const int w = w0 + u * kThreads;
+        const bool valid = w < total;
+        const int sc = valid ? div_small(w, per) : 0, r = valid ? w - sc * per : 0;
+        unsigned long long m = stems;
+        for (int k = 0; k < sc; ++k) m &= m - 1;          // the sc-th stem cell
+        const int c = stems ? __builtin_ctzll(m) : 0;
+        const int b = 1 + div_small(r, nA), p = r - (b - 1) * nA;
+        const int ii = i0 + c - b;
+        const int dmii = (valid && ii >= 0) ? (int)v.q.dmin[ii] : 0;
+        const bool ok = dmii > 0 && b >= dmii;              // 1(ii, i, .) is parsable (then the pair entries of (ii, d + b) exist)
+        ha_oa[u] = out.lda(d + b, ii, p, ok);
+        ha_x1[u] = in.ldc(ST_1, b, ii, pr_c1(p), ok);
+        ha_idx[u] = c * S + pr_t(p);
+      }
+    };
+    auto ha_add = [&]() {
+#pragma unroll
+      for (int u = 0; u < kHA; ++u) {
+        const double term = ha_oa[u] * ha_x1[u];
+        if (term != 0.) atomicAdd(&h2[ha_idx[u]], term);
+      }
+    };
+    if (total > 0) ha_load(tid);
     for (int w = tid; w < nwork; w += kThreads) {
       const int c = div_small(w, nA), p = w - c * nA;
       const int i = i0 + c, j = i + d;
@@ -1330,41 +1378,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         if (acc != 0.) atomicAdd(&h1[c * S + s1], acc);
       }
     }
-    // HA: the few stem cells of the workgroup, work item = (stem cell, parent row ii = i - b, pair) over ALL of them as one
-    // flat list, four work items' loads in flight per lane (a loop per stem cell was three to four dependent round trips for
-    // each of them).  (The rule-7 term of their P states is already in the table: k4_r7.)
-    unsigned long long stems = 0;             // bit c: cell c of the workgroup is a pair (cpb <= 64)
-    for (int c = 0; c < nc; ++c) stems |= v.q.pair_ok(i0 + c, d) ? (1ull << c) : 0ull;
-    if (stems && !(a.dbg & 1) && !(ELEMDP_KO & 1)) {
-      const int nb = W - d;                   // b = 1 .. nb: parent span d + b <= W
-      const int per = nb * nA, total = __popcll(stems) * per;
-      constexpr int kHA = 4;
-      for (int w0 = tid; w0 < total; w0 += kHA * kThreads) {
-        double oa[kHA], x1[kHA];
-        int hidx[kHA];
-#pragma unroll
-        for (int u = 0; u < kHA; ++u) {
-          const int w = w0 + u * kThreads;
-          const bool valid = w < total;
-          const int sc = valid ? div_small(w, per) : 0, r = valid ? w - sc * per : 0;
-          unsigned long long m = stems;
-          for (int k = 0; k < sc; ++k) m &= m - 1;          // the sc-th stem cell
-          const int c = __builtin_ctzll(m);
-          const int b = 1 + div_small(r, nA), p = r - (b - 1) * nA;
-          const int ii = i0 + c - b;
-          const int dmii = (valid && ii >= 0) ? (int)v.q.dmin[ii] : 0;
-          const bool ok = dmii > 0 && b >= dmii;              // 1(ii, i, .) is parsable (then the pair entries of (ii, d + b) exist)
-          oa[u] = out.lda(d + b, ii, p, ok);
-          x1[u] = in.ldc(ST_1, b, ii, pr_c1(p), ok);
-          hidx[u] = c * S + pr_t(p);
-        }
-#pragma unroll
-        for (int u = 0; u < kHA; ++u) {
-          const double term = oa[u] * x1[u];
-          if (term != 0.) atomicAdd(&h2[hidx[u]], term);
-        }
-      }
-    }
+    if (total > 0) ha_add();
+    for (int w0 = tid + kHA * kThreads; w0 < total; w0 += kHA * kThreads) { ha_load(w0); ha_add(); }
   }
   __syncthreads();
   pc.mark<6>();
@@ -1374,6 +1389,15 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   // their weights are staged into the (now free) operand staging area by all lanes with one round of loads; a work item
   // then needs a single round of table loads, selected by role without branches.
   {
+#if !ELEMDP_AHEAD_OUT
+    for (int vc = tid; vc <= nv; vc += kThreads) {
+      int p = 0;
+      for (int c = 0; c < vc; ++c) p += cnts[c];
+      pre[vc] = p;
+    }
+    __syncthreads();
+    const int n_rec = pre[nv];
+#endif
     // record area: LoopItem it[cap], double xw[2][cap], int meta[cap] (role << 16 | cell)
     const int cap = (kRecOut * 8) / 40;
     LoopItem* r_it = reinterpret_cast<LoopItem*>(sOB1);
