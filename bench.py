@@ -149,6 +149,30 @@ def minibatch_secondary(api, synth, device, n=2000, L=200, iters=40):
             "unit": "ms", "seq_per_s": 128 * iters / dt, "workload": "%d synthetic RNAs L=%d, pattern %s" % (n, L, PATTERN)}
 
 
+def count_gpus_sysfs(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs of this machine without touching HIP or torch: KFD topology nodes with SIMDs (CPU nodes have simd_count 0), limited
+    by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when set.  No KFD topology = no GPU driver = 0; None only when the directory
+    exists but cannot be read (the ranks check their own device again)."""
+    if not os.path.isdir(root):
+        return 0
+    try:
+        n = 0
+        for node in sorted(os.listdir(root)):
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(root, node, "properties")) if len(line.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        vis = os.environ.get(var)
+        if vis is not None:
+            n = min(n, len([t for t in vis.split(",") if t.strip() != ""]))
+    return n
+
+
 def launcher_command(n, argv, port=None):
     """the child that runs the N ranks of `bench.py --gpus N` (one process per GPU, RCCL): python -m torch.distributed.run"""
     if port is None:
@@ -172,10 +196,10 @@ def main():
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # launch the ranks as a CHILD before this process makes any GPU call (never re-exec a process that touched the GPU)
-        import torch
-        have = torch.cuda.device_count()       # (counting devices does not initialise the GPU)
-        if have < args.gpus:
+        # launch the ranks as a CHILD; this parent never touches torch or HIP (the GPUs are counted from the kernel driver's
+        # topology files; every rank checks its own device again)
+        have = count_gpus_sysfs()
+        if have is not None and have < args.gpus:
             raise SystemExit("bench.py --gpus %d: this machine has %d GPU(s); refusing to report a %d-GPU number" % (args.gpus, have, args.gpus))
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         raise SystemExit(subprocess.call(launcher_command(args.gpus, sys.argv[1:]), env=env))

@@ -22,6 +22,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -91,9 +92,8 @@ struct Rccl {
   static constexpr int kDouble = 8, kSum = 0;                 // ncclFloat64, ncclSum
   static Rccl& get() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-      tried = true;
+    static std::once_flag once;   // (engines are driven from two host threads when a batch is streamed)
+    std::call_once(once, [] {
       void* lib = nullptr;
       for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
         if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
@@ -104,7 +104,7 @@ struct Rccl {
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
       }
-    }
+    });
     return r;
   }
   bool ok() const { return GetUniqueId && CommInitRank && AllReduce && CommDestroy; }
@@ -220,6 +220,11 @@ class Engine {
   int n_seq() const { return n_seq_; }
   const std::vector<SeqPlan>& plans() const { return h_plans_; }
   void seq_stats(double* out, int n);
+  bool bpp_eff_known() const {
+    if (!streaming_) return true;
+    for (char c : st_have_eff_) if (!c) return false;
+    return true;
+  }
   void debug_tables(double* inside, double* outside, double* inside_o, double* outside_o, double* ENo, double* ENx, double* EH);
   void batch_pairs(int idx, uint8_t* kept, double* lnbpp, int cap);
   double last_ms[3] = {0, 0, 0};
@@ -285,6 +290,7 @@ class Engine {
   // to the inner handle, which then skips K1 and only rebuilds the plan.
   std::vector<std::vector<uint32_t>> st_mask_;
   std::vector<std::vector<double>> st_eff_;
+  std::vector<char> st_have_eff_;        // chunk k has been loaded at least once: its bpp_eff values are known
   const uint32_t* preset_bits_ = nullptr;   // (consumed by the next load_batch)
   const double* preset_eff_ = nullptr;
   size_t preset_words_ = 0;
@@ -1098,6 +1104,7 @@ void Engine::stream_setup(const uint8_t* seq, const int32_t* off, const uint8_t*
     const int nchunks = (n + st_chunk_ - 1) / st_chunk_;
     st_mask_.assign(nchunks, {});
     st_eff_.assign(nchunks, {});
+    st_have_eff_.assign(nchunks, 0);
   }
   // (the buffers of an earlier resident batch would only stand in the way of the inner engines)
   for (DevBuf* b : {&d_band_in_, &d_band_out_, &d_ext_in_, &d_ext_out_, &d_tmp_, &d_xwc_, &d_xwi_, &d_a_in_, &d_a_out_, &d_tr_band_, &d_tr_ext_})
@@ -1130,6 +1137,9 @@ void Engine::stream_load_chunk(int k, Engine& e) {
   if (cached) e.set_filter_preset(st_mask_[k].data(), st_mask_[k].size(), st_eff_[k].data());
   e.load_batch(st_seq_.data() + s0, off.data(), st_qual_.data() + q0, qoff.data(), st_fix_.empty() ? nullptr : st_fix_.data() + s0, c1 - c0);
   if (!cached && k < (int)st_mask_.size() && st_fix_.empty() && !(flags_ & ELEMDP_NO_RSS) && min_bpp_ > 0) e.filter_result(st_mask_[k], st_eff_[k]);
+  // the filter's result of the chunk, for elemdp_batch_bpp_eff (chunks write disjoint ranges)
+  for (int t = c0; t < c1; ++t) h_plans_[t].bpp_eff = e.h_plans_[t - c0].bpp_eff;
+  if (k < (int)st_have_eff_.size()) st_have_eff_[k] = 1;
 }
 
 // work(k, c0, c1, engine): chunk k = sequences [c0, c1) is resident on `engine`; the next chunk loads meanwhile
@@ -2005,6 +2015,7 @@ int elemdp_load_batch(elemdp_handle* h, const uint8_t* seq_codes, const int32_t*
 int elemdp_batch_bpp_eff(elemdp_handle* h, double* bpp_eff, int32_t n_seq) {
   ELEMDP_TRY
   if (!h || !bpp_eff || n_seq != h->e->n_seq()) throw elemdp::ArgError("elemdp_batch_bpp_eff: bad argument");
+  if (!h->e->bpp_eff_known()) throw elemdp::StateError("elemdp_batch_bpp_eff: the batch is streamed in chunks and not every chunk has been loaded yet (evaluate or scan first)");
   for (int k = 0; k < n_seq; ++k) bpp_eff[k] = h->e->plans()[k].bpp_eff;
   ELEMDP_CATCH
 }

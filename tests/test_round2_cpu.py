@@ -228,6 +228,23 @@ def test_bench_launcher_builds_the_torchrun_command_and_refuses_a_wrong_world():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout) and "{" not in r.stdout
+    # the parent counts GPUs from the KFD topology (no torch / HIP call): nodes with SIMDs, capped by the visibility variables
+    import tempfile
+    with tempfile.TemporaryDirectory() as root:
+        for k, simd in enumerate([0, 0, 256, 256, 256]):
+            os.makedirs(os.path.join(root, str(k)))
+            open(os.path.join(root, str(k), "properties"), "w").write("cpu_cores_count %d\nsimd_count %d\n" % (64 if not simd else 0, simd))
+        keep = {v: os.environ.pop(v, None) for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES")}
+        try:
+            assert bench.count_gpus_sysfs(root) == 3
+            os.environ["ROCR_VISIBLE_DEVICES"] = "0,2"
+            assert bench.count_gpus_sysfs(root) == 2
+        finally:
+            os.environ.pop("ROCR_VISIBLE_DEVICES", None)
+            for v, val in keep.items():
+                if val is not None:
+                    os.environ[v] = val
+    assert bench.count_gpus_sysfs(os.path.join(REPO, "no-such-dir")) == 0
     # --gpus N on a machine with fewer GPUs: refused before anything is launched
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)

@@ -354,11 +354,13 @@ def test_linear_bpp_filter_equals_the_log_space_filter_and_the_oracle():
     assert_log_close(ln, ln_o, rtol=1e-9, atol=1e-9, what="lnbpp, L = 1500")
 
 
-@pytest.mark.parametrize("W,C", [(20, 5), (50, 12), (100, 30), (255, 30), (33, 0)])
+@pytest.mark.parametrize("W,C", [(20, 5), (50, 12), (100, 30), (200, 30), (255, 30), (33, 0)])
 def test_bpp_filter_kernels_on_odd_shapes_against_the_oracle(W, C):
     """The filter kernels stage mask rows / bases / first-pair spans of a workgroup in LDS and take candidates four at a time:
-    band widths from 20 to 255 (the linear range), interior loops capped at 0 .. 30, lengths around the workgroup's 32 cells
-    and the band width, N bases, one batch -- kept sets and kept fractions exact, ln BPP to 1e-9 against the oracle."""
+    band widths from 20 to 200 (the linear range, kBppLinMaxSpan) and 255 (log-space filter), interior loops capped at 0 .. 30,
+    lengths around the workgroup's 32 cells and the band width, N bases, one batch -- kept sets and kept fractions exact, ln BPP
+    to 1e-9 against the oracle.  Wide bands also get a poly-GC hairpin that spans the whole band: the heaviest Boltzmann
+    weight a band of that width can hold (the linear filter must stay inside the double range up to its cut-off)."""
     rng = np.random.default_rng(1000 * W + C)
     lens = [1, 2, 6, 31, 32, 33, 64, 65, W - 1, W, W + 1, W + 34, 2 * W + 7, 180]
     seqs, quals = [], []
@@ -369,6 +371,10 @@ def test_bpp_filter_kernels_on_odd_shapes_against_the_oracle(W, C):
             s_[rng.integers(0, L, size=max(1, L // 15))] = 0          # N
         seqs.append(s_)
         quals.append(q_)
+    if W >= 100:
+        h = W // 2 - 2
+        seqs.append(np.array([3] * h + [1, 1, 1, 1] + [2] * h, dtype=np.uint8))      # G^h AAAA C^h
+        quals.append(np.zeros(2 * h + 5, dtype=np.uint8))
     eng = api.Engine("(.)", "~T2004~", W, C, 1e-4)
     eng.set_option("keep_lnbpp", 1)
     eng.load_batch(seqs, quals)
