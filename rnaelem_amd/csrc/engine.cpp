@@ -255,6 +255,7 @@ class Engine {
   void upload_automaton();
   bool opt_prune_ = true;   // transition lists pruned to the transitions of complete parses (Automaton::flatten)
   int opt_row_pad_ = 8;     // rows of the compact tables padded to a multiple of this many doubles (8 = 64-byte lines)
+  bool opt_det_ = false;    // deterministic reductions of the scaled-linear train evaluation (LinArgs::det): bit-identical repeats
   bool opt_fast_ = true;    // table-driven unary phases of the train kernels (lin_fast.h); 0 = the generic rule code
   bool opt_poison_ = false; // tests: the table slots are filled with NaN before every evaluation of the scaled-linear pipeline, so
                             // that a read of an entry nobody stored shows up in the results (the compact tables hold garbage there)
@@ -369,7 +370,7 @@ class Engine {
   int n_flagged_last_ = 0;
   DevBuf d_a_in_, d_a_out_;   // pair tables of the factorised rule 2 (lin_rules.h), per slot [W+1][Lmax+1][n_ap]
   DevBuf d_plans_sorted_;   // plan records in processing (h_order_) order
-  DevBuf d_ews_, d_xwc_, d_xwi_, d_lin_, d_lins_, d_zs_, d_flagged_;
+  DevBuf d_ews_, d_xwc_, d_xwi_, d_lin_, d_lins_, d_zs_, d_flagged_, d_det_;
   int lin_slots_ = 0;
   int opt_schedule_ = 1;   // 1 = linear (ari pass + one-state nasi pass), 0 = the reference's two full passes
   int opt_dbg_ = 0;        // timing experiments (LinArgs::dbg); results are wrong when set
@@ -536,6 +537,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "bpp_log") opt_bpp_log_ = v != 0;
   else if (key == "poison") opt_poison_ = v != 0;
   else if (key == "fast") opt_fast_ = v != 0;
+  else if (key == "deterministic") opt_det_ = v != 0;
   else if (key == "prune" || key == "row_pad") {
     if (key == "prune") opt_prune_ = v != 0;
     else opt_row_pad_ = std::max(1, (int)v);
@@ -1379,6 +1381,14 @@ void Engine::run_lin_batch() {
   const int gsz = prepare_lin(a, sched1);
   HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n_seq_, st_));
   HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
+  if (opt_det_) {   // deterministic mode: a row of counts per (sequence, block of cells), summed in block order by k4_combine
+    a.det = 1;
+    a.det_nslot = (Lmax_ + 1 + std::max(1, kThreads / a.lay.S) - 1) / std::max(1, kThreads / a.lay.S) + 1;
+    const size_t bytes = sizeof(double) * (size_t)n_seq_ * a.det_nslot * out_stride_;
+    d_det_.alloc(bytes);
+    HIP_OK(hipMemsetAsync(d_det_.as<void>(), 0, bytes, st_));
+    a.det_rows = d_det_.as<double>();
+  }
   HIP_OK(hipEventRecord(ev_[1], st_));
   lin_weights();
   poison_tables();

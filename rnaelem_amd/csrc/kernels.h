@@ -182,6 +182,9 @@ struct LinArgs {
   int32_t ext_ring;               // exterior-chain kernels keep the chain's last rows in an LDS ring (small groups only)
   int32_t n_lin;                  // doubles of the linear parameter block the band kernels stage (with or without the weight tables)
   int32_t fast;                   // train: table-driven unary phases (lin_fast.h); the host clears it where they do not apply
+  int32_t det;                    // train: deterministic reductions (one copy of every shared sum per wave, one row of counts per
+                                  // (sequence, block): det_rows[n][det_nslot][out_stride], summed in order by k4_combine)
+  double* det_rows; int32_t det_nslot;
 };
 struct LinWeightArgs {
   const LoopItem* items_inner; const LoopItem* items_left; const LoopItem* items_right;   // (may be null)

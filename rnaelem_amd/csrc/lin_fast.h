@@ -54,7 +54,8 @@ __device__ __forceinline__ int cell_in_flags(const ModelView& m, const SeqView& 
 // where they are used); stores them
 template <int kFR, int kFP, int kFL>
 __device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, const int32_t* P, const double* lin, const TableView& T,
-                                                  const double* cr, int fl, int d, int i, const double* pHB, const double* pHE) {
+                                                  const double* cr, int fl, int d, int i, const double* pHB, const double* pHE, int nrep,
+                                                  int rstride) {
   const int w0 = P[0], w1 = P[1], w2 = P[2];
   const bool isloop = w0 & 1, wr_pos = w0 & 8;
   const int kl = (w0 >> 2) & 1, nR = (w0 >> 8) & 15, nP = (w0 >> 12) & 15, nL = (w0 >> 16) & 15;
@@ -106,7 +107,8 @@ __device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, cons
       const double w = lin[A.lin_wl + 5 * ((eL[u] >> 16) & 0x7fff) + bi] * (eL[u] < 0 ? ews_i : 1.);
       sM = fma(tM[u], w, sM);
     }
-  const double HB = *pHB, HE = *pHE;
+  double HB = *pHB, HE = *pHE;
+  for (int r = 1; r < nrep; ++r) { HB += pHB[r * rstride]; HE += pHE[r * rstride]; }   // (deterministic mode: one copy per wave)
   const double vL = isloop ? (d == 0 ? ((w0 & 2) ? 1. : 0.) : sL) : 0.;   // motif_trainer.hpp:89-95
   const double vP = pok ? sP : 0.;                                          // rules 1a, 1b
   const double vB = lok ? HB : 0.;                                          // rule 2
@@ -163,7 +165,8 @@ __device__ __forceinline__ bool cell_out_mask(int fl, int k) {
 template <int kFR, int kFP, int kFL, class Sink>
 __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, const int32_t* P, const int32_t* G, const double* lin,
                                                      const TableView& in, const TableView& out, const double* cr, int fl, int d, int i,
-                                                     double invZ, bool lam_same, bool no_prf, Sink& sink, const double* ph, int CS) {
+                                                     double invZ, bool lam_same, bool no_prf, Sink& sink, const double* ph, int CS, int nrep,
+                                                     int rstride) {
   const int w0 = P[0], w1 = P[1], w2 = P[2], enl = P[3];
   const bool isloop = w0 & 1, wl_s = w0 & 16;
   const int kl = (w0 >> 2) & 1, nRR = (w0 >> 8) & 15, nRP = (w0 >> 12) & 15, nRL = (w0 >> 16) & 15;
@@ -274,7 +277,10 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
     }
   // 1 (heavy sum H1), B (child of M (5b) and of 1 (4b): its inside value is non-zero wherever a pair entry that takes it is),
   // 2 (child of 1 (4a), of 2(i,j+1,par) (3a); the rule-2 part reaches P as H2 = HA)
-  const double H1 = ph[0], H2 = ph[CS], HP = ph[2 * CS], HL = ph[3 * CS];
+  double H1 = ph[0], H2 = ph[CS], HP = ph[2 * CS], HL = ph[3 * CS];
+  for (int r = 1; r < nrep; ++r) {   // (deterministic mode: one copy per wave)
+    H1 += ph[r * rstride]; H2 += ph[r * rstride + CS]; HP += ph[r * rstride + 2 * CS]; HL += ph[r * rstride + 3 * CS];
+  }
   const double o1 = (in1 != 0.) ? H1 : 0.;
   const double oB = lok ? (mok ? oM : 0.) + o1 : 0.;
   const double o2 = (in2 != 0.) ? o1 + s2 : 0.;

@@ -58,6 +58,17 @@ namespace {
 // instructions, and the band kernels are bound by instruction issue.
 __device__ __forceinline__ int div_small(int q, int n) { return (int)(((float)q + 0.5f) * __frcp_rn((float)n)); }
 
+// Deterministic mode (LinArgs::det, option "deterministic"): every sum that lanes of DIFFERENT waves add to -- the heavy sums of
+// a workgroup, its expected counts -- gets one copy per wave (the adds of one wave reach LDS in program order, lanes of one
+// instruction in lane order), and the copies are added in wave order where they are read; a workgroup adds its counts to a
+// row of its own (sequence, block) instead of the sequence's row, and k4_combine sums those rows in block order.  Two
+// evaluations of the same batch are then bit-identical (the reference at --thread 1: motif_trainer.hpp:248-271).
+__device__ __forceinline__ double rep_sum(const double* p, int nrep, int stride) {
+  double a = p[0];
+  for (int r = 1; r < nrep; ++r) a += p[r * stride];
+  return a;
+}
+
 // statistics sink of the linear pipeline: emission counts into LDS, energy statistics lane-private
 struct LinSink {
   double* en_;
@@ -293,7 +304,7 @@ __host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int wi
 struct BlockCtx { int* dm; int* cnts; int* pre; int* base; };
 // accumulator / staging doubles of k4_out: four heavy sums per (cell, state), the statistics of the two worlds, the position
 // posteriors of the scan over the window of positions the workgroup touches (start + inner, or end), the item records
-__host__ __device__ inline int out_doubles(int CS, int nt, int win) { return 4 * CS + 2 * nt + 4 + 2 * win + kRecOut; }
+__host__ __device__ inline int out_doubles(int CS, int nt, int win, int nw = 1) { return nw * (4 * CS + 2 * nt + 4) + 2 * win + kRecOut; }
 // ints of the automaton blob a band kernel stages: everything (n_stage = n_ints) means the small part plus the run of
 // tuple lists of its direction (PART 0: inside, 1: outside); otherwise only the small part
 __host__ __device__ inline int staged_ints(const AutomatonLayout& L, int n_stage, int part) {
@@ -647,10 +658,13 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
   const int CS = cpb * S, ncS = nc * S;
+  const int NW = a.det ? kThreads / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the heavy sums (one per wave: rep_sum)
   double* hb = lds;
   double* he = hb + CS;
-  double* st1 = he + CS;                     // item records (kRecIn doubles)
-  const BlockLds BL = block_lds(2 * CS + kRecIn, cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, FAST ? kCellInD : 0);
+  double* hbA = hb + wvd * 2 * CS;           // ... the copy this lane adds to
+  double* heA = he + wvd * 2 * CS;
+  double* st1 = lds + NW * 2 * CS;           // item records (kRecIn doubles)
+  const BlockLds BL = block_lds(NW * 2 * CS + kRecIn, cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, FAST ? kCellInD : 0);
   // cell records of the table-driven unary phase: the exponentiated structural terms of the cells are fetched with the context
   // (lane = (cell, value); the addresses depend on the plan record only), the flags follow once the context is in LDS
   constexpr int kCRin = (ELEMDP_CPB_MAX * 8 + kThreads - 1) / kThreads;
@@ -667,7 +681,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   const int32_t* G = v.m.big;
   double* crec = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
   int* crfl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
-  for (int t = tid; t < 2 * CS; t += kThreads) lds[t] = 0.;
+  for (int t = tid; t < NW * 2 * CS; t += kThreads) lds[t] = 0.;
   __syncthreads();
   pc.mark<0>();
   if (FAST) {   // (read by the unary phase, behind the barriers of the heavy sums)
@@ -755,7 +769,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
           }
           v.in.a(d, i, p) = av;
         }
-        if (tg != 0xff && av != 0.) atomicAdd(&hb[c * S + tg], av);
+        if (tg != 0xff && av != 0.) atomicAdd(&hbA[c * S + tg], av);
         continue;
       }
       const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p], tgt = I[A.ap_tgt + p];
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
         }
         v.in.a(d, i, p) = av;
       }
-      if (tgt >= 0 && av != 0.) atomicAdd(&hb[c * S + tgt], av);
+      if (tgt >= 0 && av != 0.) atomicAdd(&hbA[c * S + tgt], av);
     }
   }
   __syncthreads();
@@ -838,7 +852,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
         // (the inner pair of an item is a kept pair, the loops L are stored everywhere)
         const uint32_t rP = v.in.cidx(ST_P, it.l - it.k, it.k, 0), rL1 = v.in.cidx(ST_L, it.k - i, i, 0), rL2 = v.in.cidx(ST_L, j - it.l, it.l, 0);
         const double xw0 = R.xw[xc], xw1 = R.xw[R.cap + xc];
-        double* hrow = he + c * S;
+        double* hrow = heA + c * S;
         for (int t0 = wv; t0 < nq; t0 += 4 * kTU) {
           int qa[kTU], qb[kTU];
           double x0[kTU], x1[kTU], x2[kTU];
@@ -867,10 +881,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     const int s = FAST ? G[A.f_live_in + tid - c * NL] : tid - c * NL;
     const int i = i0 + c;
     if (FAST) {
-      fast_inside_unary<kFastR, FP, kFastL>(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, hb + c * S + s, he + c * S + s);
+      fast_inside_unary<kFastR, FP, kFastL>(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, hb + c * S + s, he + c * S + s,
+                                            NW, 2 * CS);
     } else {
       const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
-      lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, hb[c * S + s], he[c * S + s], con);
+      lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, rep_sum(hb + c * S + s, NW, 2 * CS), rep_sum(he + c * S + s, NW, 2 * CS), con);
     }
   }
   pc.mark<4>();
@@ -1004,6 +1019,7 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   }
 }
 
+__host__ __device__ inline int ext_stat_doubles(int nt, int det) { return (det ? 2 : 1) * (2 * nt + 4); }
 struct LPass { double invZ; bool ari, nasi, skip; int en_off, eh_off; double invZs; bool merged; };
 // schedule 0 (reference): pass 0 = terminals (ari,nasi), pass 1 = the label's mask; schedule 1: ari only / nasi only
 __device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
@@ -1032,29 +1048,36 @@ __device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
   return pi;
 }
 
-__device__ __forceinline__ void lflush(const LinArgs& a, const LViews& v, const LPass& pi, LinSink& sink, double* l_en, double* l_eh,
-                                       int nthreads) {
-  // l_en: [worlds][n_theta], l_eh: [worlds][2]
+// l_en: [copies][2 worlds x n_theta | 2 worlds x 2] (one copy, or one per wave in the deterministic mode: rep_sum); `slot`:
+// the row of the sequence this workgroup adds to in the deterministic mode (LinArgs::det_rows)
+__device__ __forceinline__ void lflush(const LinArgs& a, const LViews& v, const LPass& pi, LinSink& sink, double* l_en, int nthreads, int slot) {
+  const int nt = a.lay.n_theta, ES = 2 * nt + 4;
+  const int NW = a.det ? nthreads / 64 : 1;
+  double* l_ehA = l_en + (a.det ? (threadIdx.x >> 6) * ES : 0) + 2 * nt;   // [worlds][2] of this lane's copy
   const int nw = pi.merged ? 2 : 1;
   const double e0 = wave_sum(sink.world == 0 ? sink.eh0 : 0.), e1 = wave_sum(sink.world == 0 ? sink.eh1 : 0.);
   if ((threadIdx.x & 63) == 0) {
-    if (e0 != 0.) atomicAdd(&l_eh[0], e0);
-    if (e1 != 0.) atomicAdd(&l_eh[1], e1);
+    if (e0 != 0.) atomicAdd(&l_ehA[0], e0);
+    if (e1 != 0.) atomicAdd(&l_ehA[1], e1);
   }
   if (pi.merged) {
     const double f0 = wave_sum(sink.world == 1 ? sink.eh0 : 0.), f1 = wave_sum(sink.world == 1 ? sink.eh1 : 0.);
     if ((threadIdx.x & 63) == 0) {
-      if (f0 != 0.) atomicAdd(&l_eh[2], f0);
-      if (f1 != 0.) atomicAdd(&l_eh[3], f1);
+      if (f0 != 0.) atomicAdd(&l_ehA[2], f0);
+      if (f1 != 0.) atomicAdd(&l_ehA[3], f1);
     }
   }
   __syncthreads();
-  const int nt = a.lay.n_theta;
-  for (int t = threadIdx.x; t < nw * nt; t += nthreads) {
-    const double val = l_en[t];
-    if (val != 0.) atomicAdd(&v.row[pi.en_off + t], val);          // (world 1 lands on the second set: en_off + n_theta + .)
+  double* drow = a.det ? a.det_rows + ((size_t)v.n * a.det_nslot + slot) * a.out_stride : nullptr;
+  for (int t = threadIdx.x; t < nw * nt + 2 * nw; t += nthreads) {
+    const bool is_en = t < nw * nt;
+    const int src = is_en ? t : 2 * nt + (t - nw * nt);                       // (world 1 lands on the second set: en_off + n_theta + .)
+    const int dst = is_en ? pi.en_off + t : pi.eh_off + (t - nw * nt);
+    const double val = rep_sum(l_en + src, NW, ES);
+    if (val == 0.) continue;
+    if (a.det) drow[dst] += val;      // (this workgroup's own row: launches of a stream are ordered)
+    else atomicAdd(&v.row[dst], val);
   }
-  if (threadIdx.x < 2 * nw && l_eh[threadIdx.x] != 0.) atomicAdd(&v.row[pi.eh_off + threadIdx.x], l_eh[threadIdx.x]);
 }
 
 // position-posterior accumulators of the scan passes (linear, global memory, batch offsets)
@@ -1103,14 +1126,14 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   make_lviews(a, blockIdx.x, v);
   const LPass pi = lpass(a, v);
   if (pi.skip) return;
-  const int n_ring = (STAGE && a.ext_ring) ? ext_ring_doubles(2 * a.lay.n_theta + 4, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
-  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), 2 * a.lay.n_theta + 4 + n_ring);
+  const int n_stat = ext_stat_doubles(a.lay.n_theta, a.det);   // (a copy per wave in the deterministic mode)
+  const int n_ring = (STAGE && a.ext_ring) ? ext_ring_doubles(n_stat, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
+  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), n_stat + n_ring);
   const int S = a.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
   TableView Or = v.out;     // the chain's rows through the LDS ring
-  if (n_ring > 0) { Or.ext = l_stat + 2 * nt + 4; Or.omask = (uint32_t)ext_ring_rows(a.wmax) - 1u; }
-  double* l_en = l_stat;
-  double* l_eh = l_stat + 2 * nt;
-  for (int t = tid; t < 2 * nt + 4; t += 128) l_stat[t] = 0.;
+  if (n_ring > 0) { Or.ext = l_stat + n_stat; Or.omask = (uint32_t)ext_ring_rows(a.wmax) - 1u; }
+  double* l_en = l_stat + (a.det ? (tid >> 6) * (2 * nt + 4) : 0);   // the copy this lane adds to
+  for (int t = tid; t < n_stat; t += 128) l_stat[t] = 0.;
   __shared__ double s_part[128];
   const int nparts = (S <= 128) ? 128 / S : 1;
   const int part = tid / S, ps = tid - part * S;
@@ -1146,7 +1169,7 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
     }
     __syncthreads();
   }
-  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, 128);
+  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_stat, 128, a.det_nslot - 1);
 }
 
 // ---- rule 7, outside direction: P(i,j,tgt) as a child of the exterior chain = sum over the split entries of tgt of
@@ -1200,16 +1223,22 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
   const int CS = cpb * S, ncS = nc * S;
-  double* h1 = lds;
+  const int NW = a.det ? kThreads / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the sums (one per wave: rep_sum)
+  const int HS = 4 * CS, ES = 2 * nt + 4;      // doubles of one copy of the heavy sums / of the statistics
+  double* h1 = lds;                            // copy 0 (the unary phase adds the copies up)
   double* h2 = h1 + CS;
   double* hp = h2 + CS;
   double* hl = hp + CS;
-  double* l_en = hl + CS;                      // [2 worlds][n_theta]
-  double* l_eh = l_en + 2 * nt;                // [2 worlds][2]
-  double* l_pos = l_eh + 4;                    // scan: [2][win] position posteriors of the window (start, inner | end, -)
+  double* h1A = h1 + wvd * HS;                 // the copy this lane adds to
+  double* h2A = h2 + wvd * HS;
+  double* hpA = hp + wvd * HS;
+  double* l_en0 = lds + NW * HS;               // statistics: [copies][2 worlds x n_theta | 2 worlds x 2]
+  double* l_en = l_en0 + wvd * ES;             // ... this lane's copy
+  double* l_eh = l_en + 2 * nt;
+  double* l_pos = l_en0 + NW * ES;             // scan: [2][win] position posteriors of the window (start, inner | end, -)
   const int win = cpb + a.wmax + 3;
   double* sOB1 = l_pos + 2 * win;              // item records of the three roles (kRecOut doubles)
-  const BlockLds BL = block_lds(out_doubles(CS, nt, cpb + a.wmax + 3), cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * cpb, FAST ? kCellOutD : 0);
+  const BlockLds BL = block_lds(out_doubles(CS, nt, cpb + a.wmax + 3, NW), cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * cpb, FAST ? kCellOutD : 0);
   // cell records of the table-driven unary phase (see k4_in): twelve global values per cell, fetched with the context
   constexpr int kCRout = (ELEMDP_CPB_MAX * 12 + kThreads - 1) / kThreads;
   double crx[kCRout];
@@ -1226,7 +1255,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   const int32_t* G = v.m.big;
   double* crec = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
   int* crfl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
-  const int n_zero = 4 * CS + 2 * nt + 4 + ((MODE == OUT_SCAN || MODE == OUT_END) ? 2 * win : 0);
+  const int n_zero = NW * (HS + ES) + ((MODE == OUT_SCAN || MODE == OUT_END) ? 2 * win : 0);
   for (int t = tid; t < n_zero; t += kThreads) lds[t] = 0.;
   __syncthreads();
   pc.mark<5>();
@@ -1343,7 +1372,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
 #pragma unroll
       for (int u = 0; u < kHA; ++u) {
         const double term = ha_oa[u] * ha_x1[u];
-        if (term != 0.) atomicAdd(&h2[ha_idx[u]], term);
+        if (term != 0.) atomicAdd(&h2A[ha_idx[u]], term);
       }
     };
     if (total > 0) ha_load(tid);
@@ -1375,7 +1404,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           if (sp3 >= 0) acc = fma(a3, b3 * c3, acc);
           if (sp3 < 0) break;
         }
-        if (acc != 0.) atomicAdd(&h1[c * S + s1], acc);
+        if (acc != 0.) atomicAdd(&h1A[c * S + s1], acc);
       }
     }
     if (total > 0) ha_add();
@@ -1445,7 +1474,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         const uint32_t r2 = role == 0 ? in.cidx(ST_L, it.j - j, j, 0) : role == 1 ? in.cidx(ST_L, it.j - it.l, it.l, 0) : in.cidx(ST_L, it.k - it.i, it.i, 0);
         const uint32_t rA = role == 0 ? in.cidx(ST_P, d, i, 0) : in.cidx(ST_L, d, i, 0);
         const double xw0 = r_xw[xc], xw1 = r_xw[cap + xc];
-        double* hrow = hp + (role == 0 ? 0 : CS) + c * S;   // hp, or hl = hp + CS
+        double* hrow = hpA + (role == 0 ? 0 : CS) + c * S;   // hp, or hl = hp + CS
         const int qc0 = (FAST ? A.fqc_out : A.qc_out1) + role * 2 * nq;
         for (int t0 = wv; t0 < nq; t0 += 4 * kTU) {
           int qa[kTU], qb[kTU];
@@ -1498,11 +1527,12 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     if (FAST) {
       h1[c * S + s] = fast_outside_unary<kFastR, FP, kFastL>(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c], d,
                                                              i0 + c, w1 ? pi.invZs : pi.invZ, v.m.lam_same != 0, v.m.no_prf != 0, sink,
-                                                             h1 + c * S + s, CS);
+                                                             h1 + c * S + s, CS, NW, HS);
     } else {
       LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
       HeavyOut H;
-      H.H1 = h1[c * S + s]; H.H2 = h2[c * S + s]; H.HP = hp[c * S + s]; H.HL = hl[c * S + s];
+      H.H1 = rep_sum(h1 + c * S + s, NW, HS); H.H2 = rep_sum(h2 + c * S + s, NW, HS);
+      H.HP = rep_sum(hp + c * S + s, NW, HS); H.HL = rep_sum(hl + c * S + s, NW, HS);
       if (!(a.dbg & 32)) H.HP += out.ld(ST_P, d, i0 + c, s, v.q.pair_ok(i0 + c, d));   // rule-7 term (k4_r7)
       H.ext_in_hp = true;
       h1[c * S + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
@@ -1576,7 +1606,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       }
     }
   }
-  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en, l_eh, kThreads);
+  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en0, kThreads, (int)bx);
   pc.mark<12>();
   pc.finish();
 }
@@ -1592,6 +1622,15 @@ __global__ __launch_bounds__(kThreads) void k4_combine(LinArgs a, int G) {
   if (row[4] != 0.) return;
   const double* zs = a.zs + (size_t)g * 4;
   const int nt = a.lay.n_theta;
+  if (a.det) {   // deterministic mode: the counts of the workgroups' own rows, in block order
+    const double* dr = a.det_rows + (size_t)n * a.det_nslot * a.out_stride;
+    for (int t = 6 + threadIdx.x; t < 6 + 2 * nt + 4; t += kThreads) {
+      double acc = 0.;
+      for (int k = 0; k < a.det_nslot; ++k) acc += dr[(size_t)k * a.out_stride + t];
+      row[t] = acc;
+    }
+    __syncthreads();
+  }
   const bool positive = a.plans[n].positive != 0;
   const double pa = zs[1] / zs[0], pn = zs[2] / zs[0];
   for (int t = threadIdx.x; t < nt + 2; t += kThreads) {
@@ -1869,7 +1908,7 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   a.wmax = Wmax;
   a.ext_ring = G <= 1024 ? 1 : 0;
   a.lmax = Lmax;
-  a.n_lin = kLinEth + nt; a.fast = 0;
+  a.n_lin = kLinEth + nt; a.fast = 0; a.det = 0;
   const size_t lds = block_lds(3 * a.cpb * S + 2 * kChunkIn * kThreads, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const long long products = (long long)a.cpb * a.lay.n_split;   // (cell, tuple) products of a workgroup
@@ -1901,7 +1940,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   a.schedule = 0;   // terminals (ari, nasi), Z = Z(ari,nasi): pass 0 of the reference schedule
   a.pass = 0;
   a.scan = 1;
-  a.n_lin = kLinEth + nt; a.fast = 0;
+  a.n_lin = kLinEth + nt; a.fast = 0; a.det = 0;
   const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const size_t lds_out = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
   const bool big = a.n_stage >= a.lay.n_ints;
@@ -1958,7 +1997,8 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   a.fast = fast ? 1 : 0;
   if (fast) a.cpb = std::min(kThreads / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);   // (states without any column take no lane)
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
-  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
+  const int NW = a.det ? kThreads / 64 : 1;
+  const size_t lds_in = block_lds(NW * 2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
   const size_t lds_stat = sizeof(double) * (2 * nt + 4);
   if (!a.no_rss)
     for (int d = 0; d <= Wmax; ++d) {
@@ -1979,13 +2019,14 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   // pattern's states, the "no motif" terminal on the shadow of (0,0), each with its own Z and statistics (lpass).
   // schedule 0: the reference's two sweeps, (ari, nasi) then the label's mask.
   const int n_pass = (a.schedule == 1 || first_pass_only) ? 1 : 2;
-  const size_t lds_b = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
+  const size_t lds_b = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3, NW), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
   if (getenv("ELEMDP_LDS_DEBUG")) fprintf(stderr, "lin group: G %d cpb %d fast %d n_lin %d staged ints in/out %d/%d lds k4_in %zu k4_out %zu\n", G, a.cpb, (int)fast, a.n_lin, staged_ints(a.lay, a.n_stage, 0), staged_ints(a.lay, a.n_stage, 1), lds_in, lds_b);
   for (int pass = 0; pass < n_pass; ++pass) {
     LinArgs b = a;
     b.pass = pass;
-    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(2 * nt + 4 + (b.ext_ring ? ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, b.nword_max, b.n_stage) : 0), kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
-    else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), lds_stat, st, b);
+    const int n_stat = ext_stat_doubles(nt, b.det);
+    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(n_stat + (b.ext_ring ? ext_ring_doubles(n_stat, Wmax, S, kLinEth + nt, Lmax, b.nword_max, b.n_stage) : 0), kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
+    else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), sizeof(double) * n_stat, st, b);
     if (!b.no_rss) {
       hipLaunchKernelGGL(k4_r7, dim3(((Lmax + 1) * (Wmax + 1) + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, b);
       for (int d = Wmax; d >= 0; --d) {
@@ -2000,7 +2041,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
       }
     }
   }
-  if ((a.schedule == 1 || a.lik_ratio) && !first_pass_only) hipLaunchKernelGGL(k4_combine, dim3(G), dim3(kThreads), 0, st, a, G);
+  if ((a.schedule == 1 || a.lik_ratio || a.det) && !first_pass_only) hipLaunchKernelGGL(k4_combine, dim3(G), dim3(kThreads), 0, st, a, G);
   return hipGetLastError();
 }
 

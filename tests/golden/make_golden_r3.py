@@ -8,6 +8,7 @@ Runs only where /root/reference exists (build container).  Fixtures are data: ou
   train_final.json   the binary without a sub-command (train, write the model to --out1, scan the training set to --out2:
                      main.cpp:47-84, what script/elem spawns) with --no-shuffle (L-BFGS-B): objective after every iteration as
                      printed, the parameters of the final model, and the scan records of the training set under that model
+  train_converged.json  the same runs to convergence (--max-iter 400): final objective, iterations, parameters, Ys / Ye per record
   dp_A2007.json      fn / gr of RNAelemTrainer::operator() with the Andronescu 2007 energy parameters (~A2007~)
 """
 import json
@@ -40,6 +41,25 @@ def main():
                     "records": [{k: r[k] for k in ("id", "Ys", "Ye", "exist_prob", "rss", "mot", "psihat")} for r in parse_scan(open(raw).read())]})
         print(fq, len(f), "iterations,", len(out[-1]["records"]), "records")
     dump("train_final.json", out)
+
+    # ---- the same runs to convergence (pgtol = --epsilon 1e-5): what an optimizer of another L-BFGS-B version has to reach
+    conv = []
+    for fq, pattern in (("positive_head6.fq", "(.....)"), ("positive.fq", "(.....)")):
+        m, raw = "/tmp/tc.model", "/tmp/tc.raw"
+        r = subprocess.run([BIN, "--fastq", os.path.join(G, fq), "--motif-pattern", pattern, "--out1", m, "--out2", raw, "--max-iter", "400",
+                            "--no-shuffle", "--batch-size", "-1", "-t", "8", "--lambda-init", "0", "--epsilon", "1e-5"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        txt = r.stdout + r.stderr
+        assert "lbfgsb converged" in txt
+        f = [float(x.group(2)) for x in re.finditer(r"^iter: (\d+) , f: ([-0-9.e+]+)", txt, re.M)]
+        recs = sorted(parse_scan(open(raw).read()), key=lambda q: q["id"])
+        conv.append({"fq": fq, "pattern": pattern, "epsilon": 1e-5, "lambda_init": 0, "rho_theta": 0.1, "rho_lambda": 0.1, "tau": 0.1,
+                     "n_iter": len(f) - 1, "final_f": float(re.search(r"final value: ([-0-9.e+]+)", txt).group(1)),
+                     "x": [float(v) for v in io.read_model(m)["x"]],
+                     "records": [{k: q[k] for k in ("id", "Ys", "Ye", "exist_prob")} for q in recs]})
+        print(fq, "converged after", conv[-1]["n_iter"], "iterations, f =", conv[-1]["final_f"])
+    dump("train_converged.json", conv)
 
 
 if __name__ == "__main__":

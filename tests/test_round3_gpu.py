@@ -58,3 +58,84 @@ def test_reference_host_on_the_library_reproduces_the_reference_lbfgsb_run(case,
         assert a["rss"][lo:hi] == b["rss"][lo:hi] and a["mot"][lo:hi] == b["mot"][lo:hi] and a["psihat"][lo:hi] == b["psihat"][lo:hi], a["id"]
         n_other += (a["rss"], a["mot"], a["psihat"]) != (b["rss"], b["mot"], b["psihat"])
     print("records whose parse differs away from the motif: %d of %d" % (n_other, len(recs)))
+
+
+def test_python_lbfgsb_loop_converges_where_the_reference_converges_on_config_a():
+    """The shipped host loop (rnaelem_amd/train.py: SciPy's L-BFGS-B 3.0) on config A to convergence, against the reference's
+    converged run (the embedded L-BFGS-B 2.1; tests/golden/train_converged.json): final regularised objective rel 1e-4,
+    parameters abs 1e-3, and the same Ys / Ye for every training record under the trained model."""
+    from rnaelem_amd import train
+    t = gload("train_converged.json")[1]
+    recs = io.read_fastq(gpath(t["fq"]))
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    eng = api.Engine(t["pattern"], "~T2004~", 50, 30, 1e-4, t["tau"])
+    eng.load_batch(seqs, quals)
+    x0 = eng.initial_params(t["lambda_init"])
+    r = train.train(eng.train_eval, x0, t["rho_theta"], t["rho_lambda"], max_iter=400, epsilon=t["epsilon"])
+    assert r["message"].startswith("CONVERGENCE"), r["message"]
+    assert r["f"] == pytest.approx(t["final_f"], rel=1e-4)
+    np.testing.assert_allclose(r["x"], t["x"], rtol=0, atol=1e-3)
+    got, _ = eng.scan(np.asarray(r["x"]))
+    ref = {rec["id"].strip(): rec for rec in t["records"]}
+    for (rid, _, _), a in zip(recs, got):
+        assert (a["Ys"], a["Ye"]) == (ref[rid.strip()]["Ys"], ref[rid.strip()]["Ye"]), rid
+
+
+def test_deterministic_mode_gives_bit_identical_evaluations():
+    """Option "deterministic" = 1: every sum that lanes of different waves share gets a copy per wave, added up in wave order;
+    the expected counts of a workgroup go to a row of its own (sequence, block), summed in block order (k4_combine); the sum
+    over sequences is a fixed tree (k_reduce).  Two evaluations of the same batch -- 10 000 x L=200, BASELINE config C, with
+    table slots reused in between -- are then bit-identical, as the reference's are at --thread 1 (motif_trainer.hpp:248-271);
+    the default mode (LDS / global fp64 atomics) agrees with it to 1e-11."""
+    eng = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+    seqs, quals = synth.synth_batch(10000, 200)
+    for k in range(0, 10000, 3):
+        quals[k][-1] = 5                       # a third of the records without the motif
+    eng.load_batch(seqs, quals)
+    x = eng.initial_params(1.0)
+    x[:-2] += np.linspace(-0.2, 0.2, len(x) - 2)
+    ref = eng.train_eval(x)
+    eng.set_option("deterministic", 1)
+    a = eng.train_eval(x)
+    eng.train_eval(x + 0.01)                   # (other values through the same table slots and count rows)
+    b = eng.train_eval(x)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    assert a[0] == pytest.approx(ref[0], rel=1e-11)
+    np.testing.assert_allclose(a[1], ref[1], rtol=1e-9, atol=1e-9)
+    ms_det = eng.last_timing()[1]
+    eng.set_option("deterministic", 0)
+    eng.train_eval(x)
+    print("deterministic mode: %.1f ms per evaluation against %.1f ms" % (ms_det, eng.last_timing()[1]))
+    # the generic kernels (option fast = 0) take the same switches
+    eng2 = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+    eng2.set_option("fast", 0)
+    eng2.set_option("deterministic", 1)
+    eng2.load_batch(seqs[:300], quals[:300])
+    c, d = eng2.train_eval(x), eng2.train_eval(x)
+    assert c[0] == d[0] and np.array_equal(c[1], d[1])
+
+
+def test_table_driven_train_kernels_equal_the_generic_ones():
+    """Option "fast" (default 1: per-state programs, pair records, weight tables, cell records -- lin_fast.h) against the generic
+    rule code (the one the CPU emulation pins to the oracle): fn, gr, kept fractions on a ragged batch, both schedules."""
+    seqs, quals = [], []
+    for L, n in ((40, 5), (200, 9), (97, 7), (130, 6)):
+        s_, q_ = synth.synth_batch(n, L, seed=700 + L)
+        seqs += s_
+        quals += q_
+    for k in range(0, len(quals), 2):
+        quals[k][-1] = 5
+    res = {}
+    for fast in (0, 1):
+        for sched in (0, 1):
+            eng = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+            eng.set_option("fast", fast)
+            eng.set_option("schedule", sched)
+            eng.load_batch(seqs, quals)
+            x = eng.initial_params(0.7)
+            x[:-2] += np.linspace(-0.3, 0.3, len(x) - 2)
+            res[(fast, sched)] = eng.train_eval(x)
+    for key, r in res.items():
+        assert r[0] == pytest.approx(res[(0, 0)][0], rel=1e-10), key
+        np.testing.assert_allclose(r[1], res[(0, 0)][1], rtol=1e-8, atol=1e-9, err_msg=str(key))
+        assert r[2] == res[(0, 0)][2] and r[3] == res[(0, 0)][3]
