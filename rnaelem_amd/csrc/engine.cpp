@@ -245,16 +245,23 @@ class Engine {
   void run_train_batch();
   void run_lin_batch();
   int prepare_lin(LinArgs& a, bool sched1, bool dense_too = false);
-  void lin_weights();
   int balanced_group(size_t per_slot_bytes);
   int group_cap_ = 8192;   // most sequences swept in lockstep (a first scan uses fewer: fresh table memory costs ~20 ms / GB)
   TrArgs log_pipeline_args();
   void init_device();
   void flatten_automaton();
   void poison_tables();
+  void lin_weights(int first = 0, int count = 0);
   void upload_automaton();
   bool opt_prune_ = true;   // transition lists pruned to the transitions of complete parses (Automaton::flatten)
   int opt_row_pad_ = 8;     // rows of the compact tables padded to a multiple of this many doubles (8 = 64-byte lines)
+  // a train evaluation covers the records [eval_first, eval_first + eval_count) of the resident batch only (count 0: all): the
+  // mini-batch trainer loads the records + negatives of several coming evaluations as ONE batch -- the filter and the plan do not
+  // depend on x, and a load of 128 sequences costs as much as one of 1024 (launch-bound) -- and evaluates them range by range
+  int opt_eval_first_ = 0, opt_eval_count_ = 0;
+  std::vector<int32_t> h_order_r_;
+  DevBuf d_order_r_, d_plans_sorted_r_;
+  int range_key_[2] = {-1, -1};
   bool opt_det_ = false;    // deterministic reductions of the scaled-linear train evaluation (LinArgs::det): bit-identical repeats
   bool opt_fast_ = true;    // table-driven unary phases of the train kernels (lin_fast.h); 0 = the generic rule code
   bool opt_poison_ = false; // tests: the table slots are filled with NaN before every evaluation of the scaled-linear pipeline, so
@@ -538,6 +545,8 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "poison") opt_poison_ = v != 0;
   else if (key == "fast") opt_fast_ = v != 0;
   else if (key == "deterministic") opt_det_ = v != 0;
+  else if (key == "eval_first") opt_eval_first_ = (int)v;
+  else if (key == "eval_count") opt_eval_count_ = (int)v;
   else if (key == "prune" || key == "row_pad") {
     if (key == "prune") opt_prune_ = v != 0;
     else opt_row_pad_ = std::max(1, (int)v);
@@ -1055,6 +1064,8 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   HIP_OK(hipStreamSynchronize(st_));
   dbg_lap("load: weights / output buffers");
   n_seq_ = n;   // committed: everything above succeeded
+  opt_eval_first_ = opt_eval_count_ = 0;   // (an evaluation range belongs to the batch it was set for)
+  range_key_[0] = range_key_[1] = -1;
 }
 
 // ---- streaming --------------------------------------------------------------------------------------------------------
@@ -1291,13 +1302,19 @@ void Engine::poison_tables() {
     if (b->bytes()) HIP_OK(hipMemsetAsync(b->as<void>(), 0xff, b->bytes(), st_));   // (all-ones bytes: NaN)
 }
 
-void Engine::lin_weights() {
+void Engine::lin_weights(int first, int count) {
   LinWeightArgs w;
   const PlanArrays pa = plan_.arrays();
   w.e_stack = pa.e_stack; w.e_ext = pa.e_ext; w.e_ml = pa.e_ml; w.e_close = pa.e_close; w.e_hp = pa.e_hp;
   w.items = pa.items;
   w.items_inner = pa.items_inner; w.items_left = pa.items_left; w.items_right = pa.items_right;
   w.n_cells = (size_t)n_cells_total_; w.n_items = (size_t)plan_.n_items;
+  if (count > 0 && count < n_seq_) {   // (records are planned in batch order: the cells of a range of records are contiguous)
+    const SeqPlan& p0 = h_plans_[first];
+    const SeqPlan& p1 = h_plans_[first + count - 1];
+    w.cell_first = (size_t)p0.cell_base;
+    w.cell_count = (size_t)(p1.cell_base + (int64_t)(p1.L + 1) * (p1.W + 1) - p0.cell_base);
+  }
   w.params = d_params_.as<double>();
   w.xwc = d_xwc_.as<double>(); w.xwi = nullptr;   // (item weights: computed where the records are staged)
   HIP_OK(launch_lin_weights(w, st_));
@@ -1378,8 +1395,33 @@ int Engine::prepare_lin(LinArgs& a, bool sched1, bool dense_too) {
 void Engine::run_lin_batch() {
   const bool sched1 = opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_ && lay_.s00 == 0 && lays_.shadow >= 0;
   LinArgs a;
-  const int gsz = prepare_lin(a, sched1);
-  HIP_OK(hipMemsetAsync(d_seq_out_.as<void>(), 0, sizeof(double) * (size_t)out_stride_ * n_seq_, st_));
+  int gsz = prepare_lin(a, sched1);
+  // the records this evaluation covers (options eval_first / eval_count), in processing order (longest first)
+  const bool ranged = opt_eval_count_ > 0 && !(opt_eval_first_ == 0 && opt_eval_count_ == n_seq_);
+  const int r0 = ranged ? opt_eval_first_ : 0, n_ev = ranged ? opt_eval_count_ : n_seq_;
+  if (r0 < 0 || n_ev <= 0 || r0 + n_ev > n_seq_) throw ArgError("eval_first / eval_count outside the resident batch");
+  const int32_t* h_ord = h_order_.data();
+  const int32_t* d_ord = d_order_.as<int32_t>();
+  const SeqPlan* d_sorted = d_plans_sorted_.as<SeqPlan>();
+  if (ranged) {
+    if (range_key_[0] != r0 || range_key_[1] != n_ev || (int)h_order_r_.size() != n_ev) {
+      h_order_r_.clear();
+      for (int idx : h_order_) if (idx >= r0 && idx < r0 + n_ev) h_order_r_.push_back(idx);
+      std::vector<SeqPlan> sorted(n_ev);
+      for (int k = 0; k < n_ev; ++k) { sorted[k] = h_plans_[h_order_r_[k]]; sorted[k].index = h_order_r_[k]; }
+      HIP_OK(hipStreamSynchronize(st_));   // (the previous evaluation may still read the arrays)
+      d_order_r_.upload(h_order_r_, st_);
+      d_plans_sorted_r_.upload(sorted, st_);
+      HIP_OK(hipStreamSynchronize(st_));   // (`sorted` is a local)
+      range_key_[0] = r0; range_key_[1] = n_ev;
+    }
+    h_ord = h_order_r_.data();
+    d_ord = d_order_r_.as<int32_t>();
+    d_sorted = d_plans_sorted_r_.as<SeqPlan>();
+    const int n_groups = (n_ev + n_slots_ - 1) / n_slots_;
+    gsz = (n_ev + n_groups - 1) / n_groups;
+  }
+  HIP_OK(hipMemsetAsync(d_seq_out_.as<double>() + (size_t)r0 * out_stride_, 0, sizeof(double) * (size_t)out_stride_ * n_ev, st_));
   HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
   if (opt_det_) {   // deterministic mode: a row of counts per (sequence, block of cells), summed in block order by k4_combine
     a.det = 1;
@@ -1390,16 +1432,16 @@ void Engine::run_lin_batch() {
     a.det_rows = d_det_.as<double>();
   }
   HIP_OK(hipEventRecord(ev_[1], st_));
-  lin_weights();
+  lin_weights(r0, n_ev);
   poison_tables();
   // Two groups at a time, each on its own stream and its own half of the table slots: the serial parts of a
   // group (exterior chains, launch tails) run under the band kernels of the other.  (Not for a handful of sequences,
   // whose tables debug_tables reads, nor under the phase profile.)
-  const int ns = (opt_group_streams_ >= 2 && n_seq_ >= 64 && n_slots_ >= 64 && !opt_profile_) ? std::min(opt_group_streams_, kMaxGroupStreams) : 1;
+  const int ns = (opt_group_streams_ >= 2 && n_ev >= 64 && n_slots_ >= 64 && !opt_profile_) ? std::min(opt_group_streams_, kMaxGroupStreams) : 1;
   const int slots_each = n_slots_ / ns;
-  int n_groups = (n_seq_ + slots_each - 1) / slots_each;
+  int n_groups = (n_ev + slots_each - 1) / slots_each;
   if (ns > 1) n_groups = ((n_groups + ns - 1) / ns) * ns;      // (every stream the same number of groups)
-  const int gsz2 = (ns == 1) ? gsz : (n_seq_ + n_groups - 1) / n_groups;
+  const int gsz2 = (ns == 1) ? gsz : (n_ev + n_groups - 1) / n_groups;
   auto shifted = [&](LinArgs x, size_t k) {   // the arguments of a group that uses the slots from k on
     x.band_in += k * x.band_stride; x.band_out += k * x.band_stride;
     x.ext_in += k * x.ext_stride; x.ext_out += k * x.ext_stride;
@@ -1413,13 +1455,13 @@ void Engine::run_lin_batch() {
     for (int k = 1; k < ns; ++k) HIP_OK(hipStreamWaitEvent(gs_[k], gstart_, 0));
   }
   int gi = 0;
-  for (int g0 = 0; g0 < n_seq_; g0 += gsz2, ++gi) {
-    const int G = std::min(gsz2, n_seq_ - g0);
+  for (int g0 = 0; g0 < n_ev; g0 += gsz2, ++gi) {
+    const int G = std::min(gsz2, n_ev - g0);
     const int k = gi % ns;
     LinArgs ak = shifted(a, (size_t)k * slots_each);
-    ak.grp = d_order_.as<int32_t>() + g0;
-    ak.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
-    const int Lg = h_plans_[h_order_[g0]].L;
+    ak.grp = d_ord + g0;
+    ak.plans_slot = d_sorted + g0;
+    const int Lg = h_plans_[h_ord[g0]].L;
     HIP_OK(launch_lin_group(ak, G, Lg, std::min(Lg, max_span_), opt_first_pass_only_, gs_[k]));
   }
   for (int k = 1; k < ns; ++k) {   // ... and the main stream continues behind them
@@ -1448,7 +1490,7 @@ void Engine::run_lin_batch() {
     }
   }
   HIP_OK(hipEventRecord(ev_[2], st_));
-  HIP_OK(launch_reduce(d_seq_out_.as<double>(), out_stride_, n_seq_, au_.n_theta(), d_partial_.as<double>(), st_));
+  HIP_OK(launch_reduce(d_seq_out_.as<double>() + (size_t)r0 * out_stride_, out_stride_, n_ev, au_.n_theta(), d_partial_.as<double>(), st_));
 }
 
 void Engine::run_train(bool) {

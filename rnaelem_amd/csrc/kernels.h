@@ -190,7 +190,8 @@ struct LinWeightArgs {
   const LoopItem* items_inner; const LoopItem* items_left; const LoopItem* items_right;   // (may be null)
   const double* e_stack; const double* e_ext; const double* e_ml; const double* e_close; const double* e_hp;
   const LoopItem* items;
-  size_t n_cells, n_items;
+  size_t n_cells, n_items;       // cells of the batch (= stride of the planes of xwc), items
+  size_t cell_first = 0, cell_count = 0;   // cells to compute (count 0: all) -- an evaluation of a range of the batch
   const double* params;
   double* xwc; double* xwi;
 };

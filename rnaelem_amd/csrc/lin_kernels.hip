@@ -221,7 +221,8 @@ __global__ __launch_bounds__(kThreads) void k4_weights(LinWeightArgs a) {
   const ParamBlock* pb = reinterpret_cast<const ParamBlock*>(a.params);
   const double l0 = pb->lambda[0], l1 = pb->lambda[1];
   const size_t stride = (size_t)gridDim.x * kThreads;
-  for (size_t c = (size_t)blockIdx.x * kThreads + threadIdx.x; c < a.n_cells; c += stride) {
+  const size_t c_lo = a.cell_first, c_hi = a.cell_count ? a.cell_first + a.cell_count : a.n_cells;
+  for (size_t c = c_lo + (size_t)blockIdx.x * kThreads + threadIdx.x; c < c_hi; c += stride) {
     const double e0 = a.e_stack[c], e1 = a.e_ext[c], e2 = a.e_ml[c], e3 = a.e_close[c], e4 = a.e_hp[c];
     a.xwc[0 * a.n_cells + c] = lin_weight(l0, e0); a.xwc[5 * a.n_cells + c] = lin_weight(l1, e0);
     a.xwc[1 * a.n_cells + c] = lin_weight(l0, e1); a.xwc[6 * a.n_cells + c] = lin_weight(l1, e1);
@@ -1891,7 +1892,8 @@ __global__ __launch_bounds__(64) void k5_cyk_ext(LinArgs a) {
 }  // namespace
 
 hipError_t launch_lin_weights(const LinWeightArgs& a, hipStream_t st) {
-  const size_t work = a.n_cells > a.n_items ? a.n_cells : a.n_items;
+  const size_t cells = a.cell_count ? a.cell_count : a.n_cells;
+  const size_t work = (a.xwi && a.n_items > cells) ? a.n_items : cells;
   if (work == 0) return hipSuccess;
   size_t blocks = (work + kThreads - 1) / kThreads;
   if (blocks > 65536) blocks = 65536;

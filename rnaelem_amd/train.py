@@ -144,7 +144,7 @@ class MiniBatches:
     one evaluation of records + negatives together; `engines`: two api.Engine objects for the same (double-buffered:
     the next batch loads on one while the other evaluates; then the callables are unused)."""
 
-    def __init__(self, seqs, quals, batch, evaluate_batch, kmer_shuf=None, pairs=None, evaluate_joint=None, engines=None):
+    def __init__(self, seqs, quals, batch, evaluate_batch, kmer_shuf=None, pairs=None, evaluate_joint=None, engines=None, lookahead=8):
         from .api import epoch_permutation, kmer_shuffle
         self._perm, self._shuffle = epoch_permutation, kmer_shuffle
         self.seqs, self.quals, self.batch = seqs, quals, batch if batch > 0 else len(seqs)
@@ -152,8 +152,13 @@ class MiniBatches:
         self.order, self.pos, self.n_shuffles, self.count = list(range(len(seqs))), 0, 0, 0
         # `engines` = two api.Engine objects: the batch of the NEXT evaluation (records + negatives: neither depends on x) is
         # loaded on one of them by a thread while the other evaluates the current one
+        # `lookahead`: the batches of that many coming evaluations are loaded as ONE batch (neither the reader's order nor the
+        # negatives depend on x; a load of 128 sequences is bound by launch latencies and costs about as much as one of 1024) and
+        # evaluated range by range (engine options eval_first / eval_count)
         self.engines = list(engines) if engines else None
+        self.lookahead = max(1, int(lookahead))
         self._pending = None
+        self._current = None
 
     def _next_batch(self):
         """advances the reader: (records, qualities, evaluation count) of the next evaluation"""
@@ -184,10 +189,15 @@ class MiniBatches:
 
         def work():
             try:
-                s1, q1, c = self._next_batch()
-                sa, qa = self._with_negatives(s1, q1, c) if self.k is not None else (s1, q1)
-                box.update(s1=s1, q1=q1, c=c)
-                eng.load_batch(sa, qa)
+                parts, sa_all, qa_all = [], [], []
+                for _ in range(self.lookahead):
+                    s1, q1, c = self._next_batch()
+                    sa, qa = self._with_negatives(s1, q1, c) if self.k is not None else (s1, q1)
+                    parts.append(dict(s1=s1, q1=q1, c=c, first=len(sa_all), count=len(sa)))
+                    sa_all += sa
+                    qa_all += qa
+                box.update(parts=parts, sa_all=sa_all, qa_all=qa_all)
+                eng.load_batch(sa_all, qa_all)
             except Exception as e:      # re-raised by the evaluation that needs the batch
                 box["error"] = e
 
@@ -202,31 +212,40 @@ class MiniBatches:
             self._pending = None
 
     def _call_prefetched(self, x):
-        if self._pending is None:
-            self._pending = self._prefetch(0)
-        cur = self._pending
-        cur["thread"].join()
-        if "error" in cur["box"]:
-            raise cur["box"]["error"]
-        cur.update(cur["box"])
-        self._pending = self._prefetch(1 - cur["slot"])       # the next batch loads while this one is evaluated
-        eng, n_rec = self.engines[cur["slot"]], len(cur["s1"])
+        if self._current is None or not self._current["parts"]:
+            if self._pending is None:
+                self._pending = self._prefetch(0)
+            cur = self._pending
+            cur["thread"].join()
+            if "error" in cur["box"]:
+                raise cur["box"]["error"]
+            cur.update(cur["box"])
+            self._current = cur
+            self._pending = self._prefetch(1 - cur["slot"])   # the next batches load while these are evaluated
+        cur = self._current
+        part = cur["parts"].pop(0)
+        eng, n_rec, first, count = self.engines[cur["slot"]], len(part["s1"]), part["first"], part["count"]
+        eng.set_option("eval_first", first)
+        eng.set_option("eval_count", count)
         fn, gr, eff, nsk = eng.train_eval(x)
-        skipped = eng.seq_stats()[:, 4] != 0
+        skipped = eng.seq_stats()[first:first + count, 4] != 0
         if self.k is None:
             return fn, gr, eff, nsk
         if not np.any(skipped[:n_rec]):
-            return fn, gr, float(eng.bpp_eff()[:n_rec].sum()), nsk
-        # a record was skipped: its negative must be left out -- the two-step evaluation on the same engine
+            return fn, gr, float(eng.bpp_eff()[first:first + n_rec].sum()), nsk
+        # a record was skipped: its negative must be left out -- the two-step evaluation on the same engine, whose resident
+        # batches are put back afterwards (rare: a partition function outside the double range)
         self._pending["thread"].join()       # (the shuffles below and the prefetch thread's share one rand())
-        eng.load_batch(cur["s1"], cur["q1"])
+        eng.load_batch(part["s1"], part["q1"])
         fn, gr, eff, nsk = eng.train_eval(x)
         sk = eng.seq_stats()[:, 4] != 0
-        negs = [self._shuffle(s, self.k, cur["c"]) for s, dead in zip(cur["s1"], sk) if not dead]
+        negs = [self._shuffle(s, self.k, part["c"]) for s, dead in zip(part["s1"], sk) if not dead]
         if negs:
             eng.load_batch(negs, [np.r_[np.zeros(len(s), dtype=np.uint8), np.uint8(1)] for s in negs])
             fn2, gr2, _, nsk2 = eng.train_eval(x)
             fn, gr, nsk = fn + fn2, np.asarray(gr) + np.asarray(gr2), nsk + nsk2
+        if cur["parts"]:
+            eng.load_batch(cur["sa_all"], cur["qa_all"])
         return fn, gr, eff, nsk
 
     def __call__(self, x):
