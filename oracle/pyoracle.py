@@ -252,16 +252,27 @@ def read_model(path):
     out = dict(pattern=d["pattern"], max_span=int(d["max-span"]), max_iloop=int(d["max-internal-loop"]),
                tau=float(d["tau"]), min_bpp=float(d["min-bpp"]), lam=json.loads(d["lambda"]),
                softmax=bool(int(d.get("theta-softmax", "0"))), no_rss=bool(int(d.get("no-rss", "0"))),
-               no_prf=bool(int(d.get("no-profile", "0"))), no_ene=bool(int(d.get("no-energy", "0"))))
+               no_prf=bool(int(d.get("no-profile", "0"))), no_ene=bool(int(d.get("no-energy", "0"))),
+               ene_param=d.get("ene-param", "~T2004~"))
     out["w"] = json.loads(d["s"] if "s" in d else d["theta"])
     return out
+
+
+def energy_param_text(name):
+    """parameter text of `ene-param` (energy_model.hpp:150-160): the two built-in sets, or a parameter file"""
+    if name == "~T2004~":
+        return open(DEFAULT_PAR).read()
+    if name == "~A2007~":
+        return open(os.path.join(REPO, "rnaelem_amd", "data", "andronescu2007.elempar")).read()
+    return open(name).read()
 
 
 def oracle_from_model(path, extra_flags=0):
     md = read_model(path)
     flags = (NO_RSS if md["no_rss"] else 0) | (NO_PRF if md["no_prf"] else 0) | (NO_ENE if md["no_ene"] else 0) | \
         (THETA_SOFTMAX if md["softmax"] else 0) | extra_flags
-    o = make_oracle(md["pattern"], md["max_span"], md["max_iloop"], min_bpp=md["min_bpp"], tau=md["tau"], flags=flags)
+    o = make_oracle(md["pattern"], md["max_span"], md["max_iloop"], min_bpp=md["min_bpp"], tau=md["tau"], flags=flags,
+                    par_text=energy_param_text(md["ene_param"]))
     x = np.array([v for row in md["w"] for v in row] + list(md["lam"]), dtype=np.float64)
     o.set_params(x)
     return o, x

@@ -61,6 +61,16 @@ def main():
         print(fq, "converged after", conv[-1]["n_iter"], "iterations, f =", conv[-1]["final_f"])
     dump("train_converged.json", conv)
 
+    # ---- fn / gr per sequence under the Andronescu 2007 parameters (energy_model.hpp:155-160): a model our writer wrote
+    # (syn_b.model with ene-param ~A2007~), evaluated by the reference's RNAelemTrainer::operator() (ref_dump dp)
+    m = io.read_model(os.path.join(G, "syn_b.model"))
+    m["ene_param"] = "~A2007~"
+    io.write_model(os.path.join(G, "syn_a2007.model"), m)
+    r = jload(run([os.path.join(RB, "ref_dump"), "dp", os.path.join(G, "syn_L100_n3.fq"), os.path.join(G, "syn_a2007.model"), "full=0"]))
+    keys = ("id", "L", "W", "positive", "bpp_eff", "Zo", "Zari", "Znasi", "f", "ENo", "EHo", "ENx", "EHx")
+    dump("dp_A2007.json", [{"model": "syn_a2007.model", "fq": "syn_L100_n3.fq", "S": r["S"], "M": r["M"],
+                            "seqs": [{k: q[k] for k in keys if k in q} for q in r["seqs"]]}])
+
 
 if __name__ == "__main__":
     main()

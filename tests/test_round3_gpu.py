@@ -139,3 +139,81 @@ def test_table_driven_train_kernels_equal_the_generic_ones():
         assert r[0] == pytest.approx(res[(0, 0)][0], rel=1e-10), key
         np.testing.assert_allclose(r[1], res[(0, 0)][1], rtol=1e-8, atol=1e-9, err_msg=str(key))
         assert r[2] == res[(0, 0)][2] and r[3] == res[(0, 0)][3]
+
+
+def test_in_library_collective_with_two_ranks(tmp_path):
+    """elemdp_comm_init(rank, 2, id) + elemdp_train_eval on two GPUs, one process each (tests/two_rank_worker.py): the batch is
+    sharded by assigned_range, every rank's evaluation all-reduces the partial vector (ncclAllReduce on the engine's stream,
+    librccl dlopen'ed) and both return the numbers of the single-engine evaluation of the whole batch.  Skipped on a box with
+    one GPU; exists so that the first multi-GPU lease exercises the in-library RCCL path beyond a world of one."""
+    import json
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    m = io.read_model(gpath("syn_b.model"))
+    recs = io.read_fastq(gpath("syn_L150_n8.fq"))
+    eng = io.engine_from_model(m, device=0)
+    eng.load_batch([s for _, s, _ in recs], [q for _, _, q in recs])
+    ref = eng.train_eval(m["x"])
+    del eng
+    uid_file = str(tmp_path / "uid.bin")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "two_rank_worker.py"), str(r), "2", uid_file, str(tmp_path / ("out%d.json" % r))],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for r in range(2):
+        got = json.load(open(str(tmp_path / ("out%d.json" % r))))
+        assert got["fn"] == pytest.approx(ref[0], rel=1e-10) and got["eff"] == pytest.approx(ref[2], rel=1e-12) and got["nsk"] == ref[3]
+        np.testing.assert_allclose(got["gr"], ref[1], rtol=1e-9, atol=1e-10)
+
+
+def test_andronescu_2007_parameters_on_the_gpu_against_the_reference():
+    """~A2007~ (energy_model.hpp:155-160) through the whole hot path -- BPP filter, plan, train evaluation -- against
+    RNAelemTrainer::operator() of the compiled reference, sequence by sequence (tests/golden/dp_A2007.json)."""
+    from tests.util import assert_log_close
+    case = gload("dp_A2007.json")[0]
+    m = io.read_model(gpath(case["model"]))
+    assert m["ene_param"] == "~A2007~"
+    recs = io.read_fastq(gpath(case["fq"]))
+    eng = io.engine_from_model(m)
+    for (rid, seq, qual), r in zip(recs, case["seqs"]):
+        eng.load_batch([seq], [qual])
+        fn, gr, eff, nsk = eng.train_eval(m["x"])
+        st = eng.seq_stats()[0]
+        for k, name in enumerate(("Zo", "Zari", "Znasi")):
+            assert_log_close(st[k], r[name], rtol=1e-10, what=name)
+        assert fn == pytest.approx(r["f"], rel=1e-9, abs=1e-10) and eff == pytest.approx(r["bpp_eff"], rel=1e-12)
+        g_ref = np.r_[np.array([v for row in r["ENo"] for v in row]) - np.array([v for row in r["ENx"] for v in row]),
+                      np.array(r["EHo"]) - np.array(r["EHx"])]
+        np.testing.assert_allclose(gr, g_ref, rtol=1e-7, atol=1e-8)
+
+
+def test_mask_trainer_with_adam_on_the_gpu_reproduces_the_reference_trace():
+    """--param-set with the default optimizer (Adam, shuffled negatives; motif_mask_trainer.hpp:66-108) with the GPU as the
+    evaluator: the objective trace and the final parameters of `RNAelem train --param-set` (train_trace_mask.json), the
+    parameters outside the set untouched."""
+    from rnaelem_amd import cli, train
+    t = [c for c in gload("train_trace_mask.json") if not c["no_shuffle"]][0]
+    recs = io.read_fastq(gpath(t["fq"]))
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    pos = api.Engine(t["pattern"], "~T2004~", 50, 30, 1e-4, 0.1)
+    neg = api.Engine(t["pattern"], "~T2004~", 50, 30, 1e-4, 0.1)
+    pos.load_batch(seqs, quals)
+
+    def ev_batch(s2, q2, x):
+        neg.load_batch(s2, q2)
+        return neg.train_eval(x)
+
+    vary = cli.parse_param_set(t["param_set"])
+    x0 = pos.initial_params(t["lambda_init"])
+    ev = train.ShuffledNegatives(seqs, pos.train_eval, lambda: pos.seq_stats()[:, 4] != 0, ev_batch, k=2)
+    r = train.train(ev, x0, 0.1, 0.1, max_iter=t["max_iter"], optimizer="adam", vary=vary)
+    fn = [row[4] for row in r["trace"]]
+    assert len(fn) == len(t["trace"])
+    for a, b in zip(fn, t["trace"]):
+        assert a == pytest.approx(b, rel=2e-5), (fn, t["trace"])
+    np.testing.assert_allclose(r["x"], t["final_x"], rtol=2e-5, atol=2e-6)
+    fixed = [i for i in range(len(x0)) if i not in vary]
+    assert np.array_equal(r["x"][fixed], x0[fixed])
