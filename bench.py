@@ -118,11 +118,17 @@ class ScanSecondary:
         t2 = time.perf_counter()
         alg = scan_algorithmic_bytes_per_seq(self.L, eng.n_state) * n
         ach = alg / (t2 - t0) / 1e9
+        traffic, traffic_src = None, None      # HBM bytes of the scan's kernels from the committed rocprofv3 --pmc passes
+        tf = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            t = json.load(open(tf)).get("scan")
+            if t and t.get("seq_len") == self.L and t.get("pattern") == self.pattern:
+                traffic, traffic_src = t["hbm_bytes_per_seq"] * n, t["source"]
         return {"metric": "scan seqs/sec (BPP filter + plan + K4/K5 sum passes + K6 Viterbi parse, fresh batch)", "value": n / (t2 - t0),
                 "unit": "seq/s", "load_s": t1 - t0, "scan_s": t2 - t1, "resident_rate": n / (t2 - t1),
                 "log_space_fallback_sequences": int(eng.last_timing()[2]),
                 "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                             "traffic": None, "algorithmic_bytes_per_seq": alg // n,
+                             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_seq": alg // n,
                              "note": "7*T + T_trace + 3*T_b (SURVEY section 8d) over the wall time of load + scan"},
                 "workload": "%d synthetic RNAs L=%d, pattern %s (S=%d), W=%d C=%d" % (n, self.L, self.pattern, eng.n_state, MAX_SPAN, MAX_ILOOP)}
 

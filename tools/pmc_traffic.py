@@ -1,13 +1,27 @@
-"""HBM traffic of the train pipeline from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd sqlite).
+"""HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd sqlite), optionally with the kernel
+times of a kernel-trace pass of the same command.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <n_seq> <n_eval> <out.json>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <n_seq> <n_eval> <out.json> [--kt <kernel_trace_dir>] [--seq-len L]
+                                [--pattern P] [--S n_states] [--scan] [--merge <existing.json>] [--source "..."]
 
-FETCH_SIZE / WRITE_SIZE are in KiB.  Following MI355X_MICROARCH.md (HBM section), on gfx950 FETCH_SIZE tallies 128-B
-read requests at 64 B, so fetched bytes = 2 x FETCH_SIZE for wide coalesced reads (our staged segment loads are 8 B per
-lane over contiguous rows: calibrated only to within that factor); WRITE_SIZE is exact for streaming stores.
-Both the raw and the corrected figure are written."""
-import glob, json, os, sqlite3, sys
+FETCH_SIZE / WRITE_SIZE are in KiB.  Following MI355X_MICROARCH.md (HBM section), on gfx950 FETCH_SIZE tallies 128-B read requests
+at 64 B, so fetched bytes = 2 x FETCH_SIZE for wide coalesced reads (our row segments are 8 B per lane over contiguous rows:
+calibrated to within that factor in profiles/r01_calib_fetch_report.txt); WRITE_SIZE is exact for streaming stores.  Both the
+raw and the corrected figure are written.  Per kernel of the evaluation pipeline the file carries
+    bytes              measured HBM bytes of one evaluation (2 * FETCH_SIZE + WRITE_SIZE, summed over its launches)
+    algorithmic_bytes  its share of SURVEY section 8(d)'s per-unit figure (k4_in: T, k4_out: 4 T per sequence; the scan kernels:
+                       their tables, see --scan) times the sequences of the run
+    ms                 its time in one evaluation (kernel trace of the same command on one stream, when --kt is given)
+    frac               algorithmic_bytes / ms against the 8 TB/s HBM peak
+"""
+import argparse, glob, json, os, sqlite3
 from collections import defaultdict
+
+PEAK = 8.0e12
+
+
+def short(name):
+    return name.replace("elemdp::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 
 def per_kernel(d, counter):
@@ -15,29 +29,77 @@ def per_kernel(d, counter):
     c = sqlite3.connect(db)
     out = defaultdict(lambda: [0, 0.0])
     for name, val in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
-        k = name.replace("elemdp::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        k = short(name)
         out[k][0] += 1
         out[k][1] += val * 1024.0
     return out
 
 
-fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-n_seq, n_eval = int(sys.argv[3]), int(sys.argv[4])
+def kernel_ms(d):
+    db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0]
+    c = sqlite3.connect(db)
+    out = defaultdict(lambda: [0, 0.0])
+    for name, n, tot in c.execute("select name, count(*), sum(end-start) from kernels group by name"):
+        out[short(name)][0] += n
+        out[short(name)][1] += tot / 1e6
+    return out
+
+
+def family(k):
+    """kernel name without its template arguments"""
+    return k.split("<")[0]
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("fetch"); ap.add_argument("write"); ap.add_argument("n_seq", type=int); ap.add_argument("n_eval", type=int); ap.add_argument("out")
+ap.add_argument("--kt"); ap.add_argument("--kt-evals", type=int, default=0)
+ap.add_argument("--seq-len", type=int, default=200); ap.add_argument("--pattern", default="((.*.))"); ap.add_argument("--S", type=int, default=22)
+ap.add_argument("--scan", action="store_true"); ap.add_argument("--merge"); ap.add_argument("--source", default="")
+a = ap.parse_args()
+fetch, write = per_kernel(a.fetch, "FETCH_SIZE"), per_kernel(a.write, "WRITE_SIZE")
+kms = kernel_ms(a.kt) if a.kt else {}
+kt_evals = a.kt_evals or a.n_eval
+L, W, S = a.seq_len, 50, a.S
+T = (L + 1) * (W + 1) * 7 * S * 8 + (L + 1) * S * 8                      # one table of one sequence (SURVEY section 8d)
+T_trace, T_b = (L + 1) * (W + 1) * 7 * S * 20, (L + 1) * (W + 1) * 7 * 8
+# train: 5 T = inside writes T, the outside sweep reads it and writes its own table for both passes of the reference (4 T);
+# scan: 7 T + T_trace + 3 T_b = two sum insides (2 T), two sum outsides (4 T), the Viterbi pass (T + its trace), the filter (3 T_b)
+# (per kernel INSTANCE: the scan runs two instances of k4_in and of k4_out, each one pass)
+alg = {"k4_in": T, "k4_out": 4 * T} if not a.scan else {"k4_in": T, "k4_out": 2 * T, "k5_cyk": T + T_trace, "k6_in": T_b, "k6_out": 2 * T_b}
+pipeline = ("k4_", "k_reduce") if not a.scan else ("k4_", "k5_", "k6_")
 rows, tot_f, tot_w = {}, 0.0, 0.0
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, [0, 0.0]), write.get(k, [0, 0.0])
-    rows[k] = {"dispatches": f[0] or w[0], "fetch_size_bytes": f[1], "write_size_bytes": w[1]}
-    if k.startswith("k4_") or k == "k_reduce":
+    row = {"dispatches": f[0] or w[0], "fetch_size_bytes": f[1], "write_size_bytes": w[1],
+           "bytes": (2 * f[1] + w[1]) / a.n_eval, "bytes_per_seq": (2 * f[1] + w[1]) / a.n_eval / a.n_seq}
+    if family(k) in alg:
+        row["algorithmic_bytes"] = alg[family(k)] * a.n_seq
+        row["traffic_over_algorithmic"] = row["bytes"] / row["algorithmic_bytes"]
+    if k in kms:
+        row["ms"] = kms[k][1] / kt_evals
+        if "algorithmic_bytes" in row:
+            row["frac"] = row["algorithmic_bytes"] / (row["ms"] * 1e-3) / PEAK
+        row["measured_GBps"] = row["bytes"] / (row["ms"] * 1e-3) / 1e9
+    rows[k] = row
+    if k.startswith(pipeline):
         tot_f += f[1]
         tot_w += w[1]
-res = {"n_seq": n_seq, "n_eval": n_eval, "seq_len": 200, "pattern": "((.*.))",
-       "train_pipeline": {"fetch_size_bytes_per_seq": tot_f / n_seq / n_eval, "write_size_bytes_per_seq": tot_w / n_seq / n_eval},
-       "hbm_bytes_per_seq": (2 * tot_f + tot_w) / n_seq / n_eval,
-       "hbm_bytes_per_seq_uncorrected": (tot_f + tot_w) / n_seq / n_eval,
-       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/run_eval.py %d 200 %d 4; bytes = 2*FETCH_SIZE + WRITE_SIZE "
-                 "(gfx950 correction of MI355X_MICROARCH.md), k4_* kernels + k_reduce" % (n_seq, n_eval),
+res = {"n_seq": a.n_seq, "n_eval": a.n_eval, "seq_len": L, "pattern": a.pattern,
+       "pipeline": {"fetch_size_bytes_per_seq": tot_f / a.n_seq / a.n_eval, "write_size_bytes_per_seq": tot_w / a.n_seq / a.n_eval},
+       "hbm_bytes_per_seq": (2 * tot_f + tot_w) / a.n_seq / a.n_eval,
+       "hbm_bytes_per_seq_uncorrected": (tot_f + tot_w) / a.n_seq / a.n_eval,
+       "algorithmic_bytes_per_seq": (7 * T + T_trace + 3 * T_b) if a.scan else 5 * T,
+       "source": a.source or "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); bytes = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of "
+                             "MI355X_MICROARCH.md); kernels %s" % ", ".join(p + "*" for p in pipeline),
        "kernels": rows}
-json.dump(res, open(sys.argv[5], "w"), indent=1)
-print(json.dumps({k: v for k, v in res.items() if k != "kernels"}, indent=1))
-for k, v in rows.items():
-    print("%-28s %5d  fetch %8.2f GB  write %8.2f GB" % (k, v["dispatches"], v["fetch_size_bytes"] / 1e9, v["write_size_bytes"] / 1e9))
+if a.merge and os.path.exists(a.merge):
+    old = json.load(open(a.merge))
+    old["scan" if a.scan else "train"] = res
+    res = old
+json.dump(res, open(a.out, "w"), indent=1)
+show = res.get("scan" if a.scan else "train", res)
+print(json.dumps({k: v for k, v in show.items() if k != "kernels"}, indent=1))
+for k, v in show["kernels"].items():
+    if "algorithmic_bytes" in v:
+        print("%-30s %5d  %8.2f MB/seq measured, %6.2f algorithmic (x%.2f)%s" % (k, v["dispatches"], v["bytes_per_seq"] / 1e6, v["algorithmic_bytes"] / a.n_seq / 1e6,
+              v["traffic_over_algorithmic"], ("  %.1f ms  frac %.3f" % (v["ms"], v["frac"])) if "frac" in v else ""))
