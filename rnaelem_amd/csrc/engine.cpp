@@ -537,7 +537,10 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "profile") opt_profile_ = v != 0;
   else if (key == "two_streams") opt_two_streams_ = v != 0;
   else if (key == "group_streams") opt_group_streams_ = (int)v;
-  else if (key == "pipeline") opt_pipeline_ = (int)v;
+  else if (key == "pipeline") {
+    if ((int)v != 3 && (int)v != 4) throw ArgError("option pipeline: 4 (scaled linear, default) or 3 (log space); the fused kernel (2) is retired");
+    opt_pipeline_ = (int)v;
+  }
   else if (key == "group") opt_group_ = (int)v;
   else if (key == "schedule") opt_schedule_ = (int)v;
   else if (key == "dbg") opt_dbg_ = (int)v;
@@ -1494,35 +1497,11 @@ void Engine::run_lin_batch() {
 }
 
 void Engine::run_train(bool) {
-  if ((flags_ & ELEMDP_LIK_RATIO) && opt_pipeline_ == 2) throw ArgError("--lik-ratio is not available on the fused kernel (pipeline 2)");
-  if (opt_pipeline_ == 4) { run_lin_batch(); return; }
+  // pipeline 4 (default): the scaled-linear batch pipeline (lin_kernels.hip), which hands sequences outside the double range to
+  // pipeline 3, the log-space batch pipeline (train_kernels.hip).  (Pipeline 2, the fused per-sequence kernel of round 1, is
+  // retired for training; its scan schedule stays as the scan's range fallback.)
   if (opt_pipeline_ == 3) { run_train_batch(); return; }
-  tables_linear_ = false;
-  ensure_slots(au_.S(), false, n_seq_);
-  DpArgs a = base_args(lay_, d_ints_.as<int32_t>(), d_params_.as<double>(), plan_, d_okbits1_.as<uint32_t>(), au_.S());
-  a.order = d_order_.as<int32_t>();
-  a.seq_out = d_seq_out_.as<double>();
-  a.out_stride = out_stride_;
-  a.lds = lds_layout(lay_, Lmax_, nword_max_, false);
-  a.first_pass_only = opt_first_pass_only_ ? 1 : 0;
-  const int n_blocks = std::min(n_slots_, n_seq_);
-  if (opt_profile_) {
-    d_prof_.alloc(sizeof(long long) * 8 * n_blocks);
-    HIP_OK(hipMemsetAsync(d_prof_.as<void>(), 0, sizeof(long long) * 8 * n_blocks, st_));
-    a.prof = d_prof_.as<long long>();
-  }
-  HIP_OK(hipMemsetAsync(d_counter_.as<void>(), 0, sizeof(int32_t), st_));
-  HIP_OK(hipEventRecord(ev_[1], st_));
-  HIP_OK(launch_dp(DP_TRAIN, a, std::min(n_slots_, n_seq_), st_));
-  HIP_OK(hipEventRecord(ev_[2], st_));
-  HIP_OK(launch_reduce(d_seq_out_.as<double>(), out_stride_, n_seq_, au_.n_theta(), d_partial_.as<double>(), st_));
-  if (opt_profile_) {
-    HIP_OK(hipStreamSynchronize(st_));
-    std::vector<long long> h(8 * (size_t)n_blocks);
-    HIP_OK(hipMemcpy(h.data(), d_prof_.as<void>(), sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
-    last_prof.assign(8, 0);
-    for (size_t k = 0; k < h.size(); ++k) last_prof[k % 8] += h[k];
-  }
+  run_lin_batch();
 }
 
 void Engine::train_partial(const double* x, int n_param_in, void* partial, bool device_ptr, bool reduce) {

@@ -559,63 +559,10 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
     sink.en_ = l_en_o;
     sink.post_[0] = sink.post_[1] = sink.post_[2] = nullptr;
 
-    if (KIND == DP_TRAIN) {
-      // ---- schedule of RNAelemTrainDP::operator() (motif_trainer.hpp:204-227)
-      sweep_inside<false>(m, q, Tin, c0, no_rss, sc, pf);
-      if (tid == 0) {
-        const double Zo = part_func(m, Tin, true, true), Za = part_func(m, Tin, true, false),
-                     Zn = part_func(m, Tin, false, true);
-        l_zs[0] = Zo; l_zs[1] = Za; l_zs[2] = Zn;
-        l_zs[3] = (isfinite(Zo) && isfinite(Za)) ? 0. : 1.;
-      }
-      __syncthreads();
-      const double Zo = l_zs[0], Za = l_zs[1], Zn = l_zs[2];
-      const bool skip = l_zs[3] != 0.;
-      double* o = a.seq_out + (size_t)n * a.out_stride;
-      if (!skip) {
-        sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, Zo, c0, true, true, sink, l_eh, no_rss, sc, pf);
-        const bool positive = p.positive != 0;
-        sink.en_ = l_en_x;
-        if (!a.first_pass_only)
-          sweep_outside<OUT_TRAIN>(m, q, Tin, Tout, positive ? Za : Zn, c0, positive, !positive, sink, l_eh + 2, no_rss, sc, pf);
-      }
-      if (tid == 0) {
-        o[0] = Zo; o[1] = Za; o[2] = Zn;
-        o[3] = skip ? 0. : Zo - (p.positive ? Za : Zn);
-        o[4] = skip ? 1. : 0.;
-        o[5] = skip ? 0. : p.bpp_eff;
-      }
-      for (int t = tid; t < nt; t += kThreads) { o[6 + t] = skip ? 0. : l_en_o[t]; o[6 + nt + t] = skip ? 0. : l_en_x[t]; }
-      if (tid < 4) o[6 + 2 * nt + tid] = skip ? 0. : l_eh[tid];
-    } else if (KIND == DP_BPP) {
-      // ---- K1: plain McCaskill through the one-state automaton, then the BPP threshold
-      // (EnergyModel::calc_BPP / fill_bpp_tables, energy_model.hpp:188-266)
-      sweep_inside<false>(m, q, Tin, c0, false, sc, pf);
-      const double Z = Tin.o(L, 0);
-      sweep_outside<OUT_NONE>(m, q, Tin, Tout, Z, c0, false, true, sink, l_eh, false, sc, pf);
-      __shared__ int tmp[kThreads / 64];
-      int kept = 0;
-      for (int wd = tid; wd < nword; wd += kThreads) {
-        const uint32_t in_bits = l_ok[wd];
-        uint32_t out_bits = 0;
-        for (int k = 0; k < 32; ++k) {
-          if (!((in_bits >> k) & 1u)) continue;
-          const int cc = wd * 32 + k;
-          const int i = cc / (W + 1), d = cc - i * (W + 1);
-          const double ln = (Tin.at(ST_P, d, i, 0) + Tout.at(ST_P, d, i, 0)) - Z;  // lnBPP, energy_model.hpp:195-201
-          if (a.lnbpp_out) a.lnbpp_out[p.cell_base + cc] = ln;
-          if (a.log_min_bpp <= ln) { out_bits |= 1u << k; ++kept; }
-        }
-        a.okbits_out[p.bits_base + wd] = out_bits;
-      }
-      const int tot = block_sum_int(kept, tmp);
-      if (tid == 0) {
-        double* o = a.seq_out + (size_t)n * a.out_stride;
-        o[0] = Z;
-        o[1] = (double)tot;
-      }
-    } else {
-      // ---- schedule of RNAelemScanDP::operator() (motif_scanner.hpp:204-252)
+    {
+      // ---- schedule of RNAelemScanDP::operator() (motif_scanner.hpp:204-252).  (The fused TRAIN and BPP schedules of round 1 are
+      // retired: training runs on the scaled-linear batch pipeline with the log-space batch pipeline as its range fallback, the
+      // filter on bpp_kernels.hip; this kernel stays as the scan's range fallback and cross-check.)
       int Ys, Ye;
       if (a.cyk_only) {   // the sum passes ran on the batch pipeline (lin_kernels.hip)
         Ys = a.sc_ys[n]; Ye = a.sc_ye[n];
@@ -766,8 +713,6 @@ hipError_t launch_dp(int kind, const DpArgs& a, int n_blocks, hipStream_t st) {
     hipLaunchKernelGGL(k_dp<K>, dim3(n_blocks), dim3(kThreads), lds, st, a);                                      \
   } while (0)
   switch (kind) {
-    case DP_TRAIN: ELEMDP_LAUNCH(DP_TRAIN); break;
-    case DP_BPP: ELEMDP_LAUNCH(DP_BPP); break;
     case DP_SCAN: ELEMDP_LAUNCH(DP_SCAN); break;
     default: return hipErrorInvalidValue;
   }

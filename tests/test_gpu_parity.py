@@ -280,8 +280,8 @@ def test_ragged_batch_and_batch_linearity():
 
 def test_scan_config_b_size_properties_and_spot_checks():
     """BASELINE config B: 1 000 synthetic RNAs of L=150, pattern '((.*.))' -- scan on the batch pipeline.
-    Size-independent properties of every record + the oracle on sampled sequences; the fused log-space kernel
-    (pipeline 2) must give the same records."""
+    Size-independent properties of every record + the oracle on sampled sequences; the fused log-space scan kernel
+    (the scan's range fallback; option pipeline = 3 runs the whole scan on it) must give the same records."""
     m = io.read_model(gpath("syn_l1.model"))
     seqs, quals = synth.synth_batch(1000, 150)
     eng = io.engine_from_model(m)
@@ -307,7 +307,7 @@ def test_scan_config_b_size_properties_and_spot_checks():
             assert_log_close(b[key], a[key], rtol=1e-8, atol=1e-6, what=key)
         assert list(a["psihat"]) == list(b["psihat"]) and a["rss"] == b["rss"]
     eng2 = io.engine_from_model(m)
-    eng2.set_option("pipeline", 2)
+    eng2.set_option("pipeline", 3)
     eng2.load_batch(seqs[:64], quals[:64])
     recs2, en2 = eng2.scan(m["x"])
     for a, b in zip(recs2, recs[:64]):
@@ -343,20 +343,21 @@ def test_staged_cyk_keeps_the_reference_tie_order(pattern):
 
 
 def test_pipelines_agree_and_linear_pipeline_is_the_one_measured():
-    """The scaled-linear pipeline (default, what bench.py times) against the log-space batch pipeline and the fused kernel
-    on a ragged batch: same fn / gr, and no sequence needed the log-space fallback."""
+    """The scaled-linear pipeline (default, what bench.py times) against the log-space batch pipeline (its range fallback) on a
+    ragged batch: same fn / gr, and no sequence needed the log-space fallback.  The fused kernel of round 1 (pipeline 2) is
+    retired for training."""
     m = io.read_model(gpath("syn_b.model"))
     recs = io.read_fastq(gpath("syn_L40_n3.fq")) + io.read_fastq(gpath("syn_L100_n3.fq")) + io.read_fastq(gpath("syn_L150_n8.fq"))
     seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
     res = {}
-    for pipe in (4, 3, 2):
+    for pipe in (4, 3):
         eng = io.engine_from_model(m)
         eng.set_option("pipeline", pipe)
         eng.load_batch(seqs, quals)
         res[pipe] = eng.train_eval(m["x"])
         if pipe == 4:
             assert eng.last_timing()[2] == 0
-    for pipe in (3, 2):
+    for pipe in (3,):
         assert res[pipe][0] == pytest.approx(res[4][0], rel=1e-11)
         np.testing.assert_allclose(res[pipe][1], res[4][1], rtol=1e-9, atol=1e-10)
         assert res[pipe][2:] == res[4][2:]
@@ -484,9 +485,8 @@ def test_lik_ratio_objective_against_reference_golden(case):
         assert fn == pytest.approx(case["fn"], rel=1e-9, abs=1e-12), (pipe, sched)
         np.testing.assert_allclose(gr, arr(case["gr"]), rtol=1e-7, atol=1e-9, err_msg=str((pipe, sched)))
         assert nsk == 0
-    eng.set_option("pipeline", 2)
     with pytest.raises(api.ElemdpError):
-        eng.train_eval(m["x"])
+        eng.set_option("pipeline", 2)            # (retired)
 
 
 def test_error_behaviour():
