@@ -529,6 +529,11 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     };
     auto attr = [&](int32_t pos, int k) { return (*ints)[pos + k]; };
     bool ok = A.n_wr < 32768 && A.n_wp < 32768 && A.n_wl < 32768 && A.tab_row < 250;
+    {   // the train kernels keep X = P * exp(lambda e_ml) in the rows of the (otherwise unused) B plane under P's columns
+      int n_p = 0;
+      for (int k = 0; k < ST; ++k) n_p = std::max(n_p, (*ints)[A.tab_cmap + ST_P * ST + k] + 1);
+      ok = ok && n_p <= A.tab_rs[ST_B];
+    }
     A.fp_max_p = 0;
     for (int k = 0; k < ST; ++k)
       for (const Csr* c : {&pair, &rpair}) A.fp_max_p = std::max(A.fp_max_p, (int32_t)c->rows[k].size() / 2);

@@ -119,7 +119,12 @@ __device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, cons
   // (the B plane is not stored: nothing reads it -- the outside pass of the train kernels decides liveness from the pair entries)
   const int cLo = fcol(w2, 2), cPo = fcol(w1, 0), c2o = fcol(w2, 1), c1o = fcol(w2, 0), cMo = fcol(w1, 2), cEo = fcol(w1, 1);
   if (cLo >= 0) T.band[T.cidx(ST_L, d, i, cLo)] = vL;
-  if (pok && cPo >= 0) T.band[T.cidx(ST_P, d, i, cPo)] = vP;
+  if (pok && cPo >= 0) {
+    T.band[T.cidx(ST_P, d, i, cPo)] = vP;
+    // X = P * exp(lambda e_ml): what rule 3b hands to the stems of the factorised rule 2 (pair phases of k4_in / k4_out).  It takes
+    // the rows of the B plane, which the train kernels leave unused, under P's columns (AutomatonLayout::fp_ok checks the fit).
+    T.band[T.cidx(ST_B, d, i, cPo)] = vP * xml;
+  }
   if (lok && c2o >= 0) T.band[T.cidx(ST_2, d, i, c2o)] = v2;
   if (lok && c1o >= 0) T.band[T.cidx(ST_1, d, i, c1o)] = v1;
   if (mok && cMo >= 0) T.band[T.cidx(ST_M, d, i, cMo)] = vM;

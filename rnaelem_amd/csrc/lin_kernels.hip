@@ -673,8 +673,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   if (FAST) {
 #pragma unroll
     for (int r = 0; r < kCRin; ++r) {
-      const int t = tid + r * kThreads, c = (t >> 3) < nc ? (t >> 3) : 0;
-      crx[r] = cell_in_fetch(v.q, d, i0 + c, t & 7);
+      crx[r] = 0.;
+      if (r * kThreads < cpb * 8) {   // (uniform: most automata need the first round only)
+        const int t = tid + r * kThreads, c = (t >> 3) < nc ? (t >> 3) : 0;
+        crx[r] = cell_in_fetch(v.q, d, i0 + c, t & 7);
+      }
     }
   }
   const BlockCtx cx = stage_context<BIG, 0, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
@@ -732,7 +735,6 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
         const int dmi = dm[c];
         double av = 0.;
         if (dmi > 0 && dmi < d) {
-          const double* xml = v.q.xwc + (size_t)(((r0 >> 24) & 1) * 5 + XT_ML) * v.q.xwc_stride;
           BitIter it;
           it.init(v.q.okbits_end, j * W1, 1, d - dmi);
           const int nch = (dmi < d - 1 && v.q.unp[j - 1]) ? (r1 >> 16) & 15 : 0;   // (the entries of (i, d-1) exist iff dmin[i] < d - 1)
@@ -750,10 +752,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
             const int sp1 = sp0 < 0 ? -1 : it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
             const int q0 = sp0 < 0 ? 1 : sp0, q1 = sp1 < 0 ? q0 : sp1, q2 = sp2 < 0 ? q0 : sp2, q3 = sp3 < 0 ? q0 : sp3;
             const bool g0 = sp0 >= 0;
-            const double a0 = v.in.ldc(ST_1, d - q0, i, c1, g0), b0 = v.in.ldc(ST_P, q0, j - q0, cP, g0), w0 = xml[v.q.cell(j - q0, q0)];
-            const double a1 = v.in.ldc(ST_1, d - q1, i, c1, g0), b1 = v.in.ldc(ST_P, q1, j - q1, cP, g0), w1 = xml[v.q.cell(j - q1, q1)];
-            const double a2 = v.in.ldc(ST_1, d - q2, i, c1, g0), b2 = v.in.ldc(ST_P, q2, j - q2, cP, g0), w2 = xml[v.q.cell(j - q2, q2)];
-            const double a3 = v.in.ldc(ST_1, d - q3, i, c1, g0), b3 = v.in.ldc(ST_P, q3, j - q3, cP, g0), w3 = xml[v.q.cell(j - q3, q3)];
+            // (b = X(k,j,t) = P * exp(lambda e_ml), stored by the unary phase of the stem's diagonal under P's column in the B plane)
+            const double a0 = v.in.ldc(ST_1, d - q0, i, c1, g0), b0 = v.in.ldc(ST_B, q0, j - q0, cP, g0);
+            const double a1 = v.in.ldc(ST_1, d - q1, i, c1, g0), b1 = v.in.ldc(ST_B, q1, j - q1, cP, g0);
+            const double a2 = v.in.ldc(ST_1, d - q2, i, c1, g0), b2 = v.in.ldc(ST_B, q2, j - q2, cP, g0);
+            const double a3 = v.in.ldc(ST_1, d - q3, i, c1, g0), b3 = v.in.ldc(ST_B, q3, j - q3, cP, g0);
             if (first) {   // tail step (its operands travelled with the first stems')
               first = false;
               const double wt = (r0 & (2 << 24)) ? v.q.ews[j - 1] : 1.;
@@ -762,10 +765,10 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
               for (int u = 0; u < kFastR; ++u)
                 if (u < nch) av = fma(pv[u], v.m.lin[A.lin_wr + 5 * ((ce[u] >> 8) & 0x7fff) + bj] * wt, av);
             }
-            if (sp0 >= 0) av = fma(a0, b0 * w0, av);
-            if (sp1 >= 0) av = fma(a1, b1 * w1, av);
-            if (sp2 >= 0) av = fma(a2, b2 * w2, av);
-            if (sp3 >= 0) av = fma(a3, b3 * w3, av);
+            if (sp0 >= 0) av = fma(a0, b0, av);
+            if (sp1 >= 0) av = fma(a1, b1, av);
+            if (sp2 >= 0) av = fma(a2, b2, av);
+            if (sp3 >= 0) av = fma(a3, b3, av);
             if (sp3 < 0) break;
           }
           v.in.a(d, i, p) = av;
@@ -1246,8 +1249,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   if (FAST) {
 #pragma unroll
     for (int r = 0; r < kCRout; ++r) {
-      const int t = tid + r * kThreads, c0 = t / 12, c = c0 < nc ? c0 : 0;
-      crx[r] = cell_out_fetch(v.q, d, i0 + c, t - c0 * 12);
+      crx[r] = 0.;
+      if (r * kThreads < cpb * 12) {   // (uniform: most automata need the first round only)
+        const int t = tid + r * kThreads, c0 = t / 12, c = c0 < nc ? c0 : 0;
+        crx[r] = cell_out_fetch(v.q, d, i0 + c, t - c0 * 12);
+      }
     }
   }
   const BlockCtx cx = stage_context<BIG, 1, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
@@ -1395,10 +1401,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
           const int sp1 = it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
           const int q1 = sp1 < 0 ? sp0 : sp1, q2 = sp2 < 0 ? sp0 : sp2, q3 = sp3 < 0 ? sp0 : sp3;
           // (the pair entries of (i, d + sp) exist: dmin[i] <= d < d + sp; the stems are kept pairs)
-          const double a0 = out.a(d + sp0, i, p), b0 = in.ldc(ST_P, sp0, j, cP), c0 = xml[v.q.cell(j, sp0)];
-          const double a1 = out.a(d + q1, i, p), b1 = in.ldc(ST_P, q1, j, cP), c1 = xml[v.q.cell(j, q1)];
-          const double a2 = out.a(d + q2, i, p), b2 = in.ldc(ST_P, q2, j, cP), c2 = xml[v.q.cell(j, q2)];
-          const double a3 = out.a(d + q3, i, p), b3 = in.ldc(ST_P, q3, j, cP), c3 = xml[v.q.cell(j, q3)];
+          // (FAST: b = X = P * exp(lambda e_ml) from the B plane's rows, see fast_inside_unary; no weight load)
+          const double a0 = out.a(d + sp0, i, p), b0 = in.ldc(FAST ? ST_B : ST_P, sp0, j, cP), c0 = FAST ? 1. : xml[v.q.cell(j, sp0)];
+          const double a1 = out.a(d + q1, i, p), b1 = in.ldc(FAST ? ST_B : ST_P, q1, j, cP), c1 = FAST ? 1. : xml[v.q.cell(j, q1)];
+          const double a2 = out.a(d + q2, i, p), b2 = in.ldc(FAST ? ST_B : ST_P, q2, j, cP), c2 = FAST ? 1. : xml[v.q.cell(j, q2)];
+          const double a3 = out.a(d + q3, i, p), b3 = in.ldc(FAST ? ST_B : ST_P, q3, j, cP), c3 = FAST ? 1. : xml[v.q.cell(j, q3)];
           acc = fma(a0, b0 * c0, acc);
           if (sp1 >= 0) acc = fma(a1, b1 * c1, acc);
           if (sp2 >= 0) acc = fma(a2, b2 * c2, acc);
