@@ -529,6 +529,10 @@ struct WorkIdx {
 #ifndef ELEMDP_KO
 #define ELEMDP_KO 0
 #endif
+#ifndef ELEMDP_KSTEMS
+#define ELEMDP_KSTEMS 6
+#endif
+constexpr int kStems = ELEMDP_KSTEMS;   // stems of the factorised rule 2 whose operands a lane has in flight together (train kernels)
 #ifndef ELEMDP_AHEAD_IN
 #define ELEMDP_AHEAD_IN 0
 #endif
@@ -747,16 +751,20 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
           }
           bool first = true;
           for (;;) {
-            const int sp0 = it.next();
-            if (sp0 < 0 && !first) break;
-            const int sp1 = sp0 < 0 ? -1 : it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
-            const int q0 = sp0 < 0 ? 1 : sp0, q1 = sp1 < 0 ? q0 : sp1, q2 = sp2 < 0 ? q0 : sp2, q3 = sp3 < 0 ? q0 : sp3;
-            const bool g0 = sp0 >= 0;
+            int sp[kStems];
+            sp[0] = it.next();
+            if (sp[0] < 0 && !first) break;
+#pragma unroll
+            for (int u = 1; u < kStems; ++u) sp[u] = sp[u - 1] < 0 ? -1 : it.next();
             // (b = X(k,j,t) = P * exp(lambda e_ml), stored by the unary phase of the stem's diagonal under P's column in the B plane)
-            const double a0 = v.in.ldc(ST_1, d - q0, i, c1, g0), b0 = v.in.ldc(ST_B, q0, j - q0, cP, g0);
-            const double a1 = v.in.ldc(ST_1, d - q1, i, c1, g0), b1 = v.in.ldc(ST_B, q1, j - q1, cP, g0);
-            const double a2 = v.in.ldc(ST_1, d - q2, i, c1, g0), b2 = v.in.ldc(ST_B, q2, j - q2, cP, g0);
-            const double a3 = v.in.ldc(ST_1, d - q3, i, c1, g0), b3 = v.in.ldc(ST_B, q3, j - q3, cP, g0);
+            double sa[kStems], sb[kStems];
+#pragma unroll
+            for (int u = 0; u < kStems; ++u) {
+              const bool g = sp[u] >= 0;
+              const int q = g ? sp[u] : 1;
+              sa[u] = v.in.ldc(ST_1, d - q, i, c1, g);
+              sb[u] = v.in.ldc(ST_B, q, j - q, cP, g);
+            }
             if (first) {   // tail step (its operands travelled with the first stems')
               first = false;
               const double wt = (r0 & (2 << 24)) ? v.q.ews[j - 1] : 1.;
@@ -765,11 +773,9 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
               for (int u = 0; u < kFastR; ++u)
                 if (u < nch) av = fma(pv[u], v.m.lin[A.lin_wr + 5 * ((ce[u] >> 8) & 0x7fff) + bj] * wt, av);
             }
-            if (sp0 >= 0) av = fma(a0, b0, av);
-            if (sp1 >= 0) av = fma(a1, b1, av);
-            if (sp2 >= 0) av = fma(a2, b2, av);
-            if (sp3 >= 0) av = fma(a3, b3, av);
-            if (sp3 < 0) break;
+#pragma unroll
+            for (int u = 0; u < kStems; ++u) av = fma(sa[u], sb[u], av);      // (0 * 0 for the slots without a stem)
+            if (sp[kStems - 1] < 0) break;
           }
           v.in.a(d, i, p) = av;
         }
@@ -1395,17 +1401,36 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         double acc = 0.;
         BitIter it;
         it.init(v.q.okbits, j * W1, 1, hi);
+        if (FAST) {   // (b = X = P * exp(lambda e_ml) from the B plane's rows, see fast_inside_unary; no weight load)
+          for (;;) {
+            int sp[kStems];
+            sp[0] = it.next();
+            if (sp[0] < 0) break;
+#pragma unroll
+            for (int u = 1; u < kStems; ++u) sp[u] = sp[u - 1] < 0 ? -1 : it.next();
+            double sa[kStems], sb[kStems];
+#pragma unroll
+            for (int u = 0; u < kStems; ++u) {
+              const bool g = sp[u] >= 0;
+              const int q = g ? sp[u] : 1;
+              sa[u] = out.lda(d + q, i, p, g);      // (the pair entries of (i, d + sp) exist: dmin[i] <= d < d + sp)
+              sb[u] = in.ldc(ST_B, q, j, cP, g);
+            }
+#pragma unroll
+            for (int u = 0; u < kStems; ++u) acc = fma(sa[u], sb[u], acc);
+            if (sp[kStems - 1] < 0) break;
+          }
+        } else
         for (;;) {
           const int sp0 = it.next();
           if (sp0 < 0) break;
           const int sp1 = it.next(), sp2 = (sp1 < 0) ? -1 : it.next(), sp3 = (sp2 < 0) ? -1 : it.next();
           const int q1 = sp1 < 0 ? sp0 : sp1, q2 = sp2 < 0 ? sp0 : sp2, q3 = sp3 < 0 ? sp0 : sp3;
           // (the pair entries of (i, d + sp) exist: dmin[i] <= d < d + sp; the stems are kept pairs)
-          // (FAST: b = X = P * exp(lambda e_ml) from the B plane's rows, see fast_inside_unary; no weight load)
-          const double a0 = out.a(d + sp0, i, p), b0 = in.ldc(FAST ? ST_B : ST_P, sp0, j, cP), c0 = FAST ? 1. : xml[v.q.cell(j, sp0)];
-          const double a1 = out.a(d + q1, i, p), b1 = in.ldc(FAST ? ST_B : ST_P, q1, j, cP), c1 = FAST ? 1. : xml[v.q.cell(j, q1)];
-          const double a2 = out.a(d + q2, i, p), b2 = in.ldc(FAST ? ST_B : ST_P, q2, j, cP), c2 = FAST ? 1. : xml[v.q.cell(j, q2)];
-          const double a3 = out.a(d + q3, i, p), b3 = in.ldc(FAST ? ST_B : ST_P, q3, j, cP), c3 = FAST ? 1. : xml[v.q.cell(j, q3)];
+          const double a0 = out.a(d + sp0, i, p), b0 = in.ldc(ST_P, sp0, j, cP), c0 = xml[v.q.cell(j, sp0)];
+          const double a1 = out.a(d + q1, i, p), b1 = in.ldc(ST_P, q1, j, cP), c1 = xml[v.q.cell(j, q1)];
+          const double a2 = out.a(d + q2, i, p), b2 = in.ldc(ST_P, q2, j, cP), c2 = xml[v.q.cell(j, q2)];
+          const double a3 = out.a(d + q3, i, p), b3 = in.ldc(ST_P, q3, j, cP), c3 = xml[v.q.cell(j, q3)];
           acc = fma(a0, b0 * c0, acc);
           if (sp1 >= 0) acc = fma(a1, b1 * c1, acc);
           if (sp2 >= 0) acc = fma(a2, b2 * c2, acc);
