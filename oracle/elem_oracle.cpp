@@ -2,7 +2,7 @@
 //
 // TEST INFRASTRUCTURE ONLY (see elem_oracle.h).  Parity status: PINNED against the reference's
 // known-answer tests and against golden vectors produced by the compiled reference
-// (tests/golden/, generator tools/make_golden.py).
+// (tests/golden/, generator tests/golden/make_golden.py).
 //
 // This is a restatement, in our own flat-array C++, of the reference's CPU algorithm.  It keeps
 // the reference's loop order and scatter-style outside pass on purpose, so that single-threaded

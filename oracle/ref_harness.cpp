@@ -4,7 +4,7 @@
 // the sources where they lie under /root/reference (nothing is copied into this repo; the binary
 // goes to oracle/_ref/ which is git-ignored).  It is used
 //   (1) in the build container to generate the golden vectors under tests/golden/
-//       (tools/make_golden.py is the committed generating script), and
+//       (tests/golden/make_golden.py is the committed generating script), and
 //   (2) on the GPU box as the timed CPU baseline of kind "reference" (`time` sub-command).
 //
 // Sub-commands print one JSON document on stdout (doubles with 17 significant digits):
