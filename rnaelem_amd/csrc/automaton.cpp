@@ -513,7 +513,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   }
   // table-driven unary phases (device_layout.h: fp_*): programs per state, static attributes per forward transition.  They
   // travel with the tuple lists of their direction (the "big" runs below), not with the small part every kernel stages.
-  std::vector<int32_t> prog_in, prog_out, attr_r, attr_p, pair_rec;
+  std::vector<int32_t> prog_in, prog_out, attr_r, attr_p, pair_rec, scan_fl;
   {
     auto colof = [&](int e, int k) { return (*ints)[A.tab_cmap + e * ST + k] & 0xff; };   // (-1 -> 0xff)
     auto base_of = [&](const Csr& c) {   // first transition id of every row
@@ -603,6 +603,18 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
         attr_p.push_back(rowoff1(attr(A.st_row_r, k)));
         attr_p.push_back(rowoff1(attr(A.st_row_l, ch)));
       }
+    // scan flags per forward transition (device_layout.h: ScanFlag), right | left | pair
+    {
+      auto sf = [&](int par, int ch) {
+        const int pl = attr(A.st_l, par), pr = attr(A.st_r, par), cl = attr(A.st_l, ch), cr = attr(A.st_r, ch), M = A.M;
+        return ((pl == 0 && cl == 1) ? SF_SL : 0) | ((cr == 0 && pr == 1) ? SF_SR : 0) | ((cl != 0 && cl != M - 1) ? SF_IL : 0) |
+               ((pr != 0 && pr != M - 1) ? SF_IR : 0) | ((pl == M - 2 && cl == M - 1) ? SF_EL : 0) |
+               ((cr == M - 2 && pr == M - 1) ? SF_ER : 0) | ((pr == M - 2) ? SF_PM2 : 0);
+      };
+      for (const Csr* c : {&right, &left, &pair})
+        for (int k = 0; k < ST; ++k)
+          for (size_t e = 0; e + 1 < c->rows[k].size(); e += 2) scan_fl.push_back(sf(k, c->rows[k][e]));
+    }
     // pair records of the factorised rule 2 (device_layout.h)
     for (int k = 0; k < A.n_ap && ok; ++k) {
       const int s1 = ap_keep[k][0], t = ap_keep[k][1], tgt = ap_keep[k][2];
@@ -687,6 +699,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   A.fp_in = append(prog_in);
   A.fqc_in = append(qci);
   A.fpr_in = append(pair_rec);
+  A.fs_in = append(scan_fl);
   A.fb_in_n = (int32_t)ints->size() - A.fb_in;
   A.fb_out = (int32_t)ints->size();
   A.f_live_out = append(live_states);
@@ -695,6 +708,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   A.fe_p = append(attr_p);
   A.fqc_out = append(qco);
   A.fpr_out = append(pair_rec);
+  A.fs_out = append(scan_fl);
   A.fb_out_n = (int32_t)ints->size() - A.fb_out;
 }
 
@@ -724,7 +738,7 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   for (int e = 0; e < 7; ++e) { ints->push_back(0); A.tab_rs[e] = 1; A.tab_cs[e] = e; }
   A.tab_row = 7; A.ap_rs = 1;
   A.fp_ok = 0; A.fp_in = A.fp_out = A.fe_r = A.fe_p = 0; A.n_wr = A.n_wp = A.n_wl = 0;
-  A.fb_in = A.fb_in_n = A.fb_out = A.fb_out_n = A.fqc_in = A.fpr_in = A.fqc_out = A.fpr_out = 0;
+  A.fb_in = A.fb_in_n = A.fb_out = A.fb_out_n = A.fqc_in = A.fpr_in = A.fqc_out = A.fpr_out = A.fs_in = A.fs_out = 0;
   A.fp_max_p = kFastP; A.n_lane = 1; A.f_live_in = A.f_live_out = 0;
   A.lin_wr = A.lin_wl = A.lin_wp = A.lin_total = 11;
   A.qc_in = A.qc_out1 = A.qc_out2 = A.qc_out3 = 0;

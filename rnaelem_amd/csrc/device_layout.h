@@ -98,6 +98,10 @@ struct AutomatonLayout {
   int32_t f_live_in, f_live_out;   // their ids (n_lane ints, one copy in either fast blob)
   int32_t fp_max_p;   // longest pair list (forward or reverse) of a state: the kernels unroll 2 or kFastP slots
   int32_t fp_in, fqc_in, fpr_in, fp_out, fe_r, fe_p, fqc_out, fpr_out;
+  // Scan passes on the table-driven kernels: what a scanner functor tests on the nodes of an emitting transition
+  // (motif_scanner.hpp:546-573, 594-622, 715-747) as one word of ScanFlag bits per forward transition, a copy in either fast
+  // blob: [fs_*, + n_wr) right, [+ n_wr, + n_wr + n_wl) left, [+ n_wr + n_wl, ...) pair transitions.
+  int32_t fs_in, fs_out;
   int32_t n_wr, n_wp, n_wl;                     // transitions per forward list = rows of the weight tables
   int32_t lin_wr, lin_wl, lin_wp, lin_total;    // offsets (doubles) of the weight tables in the linear block; its length
   // Column records of the interior-loop tuples (rule 6c), 2 ints each, in the tuple-list runs of the blob: the item sums hold
@@ -115,6 +119,16 @@ struct AutomatonLayout {
   int32_t n_ints;   // total length of the int blob
 };
 
+// nodes of the transition parent (pl, pr) -> child (cl, cr) of a pattern with nodes 0 .. M-1
+enum ScanFlag : int {
+  SF_SL = 1,    // pl == 0 && cl == 1:       the left emission starts the motif
+  SF_SR = 2,    // cr == 0 && pr == 1:       the right emission starts the motif
+  SF_IL = 4,    // cl != 0 && cl != M-1:     the left emission lies inside the motif
+  SF_IR = 8,    // pr != 0 && pr != M-1:     the right emission lies inside the motif
+  SF_EL = 16,   // pl == M-2 && cl == M-1:   the left emission is the first position behind the motif
+  SF_ER = 32,   // cr == M-2 && pr == M-1:   the right emission is the first position behind the motif
+  SF_PM2 = 64   // pr == M-2:                the motif ends with the sequence if the emission is its last position
+};
 constexpr int kFastW = 16;                        // ints per unary program
 constexpr int kFastR = 3, kFastP = 3, kFastL = 2;  // most right / pair / left transitions of a state the programs (and the kernels) hold
 

@@ -354,7 +354,7 @@ class Engine {
   int n_slots_ = 0, slots_S_ = 0, slot_override_ = 0;
   bool slots_scan_ = false;
   size_t band_stride_ = 0, ext_stride_ = 0;
-  DevBuf d_band_in_, d_band_out_, d_ext_in_, d_ext_out_, d_tr_band_, d_tr_ext_, d_tr_stack_, d_tmp_;
+  DevBuf d_band_in_, d_band_out_, d_ext_in_, d_ext_out_, d_tr_ext_, d_tr_stack_, d_tmp_;
   DevBuf d_seq_out_, d_partial_;
   int out_stride_ = 0;
   // options
@@ -711,17 +711,15 @@ void Engine::ensure_slots(int S, bool scan, int n_want, int row) {
   want = std::max(1, std::min(want, n_want));
   size_t free_b = 0, total_b = 0;
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
-  const size_t per_slot = (band + ext) * 2 * sizeof(double) + (scan ? (band + ext) * sizeof(TraceRec) + 16 * (Lmax_ + 2) : 0);
+  const size_t per_slot = (band + ext) * 2 * sizeof(double) + (scan ? ext * sizeof(TraceRec) + 16 * (Lmax_ + 2) : 0);
   if (n_slots_ >= want && slots_S_ == S && band_stride_ == band && (slots_scan_ || !scan)) return;
-  // (no reset: DevBuf::alloc keeps what is large enough -- a load_batch per evaluation must not re-allocate the tables; the
-  // trace tables of an earlier scan are given up only when the tables would not fit beside them)
+  // (no reset: DevBuf::alloc keeps what is large enough -- a load_batch per evaluation must not re-allocate the tables)
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   const size_t held_t = d_band_in_.bytes() + d_band_out_.bytes() + d_ext_in_.bytes() + d_ext_out_.bytes() + d_tmp_.bytes();
-  const size_t held_tr = d_tr_band_.bytes() + d_tr_ext_.bytes() + d_tr_stack_.bytes();
+  const size_t held_tr = d_tr_ext_.bytes() + d_tr_stack_.bytes();
   size_t budget = (size_t)((double)(free_b + held_t + held_tr) * 0.72);
   if (slot_budget_ > 0) budget = std::min(budget, slot_budget_);
   if (per_slot * (size_t)want > budget) want = (int)std::max<size_t>(1, budget / per_slot);
-  if (!scan && per_slot * (size_t)want > free_b + held_t) { d_tr_band_.reset(); d_tr_ext_.reset(); d_tr_stack_.reset(); }
   if (per_slot * want > free_b + held_t + held_tr) throw HipError("not enough device memory for one table slot");
   n_slots_ = want; slots_S_ = S; slots_scan_ = scan;
   band_stride_ = band; ext_stride_ = ext;
@@ -731,7 +729,6 @@ void Engine::ensure_slots(int S, bool scan, int n_want, int row) {
   d_ext_out_.alloc(ext * want * sizeof(double));
   d_tmp_.alloc(ext * 3 * want * sizeof(double));
   if (scan) {
-    d_tr_band_.alloc(band * want * sizeof(TraceRec));
     d_tr_ext_.alloc(ext * want * sizeof(TraceRec));
     d_tr_stack_.alloc((size_t)want * 4 * (4 * (Lmax_ + 2)) * sizeof(int32_t));
   }
@@ -1123,7 +1120,7 @@ void Engine::stream_setup(const uint8_t* seq, const int32_t* off, const uint8_t*
     st_have_eff_.assign(nchunks, 0);
   }
   // (the buffers of an earlier resident batch would only stand in the way of the inner engines)
-  for (DevBuf* b : {&d_band_in_, &d_band_out_, &d_ext_in_, &d_ext_out_, &d_tmp_, &d_xwc_, &d_xwi_, &d_a_in_, &d_a_out_, &d_tr_band_, &d_tr_ext_})
+  for (DevBuf* b : {&d_band_in_, &d_band_out_, &d_ext_in_, &d_ext_out_, &d_tmp_, &d_xwc_, &d_xwi_, &d_a_in_, &d_a_out_, &d_tr_ext_})
     b->reset();
   n_slots_ = 0; lin_slots_ = 0;
   streaming_ = true;
@@ -1749,33 +1746,21 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
     HIP_OK(hipMemsetAsync(d_flagged_.as<void>(), 0, sizeof(int32_t), st_));
     lin_weights();
     poison_tables();
-    // trace tables of the Viterbi pass: one per slot of a CYK sub-batch (as large as one band table slot each)
-    const size_t band = a.band_stride, ext = (size_t)(Lmax_ + 1) * S;
+    // trace records of the Viterbi pass: the exterior chain's rows and the traceback stack per table slot (the band targets keep
+    // none: scan_rules.h, cyk_retrace)
+    const size_t ext = (size_t)(Lmax_ + 1) * S;
     const int stack_stride = 4 * (4 * (Lmax_ + 2));
-    int tr_slots;
-    {
-      size_t free_b = 0, total_b = 0;
-      HIP_OK(hipMemGetInfo(&free_b, &total_b));
-      const size_t per = (band + ext) * sizeof(TraceRec) + (size_t)stack_stride * sizeof(int32_t);
-      const size_t have = d_tr_band_.bytes() / std::max<size_t>(band * sizeof(TraceRec), 1);
-      size_t want = std::min<size_t>((size_t)gsz, std::max<size_t>(have, (size_t)((double)free_b * 0.5) / per));
-      want = std::max<size_t>(want, std::min<size_t>((size_t)gsz, 2 * (size_t)n_cu_));
-      if (have < want) {
-        d_tr_band_.alloc(band * want * sizeof(TraceRec));
-        d_tr_ext_.alloc(ext * want * sizeof(TraceRec));
-        d_tr_stack_.alloc(want * stack_stride * sizeof(int32_t));
-      }
-      tr_slots = (int)std::max<size_t>(have, want);
-    }
+    d_tr_ext_.alloc(ext * n_slots_ * sizeof(TraceRec));
+    d_tr_stack_.alloc((size_t)n_slots_ * stack_stride * sizeof(int32_t));
     dbg_lap("scan: weights + trace slots");
-    a.tr_band = d_tr_band_.as<TraceRec>(); a.tr_ext = d_tr_ext_.as<TraceRec>();
+    a.tr_ext = d_tr_ext_.as<TraceRec>();
     a.trace_stack = d_tr_stack_.as<int32_t>(); a.trace_stack_stride = stack_stride;
     a.sc_psihat = d_psi.as<int32_t>(); a.sc_rss = d_rss.as<char>();
     const bool cyk_on_batch = !(opt_dbg_ & 64);
-    // two groups at a time (as in run_lin_batch): each on its own stream, with its half of the table and trace slots -- the
-    // five exterior chains of a group run under the band kernels of the other
-    const int ns = (opt_group_streams_ >= 2 && n >= 128 && n_slots_ >= 128 && tr_slots >= kMaxGroupStreams) ? std::min(opt_group_streams_, kMaxGroupStreams) : 1;
-    const int slots_each = n_slots_ / ns, tr_each = tr_slots / ns;
+    // two groups at a time (as in run_lin_batch): each on its own stream, with its half of the table slots -- the five exterior
+    // chains of a group run under the band kernels of the other
+    const int ns = (opt_group_streams_ >= 2 && n >= 128 && n_slots_ >= 128) ? std::min(opt_group_streams_, kMaxGroupStreams) : 1;
+    const int slots_each = n_slots_ / ns;
     int n_groups = (n + slots_each - 1) / slots_each;
     if (ns > 1) n_groups = ((n_groups + ns - 1) / ns) * ns;    // (every stream the same number of groups)
     const int gsz2 = (ns == 1) ? gsz : (n + n_groups - 1) / n_groups;
@@ -1794,24 +1779,14 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
       ak.ext_in += (size_t)k * slots_each * a.ext_stride; ak.ext_out += (size_t)k * slots_each * a.ext_stride;
       ak.zs += 4 * (size_t)k * slots_each;
       ak.a_in += (size_t)k * slots_each * a.a_stride; ak.a_out += (size_t)k * slots_each * a.a_stride;
-      ak.tr_band += (size_t)k * tr_each * a.band_stride; ak.tr_ext += (size_t)k * tr_each * a.ext_stride;
-      ak.trace_stack += (size_t)k * tr_each * stack_stride;
+      ak.tr_ext += (size_t)k * slots_each * a.ext_stride;
+      ak.trace_stack += (size_t)k * slots_each * stack_stride;
       ak.grp = d_order_.as<int32_t>() + g0;
       ak.plans_slot = d_plans_sorted_.as<SeqPlan>() + g0;
       const int Lg = h_plans_[h_order_[g0]].L;
       HIP_OK(launch_lin_scan_group(ak, G, Lg, std::min(Lg, max_span_), 0, st));
       HIP_OK(launch_lin_scan_group(ak, G, Lg, std::min(Lg, max_span_), 1, st));
-      if (cyk_on_batch)
-        for (int r0 = 0; r0 < G; r0 += tr_each) {   // K6 on the tables of slots [r0, r0 + R)
-          const int R = std::min(tr_each, G - r0);
-          LinArgs c = ak;
-          c.grp = ak.grp + r0;
-          c.plans_slot = ak.plans_slot + r0;
-          c.band_in = ak.band_in + (size_t)r0 * a.band_stride;
-          c.ext_in = ak.ext_in + (size_t)r0 * a.ext_stride;
-          const int Lr = h_plans_[h_order_[g0 + r0]].L;
-          HIP_OK(launch_cyk_group(c, R, Lr, std::min(Lr, max_span_), st));
-        }
+      if (cyk_on_batch) HIP_OK(launch_cyk_group(ak, G, Lg, std::min(Lg, max_span_), st));   // K6 on the same table slots
     }
     for (int k = 1; k < ns; ++k) {
       HIP_OK(hipEventRecord(gdone_[k], gs_[k]));
@@ -1831,14 +1806,8 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   // ---- K6 (Viterbi parse + traceback) on the fused kernel; it also runs the whole schedule for the sequences the
   // linear passes flagged (range check) and for pipeline != 4
   int n_blocks;
-  if (sums_on_batch) {   // reuse the table slots of the batch pipeline; only the trace tables are extra
+  if (sums_on_batch) {   // reuse the table and trace slots of the batch pipeline
     n_blocks = std::min(std::min(n_slots_, 2 * n_cu_), n);
-    const size_t band = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * S, ext = (size_t)(Lmax_ + 1) * S;
-    if (d_tr_band_.bytes() < band * n_blocks * sizeof(TraceRec)) {
-      d_tr_band_.alloc(band * n_blocks * sizeof(TraceRec));
-      d_tr_ext_.alloc(ext * n_blocks * sizeof(TraceRec));
-      d_tr_stack_.alloc((size_t)n_blocks * 4 * (4 * (Lmax_ + 2)) * sizeof(int32_t));
-    }
   } else {
     ensure_slots(S, true, n);
     lin_slots_ = 0;   // (the table slots were re-allocated with trace tables)
@@ -1846,7 +1815,6 @@ void Engine::scan(const double* x, int n_param_in, elemdp_scan_out* out) {
   }
   DpArgs d = base_args(lay_, d_ints_.as<int32_t>(), d_params_.as<double>(), plan_, d_okbits1_.as<uint32_t>(), S);
   d.order = d_order_.as<int32_t>();
-  d.tr_band = d_tr_band_.as<TraceRec>();
   d.tr_ext = d_tr_ext_.as<TraceRec>();
   d.trace_stack = d_tr_stack_.as<int32_t>();
   d.trace_stack_stride = 4 * (4 * (Lmax_ + 2));

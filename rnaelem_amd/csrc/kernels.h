@@ -73,7 +73,7 @@ struct DpArgs {
   double* band_in; double* band_out; double* ext_in; double* ext_out;
   size_t band_stride, ext_stride;  // in doubles
   double* tmp; size_t tmp_stride;  // heavy-sum temporaries: 3 * tmp_stride doubles per slot, tmp_stride = (Lmax+1)*S
-  TraceRec* tr_band; TraceRec* tr_ext;
+  TraceRec* tr_ext;
   // TRAIN: per-sequence results [n][out_stride] = Zo, Zari, Znasi, f, skipped, bpp_eff, ENo[nt], ENx[nt], EHo[2], EHx[2]
   double* seq_out;
   int32_t out_stride;
@@ -169,7 +169,7 @@ struct LinArgs {
   int32_t* ys; int32_t* ye;       // per batch index: argmax start / end
   double* pos_start; double* pos_inner; double* pos_end; double* exist;
   // scan, Viterbi pass on the batch pipeline: trace tables per slot (same indexing as the band / ext tables), outputs
-  TraceRec* tr_band; TraceRec* tr_ext; int32_t* sc_psihat; char* sc_rss; int32_t* trace_stack; int32_t trace_stack_stride;
+  TraceRec* tr_ext; int32_t* sc_psihat; char* sc_rss; int32_t* trace_stack; int32_t trace_stack_stride;
   long long* prof;                // optional [16] shader-clock sums per phase (thread 0 of every workgroup), or null
   // rule 2, factorised (lin_rules.h): pair tables [d][i][p] per slot (a_stride doubles each) and the end-indexed pair mask
   // (bits_base indexing, like okbits)

@@ -451,9 +451,9 @@ __device__ void sweep_cyk(const ModelView& m, const SeqView& q, const TableView&
   }
 }
 
-__device__ bool run_trace_back(const ModelView& m, const TableView& T, const TraceView& R, int L, int s0,
-                                            int32_t* path, char* rss, TraceFrame* stack, int cap) {
-  return trace_back(m, T, R, L, s0, path, rss, stack, cap);
+__device__ bool run_trace_back(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R, const Constraint& c,
+                               int L, int s0, int32_t* path, char* rss, TraceFrame* stack, int cap) {
+  return trace_back(m, q, T, R, c, L, s0, path, rss, stack, cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -598,7 +598,6 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
       }
       // Viterbi parse (calc_viterbi_alignment :172-184)
       TraceView R;
-      R.band = a.tr_band + blockIdx.x * a.band_stride;
       R.ext = a.tr_ext + blockIdx.x * a.ext_stride;
       const Constraint c2{Ys, Ye, 1};
       sweep_cyk(m, q, Tin, R, c2);
@@ -610,7 +609,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_MIN_WAVES) void k_dp(DpArgs a) {
         a.sc_ys[n] = Ys; a.sc_ye[n] = Ye;
         const int s0 = Tin.o(L, m.lay.s0m2) < Tin.o(L, m.lay.s0m1) ? m.lay.s0m1 : m.lay.s0m2;
         TraceFrame* stack = reinterpret_cast<TraceFrame*>(a.trace_stack + (size_t)blockIdx.x * a.trace_stack_stride);
-        run_trace_back(m, Tin, R, L, s0, path, rss, stack, (int)(a.trace_stack_stride * sizeof(int32_t) / sizeof(TraceFrame)));
+        run_trace_back(m, q, Tin, R, c2, L, s0, path, rss, stack, (int)(a.trace_stack_stride * sizeof(int32_t) / sizeof(TraceFrame)));
       }
     }
   }

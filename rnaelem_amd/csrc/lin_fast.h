@@ -11,8 +11,11 @@
 //     flags, the two bases a transition into / out of the cell emits, their position weights, and the exponentiated
 //     structural terms of both lambda classes, masked by the flags.
 // The generic rule code spends ~95 % of its instructions on deriving those per lane (instruction issue, not arithmetic,
-// bounds the band kernels); it stays the path of the scan passes, of automata with longer lists than kF* and of the CPU
-// emulation that pins the rules against the oracle (tests/emul).
+// bounds the band kernels); it stays the path of automata with longer lists than kF* and of the CPU emulation that pins the
+// rules against the oracle (tests/emul).
+// The scan passes run here too: what the scanner functors test on the nodes of an emitting transition
+// (motif_scanner.hpp:546-573, 594-622, 715-747; lstat_* and allow_* of the generic code) is one word of ScanFlag bits per
+// transition (AutomatonLayout::fs_in / fs_out), the comparisons of the emitted positions with the chosen start are cell flags.
 #pragma once
 #include "lin_rules.h"
 
@@ -29,7 +32,10 @@ constexpr int kCellInD = 10;    // doubles per cell, inside:  ews(i), ews(j-1), 
 constexpr int kCellOutD = 14;   // doubles per cell, outside: ews(i-1), ews(j), xcl[2], xhp[2], xml[2], xsu[2], e_cl, e_hp, e_su, e_ml
 // flag bits of a cell record
 enum : int { CF_POK = 1, CF_LOK = 2, CF_MOK = 4, CF_EOK = 8, CF_DO2 = 16, CF_DOM = 32, CF_CE = 64, CF_CP = 128,   // inside
-             CF_UP = 64, CF_DOL = 128 };                                                                            // outside reuse
+             CF_UP = 64, CF_DOL = 128,                                                                              // outside reuse
+             // scan passes under the start constraint Ys: the position the cell's left / right emission covers is Ys (inside: i,
+             // j - 1; outside: i - 1, j); outside: j is the last position of the sequence
+             CF_YL = 1 << 17, CF_YR = 1 << 18, CF_JLAST = 1 << 19 };
 __device__ __forceinline__ int fcol(int packed, int byte) { const int c = (packed >> (8 * byte)) & 0xff; return c == 0xff ? -1 : c; }
 
 // which global value lane k (0..7) of a cell fetches for the inside record, and from which cell
@@ -52,16 +58,18 @@ __device__ __forceinline__ int cell_in_flags(const ModelView& m, const SeqView& 
 
 // P,E,M,B,1,2,L of target (i, d, state of program P) from the heavy sums *pHB (rule 2) and *pHE (rule 6c, both in LDS: read
 // where they are used); stores them
-template <int kFR, int kFP, int kFL>
+// CON: the start constraint of the scan's second pass (FS = the ScanFlag words; CF_YL / CF_YR set in fl)
+template <int kFR, int kFP, int kFL, bool CON = false>
 __device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, const int32_t* P, const double* lin, const TableView& T,
                                                   const double* cr, int fl, int d, int i, const double* pHB, const double* pHE, int nrep,
-                                                  int rstride) {
+                                                  int rstride, const int32_t* FS = nullptr) {
   const int w0 = P[0], w1 = P[1], w2 = P[2];
   const bool isloop = w0 & 1, wr_pos = w0 & 8;
   const int kl = (w0 >> 2) & 1, nR = (w0 >> 8) & 15, nP = (w0 >> 12) & 15, nL = (w0 >> 16) & 15;
   const bool pok = fl & CF_POK, lok = fl & CF_LOK, mok = fl & CF_MOK, eok = fl & CF_EOK, do2 = fl & CF_DO2, doM = fl & CF_DOM;
   const bool cE = fl & CF_CE, cP = fl & CF_CP;
   const bool doL = isloop && d > 0;
+  const bool yl = CON && (fl & CF_YL), yr = CON && (fl & CF_YR);
   const int bi = (fl >> 8) & 7, bj = (fl >> 11) & 7, ty = (fl >> 14) & 7;
   const int d1 = d > 0 ? d - 1 : 0, d2 = d > 1 ? d - 2 : 0, i1 = i + 1;
   // operands of all transitions first: one round of loads
@@ -91,20 +99,29 @@ __device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, cons
 #pragma unroll
   for (int u = 0; u < kFR; ++u)
     if (u < nR) {
-      const double w = lin[A.lin_wr + 5 * ((eR[u] >> 16) & 0x7fff) + bj] * pj;
+      const int id = (eR[u] >> 16) & 0x7fff;
+      double w = lin[A.lin_wr + 5 * id + bj] * pj;
+      if (CON && yr && !(FS[id] & SF_SR)) w = 0.;   // allow_right
       sL = fma(tL[u], w, sL);
       s2 = fma(t2[u], w, s2);
     }
 #pragma unroll
   for (int u = 0; u < kFP; ++u)
     if (u < nP) {
-      const double w = lin[A.lin_wp + 8 * ((eP[u] >> 16) & 0x7fff) + ty] * ((eP[u] < 0 ? ews_i : 1.) * pj);
+      const int id = (eP[u] >> 16) & 0x7fff;
+      double w = lin[A.lin_wp + 8 * id + ty] * ((eP[u] < 0 ? ews_i : 1.) * pj);
+      if (CON && (yl || yr)) {   // allow_pair
+        const int sf = FS[A.n_wr + A.n_wl + id];
+        if ((yl && !(sf & SF_SL)) || (yr && !(sf & SF_SR))) w = 0.;
+      }
       sP = fma(w, fma(tP[u], xst, tE[u]), sP);
     }
 #pragma unroll
   for (int u = 0; u < kFL; ++u)
     if (u < nL) {
-      const double w = lin[A.lin_wl + 5 * ((eL[u] >> 16) & 0x7fff) + bi] * (eL[u] < 0 ? ews_i : 1.);
+      const int id = (eL[u] >> 16) & 0x7fff;
+      double w = lin[A.lin_wl + 5 * id + bi] * (eL[u] < 0 ? ews_i : 1.);
+      if (CON && yl && !(FS[A.n_wr + id] & SF_SL)) w = 0.;   // allow_left
       sM = fma(tM[u], w, sM);
     }
   double HB = *pHB, HE = *pHE;
@@ -165,13 +182,40 @@ __device__ __forceinline__ bool cell_out_mask(int fl, int k) {
   return true;
 }
 
-// band target (i, d, state of program P) of the train schedule's outside sweep; returns out B.  invZ: of the lane's world.
+// Position posteriors of one emitting transition in the scan passes (lstat_pair / lstat_left / lstat_right of lin_rules.h with
+// the node tests as ScanFlag bits sf): OUT_SCAN adds the posterior z to the start / inner accumulators, OUT_END to the end
+// accumulator; returns false when the start constraint of OUT_END excludes the transition.  kl / kr: the positions of the
+// left / right emission (LEFT / RIGHT: which of them the transition has); yl / yr: that position is the chosen start.
+template <int MODE, bool LEFT, bool RIGHT, class Sink>
+__device__ __forceinline__ bool fast_scan_stat(Sink& sink, int sf, int kl, int kr, bool yl, bool yr, bool jlast, double z) {
+  if (MODE == OUT_END) {
+    if ((LEFT && yl && !(sf & SF_SL)) || (RIGHT && yr && !(sf & SF_SR))) return false;
+    if (z != 0.) {
+      if (LEFT && (sf & SF_EL)) sink.pos(2, kl, z);
+      if (RIGHT && (sf & SF_ER)) sink.pos(2, kr, z);
+      if (RIGHT && (sf & SF_PM2) && jlast) sink.pos(2, kr + 1, z);
+    }
+  } else if (MODE == OUT_SCAN && z != 0.) {
+    if (LEFT && (sf & SF_SL)) sink.pos(0, kl, z);
+    if (RIGHT && (sf & SF_SR)) sink.pos(0, kr, z);
+    if (LEFT && (sf & SF_IL)) sink.pos(1, kl, z);
+    if (RIGHT && (sf & SF_IR)) sink.pos(1, kr, z);
+  }
+  return true;
+}
+
+// band target (i, d, state of program P) of an outside sweep; returns out B.  invZ: of the lane's world.
 // (heavy sums H1, H2, HP, HL of the target at ph[0], ph[CS], ph[2 CS], ph[3 CS] in LDS: read where they are used)
-template <int kFR, int kFP, int kFL, class Sink>
+// MODE: OUT_TRAIN (expected counts + energy statistics), OUT_SCAN (counts + start / inner posteriors), OUT_END (end posteriors
+// under the start constraint: CF_YL / CF_YR / CF_JLAST in fl); FS = the ScanFlag words of the scan modes.
+template <int kFR, int kFP, int kFL, int MODE, class Sink>
 __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, const int32_t* P, const int32_t* G, const double* lin,
                                                      const TableView& in, const TableView& out, const double* cr, int fl, int d, int i,
                                                      double invZ, bool lam_same, bool no_prf, Sink& sink, const double* ph, int CS, int nrep,
-                                                     int rstride) {
+                                                     int rstride, const int32_t* FS = nullptr) {
+  constexpr bool SCANM = MODE == OUT_SCAN || MODE == OUT_END;
+  const bool yl = fl & CF_YL, yr = fl & CF_YR, jlast = fl & CF_JLAST;
+  const int j = i + d;
   const int w0 = P[0], w1 = P[1], w2 = P[2], enl = P[3];
   const bool isloop = w0 & 1, wl_s = w0 & 16;
   const int kl = (w0 >> 2) & 1, nRR = (w0 >> 8) & 15, nRP = (w0 >> 12) & 15, nRL = (w0 >> 16) & 15;
@@ -226,11 +270,12 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
         const double tE = aE ? opP[u] * w : 0.;
         const double tP = aP ? opP[u] * (w * ((f & 8) ? xsu1 : xsu0)) : 0.;
         const double zP = tP * inPz, z = fma(tE, inEz, zP);
-        if (!no_prf && z != 0.) {   // expected emission counts (motif_trainer.hpp:384-388 / profile_hmm.hpp:144-179)
+        if (SCANM && !fast_scan_stat<MODE, true, true>(sink, FS[A.n_wr + A.n_wl + id], i - 1, j, yl, yr, jlast, z)) continue;
+        if (MODE != OUT_END && !no_prf && z != 0.) {   // expected emission counts (motif_trainer.hpp:384-388 / profile_hmm.hpp:144-179)
           if (f & 1) { if (ty) sink.en(offR + ty, z); }
           else { if (bl) sink.en(offL + bl, z); if (br) sink.en(offR + br, z); }
         }
-        if (zP != 0.) sink.eh(lam_same ? 0 : ((f >> 3) & 1), e_su * zP);   // motif_trainer.hpp:380-381
+        if (MODE == OUT_TRAIN && zP != 0.) sink.eh(lam_same ? 0 : ((f >> 3) & 1), e_su * zP);   // motif_trainer.hpp:380-381
         oE += tE;
         oP1b += tP;
       }
@@ -239,16 +284,18 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
 #pragma unroll
   for (int u = 0; u < kFL; ++u)
     if (u < nRL && aM) {
-      const double term = opM[u] * (lin[A.lin_wl + 5 * ((eL[u] >> 16) & 0x7fff) + bl] * (wl_s ? ews_l : 1.));
+      const int id = (eL[u] >> 16) & 0x7fff;
+      const double term = opM[u] * (lin[A.lin_wl + 5 * id + bl] * (wl_s ? ews_l : 1.));
       const double z = term * inMz;
-      if (!no_prf && z != 0. && bl) sink.en(enl + bl, z);
+      if (SCANM && !fast_scan_stat<MODE, true, false>(sink, FS[A.n_wr + id], i - 1, j, yl, yr, jlast, z)) continue;
+      if (MODE != OUT_END && !no_prf && z != 0. && bl) sink.en(enl + bl, z);
       sM += term;
     }
   if (eok && cEo >= 0) out.band[out.cidx(ST_E, d, i, cEo)] = oE;
   double oM = 0.;
   if (inM != 0.) {   // child of E (6a) and of M(i-1,j,par) (5a)
     const double t6a = oE * cr[2 + kl], z = t6a * inMz;
-    if (z != 0.) sink.eh(ehs, cr[10] * z);
+    if (MODE == OUT_TRAIN && z != 0.) sink.eh(ehs, cr[10] * z);
     oM = t6a + sM;
   }
   if (mok && cMo >= 0) out.band[out.cidx(ST_M, d, i, cMo)] = oM;
@@ -276,7 +323,8 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
       const double w = lin[A.lin_wr + 5 * id + br] * ((fr & 1) ? ews_r : 1.);
       const double t2 = a2 ? op2[u] * w : 0., tL = aL ? opL[u] * w : 0.;
       const double z = fma(t2, in2z, tL * inLz);
-      if (!no_prf && z != 0. && br) sink.en(enr + br, z);
+      if (SCANM && !fast_scan_stat<MODE, false, true>(sink, FS[id], i - 1, j, yl, yr, jlast, z)) continue;
+      if (MODE != OUT_END && !no_prf && z != 0. && br) sink.en(enr + br, z);
       s2 += t2;
       sL += tL;
     }
@@ -293,14 +341,14 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
   double oP = 0.;
   if (inP != 0.) {   // child of O (7: r7), of P(i-1,j+1,par) (1b), of 2 (3b), inner pair of interior loops (6c: HP)
     const double t3b = (o2 + H2) * cr[6 + kl], z = t3b * inPz;
-    if (z != 0.) sink.eh(ehs, cr[13] * z);
+    if (MODE == OUT_TRAIN && z != 0.) sink.eh(ehs, cr[13] * z);
     oP = oP1b + t3b + (HP + r7);
   }
   if (pok && cPo >= 0) out.band[out.cidx(ST_P, d, i, cPo)] = oP;
   double oL = 0.;
   if (inL != 0.) {   // child of E (6b), of L(i,j+1,par), loops of interior loops (6c: HL)
     const double t6b = oE * cr[4 + kl], z = t6b * inLz;
-    if (z != 0.) sink.eh(ehs, cr[11] * z);
+    if (MODE == OUT_TRAIN && z != 0.) sink.eh(ehs, cr[11] * z);
     oL = t6b + sL + HL;
   }
   if (cLo >= 0) out.band[out.cidx(ST_L, d, i, cLo)] = oL;

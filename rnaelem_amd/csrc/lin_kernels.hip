@@ -703,7 +703,9 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     }
     for (int c = tid; c < nc; c += kThreads) {
       const int i = i0 + c, j = i + d;
-      crfl[c] = cell_in_flags(v.m, v.q, d, i);
+      int fl = cell_in_flags(v.m, v.q, d, i);
+      if (CON) { const int ys = a.ys[v.n]; fl |= (i == ys ? CF_YL : 0) | (j - 1 == ys ? CF_YR : 0); }
+      crfl[c] = fl;
       crec[c * kCellInD] = v.q.ews[i];
       crec[c * kCellInD + 1] = v.q.ews[j > 0 ? j - 1 : 0];
     }
@@ -771,7 +773,11 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
               const int bj = v.q.seq[j - 1];
 #pragma unroll
               for (int u = 0; u < kFastR; ++u)
-                if (u < nch) av = fma(pv[u], v.m.lin[A.lin_wr + 5 * ((ce[u] >> 8) & 0x7fff) + bj] * wt, av);
+                if (u < nch) {
+                  const int id = (ce[u] >> 8) & 0x7fff;
+                  if (CON && j - 1 == con.ys && !(G[A.fs_in + id] & SF_SR)) continue;   // allow_right
+                  av = fma(pv[u], v.m.lin[A.lin_wr + 5 * id + bj] * wt, av);
+                }
             }
 #pragma unroll
             for (int u = 0; u < kStems; ++u) av = fma(sa[u], sb[u], av);      // (0 * 0 for the slots without a stem)
@@ -891,8 +897,8 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     const int s = FAST ? G[A.f_live_in + tid - c * NL] : tid - c * NL;
     const int i = i0 + c;
     if (FAST) {
-      fast_inside_unary<kFastR, FP, kFastL>(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, hb + c * S + s, he + c * S + s,
-                                            NW, 2 * CS);
+      fast_inside_unary<kFastR, FP, kFastL, CON>(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, hb + c * S + s,
+                                                 he + c * S + s, NW, 2 * CS, G + A.fs_in);
     } else {
       const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
       lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, rep_sum(hb + c * S + s, NW, 2 * CS), rep_sum(he + c * S + s, NW, 2 * CS), con);
@@ -1284,7 +1290,9 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     }
     for (int c = tid; c < nc; c += kThreads) {
       const int i = i0 + c, j = i + d;
-      crfl[c] = cell_out_flags(v.m, v.q, d, i);
+      int fl = cell_out_flags(v.m, v.q, d, i);
+      if (MODE == OUT_END) { const int ys = a.ys[v.n]; fl |= (i - 1 == ys ? CF_YL : 0) | (j == ys ? CF_YR : 0) | (L == j + 1 ? CF_JLAST : 0); }
+      crfl[c] = fl;
       crec[c * kCellOutD] = v.q.ews[i > 0 ? i - 1 : 0];
       crec[c * kCellOutD + 1] = v.q.ews[j < L ? j : L];
     }
@@ -1558,9 +1566,9 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     sink.world = w1 ? 1 : 0;
     sink.en_ = l_en + (w1 ? nt : 0);
     if (FAST) {
-      h1[c * S + s] = fast_outside_unary<kFastR, FP, kFastL>(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c], d,
-                                                             i0 + c, w1 ? pi.invZs : pi.invZ, v.m.lam_same != 0, v.m.no_prf != 0, sink,
-                                                             h1 + c * S + s, CS, NW, HS);
+      h1[c * S + s] = fast_outside_unary<kFastR, FP, kFastL, MODE>(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c],
+                                                                   d, i0 + c, w1 ? pi.invZs : pi.invZ, v.m.lam_same != 0, v.m.no_prf != 0, sink,
+                                                                   h1 + c * S + s, CS, NW, HS, G + A.fs_out);
     } else {
       LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
       HeavyOut H;
@@ -1609,7 +1617,10 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
                 const int id = (ce[u] >> 8) & 0x7fff;
                 const double term = op[u] * (v.m.lin[A.lin_wr + 5 * id + bj] * ((G[A.fe_r + 2 * id + 1] & 1) ? ewj : 1.));
                 const double z = term * inz;
-                if (!v.m.no_prf && z != 0. && bj) atomicAdd(&en[G[A.fe_r + 2 * id] + bj], z);
+                if ((MODE == OUT_SCAN || MODE == OUT_END) &&
+                    !fast_scan_stat<MODE, false, true>(sink, G[A.fs_out + id], i - 1, j, false, MODE == OUT_END && j == a.ys[v.n], L == j + 1, z))
+                  continue;
+                if (MODE != OUT_END && !v.m.no_prf && z != 0. && bj) atomicAdd(&en[G[A.fe_r + 2 * id] + bj], z);
                 acc += term;
               }
           }
@@ -1711,13 +1722,14 @@ __global__ __launch_bounds__(kThreads) void k5_cyk_serial(LinArgs a) {
   if (t >= (v.q.L - d + 1) * S) return;
   const int i = t / S, s = t - i * S;
   TraceView R;
-  R.band = a.tr_band + (size_t)by * a.band_stride;
-  R.ext = a.tr_ext + (size_t)by * a.ext_stride;
+  R.ext = nullptr;
   const Constraint c{a.ys[v.n], a.ye[v.n], 1};
   cyk_target(v.m, v.q, v.in, R, c, d, i, s);
 }
 
-// staged form: same workgroup shape, context and operand staging as k4_in; KOWN (cell, tuple) products per lane
+// staged form: same workgroup shape, context and operand staging as k4_in; KOWN (cell, tuple) products per lane.  Values only:
+// the traceback re-derives the winner of the targets it visits (scan_rules.h, cyk_retrace), so the maxima of the two span-long
+// candidate lists need no order bookkeeping here.
 template <bool BIG, int KOWN>
 __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   extern __shared__ double lds[];
@@ -1739,28 +1751,26 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   unsigned long long* ke = kb + CS;                                      // [CS] best key, rule 6c
   double* st1 = lds + 2 * CS;                  // [KC][CU]  rows 1(i, i+a, front states)
   double* st2 = st1 + kChunkIn * kThreads;     // [KC][CU]  rows 2(i+a, j, front states)
-  unsigned* ob = reinterpret_cast<unsigned*>(st2 + kChunkIn * kThreads);   // [CS] first ordinal reaching the best, rule 2
-  unsigned* oe = ob + CS;                                                  //                                      rule 6c
-  const BlockLds BL = block_lds(3 * CS + 2 * kChunkIn * kThreads, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
+  const BlockLds BL = block_lds(2 * CS + 2 * kChunkIn * kThreads, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
   const BlockCtx cx = stage_context<BIG, 0>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   const unsigned long long kneg = cyk_key(NEG);
-  for (int t = tid; t < CS; t += kThreads) { kb[t] = kneg; ke[t] = kneg; ob[t] = 0xffffffffu; oe[t] = 0xffffffffu; }
+  for (int t = tid; t < CS; t += kThreads) { kb[t] = kneg; ke[t] = kneg; }
   __syncthreads();
-  // rule 2: candidates 1(i,i+a,s1) + 2(i+a,j,s2), a ascending; a lane keeps the first best split point of its tuples
+  // rule 2: candidates 1(i,i+a,s1) + 2(i+a,j,s2); a lane keeps the best of its tuples over the split points
   int a_lo = d;
   for (int c = 0; c < nc; ++c) { const int x = dm[c]; if (x > 0 && x < a_lo) a_lo = x; }
   const int nsp = A.n_split;
   const double* B = v.in.band;
   const StageMap sm = stage_map(A.n_front, S, cpb, nc, tid);
   const int NU = sm.NU, CU = sm.CU, KC = kChunkIn * sm.nsub;
-  int po1[KOWN], po2[KOWN], pa[KOWN];
+  int po1[KOWN], po2[KOWN];
   double pv[KOWN];
 #pragma unroll
   for (int r = 0; r < KOWN; ++r) {
     const int w = tid + r * kThreads;
-    po1[r] = -1; po2[r] = 0; pa[r] = 0; pv[r] = NEG;
+    po1[r] = -1; po2[r] = 0; pv[r] = NEG;
     if (w < nc * nsp) {
       const int c = w / nsp, t = w - c * nsp;
       const int x = dm[c];
@@ -1783,57 +1793,41 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
       }
     }
     __syncthreads();
-    // staged slot v holds split point q0 + v (v = u * nsub + sub): ascending, as the tie rule needs
+    // (staged slot v holds split point q0 + v, v = u * nsub + sub)
 #pragma unroll
     for (int r = 0; r < KOWN; ++r)
       if (po1[r] >= 0) {
 #pragma unroll 4
         for (int u = 0; u < KC; ++u) {
           const double y = st1[u * CU + po1[r]] + st2[u * CU + po2[r]];
-          if (pv[r] < y) { pv[r] = y; pa[r] = q0 + u; }
+          pv[r] = pv[r] < y ? y : pv[r];
         }
       }
     __syncthreads();
   }
-  unsigned long long pk[KOWN];
 #pragma unroll
-  for (int r = 0; r < KOWN; ++r) {
-    pk[r] = kneg;
+  for (int r = 0; r < KOWN; ++r)
     if (po1[r] >= 0 && pv[r] != NEG) {
       const int w = tid + r * kThreads;
       const int c = w / nsp, t = w - c * nsp;
-      pk[r] = cyk_key(pv[r]);
-      atomicMax(&kb[c * S + G[A.split_tgt + t]], pk[r]);
+      atomicMax(&kb[c * S + G[A.split_tgt + t]], cyk_key(pv[r]));
     }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < KOWN; ++r)
-    if (pk[r] != kneg) {
-      const int w = tid + r * kThreads;
-      const int c = w / nsp, t = w - c * nsp;
-      const int tg = c * S + G[A.split_tgt + t];
-      if (kb[tg] == pk[r]) atomicMin(&ob[tg], (unsigned)(pa[r] * nsp + t));
-    }
-  // rule 6c: candidates P(k,l,s1) + (L(i,k,s2) + (L(l,j,s3) + lam * tsc)); items in by_outer order, then tuples.
-  // The item records are staged in LDS; two sweeps over the work items: the maximum of the keys, then the first ordinal
-  // that reaches it.  (The maximum runs over ALL records of the workgroup, so both sweeps cover every chunk.)
+  // rule 6c: candidates P(k,l,s1) + (L(i,k,s2) + (L(l,j,s3) + lam * tsc)) over the item records of the workgroup's cells (staged
+  // in LDS) x the tuples
   const int nq = A.n_quad;
   {
     const int n_rec = outer_ranges(v, i0, nc, d, true, tid, cnts, pre, base);
     const OuterRecs R = outer_recs(st1, 2 * kChunkIn * kThreads);
-#pragma unroll 1
-    for (int sweep = 0; sweep < 2; ++sweep) {
+    {
       for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
         const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
-        if (sweep == 0 || n_rec > R.cap) outer_stage<false>(v, R, p0, np, nc, tid, pre, base);
+        outer_stage<false>(v, R, p0, np, nc, tid, pre, base);
         const int total = np * nq;
         const int nqd = nq > 0 ? nq : 1, q256 = kThreads / nqd, r256 = kThreads % nqd;
         WorkIdx wi{tid / nqd, tid % nqd};
         for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
           double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], lt[kItemBatch];
           int hidx[kItemBatch];
-          unsigned ord[kItemBatch];
           bool ok[kItemBatch];
 #pragma unroll
           for (int u = 0; u < kItemBatch; ++u) {
@@ -1852,37 +1846,27 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
             x2[u] = B[v.in.idx(ST_L, j - it.l, it.l, G[A.quad_ent + 3 * t + 2])];
             lt[u] = ELEMDP_MUL_RN(v.m.lam(tgs), it.tsc);
             hidx[u] = c * S + tgs;
-            ord[u] = (unsigned)((meta & 0xffff) * nq + t);
           }
 #pragma unroll
           for (int u = 0; u < kItemBatch; ++u) {
             const double y = x0[u] + (x1[u] + (x2[u] + lt[u]));
             if (!ok[u] || y == NEG) continue;
-            const unsigned long long k = cyk_key(y);
-            if (sweep == 0) atomicMax(&ke[hidx[u]], k);
-            else if (ke[hidx[u]] == k) atomicMin(&oe[hidx[u]], ord[u]);
+            atomicMax(&ke[hidx[u]], cyk_key(y));
           }
         }
         __syncthreads();
       }
     }
   }
+  __syncthreads();
   if (tid < ncS) {
     const int c = tid / S, s = tid - c * S;
     const int i = i0 + c;
     MaxAcc hB, hE;
-    if (ob[tid] != 0xffffffffu) {
-      const int aa = (int)(ob[tid] / (unsigned)nsp), t = (int)(ob[tid] - (unsigned)aa * (unsigned)nsp);
-      hB.offer(cyk_unkey(kb[tid]), i, i + aa, TT_B_12, ST_1, G[A.split_ent + 2 * t]);
-    }
-    if (oe[tid] != 0xffffffffu) {
-      const int n = (int)(oe[tid] / (unsigned)nq), t = (int)(oe[tid] - (unsigned)n * (unsigned)nq);
-      const LoopItem it = v.q.items[v.q.by_outer_off[v.q.cell(i, d)] + n];
-      hE.offer(cyk_unkey(ke[tid]), it.k, it.l, TT_E_P, ST_P, G[A.quad_ent + 3 * t]);
-    }
+    hB.best = cyk_unkey(kb[tid]);
+    hE.best = cyk_unkey(ke[tid]);
     TraceView R;
-    R.band = a.tr_band + (size_t)by * a.band_stride;
-    R.ext = a.tr_ext + (size_t)by * a.ext_stride;
+    R.ext = nullptr;
     const Constraint con{a.ys[v.n], a.ye[v.n], 1};
     cyk_target_u(v.m, v.q, v.in, R, con, d, i, s, hB, hE);
   }
@@ -1897,7 +1881,6 @@ __global__ __launch_bounds__(64) void k5_cyk_ext(LinArgs a) {
   __syncthreads();
   const int S = a.lay.S, tid = threadIdx.x, L = v.q.L;
   TraceView R;
-  R.band = a.tr_band + (size_t)blockIdx.x * a.band_stride;
   R.ext = a.tr_ext + (size_t)blockIdx.x * a.ext_stride;
   const Constraint c{a.ys[v.n], a.ye[v.n], 1};
   for (int s = tid; s < S; s += 64) {
@@ -1917,7 +1900,7 @@ __global__ __launch_bounds__(64) void k5_cyk_ext(LinArgs a) {
   if (tid == 0) {
     const int s0 = v.in.o(L, a.lay.s0m2) < v.in.o(L, a.lay.s0m1) ? a.lay.s0m1 : a.lay.s0m2;
     TraceFrame* stack = reinterpret_cast<TraceFrame*>(a.trace_stack + (size_t)blockIdx.x * a.trace_stack_stride);
-    trace_back(v.m, v.in, R, L, s0, path, rss, stack, (int)(a.trace_stack_stride * sizeof(int32_t) / sizeof(TraceFrame)));
+    trace_back(v.m, v.q, v.in, R, c, L, s0, path, rss, stack, (int)(a.trace_stack_stride * sizeof(int32_t) / sizeof(TraceFrame)));
   }
 }
 
@@ -1943,7 +1926,7 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   a.ext_ring = G <= 1024 ? 1 : 0;
   a.lmax = Lmax;
   a.n_lin = kLinEth + nt; a.fast = 0; a.det = 0;
-  const size_t lds = block_lds(3 * a.cpb * S + 2 * kChunkIn * kThreads, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
+  const size_t lds = block_lds(2 * a.cpb * S + 2 * kChunkIn * kThreads, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const long long products = (long long)a.cpb * a.lay.n_split;   // (cell, tuple) products of a workgroup
   const int kown = products <= 2 * kThreads ? 2 : products <= 4 * kThreads ? 4 : products <= 8 * kThreads ? 8 : 0;
@@ -1974,10 +1957,16 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   a.schedule = 0;   // terminals (ari, nasi), Z = Z(ari,nasi): pass 0 of the reference schedule
   a.pass = 0;
   a.scan = 1;
-  a.n_lin = kLinEth + nt; a.fast = 0; a.det = 0;
-  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
-  const size_t lds_out = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb).total;
+  a.det = 0;
   const bool big = a.n_stage >= a.lay.n_ints;
+  // table-driven unary phases as in launch_lin_group (the scanner's node tests are flag words of the fast blobs)
+  const bool fast = a.fast && big && a.lay.fp_ok && !(a.dbg & 16) && a.lay.lin_total <= 2048;
+  a.fast = fast ? 1 : 0;
+  if (fast) a.cpb = std::min(kThreads / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);
+  a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
+  const bool fp2 = a.lay.fp_max_p <= 2;
+  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
+  const size_t lds_out = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds((a.ext_ring ? ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
   const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4 + (a.ext_ring ? ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
@@ -1988,7 +1977,9 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       if (ncell <= 0) break;                                                                                                     \
       a.d = d;                                                                                                                   \
       const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
-      if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kThreads), lds_in, st, a);                                      \
+      if (fast && fp2) hipLaunchKernelGGL((k4_in<true, CON, true, 2>), grid, dim3(kThreads), lds_in, st, a);                     \
+      else if (fast) hipLaunchKernelGGL((k4_in<true, CON, true>), grid, dim3(kThreads), lds_in, st, a);                          \
+      else if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kThreads), lds_in, st, a);                                 \
       else hipLaunchKernelGGL((k4_in<false, CON>), grid, dim3(kThreads), lds_in, st, a);                                         \
     }                                                                                                                            \
     if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, CON>), dim3(G), dim3(128), lds_ext_in, st, a);                            \
@@ -2001,7 +1992,9 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       if (ncell <= 0) continue;                                                                                                  \
       a.d = d;                                                                                                                   \
       const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
-      if (big) hipLaunchKernelGGL((k4_out<MODE, true>), grid, dim3(kThreads), lds_out, st, a);                                   \
+      if (fast && fp2) hipLaunchKernelGGL((k4_out<MODE, true, true, 2>), grid, dim3(kThreads), lds_out, st, a);                  \
+      else if (fast) hipLaunchKernelGGL((k4_out<MODE, true, true>), grid, dim3(kThreads), lds_out, st, a);                       \
+      else if (big) hipLaunchKernelGGL((k4_out<MODE, true>), grid, dim3(kThreads), lds_out, st, a);                              \
       else hipLaunchKernelGGL((k4_out<MODE, false>), grid, dim3(kThreads), lds_out, st, a);                                      \
     }                                                                                                                            \
   } while (0)

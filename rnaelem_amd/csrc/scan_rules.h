@@ -17,9 +17,12 @@ namespace elemdp {
 #define ELEMDP_MUL_RN(a, b) ((a) * (b))
 #endif
 
+// Trace records.  Only the exterior chain keeps them ([j][s], one row per position).  The band targets -- seven planes x S
+// states per cell, as much memory as the table itself -- do not: trace_back re-derives the record of each target it visits
+// (a few hundred per sequence) from the finished table with the sweep's own candidate order (cyk_retrace below).
 struct TraceView {
-  TraceRec* band;  // same indexing as TableView::band
-  TraceRec* ext;   // [j][s]
+  TraceRec* ext;
+  TraceRec* one = nullptr;   // retrace: the seven records of the one target being re-derived (no table stores)
 };
 
 struct MaxAcc {
@@ -82,6 +85,11 @@ ELEMDP_HD MaxAcc cyk_item_best(const ModelView& m, const SeqView& q, const Table
   return aE;
 }
 
+ELEMDP_HD void cyk_put(const TableView& T, const TraceView& R, int e, int d, int i, int s, const MaxAcc& a) {
+  if (R.one) R.one[e] = a.tr;
+  else T.at(e, d, i, s) = a.best;
+}
+
 // everything else of the target; hB = winner of rule 2 (used when left_ok), hE = winner of rule 6c (used when e_ok)
 ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
                             const Constraint& c, int d, int i, int s, const MaxAcc& hB, const MaxAcc& hE) {
@@ -102,8 +110,7 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
         aL.offer(T.at(ST_L, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_L_L, ST_L, s1);
       }
   }
-  T.at(ST_L, d, i, s) = aL.best;
-  R.band[T.idx(ST_L, d, i, s)] = aL.tr;
+  cyk_put(T, R, ST_L, d, i, s, aL);
 
   const bool pok = q.pair_ok(i, d);
   MaxAcc aP;
@@ -122,14 +129,12 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
                  ST_P, s1);
       }
   }
-  T.at(ST_P, d, i, s) = aP.best;
-  R.band[T.idx(ST_P, d, i, s)] = aP.tr;
+  cyk_put(T, R, ST_P, d, i, s, aP);
 
   const bool lok = q.left_ok(i, d);
   MaxAcc aB;
   if (lok) aB = hB;
-  T.at(ST_B, d, i, s) = aB.best;
-  R.band[T.idx(ST_B, d, i, s)] = aB.tr;
+  cyk_put(T, R, ST_B, d, i, s, aB);
 
   MaxAcc a2, a1;
   if (lok) {
@@ -146,10 +151,8 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
     a1.offer(a2.best, i, j, TT_1_2, ST_2, s);
     a1.offer(aB.best, i, j, TT_1_B, ST_B, s);
   }
-  T.at(ST_2, d, i, s) = a2.best;
-  R.band[T.idx(ST_2, d, i, s)] = a2.tr;
-  T.at(ST_1, d, i, s) = a1.best;
-  R.band[T.idx(ST_1, d, i, s)] = a1.tr;
+  cyk_put(T, R, ST_2, d, i, s, a2);
+  cyk_put(T, R, ST_1, d, i, s, a1);
 
   const bool mok = m_ok(m, q, i, d);
   MaxAcc aM;
@@ -162,8 +165,7 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
       }
     if (lok) aM.offer(aB.best, i, j, TT_M_B, ST_B, s);
   }
-  T.at(ST_M, d, i, s) = aM.best;
-  R.band[T.idx(ST_M, d, i, s)] = aM.tr;
+  cyk_put(T, R, ST_M, d, i, s, aM);
 
   MaxAcc aE;
   if (q.e_ok(i, d)) {
@@ -172,8 +174,7 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
     if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) aE.offer(aL.best + ELEMDP_MUL_RN(lam, t), i, j, TT_E_H, ST_L, s); }
     if (aE.best < hE.best) aE = hE;   // (the item candidates come last; the first strictly greatest one wins)
   }
-  T.at(ST_E, d, i, s) = aE.best;
-  R.band[T.idx(ST_E, d, i, s)] = aE.tr;
+  cyk_put(T, R, ST_E, d, i, s, aE);
 }
 
 ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
@@ -181,6 +182,25 @@ ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView&
   const MaxAcc hB = q.left_ok(i, d) ? cyk_split_best(m, q, T, d, i, s) : MaxAcc();
   const MaxAcc hE = q.e_ok(i, d) ? cyk_item_best(m, q, T, d, i, s) : MaxAcc();
   cyk_target_u(m, q, T, R, c, d, i, s, hB, hE);
+}
+
+// The record of band target (e, d, i, s) from the finished table: the candidates of the sweep in the sweep's order, hence the
+// same winner.  Only a B or an E target walks its span-long list again (rule 2, rule 6c); the other planes take B's value from
+// the table.
+ELEMDP_HD TraceRec cyk_retrace(const ModelView& m, const SeqView& q, const TableView& T, const Constraint& c, int e, int d, int i,
+                               int s) {
+  MaxAcc hB, hE;
+  if (q.left_ok(i, d)) {
+    if (e == ST_B) hB = cyk_split_best(m, q, T, d, i, s);
+    else hB.best = T.at(ST_B, d, i, s);
+  }
+  if (e == ST_E && q.e_ok(i, d)) hE = cyk_item_best(m, q, T, d, i, s);
+  TraceRec rec[kNumBandStates];
+  TraceView R1;
+  R1.ext = nullptr;
+  R1.one = rec;
+  cyk_target_u(m, q, T, R1, c, d, i, s, hB, hE);
+  return rec[e];
 }
 
 ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
@@ -227,8 +247,8 @@ ELEMDP_HD void fill_letters(char* rss, int from, int n, int code) {
 // Walks the trace from O(L, s0) and writes the motif node per position (`path`, psihat) and the
 // structure letters (`rss`: O L R H B I M, blank where nothing was written).  `stack` is caller
 // scratch; returns false on overflow.
-ELEMDP_HD bool trace_back(const ModelView& m, const TableView& T, const TraceView& R, int L, int s0, int32_t* path,
-                          char* rss, TraceFrame* stack, int cap) {
+ELEMDP_HD bool trace_back(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R, const Constraint& c, int L,
+                          int s0, int32_t* path, char* rss, TraceFrame* stack, int cap) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
   const int32_t* G = m.big;
@@ -244,7 +264,7 @@ ELEMDP_HD bool trace_back(const ModelView& m, const TableView& T, const TraceVie
   auto fill = [&](int from, int n, int code) { fill_letters(rss, from, n, code); };
   while (top > 0) {
     const TraceFrame f = stack[--top];
-    const TraceRec t = (f.e == ST_O) ? R.ext[(size_t)f.j * T.S + f.s] : R.band[T.idx(f.e, f.j - f.i, f.i, f.s)];
+    const TraceRec t = (f.e == ST_O) ? R.ext[(size_t)f.j * T.S + f.s] : cyk_retrace(m, q, T, c, f.e, f.j - f.i, f.i, f.s);
     if (t.t < 0) continue;  // leaf
     if (top + 3 > cap) return false;
     const int s1 = t.s1;

@@ -594,8 +594,8 @@ int emu_scan_seq(void* h, const double* x, const uint8_t* seq, int L, const uint
     run_outside<OUT_END>(m, q, in, out, ZeL, c1, s2, true, true);
     int Ye = last_argmax(Pye.data(), L + 1);
     // Viterbi parse (:172-184, 262-362)
-    std::vector<TraceRec> tr((size_t)7 * (P.W + 1) * (L + 1) * S), tro((size_t)(L + 1) * S);
-    TraceView tv{tr.data(), tro.data()};
+    std::vector<TraceRec> tro((size_t)(L + 1) * S);
+    TraceView tv{tro.data()};
     Constraint c2{Ys, Ye, 1};
     for (int d = 0; d <= q.W; ++d)
       for (int i = 0; i + d <= q.L; ++i)
@@ -607,7 +607,7 @@ int emu_scan_seq(void* h, const double* x, const uint8_t* seq, int L, const uint
     std::string r(L, ' ');
     std::vector<TraceFrame> stack((size_t)4 * (L + 2));
     int s0 = in.v.o(L, m.lay.s0m2) < in.v.o(L, m.lay.s0m1) ? m.lay.s0m1 : m.lay.s0m2;
-    trace_back(m, in.v, tv, L, s0, path.data(), &r[0], stack.data(), (int)stack.size());
+    trace_back(m, q, in.v, tv, c2, L, s0, path.data(), &r[0], stack.data(), (int)stack.size());
     double tot = NEG;
     for (double v : Pys) tot = lse2(tot, v);
     out6[0] = Ys; out6[1] = Ye; out6[2] = std::exp(tot); out6[3] = ZL; out6[4] = ZeL; out6[5] = PyNL;
@@ -718,8 +718,8 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
     const int Ye = last_argmax(lPye.data(), L + 1);
     // K6: Viterbi parse in log space (scan_rules.h)
     Tab cyk(L, P.W, S);
-    std::vector<TraceRec> tr((size_t)7 * (P.W + 1) * (L + 1) * S), tro((size_t)(L + 1) * S);
-    TraceView tv{tr.data(), tro.data()};
+    std::vector<TraceRec> tro((size_t)(L + 1) * S);
+    TraceView tv{tro.data()};
     Constraint c2{Ys, Ye, 1};
     for (int d = 0; d <= q.W; ++d)
       for (int i = 0; i + d <= q.L; ++i)
@@ -731,7 +731,7 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
     std::string r(L, ' ');
     std::vector<TraceFrame> stack((size_t)4 * (L + 2));
     int s0 = cyk.v.o(L, m.lay.s0m2) < cyk.v.o(L, m.lay.s0m1) ? m.lay.s0m1 : m.lay.s0m2;
-    trace_back(m, cyk.v, tv, L, s0, path.data(), &r[0], stack.data(), (int)stack.size());
+    trace_back(m, q, cyk.v, tv, c2, L, s0, path.data(), &r[0], stack.data(), (int)stack.size());
     double tot = 0.;
     for (double v : Pys) tot += v;
     out6[0] = Ys; out6[1] = Ye; out6[2] = tot; out6[3] = tolog(ZLm) - sl * ln2; out6[4] = tolog(ZeLm) - sl * ln2; out6[5] = PyNL;

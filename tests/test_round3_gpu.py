@@ -141,6 +141,38 @@ def test_table_driven_train_kernels_equal_the_generic_ones():
         assert r[2] == res[(0, 0)][2] and r[3] == res[(0, 0)][3]
 
 
+@pytest.mark.parametrize("pattern", ["((.*.))", "(.....)", ".(.).", "(.(.).)"])
+def test_table_driven_scan_passes_equal_the_generic_ones(pattern):
+    """The scan's four sum passes on the table-driven kernels (scanner node tests as ScanFlag words, lin_fast.h) against the
+    generic rule code (option fast = 0; pinned to the oracle by tests/emul and tests/test_gpu_parity.py): posteriors of start,
+    inner and end positions, Ys / Ye, the parse and E[N] on a ragged batch with masked positions."""
+    seqs, quals = [], []
+    for L, n in ((35, 4), (180, 6), (97, 5), (64, 5)):
+        s_, q_ = synth.synth_batch(n, L, seed=900 + L)
+        seqs += s_
+        quals += q_
+    for k in range(0, len(quals), 3):
+        quals[k][len(quals[k]) // 2] = 5
+    out = {}
+    for fast in (0, 1):
+        eng = api.Engine(pattern, "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+        eng.set_option("fast", fast)
+        eng.load_batch(seqs, quals)
+        x = eng.initial_params(0.7)
+        x[:-2] += np.linspace(-0.4, 0.4, len(x) - 2)
+        out[fast] = eng.scan(x)
+    (r0, en0), (r1, en1) = out[0], out[1]
+    np.testing.assert_allclose(en1, en0, rtol=1e-9, atol=1e-12)
+    for a_, b_ in zip(r0, r1):
+        assert (a_["Ys"], a_["Ye"]) == (b_["Ys"], b_["Ye"])
+        assert a_["rss"] == b_["rss"] and np.array_equal(a_["psihat"], b_["psihat"])
+        assert b_["exist_prob"] == pytest.approx(a_["exist_prob"], rel=1e-9)
+        for key in ("start", "inner", "end"):
+            fa, fb = np.isfinite(a_[key]), np.isfinite(b_[key])
+            assert np.array_equal(fa, fb), key
+            np.testing.assert_allclose(b_[key][fb], a_[key][fa], rtol=1e-8, atol=1e-9, err_msg=key)
+
+
 def test_in_library_collective_with_two_ranks(tmp_path):
     """elemdp_comm_init(rank, 2, id) + elemdp_train_eval on two GPUs, one process each (tests/two_rank_worker.py): the batch is
     sharded by assigned_range, every rank's evaluation all-reduces the partial vector (ncclAllReduce on the engine's stream,
