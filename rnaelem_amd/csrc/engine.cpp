@@ -244,8 +244,8 @@ class Engine {
   void run_train(bool first_pass_only);
   void run_train_batch();
   void run_lin_batch();
-  int prepare_lin(LinArgs& a, bool sched1, bool dense_too = false);
-  int balanced_group(size_t per_slot_bytes);
+  int prepare_lin(LinArgs& a, bool sched1, bool dense_too = false, int n_eval = 0);
+  int balanced_group(size_t per_slot_bytes, int n = 0);
   int group_cap_ = 8192;   // most sequences swept in lockstep (a first scan uses fewer: fresh table memory costs ~20 ms / GB)
   TrArgs log_pipeline_args();
   void init_device();
@@ -1231,7 +1231,8 @@ void Engine::stream_scan(const double* x, int n_param_in, elemdp_scan_out* out) 
 
 // Sequences swept in lockstep: as many as fit in ~55 % of the free device memory (at most 8192), then balanced so that all
 // groups of the batch have the same size (a small last group runs at lower efficiency).
-int Engine::balanced_group(size_t per_slot_bytes) {
+int Engine::balanced_group(size_t per_slot_bytes, int n) {
+  if (n <= 0) n = n_seq_;
   if (opt_group_ > 0) return opt_group_;
   size_t free_b = 0, total_b = 0;
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
@@ -1240,8 +1241,8 @@ int Engine::balanced_group(size_t per_slot_bytes) {
   if (slot_budget_ > 0) budget = std::min(budget, slot_budget_);
   long cap = (long)(budget / std::max<size_t>(per_slot_bytes, 1));
   cap = std::max(1L, std::min(cap, (long)group_cap_));
-  const long n_groups = (n_seq_ + cap - 1) / cap;
-  return (int)((n_seq_ + n_groups - 1) / n_groups);
+  const long n_groups = (n + cap - 1) / cap;
+  return (int)((n + n_groups - 1) / n_groups);
 }
 
 TrArgs Engine::log_pipeline_args() {
@@ -1320,7 +1321,7 @@ void Engine::lin_weights(int first, int count) {
   HIP_OK(launch_lin_weights(w, st_));
 }
 
-int Engine::prepare_lin(LinArgs& a, bool sched1, bool dense_too) {
+int Engine::prepare_lin(LinArgs& a, bool sched1, bool dense_too, int n_eval) {
   // schedule 1 sweeps the automaton with the shadow copy of (0,0) (one state more per table row); the scan and schedule 0
   // the plain one.  The slots are sized for the wider row.
   const bool shadow = sched1 && lays_.shadow >= 0;
@@ -1329,16 +1330,18 @@ int Engine::prepare_lin(LinArgs& a, bool sched1, bool dense_too) {
   // compact band tables (AutomatonLayout::tab_row doubles per cell); the scan's Viterbi pass sweeps dense tables over the
   // same slots (dense_too)
   const int row = std::max(std::max(lay_.tab_row, lays_.tab_row), dense_too ? kNumBandStates * lay_.S : 0);
+  // (an evaluation of a range of the resident batch -- options eval_first / eval_count -- needs slots for that range only)
+  const int n_need = n_eval > 0 ? std::min(n_eval, n_seq_) : n_seq_;
   {
     const size_t cells = (size_t)(Wmax_ + 1) * (Lmax_ + 1), ext = (size_t)(Lmax_ + 1);
     slot_override_ = balanced_group((cells * row + ext * Sa) * 2 * sizeof(double) + ext * Sa * 3 * sizeof(double) +
-                                    cells * nap * 2 * sizeof(double));
+                                    cells * nap * 2 * sizeof(double), n_need);
   }
-  ensure_slots(Sa, false, n_seq_, row);
+  ensure_slots(Sa, false, n_need, row);
   slot_override_ = 0;
   // (if the allocation had to shrink, rebalance for the slots we got)
-  const int n_groups = (n_seq_ + n_slots_ - 1) / n_slots_;
-  const int gsz = (n_seq_ + n_groups - 1) / n_groups;
+  const int n_groups = (n_need + n_slots_ - 1) / n_slots_;
+  const int gsz = (n_need + n_groups - 1) / n_groups;
   if (lin_slots_ != n_slots_) {
     d_zs_.alloc(sizeof(double) * 4 * n_slots_);
     const size_t acell = (size_t)(Wmax_ + 1) * (Lmax_ + 1);
@@ -1395,11 +1398,11 @@ int Engine::prepare_lin(LinArgs& a, bool sched1, bool dense_too) {
 void Engine::run_lin_batch() {
   const bool sched1 = opt_schedule_ == 1 && linear_ok_ && !opt_first_pass_only_ && lay_.s00 == 0 && lays_.shadow >= 0;
   LinArgs a;
-  int gsz = prepare_lin(a, sched1);
   // the records this evaluation covers (options eval_first / eval_count), in processing order (longest first)
   const bool ranged = opt_eval_count_ > 0 && !(opt_eval_first_ == 0 && opt_eval_count_ == n_seq_);
   const int r0 = ranged ? opt_eval_first_ : 0, n_ev = ranged ? opt_eval_count_ : n_seq_;
   if (r0 < 0 || n_ev <= 0 || r0 + n_ev > n_seq_) throw ArgError("eval_first / eval_count outside the resident batch");
+  int gsz = prepare_lin(a, sched1, false, n_ev);
   const int32_t* h_ord = h_order_.data();
   const int32_t* d_ord = d_order_.as<int32_t>();
   const SeqPlan* d_sorted = d_plans_sorted_.as<SeqPlan>();
