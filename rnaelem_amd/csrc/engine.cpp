@@ -177,6 +177,8 @@ struct PlanSet {
       item_in, idx_inner, idx_left, idx_right, items_inner, items_left, items_right;
   bool permuted = false;   // keep item copies in the secondary orders (resident plan of the train pipeline)
   bool inner_only = false; // build only the by_inner order (the BPP filter needs no outside values of loop cells)
+  bool sorted = true;      // the segments of the role lists are sorted by item index (Engine::ensure_sorted_plan)
+  PlanKernelArgs ka;       // the arguments the set was built with (for the sort, should a later evaluation want it)
   int64_t n_items = 0;
   PlanArrays arrays() const {
     PlanArrays a;
@@ -235,6 +237,7 @@ class Engine {
   void set_theta_from(const double* x);  // host: theta (log-softmax of x when theta-softmax)
  private:
   void build_planset(PlanSet& ps, int first, int count, const uint32_t* d_okbits);
+  void ensure_sorted_plan();
   LdsLayout lds_layout(const AutomatonLayout& lay, int Lmax, int nword_max, bool scan) const;
   DpArgs base_args(const AutomatonLayout& lay, const int32_t* d_ints, const double* d_params, const PlanSet& ps,
                    const uint32_t* d_okbits, int S);
@@ -364,6 +367,7 @@ class Engine {
   bool opt_profile_ = false;
   // 4 = scaled-linear batch pipeline (lin_kernels.hip), 3 = log-space batch pipeline, 2 = fused one-workgroup-per-sequence kernel
   int opt_pipeline_ = 4;
+  bool opt_sorted_plan_ = false;   // option "sorted_plan": sort the role lists at load_batch whatever the pipeline
   // scaled-linear pipeline
   AutomatonLayout lays_;                 // the automaton with the shadow copy of (0,0): both outside passes in one sweep
   std::vector<int32_t> intss_;
@@ -548,6 +552,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "poison") opt_poison_ = v != 0;
   else if (key == "fast") opt_fast_ = v != 0;
   else if (key == "deterministic") opt_det_ = v != 0;
+  else if (key == "sorted_plan") opt_sorted_plan_ = v != 0;
   else if (key == "eval_first") opt_eval_first_ = (int)v;
   else if (key == "eval_count") opt_eval_count_ = (int)v;
   else if (key == "prune" || key == "row_pad") {
@@ -695,9 +700,23 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   if (ps.permuted) for (DevBuf* b : {&ps.items_inner, &ps.items_left, &ps.items_right}) b->alloc(sizeof(LoopItem) * (ib + 1), true);
   a.plans = ps.d_plans.as<SeqPlan>();
   a.p = ps.arrays();
+  // The scaled-linear pipeline adds over the role lists with atomics: their order inside a segment is immaterial, and the sort
+  // is a quarter of the plan builder.  The log-space pipeline and the deterministic mode get it (here, or later through
+  // ensure_sorted_plan when the option arrives after the batch).
+  a.sort_roles = (ps.inner_only || opt_det_ || opt_pipeline_ != 4 || opt_sorted_plan_) ? 1 : 0;
   HIP_OK(launch_plan_items(a, st_));
   if (ps.permuted) HIP_OK(launch_permute_items(a, st_));
   HIP_OK(hipStreamSynchronize(st_));
+  ps.sorted = a.sort_roles != 0;
+  ps.ka = a;
+}
+
+void Engine::ensure_sorted_plan() {
+  if (plan_.sorted || plan_.count <= 0) return;
+  HIP_OK(launch_plan_sort(plan_.ka, st_));
+  if (plan_.permuted) HIP_OK(launch_permute_items(plan_.ka, st_));
+  HIP_OK(hipStreamSynchronize(st_));
+  plan_.sorted = true;
 }
 
 void Engine::ensure_slots(int S, bool scan, int n_want, int row) {
@@ -1500,6 +1519,7 @@ void Engine::run_train(bool) {
   // pipeline 4 (default): the scaled-linear batch pipeline (lin_kernels.hip), which hands sequences outside the double range to
   // pipeline 3, the log-space batch pipeline (train_kernels.hip).  (Pipeline 2, the fused per-sequence kernel of round 1, is
   // retired for training; its scan schedule stays as the scan's range fallback.)
+  if (opt_pipeline_ == 3 || opt_det_) ensure_sorted_plan();
   if (opt_pipeline_ == 3) { run_train_batch(); return; }
   run_lin_batch();
 }

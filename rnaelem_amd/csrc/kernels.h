@@ -45,6 +45,7 @@ struct PlanKernelArgs {
   int32_t ncell_max = 0, nword_max = 0, nitems_max = 0, lmax = 0;   // largest sequence of the set (grid sizes)
   int32_t wmax1 = 0;     // largest W + 1 of the set
   int32_t n_roles = 3;   // 1: only the by_inner order (plan of the BPP filter)
+  int32_t sort_roles = 1;   // sort every segment of the role lists by item index (reproducible summation order of the gathers)
 };
 
 // byte offsets of the dynamic LDS regions of the DP kernels
@@ -211,6 +212,7 @@ hipError_t launch_mask(const BatchArrays& b, const SeqPlan* plans, int n_seq, in
                        int32_t* n_canonical, hipStream_t st);
 hipError_t launch_plan_cells(const PlanKernelArgs& a, int32_t* n_items_out, hipStream_t st);
 hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st);
+hipError_t launch_plan_sort(const PlanKernelArgs& a, hipStream_t st);   // the sort of launch_plan_items alone (sort_roles = 0 before)
 hipError_t launch_permute_items(const PlanKernelArgs& a, hipStream_t st);
 hipError_t launch_dp(int kind, const DpArgs& a, int n_blocks, hipStream_t st);
 hipError_t launch_reduce(const double* seq_out, int out_stride, int n_seq, int n_theta, double* partial, hipStream_t st);

@@ -679,8 +679,6 @@ hipError_t launch_permute_items(const PlanKernelArgs& a, hipStream_t st) {
 hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
   if (a.count <= 0) return hipSuccess;
   const dim3 cells((a.ncell_max + 1 + kThreads - 1) / kThreads, a.count), items((a.nitems_max + kThreads - 1) / kThreads, a.count);
-  const dim3 rows(a.lmax + 1, a.count);
-  const bool narrow = a.wmax1 <= 64 && a.nitems_max < (1 << 26);   // 32-bit sort keys (cell << 26 | item)
   hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, -1);
   hipLaunchKernelGGL(k_plan_fill, cells, dim3(kThreads), 0, st, a);
   for (int role = 0; role < a.n_roles; ++role) {
@@ -688,6 +686,17 @@ hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
     if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_count, items, dim3(kThreads), 0, st, a, role);
     hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, role);
     if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_scatter, items, dim3(kThreads), 0, st, a, role);
+  }
+  if (a.sort_roles) return launch_plan_sort(a, st);
+  return hipGetLastError();
+}
+// The scatter leaves the segments of the role lists in arbitrary order.  Sums over them through atomic adds (the scaled-linear
+// pipeline) do not care; the gathers of the log-space pipeline and the deterministic mode want a fixed order.
+hipError_t launch_plan_sort(const PlanKernelArgs& a, hipStream_t st) {
+  if (a.count <= 0 || a.nitems_max <= 0) return hipSuccess;
+  const dim3 rows(a.lmax + 1, a.count);
+  const bool narrow = a.wmax1 <= 64 && a.nitems_max < (1 << 26);   // 32-bit sort keys (cell << 26 | item)
+  for (int role = 0; role < a.n_roles; ++role) {
     if (narrow) {
       hipLaunchKernelGGL((k_role_sort<512, 0, uint32_t>), rows, dim3(kThreads), 0, st, a, role);
       hipLaunchKernelGGL((k_role_sort<2048, 512, uint32_t>), rows, dim3(kThreads), 0, st, a, role);

@@ -32,6 +32,10 @@
 #ifndef ELEMDP_LB_OUT
 #define ELEMDP_LB_OUT 4
 #endif
+// workgroup size of the band kernels (k4_in, k4_out, k5_cyk) and of the helpers they share
+#ifndef ELEMDP_BAND_THREADS
+#define ELEMDP_BAND_THREADS 256
+#endif
 #ifndef ELEMDP_CPB_MAX
 #define ELEMDP_CPB_MAX 64
 #endif
@@ -52,6 +56,8 @@
 
 namespace elemdp {
 namespace {
+constexpr int kBT = ELEMDP_BAND_THREADS;   // threads of a band-kernel workgroup
+constexpr int kWaves = kBT / 64;
 
 // q / n for small non-negative q (< 2^20) and n > 0 through the single-precision reciprocal: (q + 1/2) * rcp(n) is off by less than
 // 1 / (2 n) from the true quotient plus 1/(2n), so the truncation is exact.  An integer division by a run-time divisor costs ~30
@@ -354,7 +360,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   int r_sm[kU], r_bg[kU];
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
-    const int t = tid + u * kThreads;
+    const int t = tid + u * kBT;
     r_sm[u] = a.ints[t < n_sm ? t : 0];
     r_bg[u] = a.ints[t < n_bg ? big_lo + t : 0];
   }
@@ -369,7 +375,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
   const int16_t r_dm = v.q.dmin[i0 + (tid < nc ? tid : 0)];
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
-    const int t = tid + u * kThreads;
+    const int t = tid + u * kBT;
     if (t < n_sm) blob[t] = r_sm[u];
     if (t < n_bg) blob[big_at + t] = r_bg[u];
   }
@@ -383,12 +389,12 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
     lseq[tid] = (pw < L) ? r_seq : (uint8_t)0;
   }
   // (larger automata / windows than the unrolled part covers)
-  for (int t = tid + kU * kThreads; t < n_sm; t += kThreads) blob[t] = a.ints[t];
-  for (int t = tid + kU * kThreads; t < n_bg; t += kThreads) blob[big_at + t] = a.ints[big_lo + t];
-  for (int t = tid + kThreads; t < n_lin; t += kThreads) llin[t] = a.lin[t];
-  for (int t = tid + kThreads; t < w1 - w0; t += kThreads) lbits[t] = (w0 + t < wend) ? v.q.okbits[w0 + t] : 0u;
-  if (PART == 0) for (int t = tid + kThreads; t < e1 - e0; t += kThreads) lbits2[t] = (e0 + t < wend) ? v.q.okbits_end[e0 + t] : 0u;
-  for (int t = tid + kThreads; t < len; t += kThreads) {
+  for (int t = tid + kU * kBT; t < n_sm; t += kBT) blob[t] = a.ints[t];
+  for (int t = tid + kU * kBT; t < n_bg; t += kBT) blob[big_at + t] = a.ints[big_lo + t];
+  for (int t = tid + kBT; t < n_lin; t += kBT) llin[t] = a.lin[t];
+  for (int t = tid + kBT; t < w1 - w0; t += kBT) lbits[t] = (w0 + t < wend) ? v.q.okbits[w0 + t] : 0u;
+  if (PART == 0) for (int t = tid + kBT; t < e1 - e0; t += kBT) lbits2[t] = (e0 + t < wend) ? v.q.okbits_end[e0 + t] : 0u;
+  for (int t = tid + kBT; t < len; t += kBT) {
     const int p = p0 + t;
     lews[t] = v.q.ews[p];
     ldmin[t] = v.q.dmin[p];
@@ -436,7 +442,7 @@ __device__ __forceinline__ StageMap stage_map(int n_front, int S, int cpb, int n
   StageMap m;
   m.NU = n_front;
   m.CU = cpb * n_front;
-  m.nsub = kThreads / m.CU;            // >= 1: cpb * S <= kThreads
+  m.nsub = kBT / m.CU;            // >= 1: cpb * S <= kBT
   m.sub = tid / m.CU;
   m.r = tid - m.sub * m.CU;
   m.cell = m.r / n_front;
@@ -463,25 +469,25 @@ template <class RangeFn, class F1, class F2, class F3, class F4>
 __device__ __forceinline__ void for_block_items(int nv, int nq, int tid, int* cnts, int* pre, int* base, RangeFn range,
                                                 F1 load_index, F2 load_item, F3 load_operands, F4 finish) {
   // nv "virtual cells" (cell x role), each with one CSR range
-  for (int vc = tid; vc < nv; vc += kThreads) {
+  for (int vc = tid; vc < nv; vc += kBT) {
     int c0 = 0, c1 = 0;
     range(vc, c0, c1);
     base[vc] = c0;
     cnts[vc] = (c1 > c0) ? c1 - c0 : 0;
   }
   __syncthreads();
-  for (int vc = tid; vc <= nv; vc += kThreads) {
+  for (int vc = tid; vc <= nv; vc += kBT) {
     int p = 0;
     for (int c = 0; c < vc; ++c) p += cnts[c];
     pre[vc] = p;
   }
   __syncthreads();
   const int total = pre[nv] * nq;
-  for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
+  for (int w0 = tid; w0 < total; w0 += kItemBatch * kBT) {
     ItemSlot sl[kItemBatch];
 #pragma unroll
     for (int u = 0; u < kItemBatch; ++u) {
-      const int w = w0 + u * kThreads;
+      const int w = w0 + u * kBT;
       sl[u].ok = w < total;
       const int wc = sl[u].ok ? w : total - 1;
       const int il = wc / nq;
@@ -508,7 +514,7 @@ __device__ __forceinline__ void for_block_items(int nv, int nq, int tid, int* cn
 
 // (record, tuple) of the work item w = x * nq + t without a division per work item: the kernels are bound by instruction
 // issue (SQ counters: the waves of a SIMD are active ~95 % of the time between them), and an integer division is ~25
-// instructions.  `step` advances by kThreads work items; q256 = kThreads / nq, r256 = kThreads % nq.
+// instructions.  `step` advances by kBT work items; q256 = kBT / nq, r256 = kBT % nq.
 struct WorkIdx {
   int x, t;
   __device__ __forceinline__ void step(int q256, int r256, int nq) {
@@ -564,7 +570,7 @@ __device__ __forceinline__ OuterRecs outer_recs(double* area, int n_doubles) {
 // (two halves: the CSR loads are issued before the pair phase of the kernel, whose own loads they travel with; the prefix
 // follows behind the barrier that ends the pair phase)
 __device__ __forceinline__ void outer_ranges_load(const LViews& v, int i0, int nc, int d, bool on, int tid, int* cnts, int* base) {
-  for (int c = tid; c < nc; c += kThreads) {
+  for (int c = tid; c < nc; c += kBT) {
     const int i = i0 + c;
     int n0 = 0, n1 = 0;
     if (on && v.q.e_ok(i, d)) { const int cell = v.q.cell(i, d); n0 = v.q.by_outer_off[cell]; n1 = v.q.by_outer_off[cell + 1]; }
@@ -573,7 +579,7 @@ __device__ __forceinline__ void outer_ranges_load(const LViews& v, int i0, int n
   }
 }
 __device__ __forceinline__ int outer_ranges_prefix(int nc, int tid, const int* cnts, int* pre) {
-  for (int c = tid; c <= nc; c += kThreads) {
+  for (int c = tid; c <= nc; c += kBT) {
     int p = 0;
     for (int k = 0; k < c; ++k) p += cnts[k];
     pre[c] = p;
@@ -584,7 +590,7 @@ __device__ __forceinline__ int outer_ranges_prefix(int nc, int tid, const int* c
 __device__ __forceinline__ int outer_ranges(const LViews& v, int i0, int nc, int d, bool on, int tid, int* cnts, int* pre, int* base) {
   outer_ranges_load(v, i0, nc, d, on, tid, cnts, base);
   __syncthreads();
-  for (int c = tid; c <= nc; c += kThreads) {
+  for (int c = tid; c <= nc; c += kBT) {
     int p = 0;
     for (int k = 0; k < c; ++k) p += cnts[k];
     pre[c] = p;
@@ -621,7 +627,7 @@ __device__ __forceinline__ RecAhead outer_fetch_ahead(const LViews& v, int n_rec
 template <bool WEIGHTS, bool AHEAD = false>
 __device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r, int p0, int np, int nc, int tid, const int* pre,
                                             const int* base, const RecAhead ahead = RecAhead{LoopItem{0., 0, 0, 0, 0}, 0, false}) {
-  for (int x = tid; x < np; x += kThreads) {
+  for (int x = tid; x < np; x += kBT) {
     const int p = p0 + x;
     LoopItem itv;
     int meta;
@@ -646,7 +652,7 @@ __device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r,
 
 // FAST: table-driven phases (lin_fast.h; train schedule, the fast blob staged); FP: longest pair list of a state (2 or 3)
 template <bool BIG, bool CON, bool FAST = false, int FP = kFastP>
-__global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
+__global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
   PhaseClock pc;
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
   const int CS = cpb * S, ncS = nc * S;
-  const int NW = a.det ? kThreads / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the heavy sums (one per wave: rep_sum)
+  const int NW = a.det ? kBT / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the heavy sums (one per wave: rep_sum)
   double* hb = lds;
   double* he = hb + CS;
   double* hbA = hb + wvd * 2 * CS;           // ... the copy this lane adds to
@@ -672,14 +678,14 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   const BlockLds BL = block_lds(NW * 2 * CS + kRecIn, cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, FAST ? kCellInD : 0);
   // cell records of the table-driven unary phase: the exponentiated structural terms of the cells are fetched with the context
   // (lane = (cell, value); the addresses depend on the plan record only), the flags follow once the context is in LDS
-  constexpr int kCRin = (ELEMDP_CPB_MAX * 8 + kThreads - 1) / kThreads;
+  constexpr int kCRin = (ELEMDP_CPB_MAX * 8 + kBT - 1) / kBT;
   double crx[kCRin];
   if (FAST) {
 #pragma unroll
     for (int r = 0; r < kCRin; ++r) {
       crx[r] = 0.;
-      if (r * kThreads < cpb * 8) {   // (uniform: most automata need the first round only)
-        const int t = tid + r * kThreads, c = (t >> 3) < nc ? (t >> 3) : 0;
+      if (r * kBT < cpb * 8) {   // (uniform: most automata need the first round only)
+        const int t = tid + r * kBT, c = (t >> 3) < nc ? (t >> 3) : 0;
         crx[r] = cell_in_fetch(v.q, d, i0 + c, t & 7);
       }
     }
@@ -689,19 +695,19 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   const int32_t* G = v.m.big;
   double* crec = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
   int* crfl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
-  for (int t = tid; t < NW * 2 * CS; t += kThreads) lds[t] = 0.;
+  for (int t = tid; t < NW * 2 * CS; t += kBT) lds[t] = 0.;
   __syncthreads();
   pc.mark<0>();
   if (FAST) {   // (read by the unary phase, behind the barriers of the heavy sums)
 #pragma unroll
     for (int r = 0; r < kCRin; ++r) {
-      const int t = tid + r * kThreads, c = t >> 3, k = t & 7;
+      const int t = tid + r * kBT, c = t >> 3, k = t & 7;
       if (c < nc) {
         const bool on = k < 4 ? v.q.pair_ok(i0 + c, d) : v.q.e_ok(i0 + c, d);
         crec[c * kCellInD + 2 + k] = on ? crx[r] : 0.;
       }
     }
-    for (int c = tid; c < nc; c += kThreads) {
+    for (int c = tid; c < nc; c += kBT) {
       const int i = i0 + c, j = i + d;
       int fl = cell_in_flags(v.m, v.q, d, i);
       if (CON) { const int ys = a.ys[v.n]; fl |= (i == ys ? CF_YL : 0) | (j - 1 == ys ? CF_YR : 0); }
@@ -731,7 +737,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
     const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
     const int W1 = v.q.W + 1;
     const int nwork = ((a.dbg & 1) || (ELEMDP_KO & 1)) ? 0 : nc * nA;
-    for (int w = tid; w < nwork; w += kThreads) {
+    for (int w = tid; w < nwork; w += kBT) {
       const int c = div_small(w, nA), p = w - c * nA;
       const int i = i0 + c, j = i + d;
       if (FAST) {   // the same sums from the pair record (AutomatonLayout::fpr_in): columns, chain entries with their weight ids
@@ -869,12 +875,12 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k4_in(LinArgs a) {
         const uint32_t rP = v.in.cidx(ST_P, it.l - it.k, it.k, 0), rL1 = v.in.cidx(ST_L, it.k - i, i, 0), rL2 = v.in.cidx(ST_L, j - it.l, it.l, 0);
         const double xw0 = R.xw[xc], xw1 = R.xw[R.cap + xc];
         double* hrow = heA + c * S;
-        for (int t0 = wv; t0 < nq; t0 += 4 * kTU) {
+        for (int t0 = wv; t0 < nq; t0 += kWaves * kTU) {
           int qa[kTU], qb[kTU];
           double x0[kTU], x1[kTU], x2[kTU];
 #pragma unroll
           for (int u = 0; u < kTU; ++u) {
-            const int t = t0 + 4 * u;
+            const int t = t0 + kWaves * u;
             const bool on = t < nq;
             qa[u] = G[qc_in + 2 * (on ? t : wv)];
             qb[u] = on ? G[qc_in + 2 * (on ? t : wv) + 1] : (4 << 16);
@@ -1220,7 +1226,7 @@ __global__ __launch_bounds__(kThreads) void k4_r7(LinArgs a) {
 
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
 template <int MODE, bool BIG, bool FAST = false, int FP = kFastP>
-__global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
+__global__ __launch_bounds__(kBT, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
   PhaseClock pc;
@@ -1239,7 +1245,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
   const int CS = cpb * S, ncS = nc * S;
-  const int NW = a.det ? kThreads / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the sums (one per wave: rep_sum)
+  const int NW = a.det ? kBT / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the sums (one per wave: rep_sum)
   const int HS = 4 * CS, ES = 2 * nt + 4;      // doubles of one copy of the heavy sums / of the statistics
   double* h1 = lds;                            // copy 0 (the unary phase adds the copies up)
   double* h2 = h1 + CS;
@@ -1256,14 +1262,14 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* sOB1 = l_pos + 2 * win;              // item records of the three roles (kRecOut doubles)
   const BlockLds BL = block_lds(out_doubles(CS, nt, cpb + a.wmax + 3, NW), cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * cpb, FAST ? kCellOutD : 0);
   // cell records of the table-driven unary phase (see k4_in): twelve global values per cell, fetched with the context
-  constexpr int kCRout = (ELEMDP_CPB_MAX * 12 + kThreads - 1) / kThreads;
+  constexpr int kCRout = (ELEMDP_CPB_MAX * 12 + kBT - 1) / kBT;
   double crx[kCRout];
   if (FAST) {
 #pragma unroll
     for (int r = 0; r < kCRout; ++r) {
       crx[r] = 0.;
-      if (r * kThreads < cpb * 12) {   // (uniform: most automata need the first round only)
-        const int t = tid + r * kThreads, c0 = t / 12, c = c0 < nc ? c0 : 0;
+      if (r * kBT < cpb * 12) {   // (uniform: most automata need the first round only)
+        const int t = tid + r * kBT, c0 = t / 12, c = c0 < nc ? c0 : 0;
         crx[r] = cell_out_fetch(v.q, d, i0 + c, t - c0 * 12);
       }
     }
@@ -1275,20 +1281,20 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   double* crec = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
   int* crfl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
   const int n_zero = NW * (HS + ES) + ((MODE == OUT_SCAN || MODE == OUT_END) ? 2 * win : 0);
-  for (int t = tid; t < n_zero; t += kThreads) lds[t] = 0.;
+  for (int t = tid; t < n_zero; t += kBT) lds[t] = 0.;
   __syncthreads();
   pc.mark<5>();
   if (FAST) {   // (read by the unary phase, behind the barriers of the heavy sums)
 #pragma unroll
     for (int r = 0; r < kCRout; ++r) {
-      const int t = tid + r * kThreads, c = t / 12, k = t - c * 12;
+      const int t = tid + r * kBT, c = t / 12, k = t - c * 12;
       if (c < nc) {
         const int i = i0 + c;
         const bool on = k < 4 ? v.q.e_ok(i, d) : k < 6 ? v.q.pair_ok(i, d) : k < 8 ? (v.q.pair_ok(i - 1, d + 2) && v.q.pair_ok(i, d)) : true;
         crec[c * kCellOutD + 2 + k] = on ? crx[r] : 0.;
       }
     }
-    for (int c = tid; c < nc; c += kThreads) {
+    for (int c = tid; c < nc; c += kBT) {
       const int i = i0 + c, j = i + d;
       int fl = cell_out_flags(v.m, v.q, d, i);
       if (MODE == OUT_END) { const int ys = a.ys[v.n]; fl |= (i - 1 == ys ? CF_YL : 0) | (j == ys ? CF_YR : 0) | (L == j + 1 ? CF_JLAST : 0); }
@@ -1311,7 +1317,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   const double* IB = in.band;
   const double* OB = out.band;
   // CSR ranges of the item sums of the three roles (consumed behind the pair phase, whose loads they travel with)
-  for (int vc = tid; vc < 3 * nc; vc += kThreads) {
+  for (int vc = tid; vc < 3 * nc; vc += kBT) {
     const int role = (vc >= nc) + (vc >= 2 * nc), c = vc - role * nc;
     const int i = i0 + c;
     const int cell = v.q.cell(i, d);
@@ -1328,7 +1334,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   // ... their prefix, and the first 256 item records fetched ahead: they arrive while the pair phases run
   // (off by default: two barriers more than the round trip saved, measured)
   __syncthreads();
-  for (int vc = tid; vc <= nv; vc += kThreads) {
+  for (int vc = tid; vc <= nv; vc += kBT) {
     int p = 0;
     for (int c = 0; c < vc; ++c) p += cnts[c];
     pre[vc] = p;
@@ -1374,7 +1380,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     auto ha_load = [&](int w0) {
 #pragma unroll
       for (int u = 0; u < kHA; ++u) {
-        const int w = w0 + u * kThreads;
+        const int w = w0 + u * kBT;
         const bool valid = w < total;
         const int sc = valid ? div_small(w, per) : 0, r = valid ? w - sc * per : 0;
         unsigned long long m = stems;
@@ -1397,7 +1403,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       }
     };
     if (total > 0) ha_load(tid);
-    for (int w = tid; w < nwork; w += kThreads) {
+    for (int w = tid; w < nwork; w += kBT) {
       const int c = div_small(w, nA), p = w - c * nA;
       const int i = i0 + c, j = i + d;
       const int s1 = pr_s1(p);
@@ -1449,7 +1455,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       }
     }
     if (total > 0) ha_add();
-    for (int w0 = tid + kHA * kThreads; w0 < total; w0 += kHA * kThreads) { ha_load(w0); ha_add(); }
+    for (int w0 = tid + kHA * kBT; w0 < total; w0 += kHA * kBT) { ha_load(w0); ha_add(); }
   }
   __syncthreads();
   pc.mark<6>();
@@ -1460,7 +1466,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   // then needs a single round of table loads, selected by role without branches.
   {
 #if !ELEMDP_AHEAD_OUT
-    for (int vc = tid; vc <= nv; vc += kThreads) {
+    for (int vc = tid; vc <= nv; vc += kBT) {
       int p = 0;
       for (int c = 0; c < vc; ++c) p += cnts[c];
       pre[vc] = p;
@@ -1478,7 +1484,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
     double ew[4] = {0., 0., 0., 0.};
     for (int p0 = 0; p0 < n_rec; p0 += cap) {
       const int np = (cap < n_rec - p0) ? cap : n_rec - p0;
-      for (int x = tid; x < np; x += kThreads) {
+      for (int x = tid; x < np; x += kBT) {
         const int p = p0 + x;
         LoopItem itv = ah_it;
         int meta = ah_meta;
@@ -1517,12 +1523,12 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
         const double xw0 = r_xw[xc], xw1 = r_xw[cap + xc];
         double* hrow = hpA + (role == 0 ? 0 : CS) + c * S;   // hp, or hl = hp + CS
         const int qc0 = (FAST ? A.fqc_out : A.qc_out1) + role * 2 * nq;
-        for (int t0 = wv; t0 < nq; t0 += 4 * kTU) {
+        for (int t0 = wv; t0 < nq; t0 += kWaves * kTU) {
           int qa[kTU], qb[kTU];
           double x0[kTU], x1[kTU], x2[kTU], aux[kTU];
 #pragma unroll
           for (int u = 0; u < kTU; ++u) {
-            const int t = t0 + 4 * u;
+            const int t = t0 + kWaves * u;
             const bool on = t < nq;
             qa[u] = G[qc0 + 2 * (on ? t : wv)];
             qb[u] = on ? G[qc0 + 2 * (on ? t : wv) + 1] : (4 << 16);
@@ -1585,7 +1591,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   if (!(a.dbg & 1) && !(a.dbg & 128) && !(ELEMDP_KO & 8)) {
     const int nA = A.n_ap;
     double* const en_keep = sink.en_;
-    for (int w = tid; w < nc * nA; w += kThreads) {
+    for (int w = tid; w < nc * nA; w += kBT) {
       const int c = div_small(w, nA), p = w - c * nA;
       if (FAST) {   // lin_outside_apair from the pair record (AutomatonLayout::fpr_out) and the weight tables
         const int32_t* PR = G + A.fpr_out + 8 * p;
@@ -1640,7 +1646,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   if (MODE == OUT_SCAN || MODE == OUT_END) {
     __syncthreads();
     const int p1 = (i0 + nc + d < L) ? i0 + nc + d : L;   // inclusive
-    for (int t = tid; t <= p1 - pos_p0; t += kThreads) {
+    for (int t = tid; t <= p1 - pos_p0; t += kBT) {
       const double v0 = l_pos[t], v1 = l_pos[win + t];
       if (MODE == OUT_SCAN) {
         if (v0 != 0. && pos_p0 + t < L) atomicAdd(&a.pos_start[v.seq_base + pos_p0 + t], v0);
@@ -1650,7 +1656,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       }
     }
   }
-  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en0, kThreads, (int)bx);
+  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_en0, kBT, (int)bx);
   pc.mark<12>();
   pc.finish();
 }
@@ -1731,7 +1737,7 @@ __global__ __launch_bounds__(kThreads) void k5_cyk_serial(LinArgs a) {
 // the traceback re-derives the winner of the targets it visits (scan_rules.h, cyk_retrace), so the maxima of the two span-long
 // candidate lists need no order bookkeeping here.
 template <bool BIG, int KOWN>
-__global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
+__global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
 
@@ -1750,13 +1756,13 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   unsigned long long* kb = reinterpret_cast<unsigned long long*>(lds);   // [CS] best key, rule 2
   unsigned long long* ke = kb + CS;                                      // [CS] best key, rule 6c
   double* st1 = lds + 2 * CS;                  // [KC][CU]  rows 1(i, i+a, front states)
-  double* st2 = st1 + kChunkIn * kThreads;     // [KC][CU]  rows 2(i+a, j, front states)
-  const BlockLds BL = block_lds(2 * CS + 2 * kChunkIn * kThreads, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
+  double* st2 = st1 + kChunkIn * kBT;     // [KC][CU]  rows 2(i+a, j, front states)
+  const BlockLds BL = block_lds(2 * CS + 2 * kChunkIn * kBT, cpb, kLinEth + a.lay.n_theta, cpb + a.wmax + 3, staged_ints(a.lay, a.n_stage, 0));
   const BlockCtx cx = stage_context<BIG, 0>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
   const unsigned long long kneg = cyk_key(NEG);
-  for (int t = tid; t < CS; t += kThreads) { kb[t] = kneg; ke[t] = kneg; }
+  for (int t = tid; t < CS; t += kBT) { kb[t] = kneg; ke[t] = kneg; }
   __syncthreads();
   // rule 2: candidates 1(i,i+a,s1) + 2(i+a,j,s2); a lane keeps the best of its tuples over the split points
   int a_lo = d;
@@ -1769,7 +1775,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   double pv[KOWN];
 #pragma unroll
   for (int r = 0; r < KOWN; ++r) {
-    const int w = tid + r * kThreads;
+    const int w = tid + r * kBT;
     po1[r] = -1; po2[r] = 0; pv[r] = NEG;
     if (w < nc * nsp) {
       const int c = w / nsp, t = w - c * nsp;
@@ -1808,7 +1814,7 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
 #pragma unroll
   for (int r = 0; r < KOWN; ++r)
     if (po1[r] >= 0 && pv[r] != NEG) {
-      const int w = tid + r * kThreads;
+      const int w = tid + r * kBT;
       const int c = w / nsp, t = w - c * nsp;
       atomicMax(&kb[c * S + G[A.split_tgt + t]], cyk_key(pv[r]));
     }
@@ -1817,21 +1823,21 @@ __global__ __launch_bounds__(kThreads, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   const int nq = A.n_quad;
   {
     const int n_rec = outer_ranges(v, i0, nc, d, true, tid, cnts, pre, base);
-    const OuterRecs R = outer_recs(st1, 2 * kChunkIn * kThreads);
+    const OuterRecs R = outer_recs(st1, 2 * kChunkIn * kBT);
     {
       for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
         const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
         outer_stage<false>(v, R, p0, np, nc, tid, pre, base);
         const int total = np * nq;
-        const int nqd = nq > 0 ? nq : 1, q256 = kThreads / nqd, r256 = kThreads % nqd;
+        const int nqd = nq > 0 ? nq : 1, q256 = kBT / nqd, r256 = kBT % nqd;
         WorkIdx wi{tid / nqd, tid % nqd};
-        for (int w0 = tid; w0 < total; w0 += kItemBatch * kThreads) {
+        for (int w0 = tid; w0 < total; w0 += kItemBatch * kBT) {
           double x0[kItemBatch], x1[kItemBatch], x2[kItemBatch], lt[kItemBatch];
           int hidx[kItemBatch];
           bool ok[kItemBatch];
 #pragma unroll
           for (int u = 0; u < kItemBatch; ++u) {
-            const int w = w0 + u * kThreads;
+            const int w = w0 + u * kBT;
             ok[u] = w < total;
             const int x = ok[u] ? wi.x : np - 1, t = ok[u] ? wi.t : nq - 1;
             wi.step(q256, r256, nqd);
@@ -1920,16 +1926,16 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   if (G <= 0) return hipSuccess;
   LinArgs a = full;
   const int S = a.lay.S, nt = a.lay.n_theta;
-  a.cpb = kThreads / S;
+  a.cpb = kBT / S;
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
   a.ext_ring = G <= 1024 ? 1 : 0;
   a.lmax = Lmax;
   a.n_lin = kLinEth + nt; a.fast = 0; a.det = 0;
-  const size_t lds = block_lds(2 * a.cpb * S + 2 * kChunkIn * kThreads, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
+  const size_t lds = block_lds(2 * a.cpb * S + 2 * kChunkIn * kBT, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const long long products = (long long)a.cpb * a.lay.n_split;   // (cell, tuple) products of a workgroup
-  const int kown = products <= 2 * kThreads ? 2 : products <= 4 * kThreads ? 4 : products <= 8 * kThreads ? 8 : 0;
+  const int kown = products <= 2 * kBT ? 2 : products <= 4 * kBT ? 4 : products <= 8 * kBT ? 8 : 0;
   const bool staged = big && kown > 0 && !(a.dbg & 8) && lds <= 64 * 1024;
   for (int d = 0; d <= Wmax; ++d) {
     const int ncell = Lmax - d + 1;
@@ -1937,9 +1943,9 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
     a.d = d;
     const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);
     if (!staged) hipLaunchKernelGGL(k5_cyk_serial, dim3((ncell * S + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
-    else if (kown == 2) hipLaunchKernelGGL((k5_cyk<true, 2>), grid, dim3(kThreads), lds, st, a);
-    else if (kown == 4) hipLaunchKernelGGL((k5_cyk<true, 4>), grid, dim3(kThreads), lds, st, a);
-    else hipLaunchKernelGGL((k5_cyk<true, 8>), grid, dim3(kThreads), lds, st, a);
+    else if (kown == 2) hipLaunchKernelGGL((k5_cyk<true, 2>), grid, dim3(kBT), lds, st, a);
+    else if (kown == 4) hipLaunchKernelGGL((k5_cyk<true, 4>), grid, dim3(kBT), lds, st, a);
+    else hipLaunchKernelGGL((k5_cyk<true, 8>), grid, dim3(kBT), lds, st, a);
   }
   hipLaunchKernelGGL(k5_cyk_ext, dim3(G), dim3(64), 0, st, a);
   return hipGetLastError();
@@ -1949,7 +1955,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   if (G <= 0) return hipSuccess;
   LinArgs a = full;
   const int S = a.lay.S, nt = a.lay.n_theta;
-  a.cpb = kThreads / S;
+  a.cpb = kBT / S;
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
   a.ext_ring = G <= 1024 ? 1 : 0;
@@ -1962,7 +1968,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   // table-driven unary phases as in launch_lin_group (the scanner's node tests are flag words of the fast blobs)
   const bool fast = a.fast && big && a.lay.fp_ok && !(a.dbg & 16) && a.lay.lin_total <= 2048;
   a.fast = fast ? 1 : 0;
-  if (fast) a.cpb = std::min(kThreads / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);
+  if (fast) a.cpb = std::min(kBT / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
   const bool fp2 = a.lay.fp_max_p <= 2;
   const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
@@ -1977,10 +1983,10 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       if (ncell <= 0) break;                                                                                                     \
       a.d = d;                                                                                                                   \
       const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
-      if (fast && fp2) hipLaunchKernelGGL((k4_in<true, CON, true, 2>), grid, dim3(kThreads), lds_in, st, a);                     \
-      else if (fast) hipLaunchKernelGGL((k4_in<true, CON, true>), grid, dim3(kThreads), lds_in, st, a);                          \
-      else if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kThreads), lds_in, st, a);                                 \
-      else hipLaunchKernelGGL((k4_in<false, CON>), grid, dim3(kThreads), lds_in, st, a);                                         \
+      if (fast && fp2) hipLaunchKernelGGL((k4_in<true, CON, true, 2>), grid, dim3(kBT), lds_in, st, a);                     \
+      else if (fast) hipLaunchKernelGGL((k4_in<true, CON, true>), grid, dim3(kBT), lds_in, st, a);                          \
+      else if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kBT), lds_in, st, a);                                 \
+      else hipLaunchKernelGGL((k4_in<false, CON>), grid, dim3(kBT), lds_in, st, a);                                         \
     }                                                                                                                            \
     if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, CON>), dim3(G), dim3(128), lds_ext_in, st, a);                            \
     else hipLaunchKernelGGL((k4_in_ext<false, CON>), dim3(G), dim3(128), 0, st, a);                                              \
@@ -1992,10 +1998,10 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       if (ncell <= 0) continue;                                                                                                  \
       a.d = d;                                                                                                                   \
       const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
-      if (fast && fp2) hipLaunchKernelGGL((k4_out<MODE, true, true, 2>), grid, dim3(kThreads), lds_out, st, a);                  \
-      else if (fast) hipLaunchKernelGGL((k4_out<MODE, true, true>), grid, dim3(kThreads), lds_out, st, a);                       \
-      else if (big) hipLaunchKernelGGL((k4_out<MODE, true>), grid, dim3(kThreads), lds_out, st, a);                              \
-      else hipLaunchKernelGGL((k4_out<MODE, false>), grid, dim3(kThreads), lds_out, st, a);                                      \
+      if (fast && fp2) hipLaunchKernelGGL((k4_out<MODE, true, true, 2>), grid, dim3(kBT), lds_out, st, a);                  \
+      else if (fast) hipLaunchKernelGGL((k4_out<MODE, true, true>), grid, dim3(kBT), lds_out, st, a);                       \
+      else if (big) hipLaunchKernelGGL((k4_out<MODE, true>), grid, dim3(kBT), lds_out, st, a);                              \
+      else hipLaunchKernelGGL((k4_out<MODE, false>), grid, dim3(kBT), lds_out, st, a);                                      \
     }                                                                                                                            \
   } while (0)
   if (phase == 0) {
@@ -2013,7 +2019,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   if (G <= 0) return hipSuccess;
   LinArgs a = full;
   const int S = a.lay.S, nt = a.lay.n_theta;
-  a.cpb = kThreads / S;
+  a.cpb = kBT / S;
   if (a.cpb > ELEMDP_CPB_MAX) a.cpb = ELEMDP_CPB_MAX;
   a.wmax = Wmax;
   a.ext_ring = G <= 1024 ? 1 : 0;
@@ -2022,9 +2028,9 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   // and the weight tables staged
   const bool fast = a.fast && big && a.lay.fp_ok && !(a.dbg & 16) && a.lay.lin_total <= 2048;
   a.fast = fast ? 1 : 0;
-  if (fast) a.cpb = std::min(kThreads / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);   // (states without any column take no lane)
+  if (fast) a.cpb = std::min(kBT / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);   // (states without any column take no lane)
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
-  const int NW = a.det ? kThreads / 64 : 1;
+  const int NW = a.det ? kBT / 64 : 1;
   const size_t lds_in = block_lds(NW * 2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
   const size_t lds_stat = sizeof(double) * (2 * nt + 4);
   if (!a.no_rss)
@@ -2032,10 +2038,10 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
       const int ncell = Lmax - d + 1;
       if (ncell <= 0) break;
       a.d = d;
-      if (fast && a.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_in<true, false, true, 2>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
-      else if (fast) hipLaunchKernelGGL((k4_in<true, false, true>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
-      else if (big) hipLaunchKernelGGL((k4_in<true, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
-      else hipLaunchKernelGGL((k4_in<false, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kThreads), lds_in, st, a);
+      if (fast && a.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_in<true, false, true, 2>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
+      else if (fast) hipLaunchKernelGGL((k4_in<true, false, true>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
+      else if (big) hipLaunchKernelGGL((k4_in<true, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
+      else hipLaunchKernelGGL((k4_in<false, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
     }
   a.lmax = Lmax;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
@@ -2060,11 +2066,11 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
         const int ncell = Lmax - d + 1;
         if (ncell <= 0) continue;
         b.d = d;
-        if (big && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);   // (timing experiment: no statistics)
-        else if (fast && b.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
-        else if (fast) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
-        else if (big) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
-        else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kThreads), lds_b, st, b);
+        if (big && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);   // (timing experiment: no statistics)
+        else if (fast && b.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
+        else if (fast) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
+        else if (big) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
+        else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
       }
     }
   }
