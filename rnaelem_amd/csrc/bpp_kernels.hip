@@ -126,7 +126,9 @@ __global__ __launch_bounds__(kThreads) void k6_terms(BppLinArgs a) {
 // a dependent global load), and candidates are taken four at a time so that their table loads are in flight together.
 constexpr int kC = 32;        // cells per workgroup
 constexpr int kStem = 8;      // lanes per cell for the stem sums
-constexpr int kSlots = 32;    // partial sums per cell for the interior loops
+constexpr int kSlots = 16;    // partial sums per cell for the interior loops: slot s takes the left ends at distance s and 31 - s
+                              // (+ 32, ..): the candidates of a left end fall off linearly with its distance, so a slot's two
+                              // ends together are the same work for every slot -- the lanes of a wave finish together
 constexpr int kWin = 384;     // staged bases
 constexpr int kB = 4;         // candidates per batch of loads
 
@@ -246,13 +248,15 @@ __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
   __syncthreads();
   // rule 6c, inside set: inner pairs (k, l), i <= k, l <= j, (k-i) + (j-l) <= C, (k,l) != (i,j); slots take the left ends k
   {
-    const EnergyTables& et = *a.et;
+    const EnergyTables& xet = *a.xet;
     const int nE = sh.n_list, amax = (q.C < d - 2) ? q.C : d - 2;
     for (int w = tid; w < nE * kSlots; w += kThreads) {
       const int ci = sh.list[w / kSlots], slot = w % kSlots;
       const int i = i0 + ci, j = i + d;
       double HE = 0.;
-      for (int da = slot; da <= amax; da += kSlots) {
+      for (int e2 = 0; e2 <= 2 * (amax / (2 * kSlots)) + 1; ++e2) {
+        const int da = (e2 >> 1) * 2 * kSlots + ((e2 & 1) ? 2 * kSlots - 1 - slot : slot);
+        if (da > amax) continue;
         const int k = i + da;
         const int lmin = (k + 2 > j - (q.C - da)) ? k + 2 : j - (q.C - da);
         Bits it;
@@ -263,19 +267,18 @@ __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
           if (sp[0] < 0) break;
 #pragma unroll
           for (int u = 1; u < kB; ++u) sp[u] = (sp[u - 1] < 0) ? -1 : it.next();
-          double tsc[kB], pv[kB];
+          double xw[kB], pv[kB];
 #pragma unroll
           for (int u = 0; u < kB; ++u) {
             const bool on = sp[u] >= 0 && !(da == 0 && k + sp[u] == j);
-            tsc[u] = ELEMDP_NEG_INF; pv[u] = 0.;
+            xw[u] = 0.; pv[u] = 0.;
             if (on) {
-              tsc[u] = a.no_ene ? 0. : loop_energy(et, sq, i - 1, j, k, k + sp[u] - 1);
+              xw[u] = a.no_ene ? 1. : loop_weight(xet, sq, i - 1, j, k, k + sp[u] - 1);
               pv[u] = q.in(BP_P, sp[u], k);
             }
           }
 #pragma unroll
-          for (int u = 0; u < kB; ++u)
-            if (tsc[u] != ELEMDP_NEG_INF) HE = fma(pv[u], exp(tsc[u]), HE);
+          for (int u = 0; u < kB; ++u) HE = fma(pv[u], xw[u], HE);
           if (sp[kB - 1] < 0) break;
         }
       }
@@ -430,16 +433,21 @@ __global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
   __syncthreads();
   // HP: the interior loops around the stem; slots take the left ends of the outer cells
   {
-    const EnergyTables& et = *a.et;
+    const EnergyTables& xet = *a.xet;
     const int nP = sh.n_list;
     for (int w = tid; w < nP * kSlots; w += kThreads) {
       const int ci = sh.list[w / kSlots], slot = w % kSlots;
       const int i = i0 + ci, j = i + d;
       const int amax = (Cc < i - 1) ? Cc : i - 1;        // outside set: k - i' <= C (no loop beyond kMaxLoop); closing pair starts at i' - 1 >= 0
       double HP = 0.;
-      for (int da = slot; da <= amax; da += kSlots) {
+      for (int e2 = 0; e2 <= 2 * (amax / (2 * kSlots)) + 1; ++e2) {
+        const int da = (e2 >> 1) * 2 * kSlots + ((e2 & 1) ? 2 * kSlots - 1 - slot : slot);
+        if (da > amax || da < 0) continue;
         const int io = i - da;                            // outer E cell (io, jo), closing pair cell (io - 1, jo - io + 2)
-        const int hi = (W < L - io + 1) ? W : L - io + 1;   // (the reference's outside set does not bound jo - j)
+        // (the reference's outside set does not bound jo - j; a loop of more than kMaxLoop unpaired bases weighs
+        // log 0, so the walk stops at jo - j = kMaxLoop - da)
+        int hi = (W < L - io + 1) ? W : L - io + 1;
+        if (!a.no_ene && hi > j - io + 2 + kMaxLoop - da) hi = j - io + 2 + kMaxLoop - da;
         Bits it;
         it.init(mk.m, (io - 1) * (W + 1), j - io + 2, hi);
         for (;;) {
@@ -448,20 +456,19 @@ __global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
           if (sp[0] < 0) break;
 #pragma unroll
           for (int u = 1; u < kB; ++u) sp[u] = (sp[u - 1] < 0) ? -1 : it.next();
-          double tsc[kB], ov[kB];
+          double xw[kB], ov[kB];
 #pragma unroll
           for (int u = 0; u < kB; ++u) {
             const int jo = io + sp[u] - 2;
             const bool on = sp[u] >= 0 && !(da == 0 && jo == j);
-            tsc[u] = ELEMDP_NEG_INF; ov[u] = 0.;
+            xw[u] = 0.; ov[u] = 0.;
             if (on) {
-              tsc[u] = a.no_ene ? 0. : loop_energy(et, sq, io - 1, jo, i, j - 1);
+              xw[u] = a.no_ene ? 1. : loop_weight(xet, sq, io - 1, jo, i, j - 1);
               ov[u] = q.out(BO_E, jo - io, io);
             }
           }
 #pragma unroll
-          for (int u = 0; u < kB; ++u)
-            if (tsc[u] != ELEMDP_NEG_INF) HP = fma(ov[u], exp(tsc[u]), HP);
+          for (int u = 0; u < kB; ++u) HP = fma(ov[u], xw[u], HP);
           if (sp[kB - 1] < 0) break;
         }
       }

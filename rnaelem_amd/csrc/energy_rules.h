@@ -98,4 +98,32 @@ ELEMDP_HD double loop_energy(const EnergyTables& e, const uint8_t* s, int i, int
   return z;
 }
 
+// exp(loop_energy) from the EXPONENTIATED tables x (exp_tables below): products instead of a sum and its exponential, 0 instead of
+// log 0.  The BPP filter, which needs every candidate loop of the canonical mask once per direction, takes this form
+// (bpp_kernels.hip); the plan keeps the logarithm (loop_energy) that the scan's max-product pass and lambda need.
+ELEMDP_HD double loop_weight(const EnergyTables& x, const uint8_t* s, int i, int j, int p, int q) {
+  const int u1 = p - i - 1, u2 = j - q - 1;
+  if (u1 < 0 || u2 < 0 || kMaxLoop < u1 + u2) return 0.;
+  const int type = bp_type(s[i], s[j]);
+  const int type2 = bp_type(s[q], s[p]);
+  const int u = u1 > u2 ? u1 : u2;
+  if (0 == u) return x.stack[type * 7 + type2];
+  if (0 == u1 || 0 == u2) {
+    if (1 == u) return x.bulge[1] * x.stack[type * 7 + type2];
+    double z = x.bulge[u];
+    if (is_au(type)) z *= x.term_au;
+    if (is_au(type2)) z *= x.term_au;
+    return z;
+  }
+  if (u <= 2) {
+    if (2 == u1 + u2) return x.int11[((type * 8 + type2) * 5 + s[i + 1]) * 5 + s[j - 1]];
+    if (1 == u1 && 2 == u2) return x.int21[(((type * 8 + type2) * 5 + s[i + 1]) * 5 + s[q + 1]) * 5 + s[j - 1]];
+    if (2 == u1 && 1 == u2) return x.int21[(((type2 * 8 + type) * 5 + s[q + 1]) * 5 + s[i + 1]) * 5 + s[p - 1]];
+    return x.int22[((((type * 8 + type2) * 5 + s[i + 1]) * 5 + s[p - 1]) * 5 + s[q + 1]) * 5 + s[j - 1]];
+  }
+  const double* mm = (1 == u1 || 1 == u2) ? x.mismatch_1ni : (5 == u1 + u2) ? x.mismatch_23i : x.mismatch_i;
+  return (x.interior[u1 + u2] * x.ninio[u1 > u2 ? u1 - u2 : u2 - u1]) *
+         (mm[type * 25 + s[i + 1] * 5 + s[j - 1]] * mm[type2 * 25 + s[q + 1] * 5 + s[p - 1]]);
+}
+
 }  // namespace elemdp

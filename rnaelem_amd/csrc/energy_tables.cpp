@@ -99,6 +99,22 @@ void load_special(Section& sec, int len, double* energy, uint32_t* key, int32_t*
 
 }  // namespace
 
+void exp_tables(const EnergyTables& e, EnergyTables* x) {
+  *x = e;
+  auto ex = [](const double* src, double* dst, size_t n) { for (size_t k = 0; k < n; ++k) dst[k] = std::exp(src[k]); };
+#define ELEMDP_EXP_TABLE(f) ex(e.f, x->f, sizeof(e.f) / sizeof(double))
+  ELEMDP_EXP_TABLE(stack); ELEMDP_EXP_TABLE(hairpin); ELEMDP_EXP_TABLE(bulge); ELEMDP_EXP_TABLE(interior); ELEMDP_EXP_TABLE(ninio);
+  ELEMDP_EXP_TABLE(mismatch_h); ELEMDP_EXP_TABLE(mismatch_i); ELEMDP_EXP_TABLE(mismatch_m); ELEMDP_EXP_TABLE(mismatch_1ni);
+  ELEMDP_EXP_TABLE(mismatch_23i); ELEMDP_EXP_TABLE(mismatch_ext); ELEMDP_EXP_TABLE(dangle5); ELEMDP_EXP_TABLE(dangle3);
+  ELEMDP_EXP_TABLE(int11); ELEMDP_EXP_TABLE(int21); ELEMDP_EXP_TABLE(int22);
+  ELEMDP_EXP_TABLE(triloop); ELEMDP_EXP_TABLE(tetraloop); ELEMDP_EXP_TABLE(hexaloop);
+#undef ELEMDP_EXP_TABLE
+  x->term_au = std::exp(e.term_au);
+  x->ml_intern = std::exp(e.ml_intern);
+  x->ml_closing = std::exp(e.ml_closing);
+  x->ml_base = std::exp(e.ml_base);
+}
+
 double log_boltzmann(int dcal, bool smooth) {
   if (!smooth) return -dcal * 10. / kKT;
   // smooth(-z) (energy_param.hpp:94-106): a C1 clamp of stabilising energies at 0

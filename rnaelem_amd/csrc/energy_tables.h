@@ -46,6 +46,10 @@ struct EnergyTables {
   double lxc37;
 };
 
+// x = the tables of e exponentiated entry by entry (Boltzmann weights instead of their logarithms; exp(log 0) = 0); the
+// special-loop keys and lxc37 are copied.  For loop_weight (energy_rules.h).
+void exp_tables(const EnergyTables& e, EnergyTables* x);
+
 // Parses ViennaRNA-2.0 format text (the shipped *.elempar files are a comment-free subset of it).
 // Throws std::runtime_error on malformed input.
 void parse_energy_text(const std::string& text, EnergyTables* out);

@@ -342,7 +342,7 @@ class Engine {
   }
   hipEvent_t gev_[kMaxGroupStreams][2] = {}, gdone_[kMaxGroupStreams] = {}, gstart_ = nullptr;
   int opt_group_streams_ = 2;
-  DevBuf d_et_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_, d_lay_, d_lay0_, d_layr_, d_intsr_;
+  DevBuf d_et_, d_xet_, d_ints_, d_ints0_, d_params_, d_params0_, d_counter_, d_lay_, d_lay0_, d_layr_, d_intsr_;
   std::vector<double> theta_;  // log-probabilities of the last evaluation (softmax Jacobian)
 
   // batch
@@ -479,6 +479,12 @@ void Engine::init_device() {
   gev_[0][0] = ev2_[0]; gev_[0][1] = ev2_[1];
   d_et_.alloc(sizeof(EnergyTables));
   HIP_OK(hipMemcpyAsync(d_et_.as<void>(), &et_, sizeof(EnergyTables), hipMemcpyHostToDevice, st_));
+  {   // Boltzmann weights of the loop tables, for the BPP filter (energy_rules.h: loop_weight)
+    std::unique_ptr<EnergyTables> x(new EnergyTables);
+    exp_tables(et_, x.get());
+    d_xet_.alloc(sizeof(EnergyTables));
+    HIP_OK(hipMemcpy(d_xet_.as<void>(), x.get(), sizeof(EnergyTables), hipMemcpyHostToDevice));
+  }
   d_ints0_.upload(ints0_, st_);
   upload_automaton();
   d_lay0_.alloc(sizeof(AutomatonLayout));
@@ -945,6 +951,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         BppLinArgs a;
         std::memset(&a, 0, sizeof(a));
         a.et = d_et_.as<EnergyTables>();
+        a.xet = d_xet_.as<EnergyTables>();
         a.plans = d_bpp_plans_.as<SeqPlan>();
         a.seq = d_seq_.as<uint8_t>();
         a.okbits = d_okbits0_.as<uint32_t>();

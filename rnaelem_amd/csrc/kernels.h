@@ -126,6 +126,7 @@ struct BppOut {
 constexpr int kBppLinMaxSpan = 200;
 struct BppLinArgs {
   const EnergyTables* et;
+  const EnergyTables* xet;         // the same tables exponentiated (exp_tables): interior loops through loop_weight
   const SeqPlan* plans;
   const uint8_t* seq;
   const uint32_t* okbits;          // canonical pair mask
