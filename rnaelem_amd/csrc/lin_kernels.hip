@@ -1878,12 +1878,17 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
   }
 }
 
-// exterior chain of the Viterbi pass and the traceback (one workgroup of 64 per sequence; lane 0 walks the trace)
+// exterior chain of the Viterbi pass and the traceback (one workgroup of 64 per sequence; lane 0 walks the trace).  Both are
+// chains of dependent look-ups: with the sequence's context and the automaton blob in LDS (STAGE, as in k4_in_ext) only the
+// table values themselves come from global memory.
+template <bool STAGE>
 __global__ __launch_bounds__(64) void k5_cyk_ext(LinArgs a) {
+  extern __shared__ double l_cyk[];
   __shared__ AutomatonLayout s_lay;
   stage_layout(a, &s_lay, 64);
   LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
+  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_cyk), 0, 64);
   __syncthreads();
   const int S = a.lay.S, tid = threadIdx.x, L = v.q.L;
   TraceView R;
@@ -1895,8 +1900,27 @@ __global__ __launch_bounds__(64) void k5_cyk_ext(LinArgs a) {
     R.ext[s] = z;
   }
   __syncthreads();
+  // a step: the lanes test the pair cells (i, j), i = j-1, j-2, .. (64 at a time); the few that are pairs with an exterior term
+  // are then walked by the lanes as states, in the same order (descending i: the first strictly greatest candidate wins)
+  const int W = v.q.W;
   for (int j = 1; j <= L; ++j) {
-    for (int s = tid; s < S; s += 64) cyk_ext_target(v.m, v.q, v.in, R, c, j, s);
+    for (int sb = 0; sb < S; sb += 64) {
+      const int s = sb + tid;
+      MaxAcc acc;
+      for (int l0 = 0; l0 < W && l0 < j; l0 += 64) {
+        const int dd = l0 + tid + 1, i = j - dd;
+        double t = ELEMDP_NEG_INF;
+        if (dd <= W && i >= 0 && v.q.pair_ok(i, dd)) t = v.q.e_ext[v.q.cell(i, dd)];
+        unsigned long long kept = __ballot(t != ELEMDP_NEG_INF);
+        while (kept) {
+          const int l = __builtin_ctzll(kept);
+          kept &= kept - 1;
+          const double tl = __shfl(t, l, 64);
+          if (s < S) cyk_ext_pair(v.m, v.in, acc, j, s, j - (l0 + l + 1), tl);
+        }
+      }
+      if (s < S) cyk_ext_finish(v.m, v.q, v.in, R, c, j, s, acc);
+    }
     __syncthreads();
   }
   int32_t* path = a.sc_psihat + v.seq_base;
@@ -1947,7 +1971,9 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
     else if (kown == 4) hipLaunchKernelGGL((k5_cyk<true, 4>), grid, dim3(kBT), lds, st, a);
     else hipLaunchKernelGGL((k5_cyk<true, 8>), grid, dim3(kBT), lds, st, a);
   }
-  hipLaunchKernelGGL(k5_cyk_ext, dim3(G), dim3(64), 0, st, a);
+  const size_t lds_ext = (size_t)ext_lds(0, kLinEth + nt, Lmax, a.nword_max, a.n_stage).total;
+  if (Lmax <= 2048 && a.nword_max <= 8192 && lds_ext <= 64 * 1024) hipLaunchKernelGGL(k5_cyk_ext<true>, dim3(G), dim3(64), lds_ext, st, a);
+  else hipLaunchKernelGGL(k5_cyk_ext<false>, dim3(G), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 

@@ -90,91 +90,109 @@ ELEMDP_HD void cyk_put(const TableView& T, const TraceView& R, int e, int d, int
   else T.at(e, d, i, s) = a.best;
 }
 
-// everything else of the target; hB = winner of rule 2 (used when left_ok), hE = winner of rule 6c (used when e_ok)
+// everything else of the target; hB = winner of rule 2 (used when left_ok), hE = winner of rule 6c (used when e_ok).
+// only >= 0 (the traceback's re-derivation): just that plane -- the values of the target's other planes it builds on are read
+// from the finished table instead of being computed again (they are what the sweep stored).
 ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
-                            const Constraint& c, int d, int i, int s, const MaxAcc& hB, const MaxAcc& hE) {
+                            const Constraint& c, int d, int i, int s, const MaxAcc& hB, const MaxAcc& hE, int only = -1) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
   const int j = i + d;
   const double NEG = ELEMDP_NEG_INF;
   const double lam = m.lam(s);
   const bool isloop = I[A.st_is_loop + s] != 0;
+  const bool all = only < 0;
+  auto want = [&](int e) { return all || only == e; };
 
   MaxAcc aL;
-  if (isloop) {
-    if (d == 0) { if (m.st_l(s) == m.st_r(s)) aL.best = 0.; }
-    else
-      for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
-        const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
-        if (!allow_right(m, c, q.L, j, s, s1)) continue;
-        aL.offer(T.at(ST_L, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_L_L, ST_L, s1);
-      }
+  if (want(ST_L)) {
+    if (isloop) {
+      if (d == 0) { if (m.st_l(s) == m.st_r(s)) aL.best = 0.; }
+      else
+        for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+          const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+          if (!allow_right(m, c, q.L, j, s, s1)) continue;
+          aL.offer(T.at(ST_L, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_L_L, ST_L, s1);
+        }
+    }
+    cyk_put(T, R, ST_L, d, i, s, aL);
   }
-  cyk_put(T, R, ST_L, d, i, s, aL);
 
   const bool pok = q.pair_ok(i, d);
   MaxAcc aP;
-  if (pok) {
-    const double est = q.e_stack[q.cell(i, d)];
-    for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {  // all 1a candidates first ...
-      const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
-      if (!allow_pair(m, c, q.L, i, j, s, s1)) continue;
-      aP.offer(T.at(ST_E, d - 2, i + 1, s1) + w_pair(m, q, s, s1, tf, i, j - 1), i + 1, j - 1, TT_P_E, ST_E, s1);
-    }
-    if (est != NEG)
-      for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {  // ... then 1b
+  if (want(ST_P)) {
+    if (pok) {
+      const double est = q.e_stack[q.cell(i, d)];
+      for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {  // all 1a candidates first ...
         const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
         if (!allow_pair(m, c, q.L, i, j, s, s1)) continue;
-        aP.offer(T.at(ST_P, d - 2, i + 1, s1) + (w_pair(m, q, s, s1, tf, i, j - 1) + ELEMDP_MUL_RN(lam, est)), i + 1, j - 1, TT_P_P,
-                 ST_P, s1);
+        aP.offer(T.at(ST_E, d - 2, i + 1, s1) + w_pair(m, q, s, s1, tf, i, j - 1), i + 1, j - 1, TT_P_E, ST_E, s1);
       }
+      if (est != NEG)
+        for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {  // ... then 1b
+          const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
+          if (!allow_pair(m, c, q.L, i, j, s, s1)) continue;
+          aP.offer(T.at(ST_P, d - 2, i + 1, s1) + (w_pair(m, q, s, s1, tf, i, j - 1) + ELEMDP_MUL_RN(lam, est)), i + 1, j - 1, TT_P_P,
+                   ST_P, s1);
+        }
+    }
+    cyk_put(T, R, ST_P, d, i, s, aP);
   }
-  cyk_put(T, R, ST_P, d, i, s, aP);
 
   const bool lok = q.left_ok(i, d);
   MaxAcc aB;
   if (lok) aB = hB;
-  cyk_put(T, R, ST_B, d, i, s, aB);
+  if (want(ST_B)) cyk_put(T, R, ST_B, d, i, s, aB);
 
   MaxAcc a2, a1;
-  if (lok) {
-    if (q.left_ok(i, d - 1) && q.unp[j - 1])
-      for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
-        const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
-        if (!allow_right(m, c, q.L, j, s, s1)) continue;
-        a2.offer(T.at(ST_2, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_2_2, ST_2, s1);
+  if (all || only == ST_2 || only == ST_1) {
+    if (lok) {
+      if (want(ST_2)) {
+        if (q.left_ok(i, d - 1) && q.unp[j - 1])
+          for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+            const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
+            if (!allow_right(m, c, q.L, j, s, s1)) continue;
+            a2.offer(T.at(ST_2, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_2_2, ST_2, s1);
+          }
+        if (pok) {
+          const double eml = q.e_ml[q.cell(i, d)];
+          if (eml != NEG) a2.offer((all ? aP.best : T.at(ST_P, d, i, s)) + ELEMDP_MUL_RN(lam, eml), i, j, TT_2_P, ST_P, s);
+        }
       }
-    if (pok) {
-      const double eml = q.e_ml[q.cell(i, d)];
-      if (eml != NEG) a2.offer(aP.best + ELEMDP_MUL_RN(lam, eml), i, j, TT_2_P, ST_P, s);
+      if (want(ST_1)) {
+        a1.offer(all ? a2.best : T.at(ST_2, d, i, s), i, j, TT_1_2, ST_2, s);
+        a1.offer(aB.best, i, j, TT_1_B, ST_B, s);
+      }
     }
-    a1.offer(a2.best, i, j, TT_1_2, ST_2, s);
-    a1.offer(aB.best, i, j, TT_1_B, ST_B, s);
+    if (want(ST_2)) cyk_put(T, R, ST_2, d, i, s, a2);
+    if (want(ST_1)) cyk_put(T, R, ST_1, d, i, s, a1);
   }
-  cyk_put(T, R, ST_2, d, i, s, a2);
-  cyk_put(T, R, ST_1, d, i, s, a1);
 
   const bool mok = m_ok(m, q, i, d);
   MaxAcc aM;
-  if (mok) {
-    if (m_ok(m, q, i + 1, d - 1) && q.unp[i])
-      for (int t = I[A.left_off + s]; t < I[A.left_off + s + 1]; ++t) {
-        const int s1 = I[A.left_ent + 2 * t], tf = I[A.left_ent + 2 * t + 1];
-        if (!allow_left(m, c, i, s, s1)) continue;
-        aM.offer(T.at(ST_M, d - 1, i + 1, s1) + w_left(m, q, s1, tf, i), i + 1, j, TT_M_M, ST_M, s1);
-      }
-    if (lok) aM.offer(aB.best, i, j, TT_M_B, ST_B, s);
+  if (want(ST_M)) {
+    if (mok) {
+      if (m_ok(m, q, i + 1, d - 1) && q.unp[i])
+        for (int t = I[A.left_off + s]; t < I[A.left_off + s + 1]; ++t) {
+          const int s1 = I[A.left_ent + 2 * t], tf = I[A.left_ent + 2 * t + 1];
+          if (!allow_left(m, c, i, s, s1)) continue;
+          aM.offer(T.at(ST_M, d - 1, i + 1, s1) + w_left(m, q, s1, tf, i), i + 1, j, TT_M_M, ST_M, s1);
+        }
+      if (lok) aM.offer(aB.best, i, j, TT_M_B, ST_B, s);
+    }
+    cyk_put(T, R, ST_M, d, i, s, aM);
   }
-  cyk_put(T, R, ST_M, d, i, s, aM);
 
-  MaxAcc aE;
-  if (q.e_ok(i, d)) {
-    const int pc = q.cell(i - 1, d + 2);
-    if (mok) { const double t = q.e_close[pc]; if (t != NEG) aE.offer(aM.best + ELEMDP_MUL_RN(lam, t), i, j, TT_E_M, ST_M, s); }
-    if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) aE.offer(aL.best + ELEMDP_MUL_RN(lam, t), i, j, TT_E_H, ST_L, s); }
-    if (aE.best < hE.best) aE = hE;   // (the item candidates come last; the first strictly greatest one wins)
+  if (want(ST_E)) {
+    MaxAcc aE;
+    if (q.e_ok(i, d)) {
+      const int pc = q.cell(i - 1, d + 2);
+      if (mok) { const double t = q.e_close[pc]; if (t != NEG) aE.offer((all ? aM.best : T.at(ST_M, d, i, s)) + ELEMDP_MUL_RN(lam, t), i, j, TT_E_M, ST_M, s); }
+      if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) aE.offer((all ? aL.best : T.at(ST_L, d, i, s)) + ELEMDP_MUL_RN(lam, t), i, j, TT_E_H, ST_L, s); }
+      if (aE.best < hE.best) aE = hE;   // (the item candidates come last; the first strictly greatest one wins)
+    }
+    cyk_put(T, R, ST_E, d, i, s, aE);
   }
-  cyk_put(T, R, ST_E, d, i, s, aE);
 }
 
 ELEMDP_HD void cyk_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
@@ -199,30 +217,27 @@ ELEMDP_HD TraceRec cyk_retrace(const ModelView& m, const SeqView& q, const Table
   TraceView R1;
   R1.ext = nullptr;
   R1.one = rec;
-  cyk_target_u(m, q, T, R1, c, d, i, s, hB, hE);
+  cyk_target_u(m, q, T, R1, c, d, i, s, hB, hE, e);
   return rec[e];
 }
 
-ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
-                              const Constraint& c, int j, int s) {
+// exterior target O(j, s) in two parts, so that the batch kernel (k5_cyk_ext) can find the pairs (i, j) of a step with all
+// its lanes and then walk only those: rule 7 for ONE pair cell (i, d = j - i) with exterior term t != log 0 ...
+ELEMDP_HD void cyk_ext_pair(const ModelView& m, const TableView& T, MaxAcc& a, int j, int s, int i, double t) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const int d = j - i;
+  const double lt = ELEMDP_MUL_RN(m.lam(s), t);
+  for (int u = G[A.split_off + s]; u < G[A.split_off + s + 1]; ++u) {
+    const int s2 = G[A.split_ent + 2 * u], s1 = G[A.split_ent + 2 * u + 1];
+    a.offer(T.o(i, s2) + (T.at(ST_P, d, i, s1) + lt), i, j, TT_O_OP, ST_P, s1);
+  }
+}
+// ... and rule 8 (the candidates behind those of rule 7), the value and the record
+ELEMDP_HD void cyk_ext_finish(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R, const Constraint& c,
+                              int j, int s, MaxAcc& a) {
   const AutomatonLayout& A = m.lay;
   const int32_t* I = m.ints;
-  const int32_t* G = m.big;
-  const double NEG = ELEMDP_NEG_INF;
-  const double lam = m.lam(s);
-  MaxAcc a;
-  const int i0 = (j - q.W > 0) ? j - q.W : 0;
-  for (int i = j - 1; i >= i0; --i) {
-    const int d = j - i;
-    if (!q.pair_ok(i, d)) continue;
-    const double t = q.e_ext[q.cell(i, d)];
-    if (t == NEG) continue;
-    const double lt = ELEMDP_MUL_RN(lam, t);
-    for (int u = G[A.split_off + s]; u < G[A.split_off + s + 1]; ++u) {
-      const int s2 = G[A.split_ent + 2 * u], s1 = G[A.split_ent + 2 * u + 1];
-      a.offer(T.o(i, s2) + (T.at(ST_P, d, i, s1) + lt), i, j, TT_O_OP, ST_P, s1);
-    }
-  }
   if (q.unp[j - 1])
     for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
       const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
@@ -231,6 +246,20 @@ ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableV
     }
   T.o(j, s) = a.best;
   R.ext[(size_t)j * T.S + s] = a.tr;
+}
+ELEMDP_HD void cyk_ext_target(const ModelView& m, const SeqView& q, const TableView& T, const TraceView& R,
+                              const Constraint& c, int j, int s) {
+  const double NEG = ELEMDP_NEG_INF;
+  MaxAcc a;
+  const int i0 = (j - q.W > 0) ? j - q.W : 0;
+  for (int i = j - 1; i >= i0; --i) {   // (candidate order: pairs by descending i, the first strictly greatest wins)
+    const int d = j - i;
+    if (!q.pair_ok(i, d)) continue;
+    const double t = q.e_ext[q.cell(i, d)];
+    if (t == NEG) continue;
+    cyk_ext_pair(m, T, a, j, s, i, t);
+  }
+  cyk_ext_finish(m, q, T, R, c, j, s, a);
 }
 
 struct TraceFrame { int16_t i, j; int8_t e; int16_t s; };
