@@ -668,6 +668,13 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   const int ncell = v.q.L - d + 1, i0 = bx * cpb;
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
+  if (CON) {
+    // The start constraint touches the emissions of position Ys only: a cell whose span does not cover Ys -- and everything below
+    // it -- has the value of the unconstrained pass, which is still in the table (same slot, same layout; the scan runs
+    // k4_in<false> first).  Only the cells i <= Ys < i + d are swept again: ~d of the L - d + 1 cells of the diagonal.
+    const int ys = a.ys[v.n];
+    if (ys < i0 || ys - d + 1 > i0 + nc - 1) return;
+  }
   const int CS = cpb * S, ncS = nc * S;
   const int NW = a.det ? kBT / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the heavy sums (one per wave: rep_sum)
   double* hb = lds;
