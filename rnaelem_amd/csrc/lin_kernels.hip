@@ -889,8 +889,9 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k4_in(LinArgs a) {
           for (int u = 0; u < kTU; ++u) {
             const int t = t0 + kWaves * u;
             const bool on = t < nq;
-            qa[u] = G[qc_in + 2 * (on ? t : wv)];
-            qb[u] = on ? G[qc_in + 2 * (on ? t : wv) + 1] : (4 << 16);
+            // (the tuple is the same for all lanes of the wave: its record in scalar registers, unpacked by the scalar unit)
+            qa[u] = __builtin_amdgcn_readfirstlane(G[qc_in + 2 * (on ? t : wv)]);
+            qb[u] = on ? __builtin_amdgcn_readfirstlane(G[qc_in + 2 * (on ? t : wv) + 1]) : (4 << 16);
             x0[u] = B[rP + (qa[u] & 0xff)]; x1[u] = B[rL1 + ((qa[u] >> 8) & 0xff)]; x2[u] = B[rL2 + ((qa[u] >> 16) & 0xff)];
           }
 #pragma unroll
