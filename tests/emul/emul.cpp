@@ -366,6 +366,34 @@ int emu_energy_table(void* h, const char* name, double* out, int cap) {
 }
 double emu_hairpin_energy(void* h, const uint8_t* seq, int L, int i, int j) { return hairpin_energy(((Emu*)h)->et, seq, i, j); }
 double emu_loop_energy(void* h, const uint8_t* seq, int L, int i, int j, int p, int q) { return loop_energy(((Emu*)h)->et, seq, i, j, p, q); }
+// exp(loop_energy) from the exponentiated tables (what the BPP filter kernels use; energy_rules.h: loop_weight)
+double emu_loop_weight(void* h, const uint8_t* seq, int L, int i, int j, int p, int q) {
+  static thread_local EnergyTables x;
+  exp_tables(((Emu*)h)->et, &x);
+  return loop_weight(x, seq, i, j, p, q);
+}
+// ScanFlag word of every forward transition (right | left | pair) with the nodes of its parent and child state: for the test
+// that re-derives the flags from the scanner's node conditions.  out: rows of 6 ints {kind, pl, pr, cl, cr, flags}.
+int emu_scan_flags(void* h, int32_t* out, int cap) {
+  Emu& E = *(Emu*)h;
+  const AutomatonLayout& A = E.lay;
+  const int32_t* I = E.ints.data();
+  int n = 0;
+  const int32_t offs[3] = {A.right_off, A.left_off, A.pair_off}, ents[3] = {A.right_ent, A.left_ent, A.pair_ent};
+  for (int kind = 0; kind < 3; ++kind)
+    for (int k = 0; k < A.S; ++k)
+      for (int t = I[offs[kind] + k]; t < I[offs[kind] + k + 1]; ++t) {
+        const int ch = I[ents[kind] + 2 * t];
+        if (n >= cap) return -1;
+        int32_t* r = out + 6 * n;
+        r[0] = kind; r[1] = I[A.st_l + k]; r[2] = I[A.st_r + k]; r[3] = I[A.st_l + ch]; r[4] = I[A.st_r + ch];
+        r[5] = I[A.fs_in + n];
+        if (I[A.fs_out + n] != r[5]) return -2;
+        ++n;
+      }
+  return (n == A.n_wr + A.n_wl + A.n_wp) ? n : -3;
+}
+int emu_pattern_nodes(void* h) { return ((Emu*)h)->lay.M; }
 double emu_sum_ext_m(void* h, const uint8_t* seq, int L, int i, int j, int ext) { return sum_ext_m(((Emu*)h)->et, seq, L, i, j, ext); }
 
 int emu_bpp(void* h, const uint8_t* seq, int L, double* lnbpp, uint8_t* kept, double* bpp_eff, double* lnZ) {

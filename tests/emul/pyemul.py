@@ -27,6 +27,10 @@ def lib():
         L.emu_hairpin_energy.argtypes = [C.c_void_p, u8, C.c_int, C.c_int, C.c_int]
         L.emu_loop_energy.restype = C.c_double
         L.emu_loop_energy.argtypes = [C.c_void_p, u8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.emu_loop_weight.restype = C.c_double
+        L.emu_loop_weight.argtypes = [C.c_void_p, u8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.emu_scan_flags.argtypes = [C.c_void_p, i32, C.c_int]
+        L.emu_pattern_nodes.argtypes = [C.c_void_p]
         L.emu_sum_ext_m.restype = C.c_double
         L.emu_sum_ext_m.argtypes = [C.c_void_p, u8, C.c_int, C.c_int, C.c_int, C.c_int]
         L.emu_bpp.argtypes = [C.c_void_p, u8, C.c_int, dp, u8, dp, dp]
@@ -80,6 +84,16 @@ class Emul:
 
     def loop_energy(self, seq, i, j, p, q):
         return lib().emu_loop_energy(self.h, _u8(seq), len(seq), i, j, p, q)
+
+    def loop_weight(self, seq, i, j, p, q):
+        return lib().emu_loop_weight(self.h, _u8(seq), len(seq), i, j, p, q)
+
+    def scan_flags(self):
+        """rows {kind 0 right / 1 left / 2 pair, pl, pr, cl, cr, ScanFlag word} of every forward transition, and M"""
+        out = np.zeros((4096, 6), dtype=np.int32)
+        n = lib().emu_scan_flags(self.h, out.ctypes.data_as(C.POINTER(C.c_int32)), 4096)
+        assert n >= 0, n
+        return out[:n].copy(), lib().emu_pattern_nodes(self.h)
 
     def sum_ext_m(self, seq, i, j, ext):
         return lib().emu_sum_ext_m(self.h, _u8(seq), len(seq), i, j, int(ext))
