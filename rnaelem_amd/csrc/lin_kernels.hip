@@ -1793,7 +1793,7 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
       if (x > 0 && x <= d && s1 < NU && s2 < NU) { po1[r] = c * NU + s1; po2[r] = c * NU + s2; }
     }
   }
-  for (int q0 = a_lo; q0 < d; q0 += KC) {
+  for (int q0 = (a.dbg & 256) ? d : a_lo; q0 < d; q0 += KC) {   // (dbg 256 / 512: timing experiments without the split / item sums)
     if (sm.act) {
 #pragma unroll
       for (int u = 0; u < kChunkIn; ++u) {
@@ -1828,9 +1828,9 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
     }
   // rule 6c: candidates P(k,l,s1) + (L(i,k,s2) + (L(l,j,s3) + lam * tsc)) over the item records of the workgroup's cells (staged
   // in LDS) x the tuples
-  const int nq = A.n_quad;
+  const int nq = (a.dbg & 512) ? 0 : A.n_quad;
   {
-    const int n_rec = outer_ranges(v, i0, nc, d, true, tid, cnts, pre, base);
+    const int n_rec = outer_ranges(v, i0, nc, d, nq > 0, tid, cnts, pre, base);
     const OuterRecs R = outer_recs(st1, 2 * kChunkIn * kBT);
     {
       for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
