@@ -124,13 +124,50 @@ struct EndWords {
   __device__ __forceinline__ uint32_t operator()(int n) const { return n < nword ? bits[n] : 0u; }
 };
 
+// The E cells that have interior loops at all (their closing pair is kept) are ~8 % of the cells of a filtered mask: a lane per
+// cell leaves a wave with a handful of busy lanes.  A workgroup therefore takes kPlanTile * kThreads consecutive cells, compacts
+// the ones with loops into an LDS list (ballot + popcount per wave) and hands THOSE to its first lanes.
+constexpr int kPlanTile = 4;
+struct LoopCells {
+  int list[kPlanTile * kThreads];
+  int wcnt[kPlanTile][kThreads / 64];
+  int n;
+};
+// has_loops(c): cell c of the sequence is an E cell whose closing pair (i-1, d+2) is kept.  Returns the number of such cells of the
+// workgroup's tile, their cell indices in sh.list (ascending).
+template <class Pred> __device__ __forceinline__ int compact_loop_cells(LoopCells& sh, int ncell, Pred has_loops) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  bool act[kPlanTile];
+  unsigned long long m[kPlanTile];
+#pragma unroll
+  for (int r = 0; r < kPlanTile; ++r) {
+    const int c = (blockIdx.x * kPlanTile + r) * kThreads + tid;
+    act[r] = c < ncell && has_loops(c);
+    m[r] = __ballot(act[r]);
+    if (lane == 0) sh.wcnt[r][wv] = __popcll(m[r]);
+  }
+  __syncthreads();
+  int before = 0;
+#pragma unroll
+  for (int r = 0; r < kPlanTile; ++r) {
+    for (int w = 0; w < kThreads / 64; ++w) {
+      const int n = sh.wcnt[r][w];
+      if (w == wv && act[r]) sh.list[before + __popcll(m[r] & ((1ull << lane) - 1ull))] = (blockIdx.x * kPlanTile + r) * kThreads + tid;
+      before += n;
+    }
+  }
+  __syncthreads();
+  return before;
+}
+
 // K-plan 1: dmin, structural terms of every kept pair, interior-loop counts per E cell
 __global__ __launch_bounds__(kThreads) void k_plan_cells(PlanKernelArgs a, int32_t* n_items_out) {
   __shared__ int tmp[kThreads / 64];
+  __shared__ LoopCells sh;
   const SeqPlan p = a.plans[a.first + blockIdx.y];
   const int L = p.L, W = p.W;
   const int ncell = (L + 1) * (W + 1);
-  if ((int)(blockIdx.x * kThreads) >= ncell) return;
+  if ((int)(blockIdx.x * kPlanTile * kThreads) >= ncell) return;
   const uint8_t* seq = a.b.seq + p.seq_base;
   const int32_t* ndot = a.fix_rss ? a.b.ndot + p.pos_base : nullptr;
   const OkBits ok{a.okbits + p.bits_base, L, W};
@@ -146,20 +183,33 @@ __global__ __launch_bounds__(kThreads) void k_plan_cells(PlanKernelArgs a, int32
     }
   }
   int32_t* cnt = a.p.by_outer_off + p.off_base;
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  int n = 0;
-  if (c < ncell) {
+  auto has_loops = [&](int c) {
+    const int i = c / (W + 1), d = c - i * (W + 1);
+    return i + d <= L && i > 0 && d + 2 <= W && ok(i - 1, d + 2);
+  };
+#pragma unroll 1
+  for (int r = 0; r < kPlanTile; ++r) {
+    const int c = (blockIdx.x * kPlanTile + r) * kThreads + threadIdx.x;
+    if (c >= ncell) continue;
     const int i = c / (W + 1), d = c - i * (W + 1);
     if (ok(i, d)) {
       const PairTerms t = pair_terms(*a.et, cfg, seq, L, ndot, i, d, ok(i + 1, d - 2));
       const size_t g = p.cell_base + c;
       a.p.e_stack[g] = t.stack; a.p.e_ext[g] = t.ext; a.p.e_ml[g] = t.ml; a.p.e_close[g] = t.close; a.p.e_hp[g] = t.hp;
     }
-    if (i + d <= L && i > 0 && d + 2 <= W && ok(i - 1, d + 2))
-      enum_interior_by_end(*a.et, cfg, seq, L, W, p.C, ndot, words, i, d, [&](int, int, double, bool) { ++n; });
-    cnt[c] = n;
+    if (!has_loops(c)) cnt[c] = 0;
   }
-  const int tot = block_sum_int(n, tmp);
+  const int n_act = compact_loop_cells(sh, ncell, has_loops);
+  int n_mine = 0;
+  for (int t = threadIdx.x; t < n_act; t += kThreads) {
+    const int c = sh.list[t];
+    const int i = c / (W + 1), d = c - i * (W + 1);
+    int n = 0;
+    enum_interior_by_end(*a.et, cfg, seq, L, W, p.C, ndot, words, i, d, [&](int, int, double, bool) { ++n; });
+    cnt[c] = n;
+    n_mine += n;
+  }
+  const int tot = block_sum_int(n_mine, tmp);
   if (threadIdx.x == 0 && tot) atomicAdd(&n_items_out[blockIdx.y], tot);
 }
 
@@ -188,28 +238,34 @@ __global__ __launch_bounds__(kThreads) void k_plan_scan(PlanKernelArgs a, int ro
 }
 
 __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanKernelArgs a) {
+  __shared__ LoopCells sh;
   const SeqPlan p = a.plans[a.first + blockIdx.y];
   const int L = p.L, W = p.W;
   const int ncell = (L + 1) * (W + 1);
-  const int c = blockIdx.x * kThreads + threadIdx.x;
-  if (c >= ncell) return;
-  const int i = c / (W + 1), d = c - i * (W + 1);
+  if ((int)(blockIdx.x * kPlanTile * kThreads) >= ncell) return;
   const OkBits ok{a.okbits + p.bits_base, L, W};
-  if (!(i + d <= L && i > 0 && d + 2 <= W && ok(i - 1, d + 2))) return;
+  const int n_act = compact_loop_cells(sh, ncell, [&](int c) {
+    const int i = c / (W + 1), d = c - i * (W + 1);
+    return i + d <= L && i > 0 && d + 2 <= W && ok(i - 1, d + 2);
+  });
   const uint8_t* seq = a.b.seq + p.seq_base;
   const int32_t* ndot = a.fix_rss ? a.b.ndot + p.pos_base : nullptr;
   const EndWords words{a.okbits_end + p.bits_base, (ncell + 31) / 32};
   const PlanCfg cfg{a.no_ene, a.min_span, a.fix_rss};
   LoopItem* items = a.p.items + p.item_base;
   uint8_t* item_in = a.p.item_in + p.item_base;
-  int pos = a.p.by_outer_off[p.off_base + c];
-  enum_interior_by_end(*a.et, cfg, seq, L, W, p.C, ndot, words, i, d, [&](int k, int l, double tsc, bool in) {
-    LoopItem it;
-    it.tsc = tsc; it.i = (int16_t)i; it.j = (int16_t)(i + d); it.k = (int16_t)k; it.l = (int16_t)l;
-    items[pos] = it;
-    item_in[pos] = in ? 1 : 0;
-    ++pos;
-  });
+  for (int t = threadIdx.x; t < n_act; t += kThreads) {
+    const int c = sh.list[t];
+    const int i = c / (W + 1), d = c - i * (W + 1);
+    int pos = a.p.by_outer_off[p.off_base + c];
+    enum_interior_by_end(*a.et, cfg, seq, L, W, p.C, ndot, words, i, d, [&](int k, int l, double tsc, bool in) {
+      LoopItem it;
+      it.tsc = tsc; it.i = (int16_t)i; it.j = (int16_t)(i + d); it.k = (int16_t)k; it.l = (int16_t)l;
+      items[pos] = it;
+      item_in[pos] = in ? 1 : 0;
+      ++pos;
+    });
+  }
 }
 
 // one role: zero the counters | count the keys | (k_plan_scan) | scatter the item indices | sort every segment
@@ -668,7 +724,7 @@ hipError_t launch_plan_cells(const PlanKernelArgs& a, int32_t* n_items_out, hipS
   hipError_t e = hipMemsetAsync(n_items_out, 0, sizeof(int32_t) * a.count, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_mask_by_end, dim3((a.nword_max + kThreads - 1) / kThreads, a.count), dim3(kThreads), 0, st, a);
-  hipLaunchKernelGGL(k_plan_cells, dim3((a.ncell_max + kThreads - 1) / kThreads, a.count), dim3(kThreads), 0, st, a, n_items_out);
+  hipLaunchKernelGGL(k_plan_cells, dim3((a.ncell_max + kPlanTile * kThreads - 1) / (kPlanTile * kThreads), a.count), dim3(kThreads), 0, st, a, n_items_out);
   return hipGetLastError();
 }
 hipError_t launch_permute_items(const PlanKernelArgs& a, hipStream_t st) {
@@ -680,7 +736,7 @@ hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
   if (a.count <= 0) return hipSuccess;
   const dim3 cells((a.ncell_max + 1 + kThreads - 1) / kThreads, a.count), items((a.nitems_max + kThreads - 1) / kThreads, a.count);
   hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, -1);
-  hipLaunchKernelGGL(k_plan_fill, cells, dim3(kThreads), 0, st, a);
+  hipLaunchKernelGGL(k_plan_fill, dim3((a.ncell_max + kPlanTile * kThreads - 1) / (kPlanTile * kThreads), a.count), dim3(kThreads), 0, st, a);
   for (int role = 0; role < a.n_roles; ++role) {
     hipLaunchKernelGGL(k_role_zero, cells, dim3(kThreads), 0, st, a, role);
     if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_count, items, dim3(kThreads), 0, st, a, role);
