@@ -578,25 +578,39 @@ __device__ __forceinline__ void outer_ranges_load(const LViews& v, int i0, int n
     cnts[c] = (n1 > n0) ? n1 - n0 : 0;
   }
 }
-__device__ __forceinline__ int outer_ranges_prefix(int nc, int tid, const int* cnts, int* pre) {
-  for (int c = tid; c <= nc; c += kBT) {
+// exclusive prefix of the LDS ints cnts[0 .. n) into pre[0 .. n], pre[n] = total (no barrier).  Up to 64 entries -- the CSR ranges
+// of a workgroup's cells -- by one wave scan: a lane that adds up its predecessors itself walks a chain of n dependent LDS reads
+// (~1 us for the 36 ranges of k4_out, in every workgroup).
+__device__ __forceinline__ void lds_prefix(int n, int tid, const int* cnts, int* pre) {
+  if (n <= 64) {
+    if (tid < 64) {
+      const int x = tid < n ? cnts[tid] : 0;
+      int incl = x;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o, 64);
+        if (tid >= o) incl += y;
+      }
+      if (tid < n) pre[tid] = incl - x;
+      if (tid == 63) pre[n] = incl;
+    }
+    return;
+  }
+  for (int c = tid; c <= n; c += kBT) {
     int p = 0;
     for (int k = 0; k < c; ++k) p += cnts[k];
     pre[c] = p;
   }
+}
+__device__ __forceinline__ int outer_ranges_prefix(int nc, int tid, const int* cnts, int* pre) {
+  lds_prefix(nc, tid, cnts, pre);
   __syncthreads();
   return pre[nc];
 }
 __device__ __forceinline__ int outer_ranges(const LViews& v, int i0, int nc, int d, bool on, int tid, int* cnts, int* pre, int* base) {
   outer_ranges_load(v, i0, nc, d, on, tid, cnts, base);
   __syncthreads();
-  for (int c = tid; c <= nc; c += kBT) {
-    int p = 0;
-    for (int k = 0; k < c; ++k) p += cnts[k];
-    pre[c] = p;
-  }
-  __syncthreads();
-  return pre[nc];
+  return outer_ranges_prefix(nc, tid, cnts, pre);
 }
 // record p of the workgroup (prefix `pre` over its nc cells): its cell and its index in the item arrays
 __device__ __forceinline__ void outer_locate(int p, int nc, const int* pre, const int* base, int& lo, int& n) {
@@ -697,6 +711,7 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k4_in(LinArgs a) {
       }
     }
   }
+  if (a.dbg & 1024) { if (nc == 12345) lds[tid] = crx[0]; return; }   // (timing experiments: the workgroup up to its plan record ...
   const BlockCtx cx = stage_context<BIG, 0, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
   const int32_t* G = v.m.big;
@@ -704,6 +719,7 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k4_in(LinArgs a) {
   int* crfl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
   for (int t = tid; t < NW * 2 * CS; t += kBT) lds[t] = 0.;
   __syncthreads();
+  if (a.dbg & 2048) return;                                             //  ... and up to its staged context)
   pc.mark<0>();
   if (FAST) {   // (read by the unary phase, behind the barriers of the heavy sums)
 #pragma unroll
@@ -1282,6 +1298,7 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
       }
     }
   }
+  if (a.dbg & 1024) { if (nc == 12345) lds[tid] = crx[0] + pi.invZ; return; }   // (timing experiments, as in k4_in)
   const BlockCtx cx = stage_context<BIG, 1, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
   if (pi.skip) return;   // (tested here: the loads behind `pi` travel with those of the context instead of before them)
   int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
@@ -1291,6 +1308,7 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   const int n_zero = NW * (HS + ES) + ((MODE == OUT_SCAN || MODE == OUT_END) ? 2 * win : 0);
   for (int t = tid; t < n_zero; t += kBT) lds[t] = 0.;
   __syncthreads();
+  if (a.dbg & 2048) return;
   pc.mark<5>();
   if (FAST) {   // (read by the unary phase, behind the barriers of the heavy sums)
 #pragma unroll
@@ -1342,11 +1360,7 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   // ... their prefix, and the first 256 item records fetched ahead: they arrive while the pair phases run
   // (off by default: two barriers more than the round trip saved, measured)
   __syncthreads();
-  for (int vc = tid; vc <= nv; vc += kBT) {
-    int p = 0;
-    for (int c = 0; c < vc; ++c) p += cnts[c];
-    pre[vc] = p;
-  }
+  lds_prefix(nv, tid, cnts, pre);
   __syncthreads();
   const int n_rec = pre[nv];
   if (tid < n_rec) {
@@ -1474,11 +1488,7 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   // then needs a single round of table loads, selected by role without branches.
   {
 #if !ELEMDP_AHEAD_OUT
-    for (int vc = tid; vc <= nv; vc += kBT) {
-      int p = 0;
-      for (int c = 0; c < vc; ++c) p += cnts[c];
-      pre[vc] = p;
-    }
+    lds_prefix(nv, tid, cnts, pre);
     __syncthreads();
     const int n_rec = pre[nv];
 #endif
