@@ -29,6 +29,12 @@
 #ifndef ELEMDP_LB_IN
 #define ELEMDP_LB_IN 4
 #endif
+// The table-driven k4_in needs 65 vector registers.  Asked for eight waves per SIMD (W8) it fits 64 with a few spilled dwords:
+// worth it where the eighth workgroup per CU then fits the LDS as well (113.4 vs 115.4 ms per 4096 x L=200 for ((.*.)): 19.7 KB
+// per workgroup), a loss where the LDS holds fewer workgroups anyway ((.....): 24.4 KB, +1 %) -- the launcher chooses.
+#ifndef ELEMDP_LB_IN_FAST
+#define ELEMDP_LB_IN_FAST 8
+#endif
 #ifndef ELEMDP_LB_OUT
 #define ELEMDP_LB_OUT 4
 #endif
@@ -665,8 +671,8 @@ __device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r,
 }
 
 // FAST: table-driven phases (lin_fast.h; train schedule, the fast blob staged); FP: longest pair list of a state (2 or 3)
-template <bool BIG, bool CON, bool FAST = false, int FP = kFastP>
-__global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k4_in(LinArgs a) {
+template <bool BIG, bool CON, bool FAST = false, int FP = kFastP, bool W8 = false>
+__global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
   PhaseClock pc;
@@ -2017,6 +2023,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   const bool fp2 = a.lay.fp_max_p <= 2;
   const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
   const size_t lds_out = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
+  const bool w8 = lds_in * 8 <= 160 * 1024;   // (the eighth k4_in workgroup of a CU fits the LDS: the 64-register variant)
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds((a.ext_ring ? ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
   const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4 + (a.ext_ring ? ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
@@ -2027,7 +2034,8 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       if (ncell <= 0) break;                                                                                                     \
       a.d = d;                                                                                                                   \
       const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
-      if (fast && fp2) hipLaunchKernelGGL((k4_in<true, CON, true, 2>), grid, dim3(kBT), lds_in, st, a);                     \
+      if (fast && fp2 && w8) hipLaunchKernelGGL((k4_in<true, CON, true, 2, true>), grid, dim3(kBT), lds_in, st, a);         \
+      else if (fast && fp2) hipLaunchKernelGGL((k4_in<true, CON, true, 2>), grid, dim3(kBT), lds_in, st, a);                \
       else if (fast) hipLaunchKernelGGL((k4_in<true, CON, true>), grid, dim3(kBT), lds_in, st, a);                          \
       else if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kBT), lds_in, st, a);                                 \
       else hipLaunchKernelGGL((k4_in<false, CON>), grid, dim3(kBT), lds_in, st, a);                                         \
@@ -2082,7 +2090,8 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
       const int ncell = Lmax - d + 1;
       if (ncell <= 0) break;
       a.d = d;
-      if (fast && a.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_in<true, false, true, 2>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
+      if (fast && a.lay.fp_max_p <= 2 && lds_in * 8 <= 160 * 1024) hipLaunchKernelGGL((k4_in<true, false, true, 2, true>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
+      else if (fast && a.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_in<true, false, true, 2>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
       else if (fast) hipLaunchKernelGGL((k4_in<true, false, true>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
       else if (big) hipLaunchKernelGGL((k4_in<true, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
       else hipLaunchKernelGGL((k4_in<false, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);

@@ -8,7 +8,7 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 pipeline = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 group = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-eng = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+eng = api.Engine(os.environ.get("ELEMDP_PATTERN", "((.*.))"), "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
 eng.set_option("pipeline", pipeline)
 if group:
     eng.set_option("group", group)
