@@ -52,7 +52,7 @@
 #define ELEMDP_RECIN 1024
 #endif
 #ifndef ELEMDP_RECOUT
-#define ELEMDP_RECOUT 1536
+#define ELEMDP_RECOUT 960
 #endif
 #include "kernels.h"
 #include "lin_rules.h"
@@ -1255,8 +1255,9 @@ __global__ __launch_bounds__(kThreads) void k4_r7(LinArgs a) {
 }
 
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
-template <int MODE, bool BIG, bool FAST = false, int FP = kFastP>
-__global__ __launch_bounds__(kBT, ELEMDP_LB_OUT) void k4_out(LinArgs a) {
+// W6: asked for six waves per SIMD (80 registers, a few spilled dwords) -- taken by the launcher where six workgroups fit the LDS
+template <int MODE, bool BIG, bool FAST = false, int FP = kFastP, bool W6 = false>
+__global__ __launch_bounds__(kBT, W6 ? 6 : ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
   PhaseClock pc;
@@ -2120,6 +2121,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
         if (ncell <= 0) continue;
         b.d = d;
         if (big && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);   // (timing experiment: no statistics)
+        else if (fast && b.lay.fp_max_p <= 2 && lds_b * 6 <= 160 * 1024) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
         else if (fast && b.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
         else if (fast) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
         else if (big) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
