@@ -24,7 +24,7 @@
 #include <cstdlib>
 
 #ifndef ELEMDP_KCI
-#define ELEMDP_KCI 4
+#define ELEMDP_KCI 2
 #endif
 #ifndef ELEMDP_LB_IN
 #define ELEMDP_LB_IN 4
@@ -34,6 +34,14 @@
 // per workgroup), a loss where the LDS holds fewer workgroups anyway ((.....): 24.4 KB, +1 %) -- the launcher chooses.
 #ifndef ELEMDP_LB_IN_FAST
 #define ELEMDP_LB_IN_FAST 8
+#endif
+// k5_cyk: 64 registers without spills when asked for eight waves per SIMD, and 17.9 KB of LDS with two split points per staging
+// round (25.9 KB with four): eight workgroups per CU instead of six, scan 982 -> 961 ms (10 000 x L=300)
+#ifndef ELEMDP_LB_CYK
+#define ELEMDP_LB_CYK 8
+#endif
+#ifndef ELEMDP_LB_OUT6
+#define ELEMDP_LB_OUT6 6
 #endif
 #ifndef ELEMDP_LB_OUT
 #define ELEMDP_LB_OUT 4
@@ -433,7 +441,7 @@ __device__ __forceinline__ BlockCtx stage_context(const LinArgs& a, LViews& v, u
 // [e][d][i][s] layout: one segment of nc*S doubles per (plane, split point)), then one lane per (cell, state tuple)
 // multiplies out of LDS.  Global loads are thereby independent of the tuple structure (every element is fetched
 // once per workgroup, 2*kChunk loads in flight per lane) and the dependent chain per diagonal stays short.
-constexpr int kChunkIn = ELEMDP_KCI;    // split points per staging round, inside  (2 segments each)
+constexpr int kChunkIn = ELEMDP_KCI;    // split points per staging round of k5_cyk (2 segments each)
 
 // Which element of a staged operand row a lane copies.  Only the first NU = n_front states of a row can be non-zero in the
 // planes of the bifurcation rule (B, 1, 2) of a complete parse (Automaton::flatten puts them first), so a staged row is
@@ -1257,7 +1265,7 @@ __global__ __launch_bounds__(kThreads) void k4_r7(LinArgs a) {
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
 // W6: asked for six waves per SIMD (80 registers, a few spilled dwords) -- taken by the launcher where six workgroups fit the LDS
 template <int MODE, bool BIG, bool FAST = false, int FP = kFastP, bool W6 = false>
-__global__ __launch_bounds__(kBT, W6 ? 6 : ELEMDP_LB_OUT) void k4_out(LinArgs a) {
+__global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
   PhaseClock pc;
@@ -1762,7 +1770,7 @@ __global__ __launch_bounds__(kThreads) void k5_cyk_serial(LinArgs a) {
 // the traceback re-derives the winner of the targets it visits (scan_rules.h, cyk_retrace), so the maxima of the two span-long
 // candidate lists need no order bookkeeping here.
 template <bool BIG, int KOWN>
-__global__ __launch_bounds__(kBT, ELEMDP_LB_IN) void k5_cyk(LinArgs a) {
+__global__ __launch_bounds__(kBT, ELEMDP_LB_CYK) void k5_cyk(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
 
