@@ -505,6 +505,11 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
         ints->push_back(live ? n++ : -1);
       }
       A.tab_rs[e] = std::max(pad, ((n + pad - 1) / pad) * pad);
+    }
+    // (the table-driven kernels keep X = P * exp(lambda e_ml) in the rows of the B plane under P's columns: those rows hold at
+    // least as many columns as P's)
+    A.tab_rs[ST_B] = std::max(A.tab_rs[ST_B], A.tab_rs[ST_P]);
+    for (int e = 0; e < 7; ++e) {
       A.tab_cs[e] = cs;
       cs += A.tab_rs[e];
     }
@@ -514,6 +519,15 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   // table-driven unary phases (device_layout.h: fp_*): programs per state, static attributes per forward transition.  They
   // travel with the tuple lists of their direction (the "big" runs below), not with the small part every kernel stages.
   std::vector<int32_t> prog_in, prog_out, attr_r, attr_p, pair_rec, scan_fl;
+  // the states that have a column in some plane, in state order: the unary phases of the table-driven kernels give them a lane each
+  // per cell, and the heavy sums of a cell are indexed by a state's position in this list (li; -1 for the others)
+  std::vector<int32_t> live_states;
+  std::vector<int> li(ST, -1);
+  for (int k = 0; k < ST; ++k) {
+    bool any = false;
+    for (int e = 0; e < 7; ++e) any = any || (*ints)[A.tab_cmap + e * ST + k] >= 0;
+    if (any) { li[k] = (int)live_states.size(); live_states.push_back(k); }
+  }
   {
     auto colof = [&](int e, int k) { return (*ints)[A.tab_cmap + e * ST + k] & 0xff; };   // (-1 -> 0xff)
     auto base_of = [&](const Csr& c) {   // first transition id of every row
@@ -621,9 +635,11 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
       const int nch = (int)chain_keep.rows[k].size() / 2, nrch = (int)rchain_keep.rows[k].size() / 2;
       if (nch > kFastR || nrch > kFastR || A.n_ap > 254 || ST > 254) { ok = false; break; }
       int32_t w[8] = {0};
-      w[0] = colof(ST_1, s1) | (colof(ST_P, t) << 8) | ((tgt >= 0 ? tgt : 0xff) << 16) |
+      // (target, s1 and t as live indices: they address the heavy sums)
+      w[0] = colof(ST_1, s1) | (colof(ST_P, t) << 8) | (((tgt >= 0 && li[tgt] >= 0) ? li[tgt] : 0xff) << 16) |
              (((attr(A.st_lam, t) ? 1 : 0) | (attr(A.st_w_r, t) ? 2 : 0) | (t == A.shadow ? 4 : 0)) << 24);
-      w[1] = s1 | (t << 8) | (nch << 16) | (nrch << 20);
+      if (li[s1] < 0 || li[t] < 0) { ok = false; break; }
+      w[1] = li[s1] | (li[t] << 8) | (nch << 16) | (nrch << 20);
       for (int u = 0; u < nch; ++u) {
         const int pc = chain_keep.rows[k][2 * u];
         w[2 + u] = pc | (fwd_id(right, br, t, ap_keep[pc][1]) << 8);
@@ -686,13 +702,12 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   // fast blobs of the table-driven train kernels (behind n_ints: the generic kernels never stage them)
   auto append = [&](const std::vector<int32_t>& v) { const int32_t pos = (int32_t)ints->size(); ints->insert(ints->end(), v.begin(), v.end()); return pos; };
   auto copy_of = [&](int32_t from, int n) { return std::vector<int32_t>(ints->begin() + from, ints->begin() + from + n); };
-  const std::vector<int32_t> qci = copy_of(A.qc_in, 2 * A.n_quad), qco = copy_of(A.qc_out1, 6 * A.n_quad);
-  std::vector<int32_t> live_states;
-  for (int k = 0; k < ST; ++k) {
-    bool any = false;
-    for (int e = 0; e < 7; ++e) any = any || (*ints)[A.tab_cmap + e * ST + k] >= 0;
-    if (any) live_states.push_back(k);
-  }
+  std::vector<int32_t> qci = copy_of(A.qc_in, 2 * A.n_quad), qco = copy_of(A.qc_out1, 6 * A.n_quad);
+  for (std::vector<int32_t>* q : {&qci, &qco})   // (the fast copies name the target by its live index; dead without one)
+    for (size_t r = 1; r < q->size(); r += 2) {
+      const int k = (*q)[r] & 0xffff, fl = (*q)[r] >> 16;
+      (*q)[r] = (li[k] >= 0 ? li[k] : 0) | ((fl | (li[k] >= 0 ? 0 : 4)) << 16);
+    }
   A.n_lane = (int32_t)live_states.size();
   A.fb_in = (int32_t)ints->size();
   A.f_live_in = append(live_states);

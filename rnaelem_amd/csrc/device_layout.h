@@ -90,6 +90,8 @@ struct AutomatonLayout {
   //     flags << 24 (bit 0 lambda class of t, 1 position weight of t's r-node, 2 t is the shadow state); s1 | t << 8 |
   //     n_chain << 16 | n_rchain << 20; 3 chain entries pc | id << 8 (tail step from pair pc, right transition id); 3 rchain
   //     entries pp | id << 8} with c1 / cP = column of s1 in plane 1 / of t in plane P, tgt = 0xff for none;
+  //     tgt, s1 and t are LIVE INDICES (position among the states that have a column at all, f_live_*): the heavy sums of a cell
+  //     are n_lane wide in the table-driven kernels, not S; the targets of the fast tuple records (fqc_*) likewise;
   //   * the column records of the interior-loop tuples (fqc_in; fqc_out = three lists of n_quad, see qc_* below).
   // fp_ok = 0: a list is longer than kFastR / kFastP / kFastL (or a column index does not fit a byte); the kernels then
   // run the generic rule code.

@@ -703,7 +703,8 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
     const int ys = a.ys[v.n];
     if (ys < i0 || ys - d + 1 > i0 + nc - 1) return;
   }
-  const int CS = cpb * S, ncS = nc * S;
+  const int HD = FAST ? A.n_lane : S;   // stride of the heavy sums per cell: the live states (table-driven: their index among them), or all
+  const int CS = cpb * HD;
   const int NW = a.det ? kBT / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the heavy sums (one per wave: rep_sum)
   double* hb = lds;
   double* he = hb + CS;
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
           }
           v.in.a(d, i, p) = av;
         }
-        if (tg != 0xff && av != 0.) atomicAdd(&hbA[c * S + tg], av);
+        if (tg != 0xff && av != 0.) atomicAdd(&hbA[c * HD + tg], av);
         continue;
       }
       const int s1 = I[A.ap_s1 + p], t = I[A.ap_t + p], tgt = I[A.ap_tgt + p];
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
         }
         v.in.a(d, i, p) = av;
       }
-      if (tgt >= 0 && av != 0.) atomicAdd(&hbA[c * S + tgt], av);
+      if (tgt >= 0 && av != 0.) atomicAdd(&hbA[c * HD + tgt], av);
     }
   }
   __syncthreads();
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
         // (the inner pair of an item is a kept pair, the loops L are stored everywhere)
         const uint32_t rP = v.in.cidx(ST_P, it.l - it.k, it.k, 0), rL1 = v.in.cidx(ST_L, it.k - i, i, 0), rL2 = v.in.cidx(ST_L, j - it.l, it.l, 0);
         const double xw0 = R.xw[xc], xw1 = R.xw[R.cap + xc];
-        double* hrow = heA + c * S;
+        double* hrow = heA + c * HD;
         for (int t0 = wv; t0 < nq; t0 += kWaves * kTU) {
           int qa[kTU], qb[kTU];
           double x0[kTU], x1[kTU], x2[kTU];
@@ -941,11 +942,11 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
     const int s = FAST ? G[A.f_live_in + tid - c * NL] : tid - c * NL;
     const int i = i0 + c;
     if (FAST) {
-      fast_inside_unary<kFastR, FP, kFastL, CON>(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, hb + c * S + s,
-                                                 he + c * S + s, NW, 2 * CS, G + A.fs_in);
+      fast_inside_unary<kFastR, FP, kFastL, CON>(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, hb + c * HD + (tid - c * NL),
+                                                 he + c * HD + (tid - c * NL), NW, 2 * CS, G + A.fs_in);
     } else {
       const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
-      lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, rep_sum(hb + c * S + s, NW, 2 * CS), rep_sum(he + c * S + s, NW, 2 * CS), con);
+      lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, rep_sum(hb + c * HD + s, NW, 2 * CS), rep_sum(he + c * HD + s, NW, 2 * CS), con);
     }
   }
   pc.mark<4>();
@@ -1283,7 +1284,8 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   const int ncell = L - d + 1, i0 = bx * cpb;
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
-  const int CS = cpb * S, ncS = nc * S;
+  const int HD = FAST ? A.n_lane : S;   // (as in k4_in)
+  const int CS = cpb * HD;
   const int NW = a.det ? kBT / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the sums (one per wave: rep_sum)
   const int HS = 4 * CS, ES = 2 * nt + 4;      // doubles of one copy of the heavy sums / of the statistics
   double* h1 = lds;                            // copy 0 (the unary phase adds the copies up)
@@ -1429,7 +1431,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
         const bool ok = dmii > 0 && b >= dmii;              // 1(ii, i, .) is parsable (then the pair entries of (ii, d + b) exist)
         ha_oa[u] = out.lda(d + b, ii, p, ok);
         ha_x1[u] = in.ldc(ST_1, b, ii, pr_c1(p), ok);
-        ha_idx[u] = c * S + pr_t(p);
+        ha_idx[u] = c * HD + pr_t(p);
       }
     };
     auto ha_add = [&]() {
@@ -1488,7 +1490,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
           if (sp3 >= 0) acc = fma(a3, b3 * c3, acc);
           if (sp3 < 0) break;
         }
-        if (acc != 0.) atomicAdd(&h1A[c * S + s1], acc);
+        if (acc != 0.) atomicAdd(&h1A[c * HD + s1], acc);
       }
     }
     if (total > 0) ha_add();
@@ -1554,7 +1556,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
         const uint32_t r2 = role == 0 ? in.cidx(ST_L, it.j - j, j, 0) : role == 1 ? in.cidx(ST_L, it.j - it.l, it.l, 0) : in.cidx(ST_L, it.k - it.i, it.i, 0);
         const uint32_t rA = role == 0 ? in.cidx(ST_P, d, i, 0) : in.cidx(ST_L, d, i, 0);
         const double xw0 = r_xw[xc], xw1 = r_xw[cap + xc];
-        double* hrow = hpA + (role == 0 ? 0 : CS) + c * S;   // hp, or hl = hp + CS
+        double* hrow = hpA + (role == 0 ? 0 : CS) + c * HD;   // hp, or hl = hp + CS
         const int qc0 = (FAST ? A.fqc_out : A.qc_out1) + role * 2 * nq;
         for (int t0 = wv; t0 < nq; t0 += kWaves * kTU) {
           int qa[kTU], qb[kTU];
@@ -1605,17 +1607,17 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
     sink.world = w1 ? 1 : 0;
     sink.en_ = l_en + (w1 ? nt : 0);
     if (FAST) {
-      h1[c * S + s] = fast_outside_unary<kFastR, FP, kFastL, MODE>(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c],
+      h1[c * HD + (tid - c * NL)] = fast_outside_unary<kFastR, FP, kFastL, MODE>(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c],
                                                                    d, i0 + c, w1 ? pi.invZs : pi.invZ, v.m.lam_same != 0, v.m.no_prf != 0, sink,
-                                                                   h1 + c * S + s, CS, NW, HS, G + A.fs_out);
+                                                                   h1 + c * HD + (tid - c * NL), CS, NW, HS, G + A.fs_out);
     } else {
       LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
       HeavyOut H;
-      H.H1 = rep_sum(h1 + c * S + s, NW, HS); H.H2 = rep_sum(h2 + c * S + s, NW, HS);
-      H.HP = rep_sum(hp + c * S + s, NW, HS); H.HL = rep_sum(hl + c * S + s, NW, HS);
+      H.H1 = rep_sum(h1 + c * HD + s, NW, HS); H.H2 = rep_sum(h2 + c * HD + s, NW, HS);
+      H.HP = rep_sum(hp + c * HD + s, NW, HS); H.HL = rep_sum(hl + c * HD + s, NW, HS);
       if (!(a.dbg & 32)) H.HP += out.ld(ST_P, d, i0 + c, s, v.q.pair_ok(i0 + c, d));   // rule-7 term (k4_r7)
       H.ext_in_hp = true;
-      h1[c * S + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
+      h1[c * HD + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
     }
   }
   __syncthreads();
@@ -1645,7 +1647,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
           }
           double acc = 0.;
           if (a_in != 0.) {
-            acc = tg != 0xff ? h1[c * S + tg] : 0.;
+            acc = tg != 0xff ? h1[c * HD + tg] : 0.;
             const double inz = a_in * (w1 ? pi.invZs : pi.invZ);
             const int bj = step ? (int)v.q.seq[j] : 0;
             const double ewj = step ? v.q.ews[j] : 1.;
@@ -1671,7 +1673,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
       const bool w1 = pi.merged && v.m.ints[A.ap_t + p] == A.shadow;
       sink.en_ = l_en + (w1 ? nt : 0);
       LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
-      lin_outside_apair<MODE>(x, d, i0 + c, p, tgt >= 0 ? h1[c * S + tgt] : 0.);
+      lin_outside_apair<MODE>(x, d, i0 + c, p, tgt >= 0 ? h1[c * HD + tgt] : 0.);
     }
     sink.en_ = en_keep;
   }
@@ -2030,9 +2032,12 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   if (fast) a.cpb = std::min(kBT / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
   const bool fp2 = a.lay.fp_max_p <= 2;
-  const size_t lds_in = block_lds(2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
-  const size_t lds_out = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
+  const int hd = fast ? a.lay.n_lane : S;   // stride of the heavy sums per cell (k4_in / k4_out: HD)
+  const size_t lds_in = block_lds(2 * a.cpb * hd + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
+  const size_t lds_out = block_lds(out_doubles(a.cpb * hd, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
   const bool w8 = lds_in * 8 <= 160 * 1024;   // (the eighth k4_in workgroup of a CU fits the LDS: the 64-register variant)
+  const bool w6 = lds_out * 6 <= 160 * 1024;  // (the sixth k4_out workgroup: the 80-register variant)
+  if (getenv("ELEMDP_LDS_DEBUG") && phase == 0) fprintf(stderr, "scan group: G %d cpb %d S %d nt %d fast %d n_lin %d fast blob in/out %d/%d ints win %d lds k4_in %zu k4_out %zu\n", G, a.cpb, S, nt, (int)fast, a.n_lin, a.lay.fb_in_n, a.lay.fb_out_n, a.cpb + Wmax + 3, lds_in, lds_out);
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds((a.ext_ring ? ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
   const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4 + (a.ext_ring ? ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
@@ -2059,7 +2064,8 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       if (ncell <= 0) continue;                                                                                                  \
       a.d = d;                                                                                                                   \
       const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
-      if (fast && fp2) hipLaunchKernelGGL((k4_out<MODE, true, true, 2>), grid, dim3(kBT), lds_out, st, a);                  \
+      if (fast && fp2 && w6) hipLaunchKernelGGL((k4_out<MODE, true, true, 2, true>), grid, dim3(kBT), lds_out, st, a);      \
+      else if (fast && fp2) hipLaunchKernelGGL((k4_out<MODE, true, true, 2>), grid, dim3(kBT), lds_out, st, a);             \
       else if (fast) hipLaunchKernelGGL((k4_out<MODE, true, true>), grid, dim3(kBT), lds_out, st, a);                       \
       else if (big) hipLaunchKernelGGL((k4_out<MODE, true>), grid, dim3(kBT), lds_out, st, a);                              \
       else hipLaunchKernelGGL((k4_out<MODE, false>), grid, dim3(kBT), lds_out, st, a);                                      \
@@ -2092,7 +2098,8 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   if (fast) a.cpb = std::min(kBT / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);   // (states without any column take no lane)
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
   const int NW = a.det ? kBT / 64 : 1;
-  const size_t lds_in = block_lds(NW * 2 * a.cpb * S + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
+  const int hd = fast ? a.lay.n_lane : S;   // stride of the heavy sums per cell (k4_in / k4_out: HD)
+  const size_t lds_in = block_lds(NW * 2 * a.cpb * hd + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
   const size_t lds_stat = sizeof(double) * (2 * nt + 4);
   if (!a.no_rss)
     for (int d = 0; d <= Wmax; ++d) {
@@ -2114,7 +2121,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   // pattern's states, the "no motif" terminal on the shadow of (0,0), each with its own Z and statistics (lpass).
   // schedule 0: the reference's two sweeps, (ari, nasi) then the label's mask.
   const int n_pass = (a.schedule == 1 || first_pass_only) ? 1 : 2;
-  const size_t lds_b = block_lds(out_doubles(a.cpb * S, nt, a.cpb + Wmax + 3, NW), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
+  const size_t lds_b = block_lds(out_doubles(a.cpb * hd, nt, a.cpb + Wmax + 3, NW), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
   if (getenv("ELEMDP_LDS_DEBUG")) fprintf(stderr, "lin group: G %d cpb %d fast %d n_lin %d staged ints in/out %d/%d lds k4_in %zu k4_out %zu\n", G, a.cpb, (int)fast, a.n_lin, staged_ints(a.lay, a.n_stage, 0), staged_ints(a.lay, a.n_stage, 1), lds_in, lds_b);
   for (int pass = 0; pass < n_pass; ++pass) {
     LinArgs b = a;
