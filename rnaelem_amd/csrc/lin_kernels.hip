@@ -1366,7 +1366,10 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
     const int cell = v.q.cell(i, d);
     const int32_t* off = role == 0 ? v.q.by_inner_off : role == 1 ? v.q.by_left_off : v.q.by_right_off;
     int n0 = 0, n1 = 0;
-    if (nq > 0 && (role != 0 || v.q.pair_ok(i, d))) { n0 = off[cell]; n1 = off[cell + 1]; }
+    // (table-driven kernels: no loop sums on the diagonal d = 0 -- the outside value of an EMPTY loop L(i,i) has no reader: it has
+    // no children, and the statistics of the emissions into it use the parent's value.  Those cells own the records of every
+    // stack and bulge of the sequence.  The generic kernels, whose tables debug_tables exports, keep them.)
+    if (nq > 0 && (role != 0 || v.q.pair_ok(i, d)) && !(FAST && role != 0 && d == 0)) { n0 = off[cell]; n1 = off[cell + 1]; }
     base[vc] = n0;
     cnts[vc] = (n1 > n0) ? n1 - n0 : 0;
   }
