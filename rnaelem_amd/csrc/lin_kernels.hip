@@ -1284,6 +1284,13 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   const int ncell = L - d + 1, i0 = bx * cpb;
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
+  if (MODE == OUT_END) {
+    // Under the start constraint the motif begins at Ys: a cell that ends at or before Ys holds no part of it, so no transition in
+    // it can be an end of the motif (its posterior is an exact 0: a derivation whose motif began earlier emits Ys with weight 0),
+    // and nothing that is swept reads its outside value -- parents, item sums and pair entries all look at cells that contain the
+    // reader.  Workgroups whose cells all satisfy j <= Ys return: on average half of the sweep.
+    if (!(a.dbg & 4096) && i0 + nc - 1 + d <= a.ys[v.n]) return;
+  }
   const int HD = FAST ? A.n_lane : S;   // (as in k4_in)
   const int CS = cpb * HD;
   const int NW = a.det ? kBT / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the sums (one per wave: rep_sum)
@@ -1603,7 +1610,10 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   }
   pc.mark<10>();
   const int NL = FAST ? A.n_lane : NA;   // lanes per cell of the unary phase: the states that have a column at all
-  if (tid < nc * NL && !(a.dbg & 4) && !(ELEMDP_KO & 4)) {
+  // (OUT_END: the cells of this workgroup that end at or before Ys take no part -- see the workgroup test above; their parents may
+  // lie in a workgroup that returned, so neither their values nor their statistics mean anything)
+  const int end_ys = (MODE == OUT_END && !(a.dbg & 4096)) ? a.ys[v.n] : -1;
+  if (tid < nc * NL && !(a.dbg & 4) && !(ELEMDP_KO & 4) && i0 + div_small(tid, NL) + d > end_ys) {
     const int c = div_small(tid, NL);
     const int s = FAST ? G[A.f_live_out + tid - c * NL] : tid - c * NL;
     const bool w1 = pi.merged && s == A.shadow;      // the shadow state: world 1 (its own Z, second set of statistics)
@@ -1631,6 +1641,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
     double* const en_keep = sink.en_;
     for (int w = tid; w < nc * nA; w += kBT) {
       const int c = div_small(w, nA), p = w - c * nA;
+      if (i0 + c + d <= end_ys) continue;
       if (FAST) {   // lin_outside_apair from the pair record (AutomatonLayout::fpr_out) and the weight tables
         const int32_t* PR = G + A.fpr_out + 8 * p;
         const int r0 = PR[0], r1 = PR[1];
