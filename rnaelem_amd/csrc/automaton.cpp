@@ -528,6 +528,9 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     for (int e = 0; e < 7; ++e) any = any || (*ints)[A.tab_cmap + e * ST + k] >= 0;
     if (any) { li[k] = (int)live_states.size(); live_states.push_back(k); }
   }
+  A.st_live = (int32_t)ints->size(); ints->insert(ints->end(), live_states.begin(), live_states.end());
+  A.st_li = (int32_t)ints->size(); ints->insert(ints->end(), li.begin(), li.end());
+  A.n_lane = (int32_t)live_states.size();
   {
     auto colof = [&](int e, int k) { return (*ints)[A.tab_cmap + e * ST + k] & 0xff; };   // (-1 -> 0xff)
     auto base_of = [&](const Csr& c) {   // first transition id of every row
@@ -754,6 +757,7 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   A.tab_row = 7; A.ap_rs = 1;
   A.fp_ok = 0; A.fp_in = A.fp_out = A.fe_r = A.fe_p = 0; A.n_wr = A.n_wp = A.n_wl = 0;
   A.fb_in = A.fb_in_n = A.fb_out = A.fb_out_n = A.fqc_in = A.fpr_in = A.fqc_out = A.fpr_out = A.fs_in = A.fs_out = 0;
+  A.st_live = one(0); A.st_li = one(0);
   A.fp_max_p = kFastP; A.n_lane = 1; A.f_live_in = A.f_live_out = 0;
   A.lin_wr = A.lin_wl = A.lin_wp = A.lin_total = 11;
   A.qc_in = A.qc_out1 = A.qc_out2 = A.qc_out3 = 0;

@@ -96,6 +96,7 @@ struct AutomatonLayout {
   // fp_ok = 0: a list is longer than kFastR / kFastP / kFastL (or a column index does not fit a byte); the kernels then
   // run the generic rule code.
   int32_t fp_ok, fb_in, fb_in_n, fb_out, fb_out_n;
+  int32_t st_live, st_li;   // the same list (n_lane ints) and its inverse (S ints, -1: no column anywhere) in the SMALL part of the blob
   int32_t n_lane;     // interval states with a column in at least one plane: the unary phases give a lane to each of them per cell
   int32_t f_live_in, f_live_out;   // their ids (n_lane ints, one copy in either fast blob)
   int32_t fp_max_p;   // longest pair list (forward or reverse) of a state: the kernels unroll 2 or kFastP slots

@@ -1786,7 +1786,7 @@ __global__ __launch_bounds__(kThreads) void k5_cyk_serial(LinArgs a) {
 // the traceback re-derives the winner of the targets it visits (scan_rules.h, cyk_retrace), so the maxima of the two span-long
 // candidate lists need no order bookkeeping here.
 template <bool BIG, int KOWN>
-__global__ __launch_bounds__(kBT, ELEMDP_LB_CYK) void k5_cyk(LinArgs a) {
+__global__ __launch_bounds__(kBT, KOWN <= 2 ? ELEMDP_LB_CYK : 6) void k5_cyk(LinArgs a) {   // (KOWN 4: 83 registers, spills at 64)
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
 
@@ -1800,7 +1800,10 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_CYK) void k5_cyk(LinArgs a) {
   const int ncell = v.q.L - d + 1, i0 = bx * cpb;
   if (i0 >= ncell) return;
   const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
-  const int CS = cpb * S, ncS = nc * S;
+  // lanes of the unary part and slots of the two maxima: the states that have a column in some plane (AutomatonLayout::st_live /
+  // st_li) -- the others are log 0 in every plane, no list refers to them and nothing is stored for them
+  const int NL = A.n_lane;
+  const int CS = cpb * NL;
   const double NEG = ELEMDP_NEG_INF;
   unsigned long long* kb = reinterpret_cast<unsigned long long*>(lds);   // [CS] best key, rule 2
   unsigned long long* ke = kb + CS;                                      // [CS] best key, rule 6c
@@ -1865,7 +1868,8 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_CYK) void k5_cyk(LinArgs a) {
     if (po1[r] >= 0 && pv[r] != NEG) {
       const int w = tid + r * kBT;
       const int c = w / nsp, t = w - c * nsp;
-      atomicMax(&kb[c * S + G[A.split_tgt + t]], cyk_key(pv[r]));
+      const int li = v.m.ints[A.st_li + G[A.split_tgt + t]];
+      if (li >= 0) atomicMax(&kb[c * NL + li], cyk_key(pv[r]));
     }
   // rule 6c: candidates P(k,l,s1) + (L(i,k,s2) + (L(l,j,s3) + lam * tsc)) over the item records of the workgroup's cells (staged
   // in LDS) x the tuples
@@ -1900,7 +1904,9 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_CYK) void k5_cyk(LinArgs a) {
             x1[u] = B[v.in.idx(ST_L, it.k - i, i, G[A.quad_ent + 3 * t + 1])];
             x2[u] = B[v.in.idx(ST_L, j - it.l, it.l, G[A.quad_ent + 3 * t + 2])];
             lt[u] = ELEMDP_MUL_RN(v.m.lam(tgs), it.tsc);
-            hidx[u] = c * S + tgs;
+            const int li = v.m.ints[A.st_li + tgs];
+            ok[u] = ok[u] && li >= 0;
+            hidx[u] = c * NL + (li >= 0 ? li : 0);
           }
 #pragma unroll
           for (int u = 0; u < kItemBatch; ++u) {
@@ -1914,8 +1920,8 @@ __global__ __launch_bounds__(kBT, ELEMDP_LB_CYK) void k5_cyk(LinArgs a) {
     }
   }
   __syncthreads();
-  if (tid < ncS) {
-    const int c = tid / S, s = tid - c * S;
+  if (tid < nc * NL) {
+    const int c = tid / NL, s = v.m.ints[A.st_live + tid - c * NL];
     const int i = i0 + c;
     MaxAcc hB, hE;
     hB.best = cyk_unkey(kb[tid]);
@@ -2005,7 +2011,16 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   a.ext_ring = G <= 1024 ? 1 : 0;
   a.lmax = Lmax;
   a.n_lin = kLinEth + nt; a.fast = 0; a.det = 0;
-  const size_t lds = block_lds(2 * a.cpb * S + 2 * kChunkIn * kBT, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
+  // cells per workgroup: a lane per (cell, live state) in the unary part, the front rows of all cells in one staging row, at most
+  // four (cell, split tuple) products per lane
+  const int NLc = std::max(a.lay.n_lane, 1);
+  a.cpb = std::min(std::min(kBT / NLc, kBT / std::max(a.lay.n_front, 1)), ELEMDP_CPB_MAX);
+#ifndef ELEMDP_CYK_PROD
+#define ELEMDP_CYK_PROD 4
+#endif
+  if (a.lay.n_split > 0) a.cpb = std::min(a.cpb, std::max(kBT / S, ELEMDP_CYK_PROD * kBT / a.lay.n_split));
+  a.cpb = std::max(a.cpb, 1);
+  const size_t lds = block_lds(2 * a.cpb * NLc + 2 * kChunkIn * kBT, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
   const long long products = (long long)a.cpb * a.lay.n_split;   // (cell, tuple) products of a workgroup
   const int kown = products <= 2 * kBT ? 2 : products <= 4 * kBT ? 4 : products <= 8 * kBT ? 8 : 0;
