@@ -158,6 +158,29 @@ def minibatch_secondary(api, synth, device, n=2000, L=200, iters=40):
             "unit": "ms", "seq_per_s": 128 * iters / dt, "workload": "%d synthetic RNAs L=%d, pattern %s" % (n, L, PATTERN)}
 
 
+def streamed_secondary(api, synth, device, resident_rate, n=60000, L=200, chunk=10000, reps=2):
+    """A training set that is evaluated chunk by chunk (option max_resident forces what the handle decides by itself when a batch does
+    not fit the device): chunk k is evaluated on one inner handle while the plan of chunk k + 1 is rebuilt on the other; the BPP
+    filter's result of every chunk stays on the host after the first pass.  value = sequences / second of an evaluation after the
+    first; `of_resident` = its ratio to the resident rate of this run."""
+    eng = api.Engine(PATTERN, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
+    eng.set_option("max_resident", chunk)
+    seqs, quals = synth.synth_batch(n, L)
+    eng.load_batch(seqs, quals)
+    x = eng.initial_params(1.0)
+    t0 = time.perf_counter()
+    eng.train_eval(x)                      # (first pass: filter + plan of every chunk)
+    t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.train_eval(x)
+    dt = (time.perf_counter() - t0) / reps
+    eng.close()
+    return {"metric": "streamed train-iter seqs/sec (chunks of %d, plan rebuilt per chunk and pass)" % chunk, "value": n / dt, "unit": "seq/s",
+            "s_per_eval": dt, "first_eval_s": t_first, "of_resident": (n / dt) / resident_rate,
+            "workload": "%d synthetic RNAs L=%d, pattern %s" % (n, L, PATTERN)}
+
+
 def count_gpus_sysfs(root="/sys/class/kfd/kfd/topology/nodes"):
     """GPUs of this machine without touching HIP or torch: KFD topology nodes with SIMDs (CPU nodes have simd_count 0), limited
     by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when set.  No KFD topology = no GPU driver = 0; None only when the directory
@@ -199,6 +222,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=SEQ_LEN)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the scan measurement (BASELINE's secondary metric)")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the streamed evaluation of 60 000 sequences (secondary_streamed)")
     ap.add_argument("--serial-passes", action="store_true",
                     help="everything on one stream (for kernel traces: with concurrent streams kernels overlap and their durations no "
                          "longer add up to the pipeline time)")
@@ -319,6 +343,9 @@ def main():
         del sec
         gc.collect()
         line["secondary_default_mode"] = minibatch_secondary(api, synth, local_rank)   # (its buffers persist: 3 untimed iterations)
+        if not args.no_streamed:
+            gc.collect()
+            line["secondary_streamed"] = streamed_secondary(api, synth, local_rank, line["value"])
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
