@@ -1578,7 +1578,10 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
             qa[u] = G[qc0 + 2 * (on ? t : wv)];
             qb[u] = on ? G[qc0 + 2 * (on ? t : wv) + 1] : (4 << 16);
             x0[u] = OB[rE + (qa[u] & 0xff)]; x1[u] = IB[r1 + ((qa[u] >> 8) & 0xff)]; x2[u] = IB[r2 + ((qa[u] >> 16) & 0xff)];
-            aux[u] = IB[rA + ((qa[u] >> 24) & 0xff)];
+            // (own inside value of the target: the posterior of the energy statistic for an inner pair, and a reason to skip the
+            // add when it is 0 -- for the loops, whose inside values are practically never 0, the load would only cost: the
+            // unary phase ignores the sum of a target whose inside value is 0 anyway)
+            aux[u] = role == 0 ? IB[rA + ((qa[u] >> 24) & 0xff)] : 1.;
           }
 #pragma unroll
           for (int u = 0; u < kTU; ++u) {
