@@ -1038,9 +1038,76 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
   const int nparts = (S <= 128) ? 128 / S : 1;
   const int part = tid / S, ps = tid - part * S;
   const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
+  // The band values a step needs (the pairs that end at j) do not depend on the chain: the FIRST pair of a lane's share of step
+  // j + 1 is fetched while step j is finished (ExtAhead), so a step with at most one pair per lane -- nearly all of them -- waits
+  // for no global round trip.  Same terms in the same order as lin_inside_ext_part.
+  constexpr int kAU = 4;
+  struct ExtAhead { int i; int nu; double xe; double pv[kAU]; int e2[kAU]; };
+  auto fetch_ahead = [&](int j, int s, int prt) {
+    ExtAhead h;
+    h.i = -1; h.nu = 0; h.xe = 0.;
+#pragma unroll
+    for (int k = 0; k < kAU; ++k) { h.pv[k] = 0.; h.e2[k] = 0; }
+    if (j > L) return h;
+    const AutomatonLayout& A = v.m.lay;
+    const int32_t* G = v.m.big;
+    const int i0 = (j - v.q.W > 0) ? j - v.q.W : 0;
+    for (int i = j - 1 - prt; i >= i0; i -= nparts)
+      if (v.q.pair_ok(i, j - i)) { h.i = i; break; }
+    if (h.i < 0) return h;
+    const int d = j - h.i, u0 = G[A.split_off + s];
+    h.nu = G[A.split_off + s + 1] - u0;
+    h.xe = xw_cell(v.q, lamk(v.m, s), XT_EXT, v.q.cell(h.i, d));
+#pragma unroll
+    for (int k = 0; k < kAU; ++k) {
+      const int u = k < h.nu ? u0 + k : (h.nu > 0 ? u0 : 0);
+      h.e2[k] = G[A.split_ent + 2 * u];
+      h.pv[k] = Tr.ld(ST_P, d, h.i, G[A.split_ent + 2 * u + 1], h.nu > 0);
+    }
+    return h;
+  };
+  auto step_with = [&](const ExtAhead& h, int j, int s, int prt) {
+    const AutomatonLayout& A = v.m.lay;
+    const int32_t* I = v.m.ints;
+    const int32_t* G = v.m.big;
+    const int kl = lamk(v.m, s);
+    double acc = 0.;
+    if (h.i >= 0) {
+      const int u0 = G[A.split_off + s];
+      double b = 0.;
+#pragma unroll
+      for (int k = 0; k < kAU; ++k)
+        if (k < h.nu) b = fma(Tr.o(h.i, h.e2[k]), h.pv[k], b);
+      for (int u = u0 + kAU; u < u0 + h.nu; ++u)
+        b = fma(Tr.o(h.i, G[A.split_ent + 2 * u]), Tr.ld(ST_P, j - h.i, h.i, G[A.split_ent + 2 * u + 1]), b);
+      acc = fma(b, h.xe, acc);
+      const int i0 = (j - v.q.W > 0) ? j - v.q.W : 0;
+      for (int i = h.i - nparts; i >= i0; i -= nparts) {   // (further pairs of the lane's share: rare)
+        const int d = j - i;
+        if (!v.q.pair_ok(i, d)) continue;
+        const double xe = xw_cell(v.q, kl, XT_EXT, v.q.cell(i, d));
+        double b2 = 0.;
+        for (int u = u0; u < u0 + h.nu; ++u)
+          b2 = fma(Tr.o(i, G[A.split_ent + 2 * u]), Tr.ld(ST_P, d, i, G[A.split_ent + 2 * u + 1]), b2);
+        acc = fma(b2, xe, acc);
+      }
+    }
+    if (prt == 0 && v.q.unp[j - 1])
+      for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
+        if (CON && !allow_right(v.m, con, v.q.L, j, s, I[A.right_ent + 2 * t])) continue;
+        acc = fma(Tr.o(j - 1, I[A.right_ent + 2 * t]), lw_right(v.m, v.q, s, I[A.right_ent + 2 * t + 1], j - 1), acc);
+      }
+    return acc;
+  };
+  const bool ahead_on = STAGE && S <= 128 && part < nparts && !(a.dbg & 8192);
+  ExtAhead nxt = ahead_on ? fetch_ahead(1, ps, part) : ExtAhead{-1, 0, 0., {0., 0., 0., 0.}, {0, 0, 0, 0}};
   for (int j = 1; j <= L; ++j) {
     if (S <= 128) {
-      if (part < nparts) s_part[tid] = lin_inside_ext_part<CON>(v.m, v.q, Tr, j, ps, con, part, nparts);
+      if (ahead_on) {
+        const ExtAhead cur = nxt;
+        nxt = fetch_ahead(j + 1, ps, part);          // (in flight while this step is summed and the workgroup meets)
+        s_part[tid] = step_with(cur, j, ps, part);
+      } else if (part < nparts) s_part[tid] = lin_inside_ext_part<CON>(v.m, v.q, Tr, j, ps, con, part, nparts);
       __syncthreads();
       if (tid < S) {
         double t = 0.;
