@@ -1388,6 +1388,7 @@ int Engine::prepare_lin(LinArgs& a, bool sched1, bool dense_too, int n_eval) {
   a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
   a.no_rss = (flags_ & ELEMDP_NO_RSS) ? 1 : 0;
   a.lik_ratio = (flags_ & ELEMDP_LIK_RATIO) ? 1 : 0;
+  a.ext_block = (flags_ & (ELEMDP_DBG_NO_TURN | ELEMDP_DBG_FIX_RSS)) ? 1 : 4;   // (pairs span >= 5 positions unless one of these)
   a.plans = plan_.d_plans.as<SeqPlan>();
   a.b.seq = d_seq_.as<uint8_t>(); a.b.ws = d_ws_.as<double>(); a.b.unp = d_unp_.as<uint8_t>(); a.b.ndot = nullptr;
   a.ews = d_ews_.as<double>();

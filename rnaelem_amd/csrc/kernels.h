@@ -182,6 +182,8 @@ struct LinArgs {
   int32_t n_stage;                // ints of the automaton blob staged in LDS: n_ints (whole blob) or n_small
   int32_t dbg;                    // timing experiments only: bit 0 skip split sums, 1 skip item sums, 2 skip the unary phase
   int32_t ext_ring;               // exterior-chain kernels keep the chain's last rows in an LDS ring (small groups only)
+  int32_t ext_block;              // steps of the inside exterior chain whose pair sums are formed side by side (4 where every pair
+                                  // spans >= 5 positions -- the default mask --, else 1)
   int32_t n_lin;                  // doubles of the linear parameter block the band kernels stage (with or without the weight tables)
   int32_t fast;                   // train: table-driven unary phases (lin_fast.h); the host clears it where they do not apply
   int32_t det;                    // train: deterministic reductions (one copy of every shared sum per wave, one row of counts per

@@ -1015,28 +1015,34 @@ __device__ __forceinline__ void stage_ext_context(const LinArgs& a, LViews& v, u
 __device__ __forceinline__ bool out_of_range(double z) { return !(z > 0.) || !(z < HUGE_VAL); }
 
 // ---- exterior chain of the inside pass, partition functions, objective (one workgroup of 128 per sequence)
+constexpr int kExtBlock = 4;
+// Launched with 128 threads, or with 512 = kExtBlock x 128 (LinArgs::ext_block = 4): the pair sums (rule 7) of four consecutive
+// steps are then formed side by side -- a pair spans >= 5 positions, so they only read chain rows that are already there -- and
+// only rule 8 and the sums of the parts stay sequential (LDS only): a quarter of the global round trips and of the long phases.
 template <bool STAGE, bool CON>
-__global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
+__global__ __launch_bounds__(128 * kExtBlock) void k4_in_ext(LinArgs a) {
   extern __shared__ double l_ext[];
   __shared__ AutomatonLayout s_lay;
-  stage_layout(a, &s_lay, 128);
+  const int NT = (int)blockDim.x, KB = NT / 128;   // (128 threads: the plain chain)
+  stage_layout(a, &s_lay, NT);
   LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
   const int n_ring = (STAGE && a.ext_ring) ? ext_ring_doubles(0, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
-  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_ext), n_ring);
+  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_ext), n_ring, NT);
   const int S = a.lay.n_active, tid = threadIdx.x, L = v.q.L;
   TableView Tr = v.in;      // the chain's rows through the LDS ring
   if (n_ring > 0) { Tr.ext = l_ext; Tr.omask = (uint32_t)ext_ring_rows(a.wmax) - 1u; }
-  for (int s = tid; s < S; s += 128) {
+  for (int s = tid; s < S; s += NT) {
     const double o0 = (s == a.lay.s00 || s == a.lay.shadow) ? 1. : 0.;   // (the shadow of (0,0) starts like it)
     v.in.o(0, s) = o0;
     if (n_ring > 0) Tr.o(0, s) = o0;
   }
   __syncthreads();
   // lanes = (part, state): the pairs ending at j are dealt to nparts lanes per state, the partial sums meet in LDS
-  __shared__ double s_part[128];
+  __shared__ double s_part[128 * kExtBlock];
   const int nparts = (S <= 128) ? 128 / S : 1;
-  const int part = tid / S, ps = tid - part * S;
+  const int blk = tid >> 7, t128 = tid & 127;       // step of the block this lane sums (0 with 128 threads)
+  const int part = t128 / S, ps = t128 - part * S;
   const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
   // The band values a step needs (the pairs that end at j) do not depend on the chain: the FIRST pair of a lane's share of step
   // j + 1 is fetched while step j is finished (ExtAhead), so a step with at most one pair per lane -- nearly all of them -- waits
@@ -1066,7 +1072,7 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
     }
     return h;
   };
-  auto step_with = [&](const ExtAhead& h, int j, int s, int prt) {
+  auto step_with = [&](const ExtAhead& h, int j, int s, int prt, bool rule8) {
     const AutomatonLayout& A = v.m.lay;
     const int32_t* I = v.m.ints;
     const int32_t* G = v.m.big;
@@ -1092,13 +1098,39 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
         acc = fma(b2, xe, acc);
       }
     }
-    if (prt == 0 && v.q.unp[j - 1])
+    if (rule8 && prt == 0 && v.q.unp[j - 1])
       for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
         if (CON && !allow_right(v.m, con, v.q.L, j, s, I[A.right_ent + 2 * t])) continue;
         acc = fma(Tr.o(j - 1, I[A.right_ent + 2 * t]), lw_right(v.m, v.q, s, I[A.right_ent + 2 * t + 1], j - 1), acc);
       }
     return acc;
   };
+  if (KB > 1) {   // blocked chain (S <= 128, staged context: the launcher's condition)
+    for (int j0 = 1; j0 <= L; j0 += KB) {
+      const int ja = j0 + blk;
+      if (part < nparts && ja <= L) s_part[tid] = step_with(fetch_ahead(ja, ps, part), ja, ps, part, false);
+      __syncthreads();
+      for (int b = 0; b < KB && j0 + b <= L; ++b) {
+        const int j = j0 + b;
+        if (tid < S) {
+          // (part 0 of the plain chain: its pairs, then rule 8 on the same accumulator; then the other parts)
+          double t = s_part[b * 128 + tid];
+          if (v.q.unp[j - 1]) {
+            const AutomatonLayout& A = v.m.lay;
+            const int32_t* I = v.m.ints;
+            for (int e = I[A.right_off + tid]; e < I[A.right_off + tid + 1]; ++e) {
+              if (CON && !allow_right(v.m, con, v.q.L, j, tid, I[A.right_ent + 2 * e])) continue;
+              t = fma(Tr.o(j - 1, I[A.right_ent + 2 * e]), lw_right(v.m, v.q, tid, I[A.right_ent + 2 * e + 1], j - 1), t);
+            }
+          }
+          for (int k = 1; k < nparts; ++k) t += s_part[b * 128 + k * S + tid];
+          v.in.o(j, tid) = t;
+          if (n_ring > 0) Tr.o(j, tid) = t;
+        }
+        __syncthreads();
+      }
+    }
+  } else {
   const bool ahead_on = STAGE && S <= 128 && part < nparts && !(a.dbg & 8192);
   ExtAhead nxt = ahead_on ? fetch_ahead(1, ps, part) : ExtAhead{-1, 0, 0., {0., 0., 0., 0.}, {0, 0, 0, 0}};
   for (int j = 1; j <= L; ++j) {
@@ -1106,7 +1138,7 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
       if (ahead_on) {
         const ExtAhead cur = nxt;
         nxt = fetch_ahead(j + 1, ps, part);          // (in flight while this step is summed and the workgroup meets)
-        s_part[tid] = step_with(cur, j, ps, part);
+        s_part[tid] = step_with(cur, j, ps, part, true);
       } else if (part < nparts) s_part[tid] = lin_inside_ext_part<CON>(v.m, v.q, Tr, j, ps, con, part, nparts);
       __syncthreads();
       if (tid < S) {
@@ -1119,6 +1151,7 @@ __global__ __launch_bounds__(128) void k4_in_ext(LinArgs a) {
       for (int s = tid; s < S; s += 128) lin_inside_ext_target<CON>(v.m, v.q, v.in, j, s, con);
     }
     __syncthreads();
+  }
   }
   if (tid == 0) {
     const double Zo = lin_part(v.m, v.in, true, true), Za = lin_part(v.m, v.in, true, false), Zn = lin_part(v.m, v.in, false, true);
@@ -2140,6 +2173,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds((a.ext_ring ? ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
   const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4 + (a.ext_ring ? ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
+  const int ext_nt = (a.ext_block == kExtBlock && a.ext_ring && a.lay.n_active <= 128 && !(a.dbg & 8192)) ? 128 * kExtBlock : 128;   // (small groups: there the chain is exposed; in a large one its four-fold footprint only takes CUs from the band kernels)
 #define ELEMDP_SCAN_PASS(CON, MODE)                                                                                              \
   do {                                                                                                                           \
     for (int d = 0; d <= Wmax; ++d) {                                                                                            \
@@ -2153,7 +2187,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       else if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kBT), lds_in, st, a);                                 \
       else hipLaunchKernelGGL((k4_in<false, CON>), grid, dim3(kBT), lds_in, st, a);                                         \
     }                                                                                                                            \
-    if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, CON>), dim3(G), dim3(128), lds_ext_in, st, a);                            \
+    if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, CON>), dim3(G), dim3(ext_nt), lds_ext_in, st, a);                         \
     else hipLaunchKernelGGL((k4_in_ext<false, CON>), dim3(G), dim3(128), 0, st, a);                                              \
     if (stage_ext) hipLaunchKernelGGL((k4_out_ext<MODE, true>), dim3(G), dim3(128), lds_ext_out, st, a);                         \
     else hipLaunchKernelGGL((k4_out_ext<MODE, false>), dim3(G), dim3(128), lds_ext_out, st, a);                                  \
@@ -2214,7 +2248,8 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   a.lmax = Lmax;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds((a.ext_ring ? ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
-  if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, false>), dim3(G), dim3(128), lds_ext_in, st, a);
+  const int ext_nt = (a.ext_block == kExtBlock && a.ext_ring && a.lay.n_active <= 128 && !(a.dbg & 8192)) ? 128 * kExtBlock : 128;   // (small groups: there the chain is exposed; in a large one its four-fold footprint only takes CUs from the band kernels)
+  if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, false>), dim3(G), dim3(ext_nt), lds_ext_in, st, a);
   else hipLaunchKernelGGL((k4_in_ext<false, false>), dim3(G), dim3(128), 0, st, a);
   // schedule 1 (automaton with the shadow state): ONE outside sweep carries both passes -- the "has motif" terminals on the
   // pattern's states, the "no motif" terminal on the shadow of (0,0), each with its own Z and statistics (lpass).
