@@ -1278,26 +1278,29 @@ __global__ __launch_bounds__(64) void k5_pick(LinArgs a, int G) {
 }
 
 // ---- exterior chain of an outside pass
+// (128 threads, or 512 = kExtBlock x 128: the pair terms of four consecutive steps side by side, as in k4_in_ext)
 template <int MODE, bool STAGE>
-__global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
+__global__ __launch_bounds__(128 * kExtBlock) void k4_out_ext(LinArgs a) {
   extern __shared__ double l_stat[];   // 2 * (n_theta + 2): statistics of the two worlds, then the staged context
   __shared__ AutomatonLayout s_lay;
-  stage_layout(a, &s_lay, 128);
+  const int NT = (int)blockDim.x, KB = NT / 128;
+  stage_layout(a, &s_lay, NT);
   LViews v(s_lay);
   make_lviews(a, blockIdx.x, v);
   const LPass pi = lpass(a, v);
   if (pi.skip) return;
   const int n_stat = ext_stat_doubles(a.lay.n_theta, a.det);   // (a copy per wave in the deterministic mode)
   const int n_ring = (STAGE && a.ext_ring) ? ext_ring_doubles(n_stat, a.wmax, a.lay.S, kLinEth + a.lay.n_theta, a.lmax, a.nword_max, a.n_stage) : 0;
-  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), n_stat + n_ring);
+  stage_ext_context<STAGE>(a, v, reinterpret_cast<unsigned char*>(l_stat), n_stat + n_ring, NT);
   const int S = a.lay.n_active, tid = threadIdx.x, nt = a.lay.n_theta;
   TableView Or = v.out;     // the chain's rows through the LDS ring
   if (n_ring > 0) { Or.ext = l_stat + n_stat; Or.omask = (uint32_t)ext_ring_rows(a.wmax) - 1u; }
   double* l_en = l_stat + (a.det ? (tid >> 6) * (2 * nt + 4) : 0);   // the copy this lane adds to
-  for (int t = tid; t < n_stat; t += 128) l_stat[t] = 0.;
-  __shared__ double s_part[128];
+  for (int t = tid; t < n_stat; t += NT) l_stat[t] = 0.;
+  __shared__ double s_part[128 * kExtBlock];
   const int nparts = (S <= 128) ? 128 / S : 1;
-  const int part = tid / S, ps = tid - part * S;
+  const int blk = tid >> 7, t128 = tid & 127;       // step of the block this lane sums (0 with 128 threads)
+  const int part = t128 / S, ps = t128 - part * S;
   // (merged schedule: the lane of the shadow state works in world 1 -- its own Z and statistics; S <= 128 there)
   const bool shadow_lane = pi.merged && ps == a.lay.shadow;
   LinSink sink;
@@ -1306,7 +1309,7 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
   sink.eh0 = sink.eh1 = 0.;
   scan_sink<MODE>(a, v, sink);
   LinOutCtx<LinSink> x{v.m, v.q, v.in, Or, shadow_lane ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
-  for (int s = tid; s < S; s += 128) {
+  for (int s = tid; s < S; s += NT) {
     double t = 0.;
     if (pi.nasi && s == a.lay.s00) t = 1.;
     if (pi.ari && (s == a.lay.s0m1 || s == a.lay.s0m2)) t = 1.;
@@ -1315,6 +1318,23 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
     if (n_ring > 0) Or.o(v.q.L, s) = t;
   }
   __syncthreads();
+  if (KB > 1) {   // blocked chain (S <= 128, staged context, not the deterministic mode: the launcher's condition)
+    for (int i0 = v.q.L - 1; i0 >= 0; i0 -= KB) {
+      const int ia = i0 - blk;
+      if (part < nparts && ia >= 0) s_part[tid] = lin_outside_ext_pairs<MODE>(x, ia, ps, part, nparts);
+      __syncthreads();
+      for (int b = 0; b < KB && i0 - b >= 0; ++b) {
+        const int i = i0 - b;
+        if (tid < S) {
+          double t = lin_outside_ext_rule8<MODE>(x, i, tid);
+          for (int k = 0; k < nparts; ++k) t += s_part[b * 128 + k * S + tid];
+          v.out.o(i, tid) = t;
+          if (n_ring > 0) Or.o(i, tid) = t;
+        }
+        __syncthreads();
+      }
+    }
+  } else
   for (int i = v.q.L - 1; i >= 0; --i) {
     if (S <= 128) {
       if (part < nparts) s_part[tid] = lin_outside_ext_part<MODE>(x, i, ps, part, nparts);
@@ -1330,7 +1350,7 @@ __global__ __launch_bounds__(128) void k4_out_ext(LinArgs a) {
     }
     __syncthreads();
   }
-  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_stat, 128, a.det_nslot - 1);
+  if (MODE == OUT_TRAIN || MODE == OUT_SCAN) lflush(a, v, pi, sink, l_stat, NT, a.det_nslot - 1);
 }
 
 // ---- rule 7, outside direction: P(i,j,tgt) as a child of the exterior chain = sum over the split entries of tgt of
@@ -2189,7 +2209,7 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
     }                                                                                                                            \
     if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, CON>), dim3(G), dim3(ext_nt), lds_ext_in, st, a);                         \
     else hipLaunchKernelGGL((k4_in_ext<false, CON>), dim3(G), dim3(128), 0, st, a);                                              \
-    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<MODE, true>), dim3(G), dim3(128), lds_ext_out, st, a);                         \
+    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<MODE, true>), dim3(G), dim3(ext_nt), lds_ext_out, st, a);                      \
     else hipLaunchKernelGGL((k4_out_ext<MODE, false>), dim3(G), dim3(128), lds_ext_out, st, a);                                  \
     hipLaunchKernelGGL(k4_r7, dim3(((Lmax + 1) * (Wmax + 1) + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);           \
     for (int d = Wmax; d >= 0; --d) {                                                                                            \
@@ -2261,7 +2281,7 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
     LinArgs b = a;
     b.pass = pass;
     const int n_stat = ext_stat_doubles(nt, b.det);
-    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(128), (size_t)ext_lds(n_stat + (b.ext_ring ? ext_ring_doubles(n_stat, Wmax, S, kLinEth + nt, Lmax, b.nword_max, b.n_stage) : 0), kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
+    if (stage_ext) hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, true>), dim3(G), dim3(b.det ? 128 : ext_nt), (size_t)ext_lds(n_stat + (b.ext_ring ? ext_ring_doubles(n_stat, Wmax, S, kLinEth + nt, Lmax, b.nword_max, b.n_stage) : 0), kLinEth + nt, Lmax, b.nword_max, b.n_stage).total, st, b);
     else hipLaunchKernelGGL((k4_out_ext<OUT_TRAIN, false>), dim3(G), dim3(128), sizeof(double) * n_stat, st, b);
     if (!b.no_rss) {
       hipLaunchKernelGGL(k4_r7, dim3(((Lmax + 1) * (Wmax + 1) + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, b);

@@ -434,6 +434,53 @@ template <int MODE, class Sink> ELEMDP_HD double lin_outside_ext_part(LinOutCtx<
   }
   return a;
 }
+// The two halves of lin_outside_ext_part for the blocked chain (k4_out_ext with 512 threads): the pair terms of a step read chain
+// rows at least five steps back, so four steps' worth is summed side by side; rule 8 (the row of the previous step) stays
+// sequential.  (The value of a step is then rule 8 + the parts' pair sums instead of (rule 8 + part 0's pairs) + the other parts:
+// the same terms, associated differently.)
+template <int MODE, class Sink> ELEMDP_HD double lin_outside_ext_rule8(LinOutCtx<Sink>& x, int i, int s) {
+  const ModelView& m = x.m;
+  const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay;
+  const int32_t* I = m.ints;
+  const double in_c = x.in.o(i, s);
+  if (in_c == 0.) return 0.;
+  const double inz = in_c * x.invZ;
+  double a = 0.;
+  if (q.unp[i])
+    for (int t = I[A.rright_off + s]; t < I[A.rright_off + s + 1]; ++t) {
+      const int par = I[A.rright_ent + 2 * t], tf = I[A.rright_ent + 2 * t + 1];
+      const double term = x.out.o(i + 1, par) * lw_right(m, q, par, tf, i);
+      if (!lstat_right<MODE>(x, i, par, s, term * inz)) continue;
+      a += term;
+    }
+  return a;
+}
+template <int MODE, class Sink> ELEMDP_HD double lin_outside_ext_pairs(LinOutCtx<Sink>& x, int i, int s, int part, int nparts) {
+  const ModelView& m = x.m;
+  const SeqView& q = x.q;
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  const double in_c = x.in.o(i, s);
+  if (in_c == 0.) return 0.;
+  const double inz = in_c * x.invZ;
+  double a = 0.;
+  const int jmax = (i + q.W < q.L) ? i + q.W : q.L;
+  for (int j = i + 1 + part; j <= jmax; j += nparts) {
+    const int d = j - i;
+    if (!q.pair_ok(i, d)) continue;
+    const int c = q.cell(i, d);
+    const double t = q.e_ext[c];
+    const double x0 = xw_cell(q, 0, XT_EXT, c), x1 = xw_cell(q, 1, XT_EXT, c);
+    for (int u = G[A.split1_off + s]; u < G[A.split1_off + s + 1]; ++u) {
+      const int par = G[A.split1_ent + 2 * u], s1 = G[A.split1_ent + 2 * u + 1];
+      const double term = x.out.o(j, par) * (x.in.ld(ST_P, d, i, s1) * (lamk(m, par) ? x1 : x0));
+      lstat_energy<MODE>(x, par, t, term * inz);
+      a += term;
+    }
+  }
+  return a;
+}
 template <int MODE, class Sink> ELEMDP_HD void lin_outside_ext_target(LinOutCtx<Sink>& x, int i, int s) {
   x.out.o(i, s) = lin_outside_ext_part<MODE>(x, i, s, 0, 1);
 }
