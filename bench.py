@@ -147,7 +147,7 @@ def minibatch_secondary(api, synth, device, n=2000, L=200, iters=40):
     rho = train.regularisation(len(x0), 0.1, 0.1)
     # untimed: until both engines have evaluated a batch of theirs (MiniBatches loads `lookahead` = 8 iterations' batches at a
     # time, alternating between the engines) -- their buffers are then at their final sizes
-    train.minimize_adam(ev, x0, rho, max_iter=18)
+    train.minimize_adam(ev, x0, rho, max_iter=2 * ev.lookahead + 2)
     t0 = time.perf_counter()
     train.minimize_adam(ev, x0, rho, max_iter=iters)
     dt = time.perf_counter() - t0

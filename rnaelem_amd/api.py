@@ -52,9 +52,11 @@ def load_library():
     """dlopen libelemdp.so (fails loudly if it has not been built: there is no fallback)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ElemdpError(-100, "libelemdp.so is not built (run `python -m rnaelem_amd.build`)")
-        L = C.CDLL(LIB_PATH)
+        # (ELEMDP_LIBRARY: another build of the same sources -- a timing variant, or the host-sanitizer build of tools/sanitize_cpu.sh)
+        path = os.environ.get("ELEMDP_LIBRARY") or LIB_PATH
+        if not os.path.exists(path):
+            raise ElemdpError(-100, "%s is not built (run `python -m rnaelem_amd.build`)" % path)
+        L = C.CDLL(path)
         dp, u8, i32 = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
         hp = C.c_void_p
         L.elemdp_last_error.restype = C.c_char_p

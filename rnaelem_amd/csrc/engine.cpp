@@ -267,6 +267,7 @@ class Engine {
   int range_key_[2] = {-1, -1};
   bool opt_det_ = false;    // deterministic reductions of the scaled-linear train evaluation (LinArgs::det): bit-identical repeats
   bool opt_fast_ = true;    // table-driven unary phases of the train kernels (lin_fast.h); 0 = the generic rule code
+  int opt_nblk_ = 0;        // blocks of cells per band-kernel workgroup (LinArgs::nblk): 0 = chosen per launch, n = n wherever they fit
   bool opt_poison_ = false; // tests: the table slots are filled with NaN before every evaluation of the scaled-linear pipeline, so
                             // that a read of an entry nobody stored shows up in the results (the compact tables hold garbage there)
   void require_device() const;
@@ -557,6 +558,7 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "bpp_log") opt_bpp_log_ = v != 0;
   else if (key == "poison") opt_poison_ = v != 0;
   else if (key == "fast") opt_fast_ = v != 0;
+  else if (key == "nblk") opt_nblk_ = std::max(0, std::min(64, (int)v));
   else if (key == "deterministic") opt_det_ = v != 0;
   else if (key == "sorted_plan") opt_sorted_plan_ = v != 0;
   else if (key == "eval_first") opt_eval_first_ = (int)v;
@@ -1207,6 +1209,10 @@ template <class Work> void Engine::stream_chunks(Work work) {
 
 void Engine::stream_train(const double* x, int n_param_in, void* partial, bool device_ptr, bool reduce) {
   if (n_param_in != n_param()) throw ArgError("n_param mismatch");
+  // (a range of the batch is evaluated by the resident scaled-linear pipeline only: run_lin_batch; anything else would return
+  // sums over the whole batch for it)
+  if (opt_eval_count_ > 0 && !(opt_eval_first_ == 0 && opt_eval_count_ == n_seq_))
+    throw ArgError("eval_first / eval_count: a streamed batch is evaluated as a whole (load fewer sequences, or raise max_resident)");
   set_theta_from(x);
   const int np = partial_len();
   std::vector<double> total(np, 0.), part(np);
@@ -1303,6 +1309,8 @@ TrArgs Engine::log_pipeline_args() {
 }
 
 void Engine::run_train_batch() {
+  if (opt_eval_count_ > 0 && !(opt_eval_first_ == 0 && opt_eval_count_ == n_seq_))
+    throw ArgError("eval_first / eval_count: the log-space pipeline (pipeline 3) evaluates the whole batch");
   slot_override_ = opt_group_ > 0 ? opt_group_ : 4096;
   ensure_slots(au_.S(), false, n_seq_);
   slot_override_ = 0;
@@ -1384,6 +1392,7 @@ int Engine::prepare_lin(LinArgs& a, bool sched1, bool dense_too, int n_eval) {
   // (table-driven unary phases: not under FIX_RSS, whose fixed pairs need not be canonical -- the weight tables are indexed
   // by the pair type)
   a.fast = (opt_fast_ && !(flags_ & ELEMDP_DBG_FIX_RSS)) ? 1 : 0;
+  a.nblk = opt_nblk_;
   a.no_prf = (flags_ & ELEMDP_NO_PROFILE) ? 1 : 0;
   a.m_min = (flags_ & ELEMDP_DBG_NO_TURN) ? 4 : 10;
   a.no_rss = (flags_ & ELEMDP_NO_RSS) ? 1 : 0;
@@ -1510,6 +1519,7 @@ void Engine::run_lin_batch() {
   }
   tables_linear_ = n_flagged == 0;
   if (n_flagged > 0) {
+    ensure_sorted_plan();   // (the log-space kernels sum the role lists in list order: kernels.h)
     TrArgs t = log_pipeline_args();
     // (dense tables over the buffers of the compact ones: as many slots as fit, at least one -- ensure_slots)
     const int n_dense = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_slots_, (band_stride_ * (size_t)n_slots_) / t.band_stride));

@@ -163,7 +163,11 @@ struct LinArgs {
   double* zs;                     // per slot: mantissas of Z(ari,nasi), Z(ari), Z(nasi), and log2 of the sequence's scale
   double* seq_out; int32_t out_stride;
   int32_t schedule, pass, d;
-  int32_t cpb;                    // cells per workgroup = kThreads / S
+  int32_t cpb;                    // cells of one block = lanes of a workgroup / lanes per cell of the unary phase
+  float rcp_nap, rcp_lane, rcp_cpb, rcp_3cpb;   // 1 / n_ap, 1 / lanes per cell, 1 / cpb, 1 / (3 cpb) for the lane -> (cell, item) splits of the band
+                                  // kernels (div_rcp: a reciprocal formed per lane costs ten instructions and a register for the whole kernel)
+  int32_t nblk;                   // blocks of cpb consecutive cells a band-kernel workgroup owns (k4_in / k4_out): the context of all
+                                  // of them is staged once, the phases then run block by block (set per launch; 0 means 1)
   int32_t* flagged;               // [0] = number of flagged sequences, [1..] = their batch indices
   // scan (sum passes K4 / K5 on this pipeline): start constraint and position-posterior accumulators (batch offsets)
   int32_t lik_ratio;              // --lik-ratio objective (ELEMDP_LIK_RATIO)

@@ -36,16 +36,16 @@ enum : int { CF_POK = 1, CF_LOK = 2, CF_MOK = 4, CF_EOK = 8, CF_DO2 = 16, CF_DOM
              // scan passes under the start constraint Ys: the position the cell's left / right emission covers is Ys (inside: i,
              // j - 1; outside: i - 1, j); outside: j is the last position of the sequence
              CF_YL = 1 << 17, CF_YR = 1 << 18, CF_JLAST = 1 << 19 };
-__device__ __forceinline__ int fcol(int packed, int byte) { const int c = (packed >> (8 * byte)) & 0xff; return c == 0xff ? -1 : c; }
+ELEMDP_HD int fcol(int packed, int byte) { const int c = (packed >> (8 * byte)) & 0xff; return c == 0xff ? -1 : c; }
 
 // which global value lane k (0..7) of a cell fetches for the inside record, and from which cell
-__device__ __forceinline__ double cell_in_fetch(const SeqView& q, int d, int i, int k) {
+ELEMDP_HD double cell_in_fetch(const SeqView& q, int d, int i, int k) {
   const int c_here = q.cell(i, d), c_up = (i > 0 && d + 2 <= q.W) ? q.cell(i - 1, d + 2) : c_here;
   const int term = k < 2 ? XT_STACK : k < 4 ? XT_ML : k < 6 ? XT_CLOSE : XT_HP;
   return xw_cell(q, k & 1, term, k < 4 ? c_here : c_up);
 }
 // flags of the inside record (reads the staged context: pair mask, dmin, unpaired flags, bases)
-__device__ __forceinline__ int cell_in_flags(const ModelView& m, const SeqView& q, int d, int i) {
+ELEMDP_HD int cell_in_flags(const ModelView& m, const SeqView& q, int d, int i) {
   const int j = i + d;
   const bool pok = q.pair_ok(i, d), lok = q.left_ok(i, d), mok = m_ok(m, q, i, d), eok = q.e_ok(i, d);
   const bool do2 = lok && d > 0 && q.left_ok(i, d - 1) && q.unp[j - 1];
@@ -60,7 +60,7 @@ __device__ __forceinline__ int cell_in_flags(const ModelView& m, const SeqView& 
 // where they are used); stores them
 // CON: the start constraint of the scan's second pass (FS = the ScanFlag words; CF_YL / CF_YR set in fl)
 template <int kFR, int kFP, int kFL, bool CON = false>
-__device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, const int32_t* P, const double* lin, const TableView& T,
+ELEMDP_HD void fast_inside_unary(const AutomatonLayout& A, const int32_t* P, const double* lin, const TableView& T,
                                                   const double* cr, int fl, int d, int i, const double* pHB, const double* pHE, int nrep,
                                                   int rstride, const int32_t* FS = nullptr) {
   const int w0 = P[0], w1 = P[1], w2 = P[2];
@@ -150,7 +150,7 @@ __device__ __forceinline__ void fast_inside_unary(const AutomatonLayout& A, cons
 
 // ---- outside --------------------------------------------------------------------------------------------------------------
 // value k (0..11) of the outside record of cell (i, d): exponentiated terms (masked later) and the raw terms of the statistics
-__device__ __forceinline__ double cell_out_fetch(const SeqView& q, int d, int i, int k) {
+ELEMDP_HD double cell_out_fetch(const SeqView& q, int d, int i, int k) {
   const int c_here = q.cell(i, d), c_up = (i > 0 && d + 2 <= q.W && i + d < q.L) ? q.cell(i - 1, d + 2) : c_here;
   switch (k) {
     case 0: case 1: return xw_cell(q, k & 1, XT_CLOSE, c_up);
@@ -163,7 +163,7 @@ __device__ __forceinline__ double cell_out_fetch(const SeqView& q, int d, int i,
     default: return q.e_ml[c_here];
   }
 }
-__device__ __forceinline__ int cell_out_flags(const ModelView& m, const SeqView& q, int d, int i) {
+ELEMDP_HD int cell_out_flags(const ModelView& m, const SeqView& q, int d, int i) {
   const int j = i + d;
   const bool pok = q.pair_ok(i, d), lok = q.left_ok(i, d), mok = m_ok(m, q, i, d), eok = q.e_ok(i, d);
   const bool up_ok = q.pair_ok(i - 1, d + 2);
@@ -175,7 +175,7 @@ __device__ __forceinline__ int cell_out_flags(const ModelView& m, const SeqView&
          (up_ok ? CF_UP : 0) | (doLc ? CF_DOL : 0) | (bl << 8) | (br << 11) | (bp_type(bl, br) << 14);
 }
 // which flag masks value k of the outside record (a value that is not masked is only used under a non-zero posterior)
-__device__ __forceinline__ bool cell_out_mask(int fl, int k) {
+ELEMDP_HD bool cell_out_mask(int fl, int k) {
   if (k < 4) return fl & CF_EOK;
   if (k < 6) return fl & CF_POK;
   if (k < 8) return (fl & CF_UP) && (fl & CF_POK);
@@ -187,7 +187,7 @@ __device__ __forceinline__ bool cell_out_mask(int fl, int k) {
 // accumulator; returns false when the start constraint of OUT_END excludes the transition.  kl / kr: the positions of the
 // left / right emission (LEFT / RIGHT: which of them the transition has); yl / yr: that position is the chosen start.
 template <int MODE, bool LEFT, bool RIGHT, class Sink>
-__device__ __forceinline__ bool fast_scan_stat(Sink& sink, int sf, int kl, int kr, bool yl, bool yr, bool jlast, double z) {
+ELEMDP_HD bool fast_scan_stat(Sink& sink, int sf, int kl, int kr, bool yl, bool yr, bool jlast, double z) {
   if (MODE == OUT_END) {
     if ((LEFT && yl && !(sf & SF_SL)) || (RIGHT && yr && !(sf & SF_SR))) return false;
     if (z != 0.) {
@@ -209,7 +209,7 @@ __device__ __forceinline__ bool fast_scan_stat(Sink& sink, int sf, int kl, int k
 // MODE: OUT_TRAIN (expected counts + energy statistics), OUT_SCAN (counts + start / inner posteriors), OUT_END (end posteriors
 // under the start constraint: CF_YL / CF_YR / CF_JLAST in fl); FS = the ScanFlag words of the scan modes.
 template <int kFR, int kFP, int kFL, int MODE, class Sink>
-__device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, const int32_t* P, const int32_t* G, const double* lin,
+ELEMDP_HD double fast_outside_unary(const AutomatonLayout& A, const int32_t* P, const int32_t* G, const double* lin,
                                                      const TableView& in, const TableView& out, const double* cr, int fl, int d, int i,
                                                      double invZ, bool lam_same, bool no_prf, Sink& sink, const double* ph, int CS, int nrep,
                                                      int rstride, const int32_t* FS = nullptr) {
@@ -300,7 +300,9 @@ __device__ __forceinline__ double fast_outside_unary(const AutomatonLayout& A, c
   }
   if (mok && cMo >= 0) out.band[out.cidx(ST_M, d, i, cMo)] = oM;
 #if ELEMDP_UNARY2
+#if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_sched_barrier(0);
+#endif
   const double in1 = in.ldc(ST_1, d, i, c1o, lok), in2 = in.ldc(ST_2, d, i, c2o, lok), inL = in.ldc(ST_L, d, i, cLo, isloop);
   const double r7 = out.ldc(ST_P, d, i, cPo, pok);
   double op2[kFR], opL[kFR];

@@ -77,6 +77,8 @@ constexpr int kWaves = kBT / 64;
 // 1 / (2 n) from the true quotient plus 1/(2n), so the truncation is exact.  An integer division by a run-time divisor costs ~30
 // instructions, and the band kernels are bound by instruction issue.
 __device__ __forceinline__ int div_small(int q, int n) { return (int)(((float)q + 0.5f) * __frcp_rn((float)n)); }
+// ... with the reciprocal formed on the host (LinArgs::rcp_*: 1.0f / n, the same rounding)
+__device__ __forceinline__ int div_rcp(int q, float rcp) { return (int)(((float)q + 0.5f) * rcp); }
 
 // Deterministic mode (LinArgs::det, option "deterministic"): every sum that lanes of DIFFERENT waves add to -- the heavy sums of
 // a workgroup, its expected counts -- gets one copy per wave (the adds of one wave reach LDS in program order, lanes of one
@@ -112,27 +114,24 @@ struct LinSink {
 // phase timer (option "profile"): thread 0 of a workgroup sums the shader clocks between marks per slot and adds
 // them to one of 64 copies of the counter row when the workgroup ends (host adds the copies)
 struct PhaseClock {
-  long long* prof;
+  // (the sums go straight to the counter row: accumulators in registers -- thirteen 64-bit values -- would stay live around the
+  // whole block loop of a band kernel, profiled or not; the last clock is read by every lane, outside divergent control flow,
+  // and so stays in scalar registers)
+  long long* row;
   long long t0;
-  long long acc[13];
   __device__ __forceinline__ void start(long long* p) {
-    prof = p;
-    if (prof && threadIdx.x == 0) {
-#pragma unroll
-      for (int k = 0; k < 13; ++k) acc[k] = 0;
-      t0 = clock64();
-    }
+    row = p ? p + 16 * ((blockIdx.x + 7 * blockIdx.y) & 63) : nullptr;
+    t0 = 0;
+    if (row) t0 = __builtin_readcyclecounter();
   }
   template <int SLOT> __device__ __forceinline__ void mark() {
-    if (prof && threadIdx.x == 0) { const long long t = clock64(); acc[SLOT] += t - t0; t0 = t; }
-  }
-  __device__ __forceinline__ void finish() {
-    if (prof && threadIdx.x == 0) {
-      long long* row = prof + 16 * ((blockIdx.x + 7 * blockIdx.y) & 63);
-#pragma unroll
-      for (int k = 0; k < 13; ++k) if (acc[k]) atomicAdd((unsigned long long*)&row[k], (unsigned long long)acc[k]);
+    if (row) {
+      const long long t = __builtin_readcyclecounter();
+      if (threadIdx.x == 0) atomicAdd((unsigned long long*)&row[SLOT], (unsigned long long)(t - t0));
+      t0 = t;
     }
   }
+  __device__ __forceinline__ void finish() {}
 };
 
 struct LViews {
@@ -692,16 +691,21 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
   make_lviews(a, by, v);
   const AutomatonLayout& A = a.lay;
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x;
+  // The workgroup owns nblk blocks of cpb consecutive cells of the diagonal (cpbT cells from i0T on): everything that does not
+  // depend on the block -- plan record, automaton blob, parameters and weight tables, the window of positions, the cell records
+  // and CSR ranges of all its cells -- is fetched and staged ONCE; the phases then run block by block on the per-block heavy
+  // sums.  (One block per workgroup paid the launch, two dependent round trips and the staging for 12 cells of work.)
+  const int nblk = a.nblk > 1 ? a.nblk : 1, cpbT = cpb * nblk;
   if (d > v.q.W) return;
-  const int ncell = v.q.L - d + 1, i0 = bx * cpb;
-  if (i0 >= ncell) return;
-  const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
+  const int ncell = v.q.L - d + 1, i0T = bx * cpbT;
+  if (i0T >= ncell) return;
+  const int ncT = (cpbT < ncell - i0T) ? cpbT : ncell - i0T;
   if (CON) {
     // The start constraint touches the emissions of position Ys only: a cell whose span does not cover Ys -- and everything below
     // it -- has the value of the unconstrained pass, which is still in the table (same slot, same layout; the scan runs
     // k4_in<false> first).  Only the cells i <= Ys < i + d are swept again: ~d of the L - d + 1 cells of the diagonal.
     const int ys = a.ys[v.n];
-    if (ys < i0 || ys - d + 1 > i0 + nc - 1) return;
+    if (ys < i0T || ys - d + 1 > i0T + ncT - 1) return;
   }
   const int HD = FAST ? A.n_lane : S;   // stride of the heavy sums per cell: the live states (table-driven: their index among them), or all
   const int CS = cpb * HD;
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
   double* hbA = hb + wvd * 2 * CS;           // ... the copy this lane adds to
   double* heA = he + wvd * 2 * CS;
   double* st1 = lds + NW * 2 * CS;           // item records (kRecIn doubles)
-  const BlockLds BL = block_lds(NW * 2 * CS + kRecIn, cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, FAST ? kCellInD : 0);
+  const BlockLds BL = block_lds(NW * 2 * CS + kRecIn, cpbT, a.n_lin, cpbT + a.wmax + 3, FAST ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, FAST ? kCellInD : 0);
   // cell records of the table-driven unary phase: the exponentiated structural terms of the cells are fetched with the context
   // (lane = (cell, value); the addresses depend on the plan record only), the flags follow once the context is in LDS
   constexpr int kCRin = (ELEMDP_CPB_MAX * 8 + kBT - 1) / kBT;
@@ -720,18 +724,18 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
 #pragma unroll
     for (int r = 0; r < kCRin; ++r) {
       crx[r] = 0.;
-      if (r * kBT < cpb * 8) {   // (uniform: most automata need the first round only)
-        const int t = tid + r * kBT, c = (t >> 3) < nc ? (t >> 3) : 0;
-        crx[r] = cell_in_fetch(v.q, d, i0 + c, t & 7);
+      if (r * kBT < cpbT * 8) {   // (uniform: most automata need the first round only)
+        const int t = tid + r * kBT, c = (t >> 3) < ncT ? (t >> 3) : 0;
+        crx[r] = cell_in_fetch(v.q, d, i0T + c, t & 7);
       }
     }
   }
-  if (a.dbg & 1024) { if (nc == 12345) lds[tid] = crx[0]; return; }   // (timing experiments: the workgroup up to its plan record ...
-  const BlockCtx cx = stage_context<BIG, 0, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
-  int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
+  if (a.dbg & 1024) { if (ncT == 12345) lds[tid] = crx[0]; return; }   // (timing experiments: the workgroup up to its plan record ...
+  const BlockCtx cx = stage_context<BIG, 0, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0T, ncT, d, cpbT);
+  int* dmT = cx.dm; int* cntsT = cx.cnts; int* pre = cx.pre; int* baseT = cx.base;
   const int32_t* G = v.m.big;
-  double* crec = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
-  int* crfl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
+  double* crecT = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
+  int* crflT = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
   for (int t = tid; t < NW * 2 * CS; t += kBT) lds[t] = 0.;
   __syncthreads();
   if (a.dbg & 2048) return;                                             //  ... and up to its staged context)
@@ -740,32 +744,41 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
 #pragma unroll
     for (int r = 0; r < kCRin; ++r) {
       const int t = tid + r * kBT, c = t >> 3, k = t & 7;
-      if (c < nc) {
-        const bool on = k < 4 ? v.q.pair_ok(i0 + c, d) : v.q.e_ok(i0 + c, d);
-        crec[c * kCellInD + 2 + k] = on ? crx[r] : 0.;
+      if (c < ncT) {
+        const bool on = k < 4 ? v.q.pair_ok(i0T + c, d) : v.q.e_ok(i0T + c, d);
+        crecT[c * kCellInD + 2 + k] = on ? crx[r] : 0.;
       }
     }
-    for (int c = tid; c < nc; c += kBT) {
-      const int i = i0 + c, j = i + d;
+    for (int c = tid; c < ncT; c += kBT) {
+      const int i = i0T + c, j = i + d;
       int fl = cell_in_flags(v.m, v.q, d, i);
       if (CON) { const int ys = a.ys[v.n]; fl |= (i == ys ? CF_YL : 0) | (j - 1 == ys ? CF_YR : 0); }
-      crfl[c] = fl;
-      crec[c * kCellInD] = v.q.ews[i];
-      crec[c * kCellInD + 1] = v.q.ews[j > 0 ? j - 1 : 0];
+      crflT[c] = fl;
+      crecT[c * kCellInD] = v.q.ews[i];
+      crecT[c * kCellInD + 1] = v.q.ews[j > 0 ? j - 1 : 0];
     }
   }
   const double* B = v.in.band;
   const int nq = ((a.dbg & 2) || (ELEMDP_KO & 2)) ? 0 : A.n_quad;
-  // CSR ranges of the item sums, their prefix, and the first 256 item records: fetched ahead, so that the records arrive while
-  // the pair phase runs (one round trip less on the workgroup's chain)
-  outer_ranges_load(v, i0, nc, d, nq > 0, tid, cnts, base);
-#if ELEMDP_AHEAD_IN
-  __syncthreads();
-  const int n_rec = outer_ranges_prefix(nc, tid, cnts, pre);
-  const RecAhead ahead = outer_fetch_ahead(v, n_rec, nc, tid, pre, base);
-#else
-  const RecAhead ahead{LoopItem{0., 0, 0, 0, 0}, 0, false};   // (off: two barriers more than the round trip saved, measured)
-#endif
+  // CSR ranges of the item sums of all cells of the workgroup (consumed behind the first pair phase, whose loads they travel with)
+  outer_ranges_load(v, i0T, ncT, d, nq > 0, tid, cntsT, baseT);
+  const RecAhead ahead{LoopItem{0., 0, 0, 0, 0}, 0, false};   // (records fetched ahead of the pair phase: two barriers more than the round trip saved, measured)
+  const int tid_wg = tid;
+  for (int blk = 0; blk * cpb < ncT; ++blk) {
+  // (the lane id behind an empty asm: what a lane derives from it -- its cell, pair record, program, tuple records -- is the same in
+  // every block, and the compiler would keep all of it in registers across the whole loop: 98 instead of 65 VGPRs)
+  int tid = tid_wg;
+  asm volatile("" : "+v"(tid));
+  const int i0 = i0T + blk * cpb, nc = (cpb < ncT - blk * cpb) ? cpb : ncT - blk * cpb;
+  if (CON) {   // (uniform: blocks without a cell that covers Ys keep the values of the unconstrained pass)
+    const int ys = a.ys[v.n];
+    if (ys < i0 || ys - d + 1 > i0 + nc - 1) continue;
+  }
+  const int* dm = dmT + blk * cpb;
+  int* cnts = cntsT + blk * cpb;
+  int* base = baseT + blk * cpb;
+  const double* crec = crecT + blk * cpb * kCellInD;
+  const int* crfl = crflT + blk * cpb;
   // rule 2, factorised (lin_rules.h, lin_inside_apair): lane = (cell, pair p = (s1, t)).  A(i,j,p) = the tail step from
   // A(i,j-1,.) plus one term per stem (k, j) that ends at j and starts behind i; B(i,j,tgt(p)) += A(i,j,p).  The stems are
   // walked four at a time: their operand loads (1(i,k,s1), P(k,j,t), exp(lambda e_ml)) are in flight together.
@@ -776,7 +789,7 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
     const int W1 = v.q.W + 1;
     const int nwork = ((a.dbg & 1) || (ELEMDP_KO & 1)) ? 0 : nc * nA;
     for (int w = tid; w < nwork; w += kBT) {
-      const int c = div_small(w, nA), p = w - c * nA;
+      const int c = div_rcp(w, a.rcp_nap), p = w - c * nA;
       const int i = i0 + c, j = i + d;
       if (FAST) {   // the same sums from the pair record (AutomatonLayout::fpr_in): columns, chain entries with their weight ids
         const int32_t* PR = G + A.fpr_in + 8 * p;
@@ -891,13 +904,11 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
   // rule 6c: E(i,j,tgt) += sum_items P(k,l,s1) * L(i,k,s2) * L(l,j,s3) * exp(lambda * tsc): work item = (item, tuple), the
   // item records staged in the (now free) operand staging area, one round of table loads per work item
   {
-#if !ELEMDP_AHEAD_IN
     const int n_rec = outer_ranges_prefix(nc, tid, cnts, pre);
-#endif
     const OuterRecs R = outer_recs(st1, kRecIn);
     for (int p0 = 0; p0 < n_rec; p0 += R.cap) {
       const int np = (R.cap < n_rec - p0) ? R.cap : n_rec - p0;
-      outer_stage<true, ELEMDP_AHEAD_IN != 0>(v, R, p0, np, nc, tid, pre, base, ahead);
+      outer_stage<true, false>(v, R, p0, np, nc, tid, pre, base, ahead);
       const int wv = tid >> 6, lane = tid & 63;
       const int qc_in = FAST ? A.fqc_in : A.qc_in;
       constexpr int kTU = kTUin;
@@ -938,18 +949,29 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
   pc.mark<3>();
   const int NL = FAST ? A.n_lane : NA;   // lanes per cell of the unary phase: the states that have a column at all
   if (tid < nc * NL && !(a.dbg & 4) && !(ELEMDP_KO & 4)) {
-    const int c = div_small(tid, NL);
+    const int c = div_rcp(tid, a.rcp_lane);
     const int s = FAST ? G[A.f_live_in + tid - c * NL] : tid - c * NL;
     const int i = i0 + c;
     if (FAST) {
       fast_inside_unary<kFastR, FP, kFastL, CON>(A, G + A.fp_in + s * kFastW, v.m.lin, v.in, crec + c * kCellInD, crfl[c], d, i, hb + c * HD + (tid - c * NL),
                                                  he + c * HD + (tid - c * NL), NW, 2 * CS, G + A.fs_in);
+      // (the lane owns these two sums: it clears them for the next block of the workgroup -- HD = NL here, and cells past nc take no adds)
+      if (nblk > 1)
+        for (int r = 0; r < NW; ++r) { hb[r * 2 * CS + tid] = 0.; he[r * 2 * CS + tid] = 0.; }
     } else {
       const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
       lin_inside_target_u<CON>(v.m, v.q, v.in, d, i, s, rep_sum(hb + c * HD + s, NW, 2 * CS), rep_sum(he + c * HD + s, NW, 2 * CS), con);
     }
   }
   pc.mark<4>();
+  if ((blk + 1) * cpb < ncT) {   // the next block's pair phase adds to the heavy sums this unary phase has read
+    if (!FAST || (a.dbg & 4) || (ELEMDP_KO & 4)) {
+      __syncthreads();
+      for (int t = tid; t < NW * 2 * CS; t += kBT) lds[t] = 0.;
+    }
+    __syncthreads();
+  }
+  }   // blocks of the workgroup
   pc.finish();
 }
 
@@ -1182,6 +1204,14 @@ __global__ __launch_bounds__(128 * kExtBlock) void k4_in_ext(LinArgs a) {
 
 __host__ __device__ inline int ext_stat_doubles(int nt, int det) { return (det ? 2 : 1) * (2 * nt + 4); }
 struct LPass { double invZ; bool ari, nasi, skip; int en_off, eh_off; double invZs; bool merged; };
+// a value that is the same in every lane, moved to scalar registers (it would otherwise occupy vector registers for the whole kernel)
+__device__ __forceinline__ double uniform_f64(double x) {
+  union { double d; int i[2]; } u;
+  u.d = x;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
 // schedule 0 (reference): pass 0 = terminals (ari,nasi), pass 1 = the label's mask; schedule 1: ari only / nasi only
 __device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
   LPass pi;
@@ -1202,8 +1232,8 @@ __device__ __forceinline__ LPass lpass(const LinArgs& a, const LViews& v) {
   // schedule 1 on an automaton with the shadow state: ONE sweep, "has motif" terminals for the pattern's states (world 0,
   // Z(ari)), the "no motif" terminal for the shadow of (0,0) (world 1, Z(nasi))
   pi.merged = a.schedule == 1 && a.lay.shadow >= 0;
-  pi.invZs = pi.merged ? 1. / v.zs[2] : 0.;
-  pi.invZ = 1. / Z;
+  pi.invZs = uniform_f64(pi.merged ? 1. / v.zs[2] : 0.);
+  pi.invZ = uniform_f64(1. / Z);
   pi.en_off = 6 + a.pass * nt;
   pi.eh_off = 6 + 2 * nt + 2 * a.pass;
   return pi;
@@ -1399,17 +1429,19 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   const LPass pi = lpass(a, v);
   const AutomatonLayout& A = a.lay;
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = a.lay.n_theta;
+  // (nblk blocks of cpb cells per workgroup, context staged once: see k4_in)
+  const int nblk = a.nblk > 1 ? a.nblk : 1, cpbT = cpb * nblk;
   if (d > v.q.W) return;
   const int L = v.q.L, W = v.q.W;
-  const int ncell = L - d + 1, i0 = bx * cpb;
-  if (i0 >= ncell) return;
-  const int nc = (cpb < ncell - i0) ? cpb : ncell - i0;
+  const int ncell = L - d + 1, i0T = bx * cpbT;
+  if (i0T >= ncell) return;
+  const int ncT = (cpbT < ncell - i0T) ? cpbT : ncell - i0T;
   if (MODE == OUT_END) {
     // Under the start constraint the motif begins at Ys: a cell that ends at or before Ys holds no part of it, so no transition in
     // it can be an end of the motif (its posterior is an exact 0: a derivation whose motif began earlier emits Ys with weight 0),
     // and nothing that is swept reads its outside value -- parents, item sums and pair entries all look at cells that contain the
     // reader.  Workgroups whose cells all satisfy j <= Ys return: on average half of the sweep.
-    if (!(a.dbg & 4096) && i0 + nc - 1 + d <= a.ys[v.n]) return;
+    if (!(a.dbg & 4096) && i0T + ncT - 1 + d <= a.ys[v.n]) return;
   }
   const int HD = FAST ? A.n_lane : S;   // (as in k4_in)
   const int CS = cpb * HD;
@@ -1426,9 +1458,9 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   double* l_en = l_en0 + wvd * ES;             // ... this lane's copy
   double* l_eh = l_en + 2 * nt;
   double* l_pos = l_en0 + NW * ES;             // scan: [2][win] position posteriors of the window (start, inner | end, -)
-  const int win = cpb + a.wmax + 3;
+  const int win = cpbT + a.wmax + 3;
   double* sOB1 = l_pos + 2 * win;              // item records of the three roles (kRecOut doubles)
-  const BlockLds BL = block_lds(out_doubles(CS, nt, cpb + a.wmax + 3, NW), cpb, a.n_lin, cpb + a.wmax + 3, FAST ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * cpb, FAST ? kCellOutD : 0);
+  const BlockLds BL = block_lds(out_doubles(CS, nt, win, NW), cpbT, a.n_lin, win, FAST ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * cpbT, FAST ? kCellOutD : 0);
   // cell records of the table-driven unary phase (see k4_in): twelve global values per cell, fetched with the context
   constexpr int kCRout = (ELEMDP_CPB_MAX * 12 + kBT - 1) / kBT;
   double crx[kCRout];
@@ -1436,19 +1468,19 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
 #pragma unroll
     for (int r = 0; r < kCRout; ++r) {
       crx[r] = 0.;
-      if (r * kBT < cpb * 12) {   // (uniform: most automata need the first round only)
-        const int t = tid + r * kBT, c0 = t / 12, c = c0 < nc ? c0 : 0;
-        crx[r] = cell_out_fetch(v.q, d, i0 + c, t - c0 * 12);
+      if (r * kBT < cpbT * 12) {   // (uniform: most automata need the first round only)
+        const int t = tid + r * kBT, c0 = t / 12, c = c0 < ncT ? c0 : 0;
+        crx[r] = cell_out_fetch(v.q, d, i0T + c, t - c0 * 12);
       }
     }
   }
-  if (a.dbg & 1024) { if (nc == 12345) lds[tid] = crx[0] + pi.invZ; return; }   // (timing experiments, as in k4_in)
-  const BlockCtx cx = stage_context<BIG, 1, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0, nc, d, cpb);
+  if (a.dbg & 1024) { if (ncT == 12345) lds[tid] = crx[0] + pi.invZ; return; }   // (timing experiments, as in k4_in)
+  const BlockCtx cx = stage_context<BIG, 1, FAST>(a, v, reinterpret_cast<unsigned char*>(lds), BL, i0T, ncT, d, cpbT);
   if (pi.skip) return;   // (tested here: the loads behind `pi` travel with those of the context instead of before them)
-  int* dm = cx.dm; int* cnts = cx.cnts; int* pre = cx.pre; int* base = cx.base;
+  int* dmT = cx.dm; int* cntsT = cx.cnts; int* pre = cx.pre; int* baseT = cx.base;
   const int32_t* G = v.m.big;
-  double* crec = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
-  int* crfl = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
+  double* crecT = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
+  int* crflT = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
   const int n_zero = NW * (HS + ES) + ((MODE == OUT_SCAN || MODE == OUT_END) ? 2 * win : 0);
   for (int t = tid; t < n_zero; t += kBT) lds[t] = 0.;
   __syncthreads();
@@ -1458,19 +1490,19 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
 #pragma unroll
     for (int r = 0; r < kCRout; ++r) {
       const int t = tid + r * kBT, c = t / 12, k = t - c * 12;
-      if (c < nc) {
-        const int i = i0 + c;
+      if (c < ncT) {
+        const int i = i0T + c;
         const bool on = k < 4 ? v.q.e_ok(i, d) : k < 6 ? v.q.pair_ok(i, d) : k < 8 ? (v.q.pair_ok(i - 1, d + 2) && v.q.pair_ok(i, d)) : true;
-        crec[c * kCellOutD + 2 + k] = on ? crx[r] : 0.;
+        crecT[c * kCellOutD + 2 + k] = on ? crx[r] : 0.;
       }
     }
-    for (int c = tid; c < nc; c += kBT) {
-      const int i = i0 + c, j = i + d;
+    for (int c = tid; c < ncT; c += kBT) {
+      const int i = i0T + c, j = i + d;
       int fl = cell_out_flags(v.m, v.q, d, i);
       if (MODE == OUT_END) { const int ys = a.ys[v.n]; fl |= (i - 1 == ys ? CF_YL : 0) | (j == ys ? CF_YR : 0) | (L == j + 1 ? CF_JLAST : 0); }
-      crfl[c] = fl;
-      crec[c * kCellOutD] = v.q.ews[i > 0 ? i - 1 : 0];
-      crec[c * kCellOutD + 1] = v.q.ews[j < L ? j : L];
+      crflT[c] = fl;
+      crecT[c * kCellOutD] = v.q.ews[i > 0 ? i - 1 : 0];
+      crecT[c * kCellOutD + 1] = v.q.ews[j < L ? j : L];
     }
   }
   LinSink sink;
@@ -1478,7 +1510,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   sink.eh0 = sink.eh1 = 0.;
   // scan: the position posteriors of this workgroup-diagonal are summed in LDS over the window of positions it touches
   // ([p0, p0 + win): i0-1 .. i0+nc+d, the window of the staged context) and added to the sequence's arrays once at the end
-  const int pos_p0 = (i0 > 0) ? i0 - 1 : 0;
+  const int pos_p0 = (i0T > 0) ? i0T - 1 : 0;
   if (MODE == OUT_SCAN) { sink.pos0 = l_pos - pos_p0; sink.pos1 = l_pos + win - pos_p0; }
   if (MODE == OUT_END) sink.pos2 = l_pos - pos_p0;
   const TableView& in = v.in;
@@ -1486,39 +1518,35 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   const int nq = ((a.dbg & 2) || (ELEMDP_KO & 2)) ? 0 : A.n_quad;
   const double* IB = in.band;
   const double* OB = out.band;
-  // CSR ranges of the item sums of the three roles (consumed behind the pair phase, whose loads they travel with)
-  for (int vc = tid; vc < 3 * nc; vc += kBT) {
-    const int role = (vc >= nc) + (vc >= 2 * nc), c = vc - role * nc;
-    const int i = i0 + c;
+  // CSR ranges of the item sums of the three roles of all cells of the workgroup, [block][role][cpb] (consumed behind the first
+  // pair phase, whose loads they travel with; the ranges of cells past the end are empty)
+  for (int vc = tid; vc < 3 * cpbT; vc += kBT) {
+    const int kb = div_rcp(vc, a.rcp_3cpb), vr = vc - kb * 3 * cpb;
+    const int role = div_rcp(vr, a.rcp_cpb), cT = kb * cpb + (vr - role * cpb);
+    const bool have = cT < ncT;
+    const int i = i0T + (have ? cT : 0);
     const int cell = v.q.cell(i, d);
     const int32_t* off = role == 0 ? v.q.by_inner_off : role == 1 ? v.q.by_left_off : v.q.by_right_off;
     int n0 = 0, n1 = 0;
     // (table-driven kernels: no loop sums on the diagonal d = 0 -- the outside value of an EMPTY loop L(i,i) has no reader: it has
     // no children, and the statistics of the emissions into it use the parent's value.  Those cells own the records of every
     // stack and bulge of the sequence.  The generic kernels, whose tables debug_tables exports, keep them.)
-    if (nq > 0 && (role != 0 || v.q.pair_ok(i, d)) && !(FAST && role != 0 && d == 0)) { n0 = off[cell]; n1 = off[cell + 1]; }
-    base[vc] = n0;
-    cnts[vc] = (n1 > n0) ? n1 - n0 : 0;
+    if (have && nq > 0 && (role != 0 || v.q.pair_ok(i, d)) && !(FAST && role != 0 && d == 0)) { n0 = off[cell]; n1 = off[cell + 1]; }
+    baseT[vc] = n0;
+    cntsT[vc] = (n1 > n0) ? n1 - n0 : 0;
   }
-  const int nv = 3 * nc;
-  LoopItem ah_it = LoopItem{0., 0, 0, 0, 0};
-  int ah_meta = -1;
-#if ELEMDP_AHEAD_OUT
-  // ... their prefix, and the first 256 item records fetched ahead: they arrive while the pair phases run
-  // (off by default: two barriers more than the round trip saved, measured)
-  __syncthreads();
-  lds_prefix(nv, tid, cnts, pre);
-  __syncthreads();
-  const int n_rec = pre[nv];
-  if (tid < n_rec) {
-    int lo, n;
-    outer_locate(tid, nv, pre, base, lo, n);
-    const int role = (lo >= nc) + (lo >= 2 * nc);
-    const LoopItem* src = role == 0 ? v.q.items_inner : role == 1 ? v.q.items_left : v.q.items_right;
-    ah_it = src[n];
-    ah_meta = (role << 16) | (lo - role * nc);
-  }
-#endif
+  const int nv = 3 * cpb;
+  const int tid_wg = tid;
+  for (int blk = 0; blk * cpb < ncT; ++blk) {
+  int tid = tid_wg;   // (behind an empty asm: see k4_in)
+  asm volatile("" : "+v"(tid));
+  const int i0 = i0T + blk * cpb, nc = (cpb < ncT - blk * cpb) ? cpb : ncT - blk * cpb;
+  if (MODE == OUT_END && !(a.dbg & 4096) && i0 + nc - 1 + d <= a.ys[v.n]) continue;   // (uniform; see the workgroup test above)
+  const int* dm = dmT + blk * cpb;
+  const int* cnts = cntsT + blk * 3 * cpb;
+  const int* base = baseT + blk * 3 * cpb;
+  const double* crec = crecT + blk * cpb * kCellOutD;
+  const int* crfl = crflT + blk * cpb;
   // rule 2, factorised, outside direction (lin_rules.h: lheavy_o1 / lheavy_o2):
   //   h1[c][s1] = H1 = sum over the stems (j, l) that start at the cell's end j = i + d:  outA(i,l,p) * P(j,l,t) * xml(j,l)
   //   h2[c][t]  = HA = sum_{ii < i} outA(ii,j,p) * 1(ii,i,s1), only where the cell itself is a stem P(i,j)
@@ -1555,7 +1583,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
         unsigned long long m = stems;
         for (int k = 0; k < sc; ++k) m &= m - 1;          // the sc-th stem cell
         const int c = stems ? __builtin_ctzll(m) : 0;
-        const int b = 1 + div_small(r, nA), p = r - (b - 1) * nA;
+        const int b = 1 + div_rcp(r, a.rcp_nap), p = r - (b - 1) * nA;
         const int ii = i0 + c - b;
         const int dmii = (valid && ii >= 0) ? (int)v.q.dmin[ii] : 0;
         const bool ok = dmii > 0 && b >= dmii;              // 1(ii, i, .) is parsable (then the pair entries of (ii, d + b) exist)
@@ -1571,9 +1599,11 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
         if (term != 0.) atomicAdd(&h2A[ha_idx[u]], term);
       }
     };
-    if (total > 0) ha_load(tid);
+    // (unconditional, like the add below: a value that is defined under a condition inside the block loop counts as live around
+    // the whole loop -- 16 registers here)
+    ha_load(tid);
     for (int w = tid; w < nwork; w += kBT) {
-      const int c = div_small(w, nA), p = w - c * nA;
+      const int c = div_rcp(w, a.rcp_nap), p = w - c * nA;
       const int i = i0 + c, j = i + d;
       const int s1 = pr_s1(p);
       const int cP = pr_cP(p);
@@ -1623,7 +1653,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
         if (acc != 0.) atomicAdd(&h1A[c * HD + s1], acc);
       }
     }
-    if (total > 0) ha_add();
+    ha_add();
     for (int w0 = tid + kHA * kBT; w0 < total; w0 += kHA * kBT) { ha_load(w0); ha_add(); }
   }
   __syncthreads();
@@ -1634,11 +1664,11 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   // their weights are staged into the (now free) operand staging area by all lanes with one round of loads; a work item
   // then needs a single round of table loads, selected by role without branches.
   {
-#if !ELEMDP_AHEAD_OUT
+    // (the unary phase of the previous block left out B of its targets in `hp`, which the pair entries behind it have read)
+    if (blk > 0) for (int t = tid; t < CS; t += kBT) hp[t] = 0.;
     lds_prefix(nv, tid, cnts, pre);
     __syncthreads();
     const int n_rec = pre[nv];
-#endif
     // record area: LoopItem it[cap], double xw[2][cap], int meta[cap] (role << 16 | cell)
     const int cap = (kRecOut * 8) / 40;
     LoopItem* r_it = reinterpret_cast<LoopItem*>(sOB1);
@@ -1646,21 +1676,19 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
     int* r_meta = reinterpret_cast<int*>(r_xw + 2 * cap);
     // energy statistics of rule 6c: a lane serves both worlds here, so [world][stack / other] sums of their own, added to
     // the workgroup's before the unary phase (four accumulators less across it)
-    double ew[4] = {0., 0., 0., 0.};
+    double ew[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ew[k] = 0.; asm volatile("" : "+v"(ew[k])); }   // (pinned here: the zeros would be set up at the top of the block loop)
     for (int p0 = 0; p0 < n_rec; p0 += cap) {
       const int np = (cap < n_rec - p0) ? cap : n_rec - p0;
       for (int x = tid; x < np; x += kBT) {
         const int p = p0 + x;
-        LoopItem itv = ah_it;
-        int meta = ah_meta;
-        if (!ELEMDP_AHEAD_OUT || p != tid) {   // (record `tid` came ahead)
-          int lo, n;
-          outer_locate(p, nv, pre, base, lo, n);   // the (role, cell) owning record p
-          const int role = (lo >= nc) + (lo >= 2 * nc);
-          const LoopItem* src = role == 0 ? v.q.items_inner : role == 1 ? v.q.items_left : v.q.items_right;
-          itv = src[n];
-          meta = (role << 16) | (lo - role * nc);
-        }
+        int lo, n;
+        outer_locate(p, nv, pre, base, lo, n);   // the (role, cell) owning record p
+        const int role = (lo >= cpb) + (lo >= 2 * cpb);
+        const LoopItem* src = role == 0 ? v.q.items_inner : role == 1 ? v.q.items_left : v.q.items_right;
+        const LoopItem itv = src[n];
+        const int meta = (role << 16) | (lo - role * cpb);
         r_it[x] = itv;
         r_xw[x] = lin_weight(v.m.lambda[0], itv.tsc);          // (exp(lambda_k * tsc), as in outer_stage)
         r_xw[cap + x] = lin_weight(v.m.lambda[1], itv.tsc);
@@ -1736,25 +1764,35 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   // (OUT_END: the cells of this workgroup that end at or before Ys take no part -- see the workgroup test above; their parents may
   // lie in a workgroup that returned, so neither their values nor their statistics mean anything)
   const int end_ys = (MODE == OUT_END && !(a.dbg & 4096)) ? a.ys[v.n] : -1;
-  if (tid < nc * NL && !(a.dbg & 4) && !(ELEMDP_KO & 4) && i0 + div_small(tid, NL) + d > end_ys) {
-    const int c = div_small(tid, NL);
+  // out B of a target goes to its slot of `hp` (copy 0) for the pair entries below; the lane clears the other sums it owns, for
+  // the next block of the workgroup: the pair phase of that block adds to h1 / h2 while the pair entries of this one still read hp,
+  // which is cleared behind the next pair phase (table-driven: HD = NL, and cells past nc take no adds)
+  if (tid < nc * NL && !(a.dbg & 4) && !(ELEMDP_KO & 4)) {
+    const int c = div_rcp(tid, a.rcp_lane);
     const int s = FAST ? G[A.f_live_out + tid - c * NL] : tid - c * NL;
-    const bool w1 = pi.merged && s == A.shadow;      // the shadow state: world 1 (its own Z, second set of statistics)
-    sink.world = w1 ? 1 : 0;
-    sink.en_ = l_en + (w1 ? nt : 0);
-    if (FAST) {
-      h1[c * HD + (tid - c * NL)] = fast_outside_unary<kFastR, FP, kFastL, MODE>(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c],
-                                                                   d, i0 + c, w1 ? pi.invZs : pi.invZ, v.m.lam_same != 0, v.m.no_prf != 0, sink,
-                                                                   h1 + c * HD + (tid - c * NL), CS, NW, HS, G + A.fs_out);
-    } else {
-      LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
-      HeavyOut H;
-      H.H1 = rep_sum(h1 + c * HD + s, NW, HS); H.H2 = rep_sum(h2 + c * HD + s, NW, HS);
-      H.HP = rep_sum(hp + c * HD + s, NW, HS); H.HL = rep_sum(hl + c * HD + s, NW, HS);
-      if (!(a.dbg & 32)) H.HP += out.ld(ST_P, d, i0 + c, s, v.q.pair_ok(i0 + c, d));   // rule-7 term (k4_r7)
-      H.ext_in_hp = true;
-      h1[c * HD + s] = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s) for the pair entries below
+    const int slot = FAST ? tid : c * HD + s;
+    double oB = 0.;
+    if (i0 + c + d > end_ys) {
+      const bool w1 = pi.merged && s == A.shadow;      // the shadow state: world 1 (its own Z, second set of statistics)
+      sink.world = w1 ? 1 : 0;
+      sink.en_ = l_en + (w1 ? nt : 0);
+      if (FAST) {
+        oB = fast_outside_unary<kFastR, FP, kFastL, MODE>(A, G + A.fp_out + s * kFastW, G, v.m.lin, in, out, crec + c * kCellOutD, crfl[c],
+                                                          d, i0 + c, w1 ? pi.invZs : pi.invZ, v.m.lam_same != 0, v.m.no_prf != 0, sink,
+                                                          h1 + slot, CS, NW, HS, G + A.fs_out);
+      } else {
+        LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
+        HeavyOut H;
+        H.H1 = rep_sum(h1 + slot, NW, HS); H.H2 = rep_sum(h2 + slot, NW, HS);
+        H.HP = rep_sum(hp + slot, NW, HS); H.HL = rep_sum(hl + slot, NW, HS);
+        if (!(a.dbg & 32)) H.HP += out.ld(ST_P, d, i0 + c, s, v.q.pair_ok(i0 + c, d));   // rule-7 term (k4_r7)
+        H.ext_in_hp = true;
+        oB = lin_outside_target_u<MODE>(x, d, i0 + c, s, H);     // out B(i,d,s)
+      }
     }
+    if (nblk > 1)
+      for (int r = 0; r < NW; ++r) { h1[r * HS + slot] = 0.; h2[r * HS + slot] = 0.; hl[r * HS + slot] = 0.; if (r) hp[r * HS + slot] = 0.; }
+    hp[slot] = oB;
   }
   __syncthreads();
   // outside values of the pair entries of the cells (lin_outside_apair): out B of the target + the tail step from
@@ -1763,7 +1801,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
     const int nA = A.n_ap;
     double* const en_keep = sink.en_;
     for (int w = tid; w < nc * nA; w += kBT) {
-      const int c = div_small(w, nA), p = w - c * nA;
+      const int c = div_rcp(w, a.rcp_nap), p = w - c * nA;
       if (i0 + c + d <= end_ys) continue;
       if (FAST) {   // lin_outside_apair from the pair record (AutomatonLayout::fpr_out) and the weight tables
         const int32_t* PR = G + A.fpr_out + 8 * p;
@@ -1784,7 +1822,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
           }
           double acc = 0.;
           if (a_in != 0.) {
-            acc = tg != 0xff ? h1[c * HD + tg] : 0.;
+            acc = tg != 0xff ? hp[c * HD + tg] : 0.;
             const double inz = a_in * (w1 ? pi.invZs : pi.invZ);
             const int bj = step ? (int)v.q.seq[j] : 0;
             const double ewj = step ? v.q.ews[j] : 1.;
@@ -1810,14 +1848,20 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
       const bool w1 = pi.merged && v.m.ints[A.ap_t + p] == A.shadow;
       sink.en_ = l_en + (w1 ? nt : 0);
       LinOutCtx<LinSink> x{v.m, v.q, in, out, w1 ? pi.invZs : pi.invZ, sink, Constraint{MODE == OUT_END ? a.ys[v.n] : -1, -1, 0}};
-      lin_outside_apair<MODE>(x, d, i0 + c, p, tgt >= 0 ? h1[c * HD + tgt] : 0.);
+      lin_outside_apair<MODE>(x, d, i0 + c, p, tgt >= 0 ? hp[c * HD + tgt] : 0.);
     }
     sink.en_ = en_keep;
   }
   pc.mark<11>();
+  if ((blk + 1) * cpb < ncT && (!FAST || (a.dbg & 4) || (ELEMDP_KO & 4))) {   // (generic rule code: the lanes do not cover every slot)
+    __syncthreads();
+    for (int t = tid; t < NW * HS; t += kBT) lds[t] = 0.;
+    __syncthreads();
+  }
+  }   // blocks of the workgroup
   if (MODE == OUT_SCAN || MODE == OUT_END) {
     __syncthreads();
-    const int p1 = (i0 + nc + d < L) ? i0 + nc + d : L;   // inclusive
+    const int p1 = (i0T + ncT + d < L) ? i0T + ncT + d : L;   // inclusive
     for (int t = tid; t <= p1 - pos_p0; t += kBT) {
       const double v0 = l_pos[t], v1 = l_pos[win + t];
       if (MODE == OUT_SCAN) {
@@ -2164,6 +2208,37 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   return hipGetLastError();
 }
 
+// Blocks of cpb cells per band-kernel workgroup (LinArgs::nblk) for a diagonal of `nb` blocks: at most `nmax` (<= ELEMDP_CPB_MAX
+// cells: the cell records and the stem mask of a workgroup), spread evenly over the fewest workgroups; one block per workgroup
+// where the whole launch is resident at once anyway (small groups: there the lifetime of ONE workgroup is the launch's duration).
+static int env_nblk(int part) {   // experiments: ELEMDP_NBLK, or ELEMDP_NBLK_IN / ELEMDP_NBLK_OUT for one direction
+  static const int v[3] = {[] { const char* e = getenv("ELEMDP_NBLK"); return e ? atoi(e) : 0; }(),
+                           [] { const char* e = getenv("ELEMDP_NBLK_IN"); return e ? atoi(e) : 0; }(),
+                           [] { const char* e = getenv("ELEMDP_NBLK_OUT"); return e ? atoi(e) : 0; }()};
+  return v[1 + part] > 0 ? v[1 + part] : v[0];
+}
+#ifndef ELEMDP_NBLK_DEFAULT
+#define ELEMDP_NBLK_DEFAULT 3
+#endif
+// req: LinArgs::nblk as the host engine passes it (option "nblk"): 0 = the policy above, n = n blocks wherever they fit;
+// part 0: k4_in, 1: k4_out
+static int nblk_max(int cpb, bool fast, bool det, int req, int part) {
+  if (!fast || det) return 1;
+  const int want = req > 0 ? req : env_nblk(part) > 0 ? env_nblk(part) : ELEMDP_NBLK_DEFAULT;
+  return std::max(1, std::min(want, ELEMDP_CPB_MAX / std::max(cpb, 1)));
+}
+static void set_rcps(LinArgs& a, bool fast) {
+  a.rcp_nap = 1.0f / (float)std::max(a.lay.n_ap, 1);
+  a.rcp_lane = 1.0f / (float)std::max(fast ? a.lay.n_lane : a.lay.n_active, 1);
+  a.rcp_cpb = 1.0f / (float)std::max(a.cpb, 1);
+  a.rcp_3cpb = 1.0f / (float)std::max(3 * a.cpb, 1);
+}
+static int nblk_for(int nb, int G, int nmax, int req) {
+  if (nmax <= 1 || (req <= 0 && (long long)nb * G <= 6144)) return 1;
+  const int nsuper = (nb + nmax - 1) / nmax;
+  return (nb + nsuper - 1) / nsuper;
+}
+
 hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax, int phase, hipStream_t st) {
   if (G <= 0) return hipSuccess;
   LinArgs a = full;
@@ -2185,11 +2260,15 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
   const bool fp2 = a.lay.fp_max_p <= 2;
   const int hd = fast ? a.lay.n_lane : S;   // stride of the heavy sums per cell (k4_in / k4_out: HD)
-  const size_t lds_in = block_lds(2 * a.cpb * hd + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
-  const size_t lds_out = block_lds(out_doubles(a.cpb * hd, nt, a.cpb + Wmax + 3), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
-  const bool w8 = lds_in * 8 <= 160 * 1024;   // (the eighth k4_in workgroup of a CU fits the LDS: the 64-register variant)
-  const bool w6 = lds_out * 6 <= 160 * 1024;  // (the sixth k4_out workgroup: the 80-register variant)
-  if (getenv("ELEMDP_LDS_DEBUG") && phase == 0) fprintf(stderr, "scan group: G %d cpb %d S %d nt %d fast %d n_lin %d fast blob in/out %d/%d ints win %d lds k4_in %zu k4_out %zu\n", G, a.cpb, S, nt, (int)fast, a.n_lin, a.lay.fb_in_n, a.lay.fb_out_n, a.cpb + Wmax + 3, lds_in, lds_out);
+  set_rcps(a, fast);
+  const int nbmax_in = nblk_max(a.cpb, fast, false, full.nblk, 0), nbmax_out = nblk_max(a.cpb, fast, false, full.nblk, 1);
+  auto lds_in_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(2 * a.cpb * hd + kRecIn, ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total; };
+  auto lds_out_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(out_doubles(a.cpb * hd, nt, ct + Wmax + 3), ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * ct, fast ? kCellOutD : 0).total; };
+  const size_t lds_in = lds_in_of(1), lds_out = lds_out_of(1);
+  // (the eighth k4_in workgroup of a CU fits the LDS: the 64-register variant; the sixth k4_out workgroup: the 80-register variant)
+  auto w8_of = [&](int nblk) { return lds_in_of(nblk) * 8 <= 160 * 1024; };
+  auto w6_of = [&](int nblk) { return lds_out_of(nblk) * 6 <= 160 * 1024; };
+  if (getenv("ELEMDP_LDS_DEBUG") && phase == 0) fprintf(stderr, "scan group: G %d cpb %d S %d nt %d fast %d n_lin %d fast blob in/out %d/%d ints win %d lds k4_in %zu k4_out %zu; with %d / %d blocks per workgroup %zu / %zu\n", G, a.cpb, S, nt, (int)fast, a.n_lin, a.lay.fb_in_n, a.lay.fb_out_n, a.cpb + Wmax + 3, lds_in, lds_out, nbmax_in, nbmax_out, lds_in_of(nbmax_in), lds_out_of(nbmax_out));
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds((a.ext_ring ? ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
   const size_t lds_ext_out = stage_ext ? (size_t)ext_lds(2 * nt + 4 + (a.ext_ring ? ext_ring_doubles(2 * nt + 4, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : sizeof(double) * (2 * nt + 4);
@@ -2200,12 +2279,15 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       const int ncell = Lmax - d + 1;                                                                                            \
       if (ncell <= 0) break;                                                                                                     \
       a.d = d;                                                                                                                   \
-      const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
-      if (fast && fp2 && w8) hipLaunchKernelGGL((k4_in<true, CON, true, 2, true>), grid, dim3(kBT), lds_in, st, a);         \
-      else if (fast && fp2) hipLaunchKernelGGL((k4_in<true, CON, true, 2>), grid, dim3(kBT), lds_in, st, a);                \
-      else if (fast) hipLaunchKernelGGL((k4_in<true, CON, true>), grid, dim3(kBT), lds_in, st, a);                          \
-      else if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kBT), lds_in, st, a);                                 \
-      else hipLaunchKernelGGL((k4_in<false, CON>), grid, dim3(kBT), lds_in, st, a);                                         \
+      const int nb = (ncell + a.cpb - 1) / a.cpb;                                                                                \
+      a.nblk = nblk_for(nb, G, nbmax_in, full.nblk);                                                                                           \
+      const dim3 grid((nb + a.nblk - 1) / a.nblk, G);                                                                            \
+      const size_t lds_i = lds_in_of(a.nblk);                                                                                    \
+      if (fast && fp2 && w8_of(a.nblk)) hipLaunchKernelGGL((k4_in<true, CON, true, 2, true>), grid, dim3(kBT), lds_i, st, a);    \
+      else if (fast && fp2) hipLaunchKernelGGL((k4_in<true, CON, true, 2>), grid, dim3(kBT), lds_i, st, a);                      \
+      else if (fast) hipLaunchKernelGGL((k4_in<true, CON, true>), grid, dim3(kBT), lds_i, st, a);                                \
+      else if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kBT), lds_i, st, a);                                       \
+      else hipLaunchKernelGGL((k4_in<false, CON>), grid, dim3(kBT), lds_i, st, a);                                               \
     }                                                                                                                            \
     if (stage_ext) hipLaunchKernelGGL((k4_in_ext<true, CON>), dim3(G), dim3(ext_nt), lds_ext_in, st, a);                         \
     else hipLaunchKernelGGL((k4_in_ext<false, CON>), dim3(G), dim3(128), 0, st, a);                                              \
@@ -2216,12 +2298,15 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       const int ncell = Lmax - d + 1;                                                                                            \
       if (ncell <= 0) continue;                                                                                                  \
       a.d = d;                                                                                                                   \
-      const dim3 grid((ncell + a.cpb - 1) / a.cpb, G);                                                                           \
-      if (fast && fp2 && w6) hipLaunchKernelGGL((k4_out<MODE, true, true, 2, true>), grid, dim3(kBT), lds_out, st, a);      \
-      else if (fast && fp2) hipLaunchKernelGGL((k4_out<MODE, true, true, 2>), grid, dim3(kBT), lds_out, st, a);             \
-      else if (fast) hipLaunchKernelGGL((k4_out<MODE, true, true>), grid, dim3(kBT), lds_out, st, a);                       \
-      else if (big) hipLaunchKernelGGL((k4_out<MODE, true>), grid, dim3(kBT), lds_out, st, a);                              \
-      else hipLaunchKernelGGL((k4_out<MODE, false>), grid, dim3(kBT), lds_out, st, a);                                      \
+      const int nb = (ncell + a.cpb - 1) / a.cpb;                                                                                \
+      a.nblk = nblk_for(nb, G, nbmax_out, full.nblk);                                                                                           \
+      const dim3 grid((nb + a.nblk - 1) / a.nblk, G);                                                                            \
+      const size_t lds_o = lds_out_of(a.nblk);                                                                                   \
+      if (fast && fp2 && w6_of(a.nblk)) hipLaunchKernelGGL((k4_out<MODE, true, true, 2, true>), grid, dim3(kBT), lds_o, st, a);  \
+      else if (fast && fp2) hipLaunchKernelGGL((k4_out<MODE, true, true, 2>), grid, dim3(kBT), lds_o, st, a);                    \
+      else if (fast) hipLaunchKernelGGL((k4_out<MODE, true, true>), grid, dim3(kBT), lds_o, st, a);                              \
+      else if (big) hipLaunchKernelGGL((k4_out<MODE, true>), grid, dim3(kBT), lds_o, st, a);                                     \
+      else hipLaunchKernelGGL((k4_out<MODE, false>), grid, dim3(kBT), lds_o, st, a);                                             \
     }                                                                                                                            \
   } while (0)
   if (phase == 0) {
@@ -2252,19 +2337,28 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
   const int NW = a.det ? kBT / 64 : 1;
   const int hd = fast ? a.lay.n_lane : S;   // stride of the heavy sums per cell (k4_in / k4_out: HD)
-  const size_t lds_in = block_lds(NW * 2 * a.cpb * hd + kRecIn, a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total;
+  set_rcps(a, fast);
+  const int nbmax_in = nblk_max(a.cpb, fast, a.det != 0, full.nblk, 0), nbmax_out = nblk_max(a.cpb, fast, a.det != 0, full.nblk, 1);
+  auto lds_in_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(NW * 2 * a.cpb * hd + kRecIn, ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total; };
+  auto lds_out_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(out_doubles(a.cpb * hd, nt, ct + Wmax + 3, NW), ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * ct, fast ? kCellOutD : 0).total; };
+  const size_t lds_in = lds_in_of(1);
   const size_t lds_stat = sizeof(double) * (2 * nt + 4);
   if (!a.no_rss)
     for (int d = 0; d <= Wmax; ++d) {
       const int ncell = Lmax - d + 1;
       if (ncell <= 0) break;
       a.d = d;
-      if (fast && a.lay.fp_max_p <= 2 && lds_in * 8 <= 160 * 1024) hipLaunchKernelGGL((k4_in<true, false, true, 2, true>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
-      else if (fast && a.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_in<true, false, true, 2>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
-      else if (fast) hipLaunchKernelGGL((k4_in<true, false, true>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
-      else if (big) hipLaunchKernelGGL((k4_in<true, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
-      else hipLaunchKernelGGL((k4_in<false, false>), dim3((ncell + a.cpb - 1) / a.cpb, G), dim3(kBT), lds_in, st, a);
+      const int nb = (ncell + a.cpb - 1) / a.cpb;
+      a.nblk = nblk_for(nb, G, nbmax_in, full.nblk);
+      const dim3 grid((nb + a.nblk - 1) / a.nblk, G);
+      const size_t lds_i = lds_in_of(a.nblk);
+      if (fast && a.lay.fp_max_p <= 2 && lds_i * 8 <= 160 * 1024) hipLaunchKernelGGL((k4_in<true, false, true, 2, true>), grid, dim3(kBT), lds_i, st, a);
+      else if (fast && a.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_in<true, false, true, 2>), grid, dim3(kBT), lds_i, st, a);
+      else if (fast) hipLaunchKernelGGL((k4_in<true, false, true>), grid, dim3(kBT), lds_i, st, a);
+      else if (big) hipLaunchKernelGGL((k4_in<true, false>), grid, dim3(kBT), lds_i, st, a);
+      else hipLaunchKernelGGL((k4_in<false, false>), grid, dim3(kBT), lds_i, st, a);
     }
+  a.nblk = 1;
   a.lmax = Lmax;
   const bool stage_ext = Lmax <= 2048 && a.nword_max <= 8192;
   const size_t lds_ext_in = stage_ext ? (size_t)ext_lds((a.ext_ring ? ext_ring_doubles(0, Wmax, S, kLinEth + nt, Lmax, a.nword_max, a.n_stage) : 0), kLinEth + nt, Lmax, a.nword_max, a.n_stage).total : 0;
@@ -2275,8 +2369,8 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   // pattern's states, the "no motif" terminal on the shadow of (0,0), each with its own Z and statistics (lpass).
   // schedule 0: the reference's two sweeps, (ari, nasi) then the label's mask.
   const int n_pass = (a.schedule == 1 || first_pass_only) ? 1 : 2;
-  const size_t lds_b = block_lds(out_doubles(a.cpb * hd, nt, a.cpb + Wmax + 3, NW), a.cpb, a.n_lin, a.cpb + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * a.cpb, fast ? kCellOutD : 0).total;
-  if (getenv("ELEMDP_LDS_DEBUG")) fprintf(stderr, "lin group: G %d cpb %d fast %d n_lin %d staged ints in/out %d/%d lds k4_in %zu k4_out %zu\n", G, a.cpb, (int)fast, a.n_lin, staged_ints(a.lay, a.n_stage, 0), staged_ints(a.lay, a.n_stage, 1), lds_in, lds_b);
+  const size_t lds_b = lds_out_of(1);
+  if (getenv("ELEMDP_LDS_DEBUG")) fprintf(stderr, "lin group: G %d cpb %d fast %d n_lin %d staged ints in/out %d/%d lds k4_in %zu k4_out %zu; with %d / %d blocks per workgroup %zu / %zu\n", G, a.cpb, (int)fast, a.n_lin, staged_ints(a.lay, a.n_stage, 0), staged_ints(a.lay, a.n_stage, 1), lds_in, lds_b, nbmax_in, nbmax_out, lds_in_of(nbmax_in), lds_out_of(nbmax_out));
   for (int pass = 0; pass < n_pass; ++pass) {
     LinArgs b = a;
     b.pass = pass;
@@ -2289,12 +2383,16 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
         const int ncell = Lmax - d + 1;
         if (ncell <= 0) continue;
         b.d = d;
-        if (big && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);   // (timing experiment: no statistics)
-        else if (fast && b.lay.fp_max_p <= 2 && lds_b * 6 <= 160 * 1024) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
-        else if (fast && b.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
-        else if (fast) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
-        else if (big) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
-        else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), dim3((ncell + b.cpb - 1) / b.cpb, G), dim3(kBT), lds_b, st, b);
+        const int nb = (ncell + b.cpb - 1) / b.cpb;
+        b.nblk = nblk_for(nb, G, nbmax_out, full.nblk);
+        const dim3 grid((nb + b.nblk - 1) / b.nblk, G);
+        const size_t lds_o = lds_out_of(b.nblk);
+        if (big && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), grid, dim3(kBT), lds_o, st, b);   // (timing experiment: no statistics)
+        else if (fast && b.lay.fp_max_p <= 2 && lds_o * 6 <= 160 * 1024) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2, true>), grid, dim3(kBT), lds_o, st, b);
+        else if (fast && b.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2>), grid, dim3(kBT), lds_o, st, b);
+        else if (fast) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true>), grid, dim3(kBT), lds_o, st, b);
+        else if (big) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true>), grid, dim3(kBT), lds_o, st, b);
+        else hipLaunchKernelGGL((k4_out<OUT_TRAIN, false>), grid, dim3(kBT), lds_o, st, b);
       }
     }
   }

@@ -157,6 +157,11 @@ class MiniBatches:
         # evaluated range by range (engine options eval_first / eval_count)
         self.engines = list(engines) if engines else None
         self.lookahead = max(1, int(lookahead))
+        if self.engines:
+            # the joint batch must stay RESIDENT on its engine (a streamed batch, or one on the log-space pipeline, is evaluated as
+            # a whole -- the engine refuses a range there): no more than ~2048 sequences at a time, negatives included
+            per_eval = self.batch * (2 if kmer_shuf is not None else 1)
+            self.lookahead = max(1, min(self.lookahead, 2048 // max(per_eval, 1)))
         self._pending = None
         self._current = None
 
@@ -210,6 +215,7 @@ class MiniBatches:
         if self._pending is not None:
             self._pending["thread"].join()
             self._pending = None
+        self._current = None      # (its remaining parts belong to a batch that may be gone with the engines)
 
     def _call_prefetched(self, x):
         if self._current is None or not self._current["parts"]:
@@ -235,7 +241,8 @@ class MiniBatches:
             return fn, gr, float(eng.bpp_eff()[first:first + n_rec].sum()), nsk
         # a record was skipped: its negative must be left out -- the two-step evaluation on the same engine, whose resident
         # batches are put back afterwards (rare: a partition function outside the double range)
-        self._pending["thread"].join()       # (the shuffles below and the prefetch thread's share one rand())
+        if self._pending is not None:
+            self._pending["thread"].join()   # (the shuffles below and the prefetch thread's share one rand())
         eng.load_batch(part["s1"], part["q1"])
         fn, gr, eff, nsk = eng.train_eval(x)
         sk = eng.seq_stats()[:, 4] != 0

@@ -8,7 +8,7 @@ CSRC = os.path.join(REPO, "rnaelem_amd", "csrc")
 LIB = os.path.join(HERE, "libelemdp_emul.so")
 SRCS = [os.path.join(HERE, "emul.cpp"), os.path.join(CSRC, "automaton.cpp"), os.path.join(CSRC, "energy_tables.cpp")]
 DEPS = SRCS + [os.path.join(CSRC, f) for f in ("dp_rules.h", "plan_rules.h", "energy_rules.h", "scan_rules.h",
-                                                "device_layout.h", "automaton.h", "energy_tables.h", "host_prep.h", "lin_rules.h", "lin_params.h")]
+                                                "device_layout.h", "automaton.h", "energy_tables.h", "host_prep.h", "lin_rules.h", "lin_params.h", "lin_fast.h")]
 
 
 def build(force=False):

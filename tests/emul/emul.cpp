@@ -20,11 +20,13 @@
 #include "../../rnaelem_amd/csrc/host_prep.h"
 #include <limits>
 #include "../../rnaelem_amd/csrc/lin_rules.h"
+#include "../../rnaelem_amd/csrc/lin_fast.h"
 #include "../../rnaelem_amd/csrc/plan_rules.h"
 #include "../../rnaelem_amd/csrc/scan_rules.h"
 
 using namespace elemdp;
 static long g_enum_checked = 0, g_enum_mismatch = 0;
+static long g_fast_cells = 0;   // cells evaluated through the table-driven forms (tests assert the path was taken)
 
 namespace {
 
@@ -35,8 +37,9 @@ enum { F_NO_RSS = 1, F_NO_PRF = 2, F_NO_ENE = 4, F_SOFTMAX = 8, F_FIX_RSS = 1 <<
 struct Emu {
   Automaton* au = nullptr;
   EnergyTables et;
-  AutomatonLayout lay, lay0, lay_r;
-  std::vector<int32_t> ints, ints0, ints_r;
+  AutomatonLayout lay, lay0, lay_r, lay_s;
+  std::vector<int32_t> ints, ints0, ints_r, ints_s;   // (_s: with the shadow copy of state (0,0): the merged outside sweep)
+  bool fast = false;   // band targets through the table-driven forms (lin_fast.h + the records of the fast blobs)
   int max_span, max_iloop, flags;
   double min_bpp, tau;
   ~Emu() { delete au; }
@@ -247,6 +250,219 @@ struct CpuSink {
   void pos(int which, int p, double z) { if (post[which]) post[which][p] = lse2(post[which][p], z); }
 };
 
+
+// ---- Table-driven band targets, serial: the FAST branches of k4_in / k4_out (lin_kernels.hip) restated per cell on top of the
+// same records of the fast blobs -- pair records (fpr_*), tuple column records (fqc_*), live-state lists, unary programs,
+// weight tables, cell records, ScanFlag words -- and the same lin_fast.h functions the kernels call.  What differs from the GPU is
+// only the order of the sums.  m.ints = the whole blob (the kernels index their staged copy with the same offsets).
+template <bool CON>
+void fast_inside_cell(const ModelView& m, const SeqView& q, const TableView& T, int d, int i, const Constraint& con) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.ints;
+  const double* lin = m.lin;
+  const int NL = A.n_lane, j = i + d, W1 = q.W + 1, nq = A.n_quad;
+  ++g_fast_cells;
+  std::vector<double> hb(NL, 0.), he(NL, 0.);
+  const int dmi = q.dmin[i];
+  // pair phase (rule 2 factorised): k4_in, FAST branch
+  for (int p = 0; p < A.n_ap; ++p) {
+    const int32_t* PR = G + A.fpr_in + 8 * p;
+    const int r0 = PR[0], r1 = PR[1];
+    const int c1 = fcol(r0, 0), cP = fcol(r0, 1), tg = (r0 >> 16) & 0xff;
+    double av = 0.;
+    if (dmi > 0 && dmi < d) {
+      const int nch = (dmi < d - 1 && q.unp[j - 1]) ? (r1 >> 16) & 15 : 0;
+      const double wt = (r0 & (2 << 24)) ? q.ews[j - 1] : 1.;
+      const int bj = q.seq[j - 1];
+      for (int u = 0; u < nch; ++u) {
+        const int ce = PR[2 + u], id = (ce >> 8) & 0x7fff;
+        if (CON && j - 1 == con.ys && !(G[A.fs_in + id] & SF_SR)) continue;   // allow_right
+        av = fma(T.lda(d - 1, i, ce & 0xff, true), lin[A.lin_wr + 5 * id + bj] * wt, av);
+      }
+      for_mask_bits(q.okbits_end, j * W1, 1, d - dmi, [&](int sp) {
+        av = fma(T.ldc(ST_1, d - sp, i, c1, true), T.ldc(ST_B, sp, j - sp, cP, true), av);   // (X = P exp(lambda e_ml) in the B rows)
+      });
+      T.a(d, i, p) = av;
+    }
+    if (tg != 0xff && av != 0.) hb[tg] += av;
+  }
+  // item sums (rule 6c): one record, all tuples through their column records
+  if (q.e_ok(i, d)) {
+    const int cell = q.cell(i, d);
+    for (int n = q.by_outer_off[cell]; n < q.by_outer_off[cell + 1]; ++n) {
+      if (!q.item_in[n]) continue;
+      const LoopItem it = q.items[n];
+      const uint32_t rP = T.cidx(ST_P, it.l - it.k, it.k, 0), rL1 = T.cidx(ST_L, it.k - i, i, 0), rL2 = T.cidx(ST_L, j - it.l, it.l, 0);
+      const double xw0 = lin_weight(m.lambda[0], it.tsc), xw1 = lin_weight(m.lambda[1], it.tsc);
+      for (int t = 0; t < nq; ++t) {
+        const int qa = G[A.fqc_in + 2 * t], qb = G[A.fqc_in + 2 * t + 1];
+        if (qb & (4 << 16)) continue;
+        const double term = T.band[rP + (qa & 0xff)] * (T.band[rL1 + ((qa >> 8) & 0xff)] * T.band[rL2 + ((qa >> 16) & 0xff)]) * ((qb & (1 << 16)) ? xw1 : xw0);
+        if (term != 0.) he[qb & 0xffff] += term;
+      }
+    }
+  }
+  // cell record + unary programs
+  double crec[kCellInD];
+  for (int k = 0; k < 8; ++k) {
+    const bool on = k < 4 ? q.pair_ok(i, d) : q.e_ok(i, d);
+    crec[2 + k] = on ? cell_in_fetch(q, d, i, k) : 0.;
+  }
+  crec[0] = q.ews[i];
+  crec[1] = q.ews[j > 0 ? j - 1 : 0];
+  int fl = cell_in_flags(m, q, d, i);
+  if (CON) fl |= (i == con.ys ? CF_YL : 0) | (j - 1 == con.ys ? CF_YR : 0);
+  for (int l = 0; l < NL; ++l) {
+    const int s = G[A.f_live_in + l];
+    fast_inside_unary<kFastR, kFastP, kFastL, CON>(A, G + A.fp_in + s * kFastW, lin, T, crec, fl, d, i, &hb[l], &he[l], 1, 0, G + A.fs_in);
+  }
+}
+
+// rule-7 term of every pair cell, written into its outside P entry before the sweep (k4_r7)
+void fast_rule7(const ModelView& m, const SeqView& q, const TableView& in, const TableView& out) {
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.big;
+  for (int i = 0; i <= q.L; ++i)
+    for (int d = 0; d <= q.W && i + d <= q.L; ++d) {
+      if (!q.pair_ok(i, d)) continue;
+      const double x0 = xw_cell(q, 0, XT_EXT, q.cell(i, d)), x1 = xw_cell(q, 1, XT_EXT, q.cell(i, d));
+      for (int s = 0; s < A.S; ++s) {
+        double acc = 0.;
+        for (int u = G[A.split2_off + s]; u < G[A.split2_off + s + 1]; ++u) {
+          const int par = G[A.split2_ent + 2 * u], s2i = G[A.split2_ent + 2 * u + 1];
+          acc = fma(out.o(i + d, par), in.o(i, s2i) * (lamk(m, par) ? x1 : x0), acc);
+        }
+        out.st(ST_P, d, i, s, acc);
+      }
+    }
+}
+
+// One cell of an outside sweep: k4_out, FAST branch.  x0: world 0 (its 1/Z and statistics); x1: world 1 = the shadow copy of
+// (0,0) in the merged sweep (same tables, its own 1/Z and statistics), or null.
+template <int MODE, class Sink>
+void fast_outside_cell(LinOutCtx<Sink>& x0, LinOutCtx<Sink>* x1, int d, int i, int ys) {
+  const ModelView& m = x0.m;
+  const SeqView& q = x0.q;
+  const TableView& in = x0.in;
+  const TableView& out = x0.out;
+  const AutomatonLayout& A = m.lay;
+  const int32_t* G = m.ints;
+  const double* lin = m.lin;
+  const bool merged = x1 != nullptr;
+  const int NL = A.n_lane, L = q.L, W = q.W, j = i + d, W1 = W + 1, nq = A.n_quad;
+  if (MODE == OUT_END && j <= ys) return;      // (cells that end at or before Ys take no part: see k4_out)
+  ++g_fast_cells;
+  std::vector<double> h(4 * NL, 0.);
+  double* h1 = h.data();
+  double* h2 = h1 + NL;
+  double* hp = h2 + NL;
+  double* hl = hp + NL;
+  const int dmi = q.dmin[i];
+  // H1: stems (j, l) that start at the cell's end
+  for (int p = 0; p < A.n_ap; ++p) {
+    const int32_t* PR = G + A.fpr_out + 8 * p;
+    const int s1 = PR[1] & 0xff, cP = fcol(PR[0], 1);
+    if (dmi > 0 && dmi <= d) {
+      const int hi = (W - d < L - j) ? W - d : L - j;
+      double acc = 0.;
+      for_mask_bits(q.okbits, j * W1, 1, hi, [&](int sp) { acc = fma(out.lda(d + sp, i, p, true), in.ldc(ST_B, sp, j, cP, true), acc); });
+      if (acc != 0.) h1[s1] += acc;
+    }
+  }
+  // HA where the cell itself is a stem
+  if (q.pair_ok(i, d))
+    for (int b = 1; b <= W - d; ++b) {
+      const int ii = i - b;
+      const int dmii = ii >= 0 ? (int)q.dmin[ii] : 0;
+      if (!(dmii > 0 && b >= dmii)) continue;
+      for (int p = 0; p < A.n_ap; ++p) {
+        const int32_t* PR = G + A.fpr_out + 8 * p;
+        const double term = out.lda(d + b, ii, p, true) * in.ldc(ST_1, b, ii, fcol(PR[0], 0), true);
+        if (term != 0.) h2[(PR[1] >> 8) & 0xff] += term;
+      }
+    }
+  // item sums of the three roles
+  for (int role = 0; role < 3; ++role) {
+    if (role == 0 && !q.pair_ok(i, d)) continue;
+    if (role != 0 && d == 0) continue;
+    const int cell = q.cell(i, d);
+    const int32_t* off = role == 0 ? q.by_inner_off : role == 1 ? q.by_left_off : q.by_right_off;
+    const int32_t* idx = role == 0 ? q.by_inner_idx : role == 1 ? q.by_left_idx : q.by_right_idx;
+    for (int n = off[cell]; n < off[cell + 1]; ++n) {
+      const LoopItem it = q.items[idx[n]];
+      const uint32_t rE = out.cidx(ST_E, it.j - it.i, it.i, 0);
+      const uint32_t rPi = in.cidx(ST_P, it.l - it.k, it.k, 0);
+      const uint32_t r1 = role == 0 ? in.cidx(ST_L, i - it.i, it.i, 0) : rPi;
+      const uint32_t r2 = role == 0 ? in.cidx(ST_L, it.j - j, j, 0) : role == 1 ? in.cidx(ST_L, it.j - it.l, it.l, 0) : in.cidx(ST_L, it.k - it.i, it.i, 0);
+      const uint32_t rA = role == 0 ? in.cidx(ST_P, d, i, 0) : in.cidx(ST_L, d, i, 0);
+      const double xw0 = lin_weight(m.lambda[0], it.tsc), xw1 = lin_weight(m.lambda[1], it.tsc);
+      double* hrow = role == 0 ? hp : hl;
+      const int qc0 = A.fqc_out + role * 2 * nq;
+      for (int t = 0; t < nq; ++t) {
+        const int qa = G[qc0 + 2 * t], qb = G[qc0 + 2 * t + 1];
+        if (qb & (4 << 16)) continue;
+        const double a0 = out.band[rE + (qa & 0xff)], a1 = in.band[r1 + ((qa >> 8) & 0xff)], a2 = in.band[r2 + ((qa >> 16) & 0xff)];
+        const double aux = role == 0 ? in.band[rA + ((qa >> 24) & 0xff)] : 1.;
+        const double term = a0 * (a1 * a2) * ((qb & (1 << 16)) ? xw1 : xw0);
+        if (aux == 0. || term == 0.) continue;
+        hrow[qb & 0xffff] += term;
+        if (MODE == OUT_TRAIN && role == 0) {
+          const bool w1 = merged && (qb & (2 << 16));
+          const bool k1 = !m.lam_same && (qb & (1 << 16));
+          LinOutCtx<Sink>& xw = w1 ? *x1 : x0;
+          xw.sink.eh(k1 ? 1 : 0, it.tsc * term * (aux * xw.invZ));
+        }
+      }
+    }
+  }
+  // cell record + unary programs; out B of the targets for the pair entries
+  double crec[kCellOutD];
+  for (int k = 0; k < 12; ++k) {
+    const bool on = k < 4 ? q.e_ok(i, d) : k < 6 ? q.pair_ok(i, d) : k < 8 ? (q.pair_ok(i - 1, d + 2) && q.pair_ok(i, d)) : true;
+    crec[2 + k] = on ? cell_out_fetch(q, d, i, k) : 0.;
+  }
+  crec[0] = q.ews[i > 0 ? i - 1 : 0];
+  crec[1] = q.ews[j < L ? j : L];
+  int fl = cell_out_flags(m, q, d, i);
+  if (MODE == OUT_END) fl |= (i - 1 == ys ? CF_YL : 0) | (j == ys ? CF_YR : 0) | (L == j + 1 ? CF_JLAST : 0);
+  std::vector<double> oB(NL, 0.);
+  for (int l = 0; l < NL; ++l) {
+    const int s = G[A.f_live_out + l];
+    LinOutCtx<Sink>& xw = (merged && s == A.shadow) ? *x1 : x0;
+    oB[l] = fast_outside_unary<kFastR, kFastP, kFastL, MODE>(A, G + A.fp_out + s * kFastW, G, lin, in, out, crec, fl, d, i, xw.invZ, m.lam_same != 0,
+                                                             m.no_prf != 0, xw.sink, h1 + l, NL, 1, 0, G + A.fs_out);
+  }
+  // pair entries (lin_outside_apair from the pair record)
+  for (int p = 0; p < A.n_ap; ++p) {
+    const int32_t* PR = G + A.fpr_out + 8 * p;
+    const int r0 = PR[0], r1 = PR[1];
+    const int tg = (r0 >> 16) & 0xff;
+    if (!(dmi > 0 && dmi < d)) continue;
+    LinOutCtx<Sink>& xw = (merged && (r0 & (4 << 24))) ? *x1 : x0;
+    const bool step = d + 1 <= W && j < L && q.unp[j];
+    const int nr = step ? (r1 >> 20) & 15 : 0;
+    const double a_in = in.a(d, i, p);
+    double acc = 0.;
+    if (a_in != 0.) {
+      acc = tg != 0xff ? oB[tg] : 0.;
+      const double inz = a_in * xw.invZ;
+      const int bj = step ? (int)q.seq[j] : 0;
+      const double ewj = step ? q.ews[j] : 1.;
+      for (int u = 0; u < nr; ++u) {
+        const int ce = PR[5 + u], id = (ce >> 8) & 0x7fff;
+        const double term = out.lda(d + 1, i, ce & 0xff, true) * (lin[A.lin_wr + 5 * id + bj] * ((G[A.fe_r + 2 * id + 1] & 1) ? ewj : 1.));
+        const double z = term * inz;
+        if ((MODE == OUT_SCAN || MODE == OUT_END) &&
+            !fast_scan_stat<MODE, false, true>(xw.sink, G[A.fs_out + id], i - 1, j, false, MODE == OUT_END && j == ys, L == j + 1, z))
+          continue;
+        if (MODE != OUT_END && !m.no_prf && z != 0. && bj) xw.sink.en(G[A.fe_r + 2 * id] + bj, z);
+        acc += term;
+      }
+    }
+    out.a(d, i, p) = acc;
+  }
+}
+
 template <int MODE>
 void run_outside(const ModelView& m, const SeqView& q, Tab& in, Tab& out, double Z, const Constraint& c, CpuSink& sink,
                  bool ari, bool nasi) {
@@ -319,6 +535,7 @@ extern "C" {
 // plans built so far / differences between the two interior-loop enumerators (must stay 0)
 long emu_enum_checked() { return g_enum_checked; }
 long emu_enum_mismatches() { return g_enum_mismatch; }
+long emu_fast_cells() { return g_fast_cells; }
 
 
 const char* emu_last_error() { return g_err.c_str(); }
@@ -331,6 +548,7 @@ void* emu_create(const char* pattern, const char* par_text, int max_span, int ma
     parse_energy_text(par_text, &E->et);
     E->au->flatten(&E->lay, &E->ints);
     E->au->flatten(&E->lay_r, &E->ints_r, true);
+    E->au->flatten(&E->lay_s, &E->ints_s, false, false, true);
     flatten_trivial(&E->lay0, &E->ints0);
     E->max_span = max_span; E->max_iloop = max_iloop; E->min_bpp = min_bpp; E->tau = tau; E->flags = flags;
     return E;
@@ -341,6 +559,14 @@ void emu_set_prune(void* h, int prune) {
   Emu* E = (Emu*)h;
   E->au->flatten(&E->lay, &E->ints, false, prune != 0);
   E->au->flatten(&E->lay_r, &E->ints_r, true, prune != 0);
+  E->au->flatten(&E->lay_s, &E->ints_s, false, prune != 0, true);
+}
+// 1: the table-driven forms of the band targets (what k4_in / k4_out run with FAST); returns whether the automaton's lists fit
+// the programs (AutomatonLayout::fp_ok) -- otherwise the generic rule code runs, as on the GPU
+int emu_set_fast(void* h, int fast) {
+  Emu* E = (Emu*)h;
+  E->fast = fast != 0;
+  return (E->lay.fp_ok ? 1 : 0) | (E->lay_r.fp_ok ? 2 : 0) | (E->lay_s.fp_ok ? 4 : 0) | (E->lay_s.shadow >= 0 ? 8 : 0);
 }
 void emu_destroy(void* h) { delete (Emu*)h; }
 int emu_n_param(void* h) { return ((Emu*)h)->au->n_theta() + 2; }
@@ -484,9 +710,17 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
         for (int c = 0; c < E.au->row_width(r); ++c) theta[E.au->row_offset(r) + c] = x[E.au->row_offset(r) + c] - tot;
       }
     const bool no_prf = E.flags & F_NO_PRF;
+    // schedule 2: the train schedule of the GPU's default -- ONE outside sweep on the automaton with the shadow copy of (0,0)
+    // (DESIGN.md 2.3): "has motif" terminals on the pattern's states (world 0: Z(ari), statistics A), the "no motif" terminal
+    // on the shadow (world 1: Z(nasi), statistics B); combined like schedule 1.  No table export.
+    const bool merged = schedule == 2;
+    if (merged && (E.lay_s.shadow < 0 || inside || outside)) throw std::runtime_error("schedule 2: no shadow state / no table export");
+    if (merged) inside_o = outside_o = nullptr;   // (exports are in the numbering of the plain automaton)
+    const AutomatonLayout& LY = merged ? E.lay_s : E.lay;
+    const std::vector<int32_t>& IY = merged ? E.ints_s : E.ints;
     std::vector<double> lin;
-    make_lin_params(E.lay, E.ints.data(), theta.data(), E.tau, no_prf, &lin);
-    ModelView m = make_view(E.lay, E.ints, theta.data(), x[nt], x[nt + 1], std::log(E.tau), no_prf, E.flags & F_NO_TURN);
+    make_lin_params(LY, IY.data(), theta.data(), E.tau, no_prf, &lin);
+    ModelView m = make_view(LY, IY, theta.data(), x[nt], x[nt + 1], std::log(E.tau), no_prf, E.flags & F_NO_TURN);
     m.lin = lin.data();
     ModelView mr = make_view(E.lay_r, E.ints_r, theta.data(), x[nt], x[nt + 1], std::log(E.tau), no_prf, E.flags & F_NO_TURN);
     mr.lin = lin.data();
@@ -507,13 +741,16 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
     std::vector<double> cum(L + 1, 0.);   // log2 of prod_{p<j} psb
     for (int p = 0; p < L; ++p) cum[p + 1] = cum[p] + lin[kLinPl2 + seq[p]];
     const double ln2 = 0.69314718055994530942;
-    LinTab in(L, P.W, m.lay, E.ints.data()), out(L, P.W, m.lay, E.ints.data());
+    LinTab in(L, P.W, m.lay, IY.data()), out(L, P.W, m.lay, IY.data());
+    const bool fast = E.fast && m.lay.fp_ok;     // (table-driven forms: fast_inside_cell / fast_outside_cell)
+    const Constraint c0{-1, -1, 0};
     for (int d = 0; d <= q.W; ++d)
       for (int i = 0; i + d <= q.L; ++i) {
+        if (fast) { fast_inside_cell<false>(m, q, in.v, d, i, c0); continue; }
         lin_inside_cell_pairs(m, q, in.v, d, i);     // rule 2, factorised: the pair table of the cell first
         for (int s = 0; s < S; ++s) lin_inside_target(m, q, in.v, d, i, s);
       }
-    for (int s = 0; s < S; ++s) in.v.o(0, s) = (s == m.lay.s00) ? 1. : 0.;
+    for (int s = 0; s < S; ++s) in.v.o(0, s) = (s == m.lay.s00 || s == m.lay.shadow) ? 1. : 0.;   // (the shadow of (0,0) starts like it)
     for (int j = 1; j <= L; ++j)
       for (int s = 0; s < S; ++s) lin_inside_ext_target(m, q, in.v, j, s);
     const double Zo = lin_part(m, in.v, true, true), Za = lin_part(m, in.v, true, false), Zn = lin_part(m, in.v, false, true);
@@ -530,7 +767,7 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
     if (inside_o) for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) inside_o[(size_t)j * S + E.ints[E.lay.st_ref + s]] = tolog(in.v.o(j, s), cum[j]);
     if (inside) copy_tab(in, inside, false);
     auto bad = [](double z) { return !(z > 0.) || !std::isfinite(z); };
-    if (bad(Zo) || bad(Za) || (schedule == 1 && bad(Zn))) { out9[5] = 2; return 0; }
+    if (bad(Zo) || bad(Za) || (schedule >= 1 && bad(Zn))) { out9[5] = 2; return 0; }
     const bool positive = !(P.ws[L] > NEG);
     std::vector<double> enA(nt + 1, 0.), enB(nt + 1, 0.);
     double ehA[2] = {0, 0}, ehB[2] = {0, 0};
@@ -543,8 +780,11 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
       if (ari) { out.v.o(L, mm.lay.s0m1) = 1.; out.v.o(L, mm.lay.s0m2) = 1.; }
       for (int i = L - 1; i >= 0; --i)
         for (int s = 0; s < NA; ++s) lin_outside_ext_target<OUT_TRAIN>(xo, i, s);
+      const bool f = fast && &mm == &m;     // (the one-state automaton's programs index its own columns, not these tables')
+      if (f) fast_rule7(mm, q, in.v, out.v);
       for (int d = q.W; d >= 0; --d)
         for (int i = 0; i + d <= L; ++i) {
+          if (f) { fast_outside_cell<OUT_TRAIN>(xo, (LinOutCtx<CpuSink>*)nullptr, d, i, -1); continue; }
           for (int s = 0; s < NA; ++s) lin_outside_target<OUT_TRAIN>(xo, d, i, s);
           lin_outside_cell_pairs<OUT_TRAIN>(xo, d, i);
         }
@@ -561,7 +801,28 @@ int emu_train_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const
           for (int t = 0; t < S; ++t)
             if (q.left_ok(i, d) && in.v.ld(ST_2, d, i, t) != 0.) out.v.st(ST_2, d, i, t, out.v.ld(ST_2, d, i, t) + lheavy_o2(xo, d, i, t));
     };
-    if (schedule == 0) {
+    if (merged) {
+      CpuSink sA{enA.data(), ehA, {nullptr, nullptr, nullptr}}, sB{enB.data(), ehB, {nullptr, nullptr, nullptr}};
+      LinOutCtx<CpuSink> x0{m, q, in.v, out.v, 1. / Za, sA}, x1{m, q, in.v, out.v, 1. / Zn, sB};
+      const int NA = m.lay.n_active, sh = m.lay.shadow;
+      for (int s = 0; s < S; ++s) out.v.o(L, s) = 0.;
+      out.v.o(L, m.lay.s0m1) = 1.; out.v.o(L, m.lay.s0m2) = 1.; out.v.o(L, sh) = 1.;
+      for (int i = L - 1; i >= 0; --i)
+        for (int s = 0; s < NA; ++s) lin_outside_ext_target<OUT_TRAIN>(s == sh ? x1 : x0, i, s);
+      if (fast) fast_rule7(m, q, in.v, out.v);
+      for (int d = q.W; d >= 0; --d)
+        for (int i = 0; i + d <= L; ++i) {
+          if (fast) { fast_outside_cell<OUT_TRAIN>(x0, &x1, d, i, -1); continue; }
+          for (int s = 0; s < NA; ++s) lin_outside_target<OUT_TRAIN>(s == sh ? x1 : x0, d, i, s);
+          for (int p = 0; p < m.lay.n_ap; ++p) {
+            const int tgt = m.ints[m.lay.ap_tgt + p];
+            lin_outside_apair<OUT_TRAIN>(m.ints[m.lay.ap_t + p] == sh ? x1 : x0, d, i, p, tgt >= 0 ? out.v.ld(ST_B, d, i, tgt, q.left_ok(i, d)) : 0.);
+          }
+        }
+      const double pa = Za / Zo, pn = Zn / Zo;
+      for (int t = 0; t < nt; ++t) { const double a = enA[t], b = enB[t]; enA[t] = pa * a + pn * b; enB[t] = positive ? a : b; }
+      for (int t = 0; t < 2; ++t) { const double a = ehA[t], b = ehB[t]; ehA[t] = pa * a + pn * b; ehB[t] = positive ? a : b; }
+    } else if (schedule == 0) {
       run_out(m, Zo, true, true, enA, ehA);
       if (outside) { complete_plane2(); copy_tab(out, outside, true); }
       if (outside_o) for (int j = 0; j <= L; ++j) for (int s = 0; s < S; ++s) outside_o[(size_t)j * S + E.ints[E.lay.st_ref + s]] = tolog(out.v.o(j, s), cum[L] - cum[j]);
@@ -691,10 +952,12 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
     q.ews = ews.data(); q.xwc = xwc.data(); q.xwc_stride = nc; q.xwi = xwi.data(); q.xwi_stride = ni;
     LinTab in(L, P.W, m.lay, E.ints.data()), out(L, P.W, m.lay, E.ints.data());
     auto zero = [](LinTab& T) { T.poison(); };
+    const bool fast = E.fast && m.lay.fp_ok;
     auto run_in = [&](const Constraint& c, bool con) {
       zero(in);
       for (int d = 0; d <= q.W; ++d)
         for (int i = 0; i + d <= q.L; ++i) {
+          if (fast) { if (con) fast_inside_cell<true>(m, q, in.v, d, i, c); else fast_inside_cell<false>(m, q, in.v, d, i, c); continue; }
           if (con) lin_inside_cell_pairs<true>(m, q, in.v, d, i, c); else lin_inside_cell_pairs<false>(m, q, in.v, d, i, c);
           for (int s = 0; s < S; ++s) { if (con) lin_inside_target<true>(m, q, in.v, d, i, s, c); else lin_inside_target<false>(m, q, in.v, d, i, s, c); }
         }
@@ -718,7 +981,9 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
       LinOutCtx<CpuLinSink> xo{m, q, in.v, out.v, 1. / ZLm, s1, c0};
       out.v.o(L, m.lay.s00) = 1.; out.v.o(L, m.lay.s0m1) = 1.; out.v.o(L, m.lay.s0m2) = 1.;
       for (int i = L - 1; i >= 0; --i) for (int s = 0; s < S; ++s) lin_outside_ext_target<OUT_SCAN>(xo, i, s);
+      if (fast) fast_rule7(m, q, in.v, out.v);
       for (int d = q.W; d >= 0; --d) for (int i = 0; i + d <= L; ++i) {
+        if (fast) { fast_outside_cell<OUT_SCAN>(xo, (LinOutCtx<CpuLinSink>*)nullptr, d, i, -1); continue; }
         for (int s = 0; s < S; ++s) lin_outside_target<OUT_SCAN>(xo, d, i, s);
         lin_outside_cell_pairs<OUT_SCAN>(xo, d, i);
       }
@@ -737,7 +1002,9 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
       LinOutCtx<CpuLinSink> xo{m, q, in.v, out.v, 1. / ZeLm, s2, c1};
       out.v.o(L, m.lay.s00) = 1.; out.v.o(L, m.lay.s0m1) = 1.; out.v.o(L, m.lay.s0m2) = 1.;
       for (int i = L - 1; i >= 0; --i) for (int s = 0; s < S; ++s) lin_outside_ext_target<OUT_END>(xo, i, s);
+      if (fast) fast_rule7(m, q, in.v, out.v);
       for (int d = q.W; d >= 0; --d) for (int i = 0; i + d <= L; ++i) {
+        if (fast) { fast_outside_cell<OUT_END>(xo, (LinOutCtx<CpuLinSink>*)nullptr, d, i, Ys); continue; }
         for (int s = 0; s < S; ++s) lin_outside_target<OUT_END>(xo, d, i, s);
         lin_outside_cell_pairs<OUT_END>(xo, d, i);
       }

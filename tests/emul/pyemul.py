@@ -22,6 +22,9 @@ def lib():
         L.emu_n_state.argtypes = [C.c_void_p]
         L.emu_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.emu_set_prune.argtypes = [C.c_void_p, C.c_int]
+        L.emu_set_fast.argtypes = [C.c_void_p, C.c_int]
+        L.emu_set_fast.restype = C.c_int
+        L.emu_fast_cells.restype = C.c_long
         L.emu_energy_table.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int]
         L.emu_hairpin_energy.restype = C.c_double
         L.emu_hairpin_energy.argtypes = [C.c_void_p, u8, C.c_int, C.c_int, C.c_int]
@@ -67,6 +70,12 @@ class Emul:
 
     def set_prune(self, on):
         lib().emu_set_prune(self.h, int(bool(on)))
+
+    def set_fast(self, on):
+        """band targets through the table-driven forms (lin_fast.h and the records of the fast blobs: what k4_in / k4_out run by
+        default); returns a bit mask: 1 the automaton's lists fit the programs, 2 the one-state automaton's, 4 the shadow
+        automaton's, 8 there is a shadow state"""
+        return int(lib().emu_set_fast(self.h, int(bool(on))))
 
     def describe(self):
         buf = C.create_string_buffer(1 << 20)

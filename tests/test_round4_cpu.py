@@ -1,0 +1,89 @@
+"""Round 4, CPU: the TABLE-DRIVEN forms of the band targets -- what k4_in / k4_out run by default (lin_fast.h: unary programs,
+weight tables, cell records, ScanFlag words; the pair records and tuple column records of the fast blobs) -- and the merged
+outside sweep on the automaton with the shadow copy of state (0,0), compiled into the serial test driver (tests/emul) and
+pinned to the oracle on the same cases as the generic rule code.  The GPU-less container thereby checks the path the bench
+measures, not only the rules it was derived from."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.emul.pyemul import lib
+from tests.test_emul_vs_oracle import CASES, SCAN, model_pair
+from tests.util import assert_log_close, gpath
+
+
+@pytest.mark.parametrize("model,fq", CASES)
+@pytest.mark.parametrize("schedule", [0, 2])
+@pytest.mark.parametrize("prune", [0, 1])
+def test_table_driven_train_forms_match_oracle(model, fq, schedule, prune):
+    """schedule 0: the reference's two outside passes (RNAelemTrainDP::operator(), motif_trainer.hpp:204-227); 2: ONE sweep on
+    the automaton with the shadow state, as elemdp_train_eval runs it.  Inside tables, partition functions,
+    f, expected counts and energy statistics against the oracle."""
+    o, e, x = model_pair(model)
+    e.set_prune(prune)
+    mask = e.set_fast(1)
+    if schedule == 2 and not mask & 8:
+        pytest.skip("automaton without a shadow state")
+    full = schedule == 0 and fq in ("tiny.fq", "0.fq", "syn_L40_n3.fq") and not prune
+    before = lib().emu_fast_cells()
+    for rid, seq, qual in po.read_fastq(gpath(fq)):
+        a = o.train_seq(seq, qual, tables=full)
+        b = e.train_seq(x, seq, qual, tables=full, linear=schedule)
+        for k in ("Zo", "Zari", "Znasi"):
+            assert_log_close(b[k], a[k], rtol=1e-11, what=k)
+        if a["skipped"] or (schedule == 2 and not np.isfinite(a["Znasi"])):
+            assert b["skipped"] == 2
+            continue
+        assert b["skipped"] == 0
+        assert b["f"] == pytest.approx(a["f"], rel=1e-10, abs=1e-12)
+        for k in ("ENo", "ENx", "EHo", "EHx"):
+            np.testing.assert_allclose(b[k], a[k], rtol=1e-9, atol=1e-11, err_msg=k)
+        if schedule == 0:
+            assert_log_close(b["inside_o"], a["inside_o"], rtol=1e-10, what="inside_o")
+            assert_log_close(b["outside_o"], a["outside_o"], rtol=1e-10, what="outside_o")
+    took = lib().emu_fast_cells() - before
+    fits = mask & (4 if schedule == 2 else 1)
+    assert (took > 0) == bool(fits), "table-driven forms taken for %d cells, fp_ok mask %d" % (took, mask)
+
+
+@pytest.mark.parametrize("model,fq", CASES[:4])
+def test_merged_sweep_with_the_generic_rules_matches_oracle(model, fq):
+    """The merged sweep alone (generic rule code, worlds chosen per state / per pair): separates a fault of the shadow automaton
+    from one of the table-driven forms."""
+    o, e, x = model_pair(model)
+    e.set_prune(1)
+    if not e.set_fast(0) & 8:
+        pytest.skip("automaton without a shadow state")
+    for rid, seq, qual in po.read_fastq(gpath(fq)):
+        a = o.train_seq(seq, qual)
+        b = e.train_seq(x, seq, qual, linear=2)
+        if a["skipped"] or not np.isfinite(a["Znasi"]):
+            continue
+        assert b["f"] == pytest.approx(a["f"], rel=1e-10, abs=1e-12)
+        for k in ("ENo", "ENx", "EHo", "EHx"):
+            np.testing.assert_allclose(b[k], a[k], rtol=1e-9, atol=1e-11, err_msg=k)
+
+
+@pytest.mark.parametrize("model,fq", SCAN)
+@pytest.mark.parametrize("prune", [0, 1])
+def test_table_driven_scan_passes_match_oracle(model, fq, prune):
+    """The scan's four sum passes through the table-driven forms: start / inner posteriors, the start constraint as cell flags
+    and ScanFlag words, end posteriors with the cells left of Ys left out (motif_scanner.hpp:186-252, :546-573, :594-622,
+    :715-747); the Viterbi pass stays the generic max-plus code."""
+    o, e, x = model_pair(model)
+    e.set_prune(prune)
+    mask = e.set_fast(1)
+    before = lib().emu_fast_cells()
+    for rid, seq, qual in po.read_fastq(gpath(fq)):
+        a = o.scan_seq(seq, qual)
+        b = e.scan_seq(x, seq, qual, linear=True)
+        assert (a["Ys"], a["Ye"]) == (b["Ys"], b["Ye"])
+        for k in ("ZL", "ZeL", "PyNL"):
+            assert_log_close(b[k], a[k], rtol=1e-10, atol=1e-10, what=k)
+        for k in ("start", "end", "inner"):
+            assert_log_close(b[k], a[k], rtol=1e-9, atol=1e-9, what=k)
+        assert b["exist_prob"] == pytest.approx(a["exist_prob"], rel=1e-10)
+        assert list(a["psihat"]) == list(b["psihat"])
+        assert a["rss"] == b["rss"]
+        np.testing.assert_allclose(b["EN"], a["EN"], rtol=1e-9, atol=1e-11)
+    assert (lib().emu_fast_cells() > before) == bool(mask & 1)
