@@ -181,6 +181,66 @@ def streamed_secondary(api, synth, device, resident_rate, n=60000, L=200, chunk=
             "workload": "%d synthetic RNAs L=%d, pattern %s" % (n, L, PATTERN)}
 
 
+def scan_streamed_secondary(api, synth, device, n=100000, L=300, chunk=12500, pattern="(.....)"):
+    """BASELINE config E at its own size on ONE GPU: `elem scan` of 100 000 sequences of L = 300, streamed in chunks (option
+    max_resident; the BPP filter + plan of chunk k + 1 are built on a second inner engine while chunk k is scanned), records kept
+    in input order.  value = sequences / second of load_batch + scan (wall clock).  (On 8 GPUs every rank scans 12 500 of them:
+    `per_gpu_at_shard`.)"""
+    eng = api.Engine(pattern, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
+    eng.set_option("max_resident", chunk)
+    x = eng.initial_params(1.0)
+    # untimed: two chunks of another batch through both inner engines (their plan and table buffers are then allocated: fresh
+    # device memory costs ~20 ms / GB, a one-off of the process as in ScanSecondary)
+    seqs, quals = synth.synth_batch(2 * chunk + 1, L, seed=98)
+    eng.load_batch(seqs, quals)
+    eng.scan(x)
+    seqs, quals = synth.synth_batch(n, L, seed=99)
+    t0 = time.perf_counter()
+    eng.load_batch(seqs, quals)
+    t1 = time.perf_counter()
+    recs, _ = eng.scan(x)
+    t2 = time.perf_counter()
+    assert len(recs) == n
+    eng.close()
+    return {"metric": "streamed scan seqs/sec (config E's size: load + scan, chunks of %d)" % chunk, "value": n / (t2 - t0), "unit": "seq/s",
+            "load_s": t1 - t0, "scan_s": t2 - t1, "workload": "%d synthetic RNAs L=%d, pattern %s" % (n, L, pattern)}
+
+
+def shard_projection(api, synth, device, steps=5):
+    """What ONE GPU does at the shard sizes of the 8-GPU configurations D and E (10 000 / 8 train, 100 000 / 8 scan): measured on
+    this GPU, labelled as a PROJECTION of the per-GPU rate of an 8-GPU run (no 8-GPU node was measured; the collective of D adds
+    one all-reduce of ~60 doubles per step, E has none)."""
+    eng = api.Engine(PATTERN, "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
+    seqs, quals = synth.synth_batch(N_SEQ // 8, SEQ_LEN)
+    eng.load_batch(seqs, quals)
+    x = eng.initial_params(1.0)
+    eng.train_eval(x)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_eval(x)
+    dt = (time.perf_counter() - t0) / steps
+    eng.close()
+    n_scan, L_scan = 100000 // 8, 300
+    sc = api.Engine("(.....)", "~T2004~", MAX_SPAN, MAX_ILOOP, 1e-4, 0.1, 0, device)
+    xs = sc.initial_params(1.0)
+    s2, q2 = synth.synth_batch(n_scan, L_scan, seed=5)
+    t0 = time.perf_counter()
+    sc.load_batch(s2, q2)
+    sc.scan(xs)
+    ds_cold = time.perf_counter() - t0      # (a fresh engine: device buffers of plan and table slots allocated on the way, ~20 ms / GB)
+    s2, q2 = synth.synth_batch(n_scan, L_scan, seed=6)
+    t0 = time.perf_counter()
+    sc.load_batch(s2, q2)
+    sc.scan(xs)
+    ds = time.perf_counter() - t0
+    sc.close()
+    return {"label": "projection: one GPU at the per-rank shard of the 8-GPU configurations (not an 8-GPU measurement)",
+            "train_D": {"shard": N_SEQ // 8, "seq_len": SEQ_LEN, "ms_per_step": dt * 1e3, "per_gpu_seq_per_s": (N_SEQ // 8) / dt,
+                        "projected_8gpu_seq_per_s": N_SEQ / dt},
+            "scan_E": {"shard": n_scan, "seq_len": L_scan, "s_load_plus_scan": ds, "s_first_batch_of_a_fresh_engine": ds_cold,
+                       "per_gpu_seq_per_s": n_scan / ds, "projected_8gpu_seq_per_s": 8 * n_scan / ds}}
+
+
 def count_gpus_sysfs(root="/sys/class/kfd/kfd/topology/nodes"):
     """GPUs of this machine without touching HIP or torch: KFD topology nodes with SIMDs (CPU nodes have simd_count 0), limited
     by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when set.  No KFD topology = no GPU driver = 0; None only when the directory
@@ -346,6 +406,10 @@ def main():
         if not args.no_streamed:
             gc.collect()
             line["secondary_streamed"] = streamed_secondary(api, synth, local_rank, line["value"])
+            gc.collect()
+            line["secondary_scan_streamed"] = scan_streamed_secondary(api, synth, local_rank)
+        gc.collect()
+        line["per_gpu_at_shard"] = shard_projection(api, synth, local_rank)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -81,18 +81,32 @@ int elemdp_initial_params(const elemdp_handle* h, double lambda_init, double* x,
 /* JSON description of the automaton (states, transition lists) for inspection / host-logic tests. */
 int elemdp_describe(const elemdp_handle* h, char* buf, int32_t cap);
 
-/* Engine knobs (not part of the reference interface): "slots" = number of persistent workgroups /
- * table slots (default 2 per CU), "keep_lnbpp" = keep ln BPP of the filter for elemdp_batch_pairs,
- * "first_pass_only" = debug: stop a train evaluation after the first outside pass; "pipeline" = 4 (default: scaled-linear
- * batch pipeline) / 3 (log-space batch pipeline) / 2 (fused kernel); "group" = sequences swept in lockstep (0 = as many as
- * fit); "schedule" = 1 (default: ari-only + one-state nasi-only outside passes) / 0 (the reference's two passes);
- * "prune" = 1 (default: transition lists without the transitions that cannot occur in a complete parse) / 0 (the complete
- * lists of the reference's automaton); "two_streams" = second outside pass on a second stream (default 1); "group_streams" =
- * groups evaluated concurrently (default 2); "max_resident" = most sequences kept resident at a time (0 = as many as the device
- * memory holds): a larger batch is STREAMED -- elemdp_train_eval / elemdp_scan then run it in chunks of that size, the BPP
- * filter + plan of chunk k+1 being built (second inner engine, second host thread) while chunk k is evaluated, and the chunks'
- * partial sums added in chunk order; set before elemdp_load_batch; "profile" = in-kernel phase clocks
- * for elemdp_debug_profile; "dbg" = switch phases off (measurements only). */
+/* Engine knobs (not part of the reference interface).  Unknown keys are ELEMDP_EARG.
+ *   evaluation
+ *     "pipeline"        4 (default): scaled-linear batch pipeline, which hands sequences outside the double range to the log-space
+ *                       one; 3: log-space batch pipeline for everything.  (2, the fused kernel of round 1, is retired.)
+ *     "schedule"        1 (default): ONE outside sweep for both passes of motif_trainer.hpp:209-225 -- "has motif" terminals on
+ *                       the pattern's states, "no motif" terminal on a shadow copy of state (0,0); 0: the reference's two sweeps
+ *     "fast"            1 (default): table-driven band kernels (per-state programs, weight tables, cell records); 0: generic rule code
+ *     "nblk"            blocks of cells a band-kernel workgroup owns: 0 (default) = chosen per launch, n = n wherever they fit
+ *     "deterministic"   1: bit-identical repeats of elemdp_train_eval (fixed summation order, as the reference at --thread 1); slower
+ *     "eval_first", "eval_count"   a train evaluation covers the records [first, first + count) of the resident batch only
+ *                       (count 0 = all; reset by elemdp_load_batch).  Refused (ELEMDP_EARG) for a streamed batch and for pipeline 3
+ *     "prune"           1 (default): transition lists without what cannot occur in a complete parse; 0: the reference's complete lists
+ *     "first_pass_only" debug: stop a train evaluation after the first outside pass
+ *   batches
+ *     "max_resident"    most sequences kept resident at a time (0 = as many as the device memory holds): a larger batch is STREAMED --
+ *                       elemdp_train_eval / elemdp_scan run it in chunks of that size, the BPP filter + plan of chunk k+1 built on a
+ *                       second inner engine and host thread while chunk k is evaluated, partial sums added in chunk order; set
+ *                       before elemdp_load_batch
+ *     "group"           sequences swept in lockstep (0 = as many as fit); "group_streams": groups evaluated concurrently (default 2);
+ *                       "two_streams": second outside pass of schedule 0 on a second stream (default 1); "slots": table slots
+ *     "keep_lnbpp"      keep ln BPP of the filter for elemdp_batch_pairs; "bpp_log": 1 = log-space BPP filter for every band
+ *     "sorted_plan"     1: role lists of the plan sorted per cell (reproducible summation order of the log-space pipeline)
+ *     "row_pad"         padding of the compact table rows in doubles (default 8 = 64-byte lines)
+ *   measurement / tests
+ *     "profile"         in-kernel phase clocks for elemdp_debug_profile; "dbg": switch phases off (results invalid);
+ *     "poison"          1: every table is filled with NaN before an evaluation (an unmasked read of an entry nobody stored shows) */
 int elemdp_set_option(elemdp_handle* h, const char* key, double value);
 
 /* Replaces the resident batch (== FastqReader contents, fastq_io.hpp:64-108):

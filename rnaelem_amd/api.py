@@ -62,6 +62,8 @@ def load_library():
         L.elemdp_last_error.restype = C.c_char_p
         L.elemdp_kernel_name.restype = C.c_char_p
         L.elemdp_set_data_dir.argtypes = [C.c_char_p]
+        if path != LIB_PATH:      # (the library looks for its energy parameter files next to itself)
+            L.elemdp_set_data_dir(os.path.join(os.path.dirname(LIB_PATH), "data").encode())
         L.elemdp_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(hp)]
         L.elemdp_destroy.argtypes = [hp]
         for f in ("elemdp_n_param", "elemdp_n_state", "elemdp_n_node", "elemdp_partial_len"):

@@ -2,11 +2,13 @@
 //
 // Same diagonal-synchronous batch pipeline as train_kernels.hip (a group of G sequences swept in
 // lockstep, kernel boundaries = dependencies), but a term of the O(L W^2) rules is one FMA on two
-// table loads instead of an exp, so the pipeline is bound by the table traffic, not by the VALU:
+// table loads instead of an exp.  The band kernels are bound by instruction issue and by the dependent round trips of a
+// workgroup (HBM traffic is at 1.3 x the algorithmic bytes and 40 % of the peak), hence table-driven phases,
+// several blocks of cells per workgroup and as many resident workgroups as registers and LDS allow:
 //   k4_weights   once per evaluation: exp(lambda_k * structural term) of every cell (the loop items' terms are
 //                exponentiated where their records are staged)
-//   k4_in(d)     ONE launch per diagonal: workgroup = cpb = 256/S consecutive cells of one sequence; set-up (context of the
-//                workgroup staged in LDS), pair phase (rule 2 factorised: lane = (cell, pair)), item sums (rule 6c: lane =
+//   k4_in(d)     ONE launch per diagonal: workgroup = nblk blocks of cpb = 256/lanes-per-cell consecutive cells of one sequence;
+//                set-up once (context of all its cells staged in LDS), then per block: pair phase (rule 2 factorised: lane = (cell, pair)), item sums (rule 6c: lane =
 //                (record, tuple), records staged in LDS), then one lane per (cell, state) finishes P,E,M,B,1,2,L -- the heavy
 //                sums never touch HBM
 //   k4_in_ext    exterior chain, partition functions, objective, range check (flags the sequence)
@@ -678,7 +680,9 @@ __device__ __forceinline__ void outer_stage(const LViews& v, const OuterRecs& r,
 }
 
 // FAST: table-driven phases (lin_fast.h; train schedule, the fast blob staged); FP: longest pair list of a state (2 or 3)
-template <bool BIG, bool CON, bool FAST = false, int FP = kFastP, bool W8 = false>
+// MB: the workgroup owns several blocks of cells (LinArgs::nblk > 1) -- a loop around the phases that costs registers (values that
+// are the same in every block stay live around it), so the one-block form is a kernel of its own: small groups and the scan
+template <bool BIG, bool CON, bool FAST = false, int FP = kFastP, bool W8 = false, bool MB = false>
 __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4_in(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
   // depend on the block -- plan record, automaton blob, parameters and weight tables, the window of positions, the cell records
   // and CSR ranges of all its cells -- is fetched and staged ONCE; the phases then run block by block on the per-block heavy
   // sums.  (One block per workgroup paid the launch, two dependent round trips and the staging for 12 cells of work.)
-  const int nblk = a.nblk > 1 ? a.nblk : 1, cpbT = cpb * nblk;
+  const int nblk = (MB && a.nblk > 1) ? a.nblk : 1, cpbT = cpb * nblk;
   if (d > v.q.W) return;
   const int ncell = v.q.L - d + 1, i0T = bx * cpbT;
   if (i0T >= ncell) return;
@@ -764,11 +768,11 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
   outer_ranges_load(v, i0T, ncT, d, nq > 0, tid, cntsT, baseT);
   const RecAhead ahead{LoopItem{0., 0, 0, 0, 0}, 0, false};   // (records fetched ahead of the pair phase: two barriers more than the round trip saved, measured)
   const int tid_wg = tid;
-  for (int blk = 0; blk * cpb < ncT; ++blk) {
+  for (int blk = 0; MB ? blk * cpb < ncT : blk < 1; ++blk) {
   // (the lane id behind an empty asm: what a lane derives from it -- its cell, pair record, program, tuple records -- is the same in
   // every block, and the compiler would keep all of it in registers across the whole loop: 98 instead of 65 VGPRs)
   int tid = tid_wg;
-  asm volatile("" : "+v"(tid));
+  if (MB) asm volatile("" : "+v"(tid));
   const int i0 = i0T + blk * cpb, nc = (cpb < ncT - blk * cpb) ? cpb : ncT - blk * cpb;
   if (CON) {   // (uniform: blocks without a cell that covers Ys keep the values of the unconstrained pass)
     const int ys = a.ys[v.n];
@@ -964,7 +968,7 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
     }
   }
   pc.mark<4>();
-  if ((blk + 1) * cpb < ncT) {   // the next block's pair phase adds to the heavy sums this unary phase has read
+  if (MB && (blk + 1) * cpb < ncT) {   // the next block's pair phase adds to the heavy sums this unary phase has read
     if (!FAST || (a.dbg & 4) || (ELEMDP_KO & 4)) {
       __syncthreads();
       for (int t = tid; t < NW * 2 * CS; t += kBT) lds[t] = 0.;
@@ -1415,7 +1419,7 @@ __global__ __launch_bounds__(kThreads) void k4_r7(LinArgs a) {
 
 // ---- outside, diagonal d: dynamic LDS = 4 * cpb * S + n_theta + 2 doubles
 // W6: asked for six waves per SIMD (80 registers, a few spilled dwords) -- taken by the launcher where six workgroups fit the LDS
-template <int MODE, bool BIG, bool FAST = false, int FP = kFastP, bool W6 = false>
+template <int MODE, bool BIG, bool FAST = false, int FP = kFastP, bool W6 = false, bool MB = false>
 __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_out(LinArgs a) {
   extern __shared__ double lds[];
   // (the automaton layout is read from the kernel arguments: constant offsets, scalar registers)
@@ -1430,7 +1434,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   const AutomatonLayout& A = a.lay;
   const int S = a.lay.S, NA = a.lay.n_active, d = a.d, cpb = a.cpb, tid = threadIdx.x, nt = a.lay.n_theta;
   // (nblk blocks of cpb cells per workgroup, context staged once: see k4_in)
-  const int nblk = a.nblk > 1 ? a.nblk : 1, cpbT = cpb * nblk;
+  const int nblk = (MB && a.nblk > 1) ? a.nblk : 1, cpbT = cpb * nblk;
   if (d > v.q.W) return;
   const int L = v.q.L, W = v.q.W;
   const int ncell = L - d + 1, i0T = bx * cpbT;
@@ -1537,9 +1541,9 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   }
   const int nv = 3 * cpb;
   const int tid_wg = tid;
-  for (int blk = 0; blk * cpb < ncT; ++blk) {
+  for (int blk = 0; MB ? blk * cpb < ncT : blk < 1; ++blk) {
   int tid = tid_wg;   // (behind an empty asm: see k4_in)
-  asm volatile("" : "+v"(tid));
+  if (MB) asm volatile("" : "+v"(tid));
   const int i0 = i0T + blk * cpb, nc = (cpb < ncT - blk * cpb) ? cpb : ncT - blk * cpb;
   if (MODE == OUT_END && !(a.dbg & 4096) && i0 + nc - 1 + d <= a.ys[v.n]) continue;   // (uniform; see the workgroup test above)
   const int* dm = dmT + blk * cpb;
@@ -1665,7 +1669,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   // then needs a single round of table loads, selected by role without branches.
   {
     // (the unary phase of the previous block left out B of its targets in `hp`, which the pair entries behind it have read)
-    if (blk > 0) for (int t = tid; t < CS; t += kBT) hp[t] = 0.;
+    if (MB && blk > 0) for (int t = tid; t < CS; t += kBT) hp[t] = 0.;
     lds_prefix(nv, tid, cnts, pre);
     __syncthreads();
     const int n_rec = pre[nv];
@@ -1853,7 +1857,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
     sink.en_ = en_keep;
   }
   pc.mark<11>();
-  if ((blk + 1) * cpb < ncT && (!FAST || (a.dbg & 4) || (ELEMDP_KO & 4))) {   // (generic rule code: the lanes do not cover every slot)
+  if (MB && (blk + 1) * cpb < ncT && (!FAST || (a.dbg & 4) || (ELEMDP_KO & 4))) {   // (generic rule code: the lanes do not cover every slot)
     __syncthreads();
     for (int t = tid; t < NW * HS; t += kBT) lds[t] = 0.;
     __syncthreads();
@@ -2186,6 +2190,10 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
 #define ELEMDP_CYK_PROD 4
 #endif
   if (a.lay.n_split > 0) a.cpb = std::min(a.cpb, std::max(kBT / S, ELEMDP_CYK_PROD * kBT / a.lay.n_split));
+  // (at least two split points per staging lane group: with the five front states of (.....) 32 cells left a third of the lanes idle
+  // in every staging round and took twice the rounds -- 25 cells: scan 857 -> 821 ms per 10 000 x L=300)
+  a.cpb = std::min(a.cpb, std::max(8, kBT / (2 * std::max(a.lay.n_front, 1))));
+  if (const char* e = getenv("ELEMDP_CYK_CPB")) a.cpb = std::min(a.cpb, std::max(1, atoi(e)));   // (experiments)
   a.cpb = std::max(a.cpb, 1);
   const size_t lds = block_lds(2 * a.cpb * NLc + 2 * kChunkIn * kBT, a.cpb, kLinEth + nt, a.cpb + Wmax + 3, staged_ints(a.lay, a.n_stage, 0)).total;
   const bool big = a.n_stage >= a.lay.n_ints;
@@ -2211,6 +2219,10 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
 // Blocks of cpb cells per band-kernel workgroup (LinArgs::nblk) for a diagonal of `nb` blocks: at most `nmax` (<= ELEMDP_CPB_MAX
 // cells: the cell records and the stem mask of a workgroup), spread evenly over the fewest workgroups; one block per workgroup
 // where the whole launch is resident at once anyway (small groups: there the lifetime of ONE workgroup is the launch's duration).
+// DEFAULT: ONE block.  Three blocks per workgroup stage the context a third as often and measured the same on the bench
+// (257.9 against 258.0 ms per step of 10 000 x L=200 on one box, 107.3 against 105.7 ms per 4096): the set-up they save is not
+// what bounds the kernels, and they cost a resident workgroup per CU (LDS) -- DESIGN.md 4.2d.  Option "nblk" / ELEMDP_NBLK keep
+// the form reachable (tests/test_round4_gpu.py runs it against the one-block kernels and the oracle).
 static int env_nblk(int part) {   // experiments: ELEMDP_NBLK, or ELEMDP_NBLK_IN / ELEMDP_NBLK_OUT for one direction
   static const int v[3] = {[] { const char* e = getenv("ELEMDP_NBLK"); return e ? atoi(e) : 0; }(),
                            [] { const char* e = getenv("ELEMDP_NBLK_IN"); return e ? atoi(e) : 0; }(),
@@ -2218,13 +2230,15 @@ static int env_nblk(int part) {   // experiments: ELEMDP_NBLK, or ELEMDP_NBLK_IN
   return v[1 + part] > 0 ? v[1 + part] : v[0];
 }
 #ifndef ELEMDP_NBLK_DEFAULT
-#define ELEMDP_NBLK_DEFAULT 3
+#define ELEMDP_NBLK_DEFAULT 1
 #endif
 // req: LinArgs::nblk as the host engine passes it (option "nblk"): 0 = the policy above, n = n blocks wherever they fit;
 // part 0: k4_in, 1: k4_out
 static int nblk_max(int cpb, bool fast, bool det, int req, int part) {
   if (!fast || det) return 1;
-  const int want = req > 0 ? req : env_nblk(part) > 0 ? env_nblk(part) : ELEMDP_NBLK_DEFAULT;
+  // default: up to ELEMDP_NBLK_DEFAULT blocks and ~40 cells per workgroup -- an automaton with few live states has large blocks
+  // already (cpb = 32 for (.....): a second block there costs two of six resident workgroups and the scan got 15 % slower)
+  const int want = req > 0 ? req : env_nblk(part) > 0 ? env_nblk(part) : std::min(ELEMDP_NBLK_DEFAULT, 40 / std::max(cpb, 1));
   return std::max(1, std::min(want, ELEMDP_CPB_MAX / std::max(cpb, 1)));
 }
 static void set_rcps(LinArgs& a, bool fast) {
@@ -2261,7 +2275,10 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
   const bool fp2 = a.lay.fp_max_p <= 2;
   const int hd = fast ? a.lay.n_lane : S;   // stride of the heavy sums per cell (k4_in / k4_out: HD)
   set_rcps(a, fast);
-  const int nbmax_in = nblk_max(a.cpb, fast, false, full.nblk, 0), nbmax_out = nblk_max(a.cpb, fast, false, full.nblk, 1);
+  // (the scan's sum passes keep one block per workgroup unless option "nblk" asks: with (.....) -- few live states, 18 cells per
+  // block already -- a second block costs a resident workgroup per CU and measured 10 % slower, profiles/r04_*)
+  const bool mb_scan = full.nblk > 0 || env_nblk(0) > 0 || env_nblk(1) > 0;
+  const int nbmax_in = mb_scan ? nblk_max(a.cpb, fast, false, full.nblk, 0) : 1, nbmax_out = mb_scan ? nblk_max(a.cpb, fast, false, full.nblk, 1) : 1;
   auto lds_in_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(2 * a.cpb * hd + kRecIn, ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total; };
   auto lds_out_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(out_doubles(a.cpb * hd, nt, ct + Wmax + 3), ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * ct, fast ? kCellOutD : 0).total; };
   const size_t lds_in = lds_in_of(1), lds_out = lds_out_of(1);
@@ -2283,7 +2300,9 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       a.nblk = nblk_for(nb, G, nbmax_in, full.nblk);                                                                                           \
       const dim3 grid((nb + a.nblk - 1) / a.nblk, G);                                                                            \
       const size_t lds_i = lds_in_of(a.nblk);                                                                                    \
-      if (fast && fp2 && w8_of(a.nblk)) hipLaunchKernelGGL((k4_in<true, CON, true, 2, true>), grid, dim3(kBT), lds_i, st, a);    \
+      if (a.nblk > 1 && fp2) hipLaunchKernelGGL((k4_in<true, CON, true, 2, false, true>), grid, dim3(kBT), lds_i, st, a);        \
+      else if (a.nblk > 1) hipLaunchKernelGGL((k4_in<true, CON, true, kFastP, false, true>), grid, dim3(kBT), lds_i, st, a);     \
+      else if (fast && fp2 && w8_of(a.nblk)) hipLaunchKernelGGL((k4_in<true, CON, true, 2, true>), grid, dim3(kBT), lds_i, st, a); \
       else if (fast && fp2) hipLaunchKernelGGL((k4_in<true, CON, true, 2>), grid, dim3(kBT), lds_i, st, a);                      \
       else if (fast) hipLaunchKernelGGL((k4_in<true, CON, true>), grid, dim3(kBT), lds_i, st, a);                                \
       else if (big) hipLaunchKernelGGL((k4_in<true, CON>), grid, dim3(kBT), lds_i, st, a);                                       \
@@ -2302,7 +2321,9 @@ hipError_t launch_lin_scan_group(const LinArgs& full, int G, int Lmax, int Wmax,
       a.nblk = nblk_for(nb, G, nbmax_out, full.nblk);                                                                                           \
       const dim3 grid((nb + a.nblk - 1) / a.nblk, G);                                                                            \
       const size_t lds_o = lds_out_of(a.nblk);                                                                                   \
-      if (fast && fp2 && w6_of(a.nblk)) hipLaunchKernelGGL((k4_out<MODE, true, true, 2, true>), grid, dim3(kBT), lds_o, st, a);  \
+      if (a.nblk > 1 && fp2) hipLaunchKernelGGL((k4_out<MODE, true, true, 2, false, true>), grid, dim3(kBT), lds_o, st, a);      \
+      else if (a.nblk > 1) hipLaunchKernelGGL((k4_out<MODE, true, true, kFastP, false, true>), grid, dim3(kBT), lds_o, st, a);   \
+      else if (fast && fp2 && w6_of(a.nblk)) hipLaunchKernelGGL((k4_out<MODE, true, true, 2, true>), grid, dim3(kBT), lds_o, st, a); \
       else if (fast && fp2) hipLaunchKernelGGL((k4_out<MODE, true, true, 2>), grid, dim3(kBT), lds_o, st, a);                    \
       else if (fast) hipLaunchKernelGGL((k4_out<MODE, true, true>), grid, dim3(kBT), lds_o, st, a);                              \
       else if (big) hipLaunchKernelGGL((k4_out<MODE, true>), grid, dim3(kBT), lds_o, st, a);                                     \
@@ -2352,7 +2373,9 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
       a.nblk = nblk_for(nb, G, nbmax_in, full.nblk);
       const dim3 grid((nb + a.nblk - 1) / a.nblk, G);
       const size_t lds_i = lds_in_of(a.nblk);
-      if (fast && a.lay.fp_max_p <= 2 && lds_i * 8 <= 160 * 1024) hipLaunchKernelGGL((k4_in<true, false, true, 2, true>), grid, dim3(kBT), lds_i, st, a);
+      if (a.nblk > 1 && a.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_in<true, false, true, 2, false, true>), grid, dim3(kBT), lds_i, st, a);
+      else if (a.nblk > 1) hipLaunchKernelGGL((k4_in<true, false, true, kFastP, false, true>), grid, dim3(kBT), lds_i, st, a);
+      else if (fast && a.lay.fp_max_p <= 2 && lds_i * 8 <= 160 * 1024) hipLaunchKernelGGL((k4_in<true, false, true, 2, true>), grid, dim3(kBT), lds_i, st, a);
       else if (fast && a.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_in<true, false, true, 2>), grid, dim3(kBT), lds_i, st, a);
       else if (fast) hipLaunchKernelGGL((k4_in<true, false, true>), grid, dim3(kBT), lds_i, st, a);
       else if (big) hipLaunchKernelGGL((k4_in<true, false>), grid, dim3(kBT), lds_i, st, a);
@@ -2388,6 +2411,8 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
         const dim3 grid((nb + b.nblk - 1) / b.nblk, G);
         const size_t lds_o = lds_out_of(b.nblk);
         if (big && (b.dbg & 16)) hipLaunchKernelGGL((k4_out<OUT_NONE, true>), grid, dim3(kBT), lds_o, st, b);   // (timing experiment: no statistics)
+        else if (b.nblk > 1 && b.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2, false, true>), grid, dim3(kBT), lds_o, st, b);
+        else if (b.nblk > 1) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, kFastP, false, true>), grid, dim3(kBT), lds_o, st, b);
         else if (fast && b.lay.fp_max_p <= 2 && lds_o * 6 <= 160 * 1024) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2, true>), grid, dim3(kBT), lds_o, st, b);
         else if (fast && b.lay.fp_max_p <= 2) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true, 2>), grid, dim3(kBT), lds_o, st, b);
         else if (fast) hipLaunchKernelGGL((k4_out<OUT_TRAIN, true, true>), grid, dim3(kBT), lds_o, st, b);

@@ -1,5 +1,6 @@
 """ctypes wrapper of the test-only CPU emulation (tests/emul/emul.cpp)."""
 import ctypes as C
+import os
 import json
 
 import numpy as np
@@ -12,7 +13,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(_build.build())
+        # (ELEMDP_EMUL_LIBRARY: another build of the driver, e.g. the sanitizer build of tools/sanitize_cpu.sh)
+        L = C.CDLL(os.environ.get("ELEMDP_EMUL_LIBRARY") or _build.build())
         dp, u8, i32 = C.POINTER(C.c_double), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
         L.emu_create.restype = C.c_void_p
         L.emu_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]

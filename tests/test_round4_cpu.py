@@ -87,3 +87,33 @@ def test_table_driven_scan_passes_match_oracle(model, fq, prune):
         assert a["rss"] == b["rss"]
         np.testing.assert_allclose(b["EN"], a["EN"], rtol=1e-9, atol=1e-11)
     assert (lib().emu_fast_cells() > before) == bool(mask & 1)
+
+
+# ---- --lik-ratio together with shuffled negatives (the default Adam mode): motif_trainer.hpp:156-202 with :145-152 ----------
+from rnaelem_amd import api, io, train   # noqa: E402
+from tests.util import gload             # noqa: E402
+
+LIK_SHUFFLE = gload("train_trace_lik_shuffle.json")
+
+
+@pytest.mark.parametrize("t", LIK_SHUFFLE, ids=["%s-%s-batch%d" % (c["fq"], c["pattern"], c["batch_size"]) for c in LIK_SHUFFLE])
+def test_lik_ratio_with_shuffled_negatives_reproduces_the_reference_trace_with_the_oracle(t):
+    """`RNAelem train --lik-ratio` without --no-shuffle: every record and its per-iteration negative under the likelihood-ratio
+    objective (a negative contributes Z(ari) - Z(ari,nasi)), Adam, whole batch and mini-batches of 2 (into the third epoch).
+    The data term and |gr|^2 the reference prints at every iteration, to their 6 printed digits."""
+    recs = io.read_fastq(gpath(t["fq"]))
+    seqs, quals = [s for _, s, _ in recs], [q for _, _, q in recs]
+    o = po.make_oracle(t["pattern"], 50, 30, min_bpp=1e-4, tau=t["tau"], flags=po.LIK_RATIO)
+
+    def ev_batch(s2, q2, x):
+        o.set_params(x)
+        skipped = np.array([o.train_seq(s, q)["skipped"] for s, q in zip(s2, q2)], dtype=bool)
+        return o.train_eval(x, s2, q2, n_threads=4) + (skipped,)
+
+    ev = train.MiniBatches(seqs, quals, t["batch_size"], ev_batch, kmer_shuf=t["kmer_shuf"])
+    x0 = api.Engine(t["pattern"]).initial_params(t["lambda_init"])
+    r = train.minimize_adam(ev, x0, train.regularisation(len(x0), t["rho_theta"], t["rho_lambda"]), max_iter=t["max_iter"])
+    assert len(r["trace"]) == len(t["iter_fn"])
+    for row, y, g2 in zip(r["trace"], t["iter_fn"], t["iter_gnorm"]):
+        assert row[4] == pytest.approx(y, rel=2e-5, abs=1e-9)
+        assert row[2] == pytest.approx(g2, rel=2e-5)
