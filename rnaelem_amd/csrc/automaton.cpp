@@ -685,6 +685,26 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
     return pos;
   };
   A.qc_in = emit_qc(quad, 0);
+  // deterministic mode: the tuples of a column-record list dealt to four waves by target (device_layout.h: qd_*)
+  auto emit_det = [&](const std::vector<int32_t>& q, size_t first, int n, std::vector<int32_t>* out) {
+    std::vector<int32_t> ids[4];
+    for (int t = 0; t < n; ++t) {
+      const int w = q[2 * (first + t) + 1];
+      if ((w >> 16) & 4) continue;           // dead tuple
+      ids[(w & 0xffff) & 3].push_back(t);
+    }
+    int off = 0;
+    for (int k = 0; k < 4; ++k) { out->push_back(off); off += (int)ids[k].size(); }
+    out->push_back(off);
+    const size_t at = out->size();
+    for (int k = 0; k < 4; ++k) out->insert(out->end(), ids[k].begin(), ids[k].end());
+    out->resize(at + n, 0);
+  };
+  {
+    const std::vector<int32_t> q(ints->begin() + A.qc_in, ints->begin() + A.qc_in + 2 * quad.count());
+    A.qd_in = (int32_t)ints->size();
+    emit_det(q, 0, quad.count(), ints);
+  }
   A.big_in_end = (int32_t)ints->size();
   put(split1, &A.split1_off, &A.split1_ent);
   put(split2, &A.split2_off, &A.split2_ent);
@@ -701,6 +721,11 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   A.qc_out3 = emit_qc(quad3, 2);
   A.n_split = split.count();
   A.n_quad = quad.count();
+  {
+    const std::vector<int32_t> q(ints->begin() + A.qc_out1, ints->begin() + A.qc_out1 + 6 * A.n_quad);
+    A.qd_out = (int32_t)ints->size();
+    for (int role = 0; role < 3; ++role) emit_det(q, (size_t)role * A.n_quad, A.n_quad, ints);
+  }
   A.n_ints = (int32_t)ints->size();
   // fast blobs of the table-driven train kernels (behind n_ints: the generic kernels never stage them)
   auto append = [&](const std::vector<int32_t>& v) { const int32_t pos = (int32_t)ints->size(); ints->insert(ints->end(), v.begin(), v.end()); return pos; };
@@ -716,6 +741,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   A.f_live_in = append(live_states);
   A.fp_in = append(prog_in);
   A.fqc_in = append(qci);
+  { std::vector<int32_t> dl; emit_det(qci, 0, A.n_quad, &dl); A.fqd_in = append(dl); }
   A.fpr_in = append(pair_rec);
   A.fs_in = append(scan_fl);
   A.fb_in_n = (int32_t)ints->size() - A.fb_in;
@@ -725,6 +751,7 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
   A.fe_r = append(attr_r);
   A.fe_p = append(attr_p);
   A.fqc_out = append(qco);
+  { std::vector<int32_t> dl; for (int role = 0; role < 3; ++role) emit_det(qco, (size_t)role * A.n_quad, A.n_quad, &dl); A.fqd_out = append(dl); }
   A.fpr_out = append(pair_rec);
   A.fs_out = append(scan_fl);
   A.fb_out_n = (int32_t)ints->size() - A.fb_out;
@@ -757,6 +784,7 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   A.tab_row = 7; A.ap_rs = 1;
   A.fp_ok = 0; A.fp_in = A.fp_out = A.fe_r = A.fe_p = 0; A.n_wr = A.n_wp = A.n_wl = 0;
   A.fb_in = A.fb_in_n = A.fb_out = A.fb_out_n = A.fqc_in = A.fpr_in = A.fqc_out = A.fpr_out = A.fs_in = A.fs_out = 0;
+  A.qd_in = A.qd_out = A.fqd_in = A.fqd_out = 0;
   A.st_live = one(0); A.st_li = one(0);
   A.fp_max_p = kFastP; A.n_lane = 1; A.f_live_in = A.f_live_out = 0;
   A.lin_wr = A.lin_wl = A.lin_wp = A.lin_total = 11;

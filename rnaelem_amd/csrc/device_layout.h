@@ -115,6 +115,11 @@ struct AutomatonLayout {
   //   qc_out1 (quad1 order, target = the inner pair's P state): out E [par], L [s2], L [s3], own = P [target]
   //   qc_out2 / qc_out3 (quad2 / quad3 order, target = a loop's L state): out E [par], P [s1], L [other loop], own = L [target]
   int32_t qc_in, qc_out1, qc_out2, qc_out3;
+  // Deterministic mode (LinArgs::det): the tuples of a list dealt to the four waves of a band-kernel workgroup BY TARGET (target
+  // index & 3), so that every heavy sum is added to by one wave only -- its adds then reach LDS in program order, lanes of one
+  // instruction in lane order.  Per list 5 offsets (into the ids that follow them) + n_quad tuple ids: qd_in for qc_in, qd_out for the
+  // three lists at qc_out1 (5 + n_quad ints each); fqd_in / fqd_out: the same for the fast copies (targets = live indices).
+  int32_t qd_in, qd_out, fqd_in, fqd_out;
   int32_t n_small;  // the first n_small ints (per-state attributes, unary lists) are staged in LDS;
                     // the tuple lists behind them are read from global memory (ModelView::big)
   int32_t big_in_end;  // the tuple lists behind n_small come in two runs: [n_small, big_in_end) = lists of the inside

@@ -190,8 +190,12 @@ struct LinArgs {
                                   // spans >= 5 positions -- the default mask --, else 1)
   int32_t n_lin;                  // doubles of the linear parameter block the band kernels stage (with or without the weight tables)
   int32_t fast;                   // train: table-driven unary phases (lin_fast.h); the host clears it where they do not apply
-  int32_t det;                    // train: deterministic reductions (one copy of every shared sum per wave, one row of counts per
-                                  // (sequence, block): det_rows[n][det_nslot][out_stride], summed in order by k4_combine)
+  int32_t det;                    // train: deterministic reductions -- every heavy sum of a workgroup gets its adds from ONE wave (pairs of
+                                  // a cell in one wave: det_sh; tuples dealt to the waves by target: AutomatonLayout::qd_*), the
+                                  // statistics one copy per wave, one row of counts per (sequence, block):
+                                  // det_rows[n][det_nslot][out_stride], summed in order by k4_combine
+  int32_t det_sh;                 // log2 of the lanes a cell's pairs take in the pair phases of the deterministic mode (a power of two
+                                  // >= n_ap, so that no cell straddles two waves); -1: more than 64 pairs, one wave does the phase
   double* det_rows; int32_t det_nslot;
 };
 struct LinWeightArgs {

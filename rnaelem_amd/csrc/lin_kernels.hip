@@ -82,11 +82,14 @@ __device__ __forceinline__ int div_small(int q, int n) { return (int)(((float)q 
 // ... with the reciprocal formed on the host (LinArgs::rcp_*: 1.0f / n, the same rounding)
 __device__ __forceinline__ int div_rcp(int q, float rcp) { return (int)(((float)q + 0.5f) * rcp); }
 
-// Deterministic mode (LinArgs::det, option "deterministic"): every sum that lanes of DIFFERENT waves add to -- the heavy sums of
-// a workgroup, its expected counts -- gets one copy per wave (the adds of one wave reach LDS in program order, lanes of one
-// instruction in lane order), and the copies are added in wave order where they are read; a workgroup adds its counts to a
-// row of its own (sequence, block) instead of the sequence's row, and k4_combine sums those rows in block order.  Two
-// evaluations of the same batch are then bit-identical (the reference at --thread 1: motif_trainer.hpp:248-271).
+// Deterministic mode (LinArgs::det, option "deterministic"): two evaluations of the same batch are bit-identical (the reference at
+// --thread 1: motif_trainer.hpp:248-271).  An LDS sum that lanes of DIFFERENT waves add to has no fixed order; the adds of ONE wave
+// reach LDS in program order, lanes of one instruction in lane order.  So every heavy sum of a workgroup gets its adds from one
+// wave only: the pairs of a cell sit in one wave (LinArgs::det_sh: a power of two of lanes per cell), the tuples of the item sums
+// are dealt to the waves by target (AutomatonLayout::qd_*), the stem cells of HA by wave; the expected counts, which every lane may
+// add to, keep one copy per wave, added in wave order where they are flushed (rep_sum); a workgroup adds its counts to a row of
+// its own (sequence, block) instead of the sequence's row, and k4_combine sums those rows in block order.  (Round 3 kept a copy
+// of EVERY shared sum per wave: 32 KB of LDS for k4_out, half the resident workgroups, 1.7 - 1.9 x the time.)
 __device__ __forceinline__ double rep_sum(const double* p, int nrep, int stride) {
   double a = p[0];
   for (int r = 1; r < nrep; ++r) a += p[r * stride];
@@ -324,9 +327,10 @@ __host__ __device__ inline BlockLds block_lds(int nd, int cpb, int n_lin, int wi
   return b;
 }
 struct BlockCtx { int* dm; int* cnts; int* pre; int* base; };
-// accumulator / staging doubles of k4_out: four heavy sums per (cell, state), the statistics of the two worlds, the position
+// accumulator / staging doubles of k4_out: four heavy sums per (cell, state), the statistics of the two worlds (nw copies: one per
+// wave in the deterministic mode), the position
 // posteriors of the scan over the window of positions the workgroup touches (start + inner, or end), the item records
-__host__ __device__ inline int out_doubles(int CS, int nt, int win, int nw = 1) { return nw * (4 * CS + 2 * nt + 4) + 2 * win + kRecOut; }
+__host__ __device__ inline int out_doubles(int CS, int nt, int win, int nw = 1, bool scan = true) { return 4 * CS + nw * (2 * nt + 4) + (scan ? 2 * win : 0) + kRecOut; }
 // ints of the automaton blob a band kernel stages: everything (n_stage = n_ints) means the small part plus the run of
 // tuple lists of its direction (PART 0: inside, 1: outside); otherwise only the small part
 __host__ __device__ inline int staged_ints(const AutomatonLayout& L, int n_stage, int part) {
@@ -713,11 +717,11 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
   }
   const int HD = FAST ? A.n_lane : S;   // stride of the heavy sums per cell: the live states (table-driven: their index among them), or all
   const int CS = cpb * HD;
-  const int NW = a.det ? kBT / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the heavy sums (one per wave: rep_sum)
+  constexpr int NW = 1;                      // (one copy of the heavy sums in either mode: see the deterministic mode above)
   double* hb = lds;
   double* he = hb + CS;
-  double* hbA = hb + wvd * 2 * CS;           // ... the copy this lane adds to
-  double* heA = he + wvd * 2 * CS;
+  double* hbA = hb;
+  double* heA = he;
   double* st1 = lds + NW * 2 * CS;           // item records (kRecIn doubles)
   const BlockLds BL = block_lds(NW * 2 * CS + kRecIn, cpbT, a.n_lin, cpbT + a.wmax + 3, FAST ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, FAST ? kCellInD : 0);
   // cell records of the table-driven unary phase: the exponentiated structural terms of the cells are fetched with the context
@@ -791,9 +795,13 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
     const int32_t* I = v.m.ints;
     const Constraint con{CON ? a.ys[v.n] : -1, -1, 0};
     const int W1 = v.q.W + 1;
-    const int nwork = ((a.dbg & 1) || (ELEMDP_KO & 1)) ? 0 : nc * nA;
-    for (int w = tid; w < nwork; w += kBT) {
-      const int c = div_rcp(w, a.rcp_nap), p = w - c * nA;
+    // (deterministic mode: a cell's pairs take 2^det_sh lanes, so no cell straddles two waves; more than 64 pairs: wave 0 alone)
+    const int pad = (a.det && a.det_sh >= 0) ? (1 << a.det_sh) : nA;
+    const int nwork = ((a.dbg & 1) || (ELEMDP_KO & 1)) ? 0 : nc * pad;
+    const bool one_wave = a.det && a.det_sh < 0;
+    for (int w = one_wave ? ((tid < 64) ? tid : nwork) : tid; w < nwork; w += one_wave ? 64 : kBT) {
+      const int c = (a.det && a.det_sh >= 0) ? (w >> a.det_sh) : div_rcp(w, a.rcp_nap), p = w - c * pad;
+      if (p >= nA) continue;
       const int i = i0 + c, j = i + d;
       if (FAST) {   // the same sums from the pair record (AutomatonLayout::fpr_in): columns, chain entries with their weight ids
         const int32_t* PR = G + A.fpr_in + 8 * p;
@@ -928,16 +936,21 @@ __global__ __launch_bounds__(kBT, W8 ? ELEMDP_LB_IN_FAST : ELEMDP_LB_IN) void k4
         const uint32_t rP = v.in.cidx(ST_P, it.l - it.k, it.k, 0), rL1 = v.in.cidx(ST_L, it.k - i, i, 0), rL2 = v.in.cidx(ST_L, j - it.l, it.l, 0);
         const double xw0 = R.xw[xc], xw1 = R.xw[R.cap + xc];
         double* hrow = heA + c * HD;
-        for (int t0 = wv; t0 < nq; t0 += kWaves * kTU) {
+        // the wave's tuples: every fourth one, or (deterministic mode) the ones whose targets are its own (qd_in: offsets, ids)
+        const int qd = FAST ? A.fqd_in : A.qd_in;
+        const int m0 = a.det ? __builtin_amdgcn_readfirstlane(G[qd + wv]) : 0;
+        const int n_mine = a.det ? __builtin_amdgcn_readfirstlane(G[qd + wv + 1]) - m0 : (nq > wv ? (nq - wv + kWaves - 1) / kWaves : 0);
+        for (int k0 = 0; k0 < n_mine; k0 += kTU) {
           int qa[kTU], qb[kTU];
           double x0[kTU], x1[kTU], x2[kTU];
 #pragma unroll
           for (int u = 0; u < kTU; ++u) {
-            const int t = t0 + kWaves * u;
-            const bool on = t < nq;
+            const bool on = k0 + u < n_mine;
+            const int kk = on ? k0 + u : 0;
+            const int t = a.det ? __builtin_amdgcn_readfirstlane(G[qd + 5 + m0 + kk]) : wv + kWaves * kk;
             // (the tuple is the same for all lanes of the wave: its record in scalar registers, unpacked by the scalar unit)
-            qa[u] = __builtin_amdgcn_readfirstlane(G[qc_in + 2 * (on ? t : wv)]);
-            qb[u] = on ? __builtin_amdgcn_readfirstlane(G[qc_in + 2 * (on ? t : wv) + 1]) : (4 << 16);
+            qa[u] = __builtin_amdgcn_readfirstlane(G[qc_in + 2 * t]);
+            qb[u] = on ? __builtin_amdgcn_readfirstlane(G[qc_in + 2 * t + 1]) : (4 << 16);
             x0[u] = B[rP + (qa[u] & 0xff)]; x1[u] = B[rL1 + ((qa[u] >> 8) & 0xff)]; x2[u] = B[rL2 + ((qa[u] >> 16) & 0xff)];
           }
 #pragma unroll
@@ -1449,22 +1462,26 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   }
   const int HD = FAST ? A.n_lane : S;   // (as in k4_in)
   const int CS = cpb * HD;
-  const int NW = a.det ? kBT / 64 : 1, wvd = a.det ? tid >> 6 : 0;   // copies of the sums (one per wave: rep_sum)
-  const int HS = 4 * CS, ES = 2 * nt + 4;      // doubles of one copy of the heavy sums / of the statistics
-  double* h1 = lds;                            // copy 0 (the unary phase adds the copies up)
+  // ONE copy of the heavy sums (deterministic mode: each gets its adds from one wave, see the top of the file); the statistics,
+  // which every lane may add to, one copy per wave there (rep_sum)
+  constexpr int NW = 1;
+  const int NWS = a.det ? kBT / 64 : 1, wvd = a.det ? tid >> 6 : 0;
+  const int HS = 4 * CS, ES = 2 * nt + 4;      // doubles of the heavy sums / of one copy of the statistics
+  double* h1 = lds;
   double* h2 = h1 + CS;
   double* hp = h2 + CS;
   double* hl = hp + CS;
-  double* h1A = h1 + wvd * HS;                 // the copy this lane adds to
-  double* h2A = h2 + wvd * HS;
-  double* hpA = hp + wvd * HS;
-  double* l_en0 = lds + NW * HS;               // statistics: [copies][2 worlds x n_theta | 2 worlds x 2]
+  double* h1A = h1;
+  double* h2A = h2;
+  double* hpA = hp;
+  double* l_en0 = lds + HS;                    // statistics: [copies][2 worlds x n_theta | 2 worlds x 2]
   double* l_en = l_en0 + wvd * ES;             // ... this lane's copy
   double* l_eh = l_en + 2 * nt;
-  double* l_pos = l_en0 + NW * ES;             // scan: [2][win] position posteriors of the window (start, inner | end, -)
+  double* l_pos = l_en0 + NWS * ES;            // scan: [2][win] position posteriors of the window (start, inner | end, -)
   const int win = cpbT + a.wmax + 3;
-  double* sOB1 = l_pos + 2 * win;              // item records of the three roles (kRecOut doubles)
-  const BlockLds BL = block_lds(out_doubles(CS, nt, win, NW), cpbT, a.n_lin, win, FAST ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * cpbT, FAST ? kCellOutD : 0);
+  constexpr bool kScanMode = MODE == OUT_SCAN || MODE == OUT_END;
+  double* sOB1 = l_pos + (kScanMode ? 2 * win : 0);   // item records of the three roles (kRecOut doubles; no position window in training)
+  const BlockLds BL = block_lds(out_doubles(CS, nt, win, NWS, kScanMode), cpbT, a.n_lin, win, FAST ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * cpbT, FAST ? kCellOutD : 0);
   // cell records of the table-driven unary phase (see k4_in): twelve global values per cell, fetched with the context
   constexpr int kCRout = (ELEMDP_CPB_MAX * 12 + kBT - 1) / kBT;
   double crx[kCRout];
@@ -1485,7 +1502,7 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
   const int32_t* G = v.m.big;
   double* crecT = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(lds) + BL.crec);
   int* crflT = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + BL.crfl);
-  const int n_zero = NW * (HS + ES) + ((MODE == OUT_SCAN || MODE == OUT_END) ? 2 * win : 0);
+  const int n_zero = HS + NWS * ES + ((MODE == OUT_SCAN || MODE == OUT_END) ? 2 * win : 0);
   for (int t = tid; t < n_zero; t += kBT) lds[t] = 0.;
   __syncthreads();
   if (a.dbg & 2048) return;
@@ -1578,12 +1595,9 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
     constexpr int kHA = 4;
     double ha_oa[kHA], ha_x1[kHA];
     int ha_idx[kHA];
-    auto ha_load = [&](int w0) {
-#pragma unroll
-      for (int u = 0; u < kHA; ++u) {
-        const int w = w0 + u * kBT;
-        const bool valid = w < total;
-        const int sc = valid ? div_small(w, per) : 0, r = valid ? w - sc * per : 0;
+    // work item (sc-th stem cell, r = (b - 1) * nA + p) into slot u of the batch
+    auto ha_slot = [&](int u, bool valid, int sc, int r) {
+      {
         unsigned long long m = stems;
         for (int k = 0; k < sc; ++k) m &= m - 1;          // the sc-th stem cell
         const int c = stems ? __builtin_ctzll(m) : 0;
@@ -1596,6 +1610,15 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
         ha_idx[u] = c * HD + pr_t(p);
       }
     };
+    auto ha_load = [&](int w0) {      // flat list over all stem cells of the block: w = sc * per + r
+#pragma unroll
+      for (int u = 0; u < kHA; ++u) {
+        const int w = w0 + u * kBT;
+        const bool valid = w < total;
+        const int sc = valid ? div_small(w, per) : 0;
+        ha_slot(u, valid, sc, valid ? w - sc * per : 0);
+      }
+    };
     auto ha_add = [&]() {
 #pragma unroll
       for (int u = 0; u < kHA; ++u) {
@@ -1605,9 +1628,14 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
     };
     // (unconditional, like the add below: a value that is defined under a condition inside the block loop counts as live around
     // the whole loop -- 16 registers here)
-    ha_load(tid);
-    for (int w = tid; w < nwork; w += kBT) {
-      const int c = div_rcp(w, a.rcp_nap), p = w - c * nA;
+    ha_load(a.det ? total : tid);      // (deterministic mode: HA follows the H1 sums, a stem cell per wave)
+    // (deterministic mode: a cell's pairs in one wave, as in k4_in)
+    const int pad = (a.det && a.det_sh >= 0) ? (1 << a.det_sh) : nA;
+    const bool one_wave = a.det && a.det_sh < 0;
+    const int nwork_l = nwork ? nc * pad : 0;
+    for (int w = one_wave ? ((tid < 64) ? tid : nwork_l) : tid; w < nwork_l; w += one_wave ? 64 : kBT) {
+      const int c = (a.det && a.det_sh >= 0) ? (w >> a.det_sh) : div_rcp(w, a.rcp_nap), p = w - c * pad;
+      if (p >= nA) continue;
       const int i = i0 + c, j = i + d;
       const int s1 = pr_s1(p);
       const int cP = pr_cP(p);
@@ -1657,8 +1685,18 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
         if (acc != 0.) atomicAdd(&h1A[c * HD + s1], acc);
       }
     }
-    ha_add();
-    for (int w0 = tid + kHA * kBT; w0 < total; w0 += kHA * kBT) { ha_load(w0); ha_add(); }
+    if (!a.det) {
+      ha_add();
+      for (int w0 = tid + kHA * kBT; w0 < total; w0 += kHA * kBT) { ha_load(w0); ha_add(); }
+    } else {      // every stem cell's sums from ONE wave: wave w takes the stem cells w, w + 4, ..; its lanes the (row, pair) items
+      const int nst = __popcll(stems), wvh = tid >> 6, lnh = tid & 63;
+      for (int sc = wvh; sc < nst; sc += kWaves)
+        for (int r0 = lnh; r0 < per; r0 += 64 * kHA) {
+#pragma unroll
+          for (int u = 0; u < kHA; ++u) { const int r = r0 + 64 * u; ha_slot(u, r < per, sc, r < per ? r : 0); }
+          ha_add();
+        }
+    }
   }
   __syncthreads();
   pc.mark<6>();
@@ -1720,15 +1758,28 @@ __global__ __launch_bounds__(kBT, W6 ? ELEMDP_LB_OUT6 : ELEMDP_LB_OUT) void k4_o
         const double xw0 = r_xw[xc], xw1 = r_xw[cap + xc];
         double* hrow = hpA + (role == 0 ? 0 : CS) + c * HD;   // hp, or hl = hp + CS
         const int qc0 = (FAST ? A.fqc_out : A.qc_out1) + role * 2 * nq;
-        for (int t0 = wv; t0 < nq; t0 += kWaves * kTU) {
+        // the wave's tuples of the lane's role: every fourth one, or (deterministic mode) the ones whose targets are the wave's own
+        // (qd_out: offsets + ids per role); the loop runs to the longest of the three roles' shares
+        const int qd0 = (FAST ? A.fqd_out : A.qd_out) + role * (5 + nq);
+        const int m0 = a.det ? G[qd0 + wv] : 0;
+        const int n_mine = a.det ? G[qd0 + wv + 1] - m0 : (nq > wv ? (nq - wv + kWaves - 1) / kWaves : 0);
+        int n_loop = n_mine;
+        if (a.det) {
+          const int qdb = FAST ? A.fqd_out : A.qd_out;
+          n_loop = 0;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) { const int nr = G[qdb + r * (5 + nq) + wv + 1] - G[qdb + r * (5 + nq) + wv]; n_loop = nr > n_loop ? nr : n_loop; }
+        }
+        for (int k0 = 0; k0 < n_loop; k0 += kTU) {
           int qa[kTU], qb[kTU];
           double x0[kTU], x1[kTU], x2[kTU], aux[kTU];
 #pragma unroll
           for (int u = 0; u < kTU; ++u) {
-            const int t = t0 + kWaves * u;
-            const bool on = t < nq;
-            qa[u] = G[qc0 + 2 * (on ? t : wv)];
-            qb[u] = on ? G[qc0 + 2 * (on ? t : wv) + 1] : (4 << 16);
+            const bool on = k0 + u < n_mine;
+            const int kk = on ? k0 + u : 0;
+            const int t = !on ? (nq > wv ? wv : 0) : a.det ? G[qd0 + 5 + m0 + kk] : wv + kWaves * kk;
+            qa[u] = G[qc0 + 2 * t];
+            qb[u] = on ? G[qc0 + 2 * t + 1] : (4 << 16);
             x0[u] = OB[rE + (qa[u] & 0xff)]; x1[u] = IB[r1 + ((qa[u] >> 8) & 0xff)]; x2[u] = IB[r2 + ((qa[u] >> 16) & 0xff)];
             // (own inside value of the target: the posterior of the energy statistic for an inner pair, and a reason to skip the
             // add when it is 0 -- for the loops, whose inside values are practically never 0, the load would only cost: the
@@ -2246,6 +2297,9 @@ static void set_rcps(LinArgs& a, bool fast) {
   a.rcp_lane = 1.0f / (float)std::max(fast ? a.lay.n_lane : a.lay.n_active, 1);
   a.rcp_cpb = 1.0f / (float)std::max(a.cpb, 1);
   a.rcp_3cpb = 1.0f / (float)std::max(3 * a.cpb, 1);
+  // deterministic mode: lanes per cell in the pair phases = the power of two >= n_ap (no cell then straddles two waves)
+  a.det_sh = -1;
+  if (a.lay.n_ap <= 64) { a.det_sh = 0; while ((1 << a.det_sh) < a.lay.n_ap) ++a.det_sh; }
 }
 static int nblk_for(int nb, int G, int nmax, int req) {
   if (nmax <= 1 || (req <= 0 && (long long)nb * G <= 6144)) return 1;
@@ -2356,12 +2410,12 @@ hipError_t launch_lin_group(const LinArgs& full, int G, int Lmax, int Wmax, bool
   a.fast = fast ? 1 : 0;
   if (fast) a.cpb = std::min(kBT / std::max(a.lay.n_lane, 1), ELEMDP_CPB_MAX);   // (states without any column take no lane)
   a.n_lin = fast ? a.lay.lin_total : kLinEth + nt;
-  const int NW = a.det ? kBT / 64 : 1;
+  const int NW = a.det ? kBT / 64 : 1;   // (copies of the statistics of k4_out: one per wave in the deterministic mode)
   const int hd = fast ? a.lay.n_lane : S;   // stride of the heavy sums per cell (k4_in / k4_out: HD)
   set_rcps(a, fast);
   const int nbmax_in = nblk_max(a.cpb, fast, a.det != 0, full.nblk, 0), nbmax_out = nblk_max(a.cpb, fast, a.det != 0, full.nblk, 1);
-  auto lds_in_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(NW * 2 * a.cpb * hd + kRecIn, ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total; };
-  auto lds_out_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(out_doubles(a.cpb * hd, nt, ct + Wmax + 3, NW), ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * ct, fast ? kCellOutD : 0).total; };
+  auto lds_in_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(2 * a.cpb * hd + kRecIn, ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_in_n : staged_ints(a.lay, a.n_stage, 0), 0, fast ? kCellInD : 0).total; };
+  auto lds_out_of = [&](int nblk) { const int ct = a.cpb * nblk; return (size_t)block_lds(out_doubles(a.cpb * hd, nt, ct + Wmax + 3, NW, false), ct, a.n_lin, ct + Wmax + 3, fast ? a.lay.fb_out_n : staged_ints(a.lay, a.n_stage, 1), 3 * ct, fast ? kCellOutD : 0).total; };
   const size_t lds_in = lds_in_of(1);
   const size_t lds_stat = sizeof(double) * (2 * nt + 4);
   if (!a.no_rss)

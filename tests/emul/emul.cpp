@@ -619,6 +619,46 @@ int emu_scan_flags(void* h, int32_t* out, int cap) {
       }
   return (n == A.n_wr + A.n_wl + A.n_wp) ? n : -3;
 }
+// Deterministic-mode tuple lists (AutomatonLayout::qd_* / fqd_*): every live tuple of a column-record list appears exactly once, in
+// the share of the wave (target & 3); dead tuples in none.  Returns 0, or the number of the first violated rule.
+static int check_det(const std::vector<int32_t>& I, int qc, int qd, int n) {
+  std::vector<int> seen(n, 0);
+  if (I[qd] != 0) return 1;
+  for (int w = 0; w < 4; ++w) {
+    if (I[qd + w + 1] < I[qd + w] || I[qd + w + 1] > n) return 2;
+    for (int k = I[qd + w]; k < I[qd + w + 1]; ++k) {
+      const int t = I[qd + 5 + k];
+      if (t < 0 || t >= n) return 3;
+      const int word = I[qc + 2 * t + 1];
+      if ((word >> 16) & 4) return 4;                 // a dead tuple was dealt
+      if (((word & 0xffff) & 3) != w) return 5;       // to the wrong wave
+      if (seen[t]++) return 6;
+    }
+  }
+  for (int t = 0; t < n; ++t) if (!seen[t] && !((I[qc + 2 * t + 1] >> 16) & 4)) return 7;   // a live tuple was left out
+  return 0;
+}
+int emu_check_det_lists(void* h) {
+  Emu& E = *(Emu*)h;
+  const AutomatonLayout* lays[3] = {&E.lay, &E.lay_r, &E.lay_s};
+  const std::vector<int32_t>* ints[3] = {&E.ints, &E.ints_r, &E.ints_s};
+  for (int k = 0; k < 3; ++k) {
+    const AutomatonLayout& A = *lays[k];
+    const std::vector<int32_t>& I = *ints[k];
+    const int nq = A.n_quad;
+    if (int r = check_det(I, A.qc_in, A.qd_in, nq)) return 100 * (k + 1) + r;
+    if (int r = check_det(I, A.fqc_in, A.fqd_in, nq)) return 100 * (k + 1) + 10 + r;
+    for (int role = 0; role < 3; ++role) {
+      if (int r = check_det(I, A.qc_out1 + role * 2 * nq, A.qd_out + role * (5 + nq), nq)) return 100 * (k + 1) + 20 + 10 * role + r;
+      if (int r = check_det(I, A.fqc_out + role * 2 * nq, A.fqd_out + role * (5 + nq), nq)) return 100 * (k + 1) + 50 + 10 * role + r;
+    }
+    if (!(A.qd_in >= A.n_small && A.qd_in + 5 + nq <= A.big_in_end)) return 100 * (k + 1) + 91;     // staged with the inside run
+    if (!(A.qd_out >= A.big_in_end && A.qd_out + 3 * (5 + nq) <= A.n_ints)) return 100 * (k + 1) + 92;
+    if (!(A.fqd_in >= A.fb_in && A.fqd_in + 5 + nq <= A.fb_in + A.fb_in_n)) return 100 * (k + 1) + 93;
+    if (!(A.fqd_out >= A.fb_out && A.fqd_out + 3 * (5 + nq) <= A.fb_out + A.fb_out_n)) return 100 * (k + 1) + 94;
+  }
+  return 0;
+}
 int emu_pattern_nodes(void* h) { return ((Emu*)h)->lay.M; }
 double emu_sum_ext_m(void* h, const uint8_t* seq, int L, int i, int j, int ext) { return sum_ext_m(((Emu*)h)->et, seq, L, i, j, ext); }
 

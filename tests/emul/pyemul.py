@@ -27,6 +27,7 @@ def lib():
         L.emu_set_fast.argtypes = [C.c_void_p, C.c_int]
         L.emu_set_fast.restype = C.c_int
         L.emu_fast_cells.restype = C.c_long
+        L.emu_check_det_lists.argtypes = [C.c_void_p]
         L.emu_energy_table.argtypes = [C.c_void_p, C.c_char_p, dp, C.c_int]
         L.emu_hairpin_energy.restype = C.c_double
         L.emu_hairpin_energy.argtypes = [C.c_void_p, u8, C.c_int, C.c_int, C.c_int]

@@ -8,7 +8,7 @@ import pytest
 
 from oracle import pyoracle as po
 from tests.emul.pyemul import lib
-from tests.test_emul_vs_oracle import CASES, SCAN, model_pair
+from tests.test_emul_vs_oracle import CASES, PAR, SCAN, model_pair
 from tests.util import assert_log_close, gpath
 
 
@@ -117,3 +117,15 @@ def test_lik_ratio_with_shuffled_negatives_reproduces_the_reference_trace_with_t
     for row, y, g2 in zip(r["trace"], t["iter_fn"], t["iter_gnorm"]):
         assert row[4] == pytest.approx(y, rel=2e-5, abs=1e-9)
         assert row[2] == pytest.approx(g2, rel=2e-5)
+
+
+@pytest.mark.parametrize("pattern", ["((.*.))", "(.....)", ".(.).", "(.(.).)", "(.*)", "((((.....))))"])
+@pytest.mark.parametrize("prune", [0, 1])
+def test_deterministic_mode_tuple_lists(pattern, prune):
+    """The tuple lists of the deterministic mode (AutomatonLayout::qd_* / fqd_*): the tuples of every interior-loop column-record
+    list dealt to the four waves of a workgroup by target -- each live tuple in exactly one share, the share of its target, dead
+    tuples in none, and every list inside the run of the blob its kernel stages (plain, one-state and shadow automaton)."""
+    from tests.emul.pyemul import Emul
+    e = Emul(pattern, PAR)
+    e.set_prune(prune)
+    assert lib().emu_check_det_lists(e.h) == 0
