@@ -206,6 +206,7 @@ class Engine {
   int n_state() const { return au_.S(); }
   int n_node() const { return au_.M(); }
   const Automaton& automaton() const { return au_; }
+  const AutomatonLayout& layout() const { return lays_.shadow >= 0 ? lays_ : lay_; }   // (what a train evaluation sweeps)
   bool softmax() const { return flags_ & ELEMDP_THETA_SOFTMAX; }
 
   void load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* qual, const int32_t* qoff, const char* fix, int n);
@@ -2034,6 +2035,15 @@ int elemdp_initial_params(const elemdp_handle* h, double lambda_init, double* x,
 int elemdp_describe(const elemdp_handle* h, char* buf, int32_t cap) {
   if (!h || !buf) return ELEMDP_EINVAL;
   std::string s = h->e->automaton().to_json();
+  {   // sizes of the flattened automaton the kernels sweep (pruned as the options say): for inspection and tests
+    const elemdp::AutomatonLayout& L = h->e->layout();
+    char extra[320];
+    std::snprintf(extra, sizeof(extra), ", \"layout\": {\"S\": %d, \"n_ap\": %d, \"n_quad\": %d, \"n_split\": %d, \"n_lane\": %d, \"n_front\": %d, \"fp_ok\": %d, "
+                  "\"shadow\": %d, \"n_ints\": %d, \"fast_blob_in\": %d, \"fast_blob_out\": %d}}",
+                  L.S, L.n_ap, L.n_quad, L.n_split, L.n_lane, L.n_front, L.fp_ok, L.shadow, L.n_ints, L.fb_in_n, L.fb_out_n);
+    const size_t close = s.rfind('}');
+    if (close != std::string::npos) s = s.substr(0, close) + extra;
+  }
   if ((int)s.size() + 1 > cap) return ELEMDP_EINVAL;
   std::memcpy(buf, s.c_str(), s.size() + 1);
   return (int)s.size();

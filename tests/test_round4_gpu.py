@@ -217,3 +217,27 @@ def test_streamed_scan_of_several_large_chunks_equals_the_resident_scan():
         a = o.scan_seq(seqs[k], quals[k])
         assert (r1[k]["Ys"], r1[k]["Ye"]) == (a["Ys"], a["Ye"]) and r1[k]["rss"] == a["rss"]
         assert r1[k]["exist_prob"] == pytest.approx(a["exist_prob"], rel=1e-8)
+
+
+@pytest.mark.parametrize("pattern,prune", [("((.*.))", 1), ("(.....)", 1), ("(.*.)(.*.)(.*.)", 1), ("(.*.)(.*.)(.*.)", 0), ("((.*.))", 0)])
+def test_deterministic_mode_on_other_automata(pattern, prune):
+    """Option "deterministic" (one copy of the heavy sums, every sum single-writer: pairs of a cell in one wave, tuples dealt to the
+    waves by target, stem cells by wave) on automata of other shapes: the complete lists of `(.*.)(.*.)(.*.)` have 124 pairs -- more
+    than a wave, so one wave alone walks the pair phases -- and run the generic kernels.  Repeats are bit-identical (also after an
+    evaluation at another point through the same slots), and equal the default mode to its own reproducibility."""
+    seqs, quals = ragged(1900, ((30, 4), (120, 6), (61, 5), (200, 4)))
+    for k in range(0, len(quals), 3):
+        quals[k][-1] = 5
+    eng = api.Engine(pattern, "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+    eng.set_option("prune", prune)
+    eng.load_batch(seqs, quals)
+    x = eng.initial_params(0.6)
+    x[:-2] += np.linspace(-0.25, 0.25, len(x) - 2)
+    ref = eng.train_eval(x)
+    eng.set_option("deterministic", 1)
+    a = eng.train_eval(x)
+    eng.train_eval(x + 0.01)
+    b = eng.train_eval(x)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
+    assert a[0] == pytest.approx(ref[0], rel=1e-11)
+    np.testing.assert_allclose(a[1], ref[1], rtol=1e-9, atol=1e-9)
