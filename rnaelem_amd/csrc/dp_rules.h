@@ -227,6 +227,24 @@ struct TableView {
     const int c = col(e, s);
     if (live && c >= 0) band[cidx(e, d, i, c)] = v;
   }
+  // ---- the Viterbi pass (max-plus, scan_rules.h) on either layout: dense [e][d][i][s] (the fused scan kernel, the CPU driver), or
+  // -- cyk_compact, the batch pipeline -- the compact rows above with EVERY cell stored (log 0 where a cell is not parsable) and a
+  // missing column read as log 0 / never written: an entry without a column cannot occur in a complete parse, so no kept transition
+  // reads it (Automaton::flatten keeps a transition only under a useful parent, and its children are then useful themselves).
+  // The dense table of (.....) is 203 doubles per cell, the compact one 64; the split points of rule 2 read rows of 5 front
+  // states out of 232-byte rows there, out of 64-byte rows here.
+  int32_t cyk_compact = 0;
+  ELEMDP_HD double ldm(int e, int d, int i, int s) const {
+    if (!cyk_compact) return band[idx(e, d, i, s)];
+    const int c = col(e, s);
+    const double v = band[c >= 0 ? cidx(e, d, i, c) : 0u];
+    return c >= 0 ? v : ELEMDP_NEG_INF;
+  }
+  ELEMDP_HD void stm(int e, int d, int i, int s, double v) const {
+    if (!cyk_compact) { band[idx(e, d, i, s)] = v; return; }
+    const int c = col(e, s);
+    if (c >= 0) band[cidx(e, d, i, c)] = v;
+  }
   // pair table: an entry (d, i, .) exists iff 0 < dmin[i] < d
   ELEMDP_HD double lda(int d, int i, int p, bool live = true) const {
     const double v = ap[live ? aidx(d, i, p) : 0u];

@@ -194,6 +194,7 @@ struct LinArgs {
                                   // a cell in one wave: det_sh; tuples dealt to the waves by target: AutomatonLayout::qd_*), the
                                   // statistics one copy per wave, one row of counts per (sequence, block):
                                   // det_rows[n][det_nslot][out_stride], summed in order by k4_combine
+  int32_t cyk_compact;            // scan, Viterbi pass: the table in the compact layout (TableView::ldm / stm), set by launch_cyk_group
   int32_t det_sh;                 // log2 of the lanes a cell's pairs take in the pair phases of the deterministic mode (a power of two
                                   // >= n_ap, so that no cell straddles two waves); -1: more than 64 pairs, one wave does the phase
   double* det_rows; int32_t det_nslot;

@@ -290,6 +290,37 @@ __global__ __launch_bounds__(kThreads) void k_role_scatter(PlanKernelArgs a, int
   const int pos = atomicAdd(&a.p.cursor[p.off_base + key], 1);
   role_idx(a.p, role)[p.item_base + role_off(a.p, role)[p.off_base + key] + pos] = t;
 }
+// The three roles in one pass each (plans that keep item copies in the secondary orders: PlanArrays::items_inner .. are allocated
+// before the lists are built and serve as scratch here).  The count pass keeps the RANK its atomicAdd returns -- the position of
+// the item among the items of its key -- so the scatter pass needs no cursor and no atomics, and an item is read once per pass
+// instead of once per role and pass: 12 launches -> 6, six atomics per item -> three.
+__global__ __launch_bounds__(kThreads) void k_role_zero3(PlanKernelArgs a) {
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
+  const int c = blockIdx.x * kThreads + threadIdx.x;
+  if (c > (p.L + 1) * (p.W + 1)) return;
+  a.p.by_inner_off[p.off_base + c] = 0;
+  a.p.by_left_off[p.off_base + c] = 0;
+  a.p.by_right_off[p.off_base + c] = 0;
+}
+__global__ __launch_bounds__(kThreads) void k_role_count3(PlanKernelArgs a) {
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= p.n_items) return;
+  const LoopItem it = a.p.items[p.item_base + t];
+  int32_t* rank = reinterpret_cast<int32_t*>(a.p.items_inner) + (size_t)(p.item_base + t) * 3;
+#pragma unroll
+  for (int role = 0; role < 3; ++role) rank[role] = atomicAdd(&role_off(a.p, role)[p.off_base + role_key(it, role, p.W)], 1);
+}
+__global__ __launch_bounds__(kThreads) void k_role_scatter3(PlanKernelArgs a) {
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= p.n_items) return;
+  const LoopItem it = a.p.items[p.item_base + t];
+  const int32_t* rank = reinterpret_cast<const int32_t*>(a.p.items_inner) + (size_t)(p.item_base + t) * 3;
+#pragma unroll
+  for (int role = 0; role < 3; ++role)
+    role_idx(a.p, role)[p.item_base + role_off(a.p, role)[p.off_base + role_key(it, role, p.W)] + rank[role]] = t;
+}
 // Sorts every segment of one role by item index (the scatter above leaves them in arbitrary order).  The segments of the
 // cells (i, 0..W) of one row are contiguous in the CSR array: a workgroup takes a row, builds the composite values
 // (cell << 32 | item index) in LDS, bitonic-sorts the whole row -- the cells are already grouped, so this sorts inside every
@@ -737,6 +768,12 @@ hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
   const dim3 cells((a.ncell_max + 1 + kThreads - 1) / kThreads, a.count), items((a.nitems_max + kThreads - 1) / kThreads, a.count);
   hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, -1);
   hipLaunchKernelGGL(k_plan_fill, dim3((a.ncell_max + kPlanTile * kThreads - 1) / (kPlanTile * kThreads), a.count), dim3(kThreads), 0, st, a);
+  if (a.n_roles == 3 && a.p.items_inner) {      // (ranks kept in the buffer of the item copies, which launch_permute_items fills later)
+    hipLaunchKernelGGL(k_role_zero3, cells, dim3(kThreads), 0, st, a);
+    if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_count3, items, dim3(kThreads), 0, st, a);
+    for (int role = 0; role < 3; ++role) hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, role);
+    if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_scatter3, items, dim3(kThreads), 0, st, a);
+  } else
   for (int role = 0; role < a.n_roles; ++role) {
     hipLaunchKernelGGL(k_role_zero, cells, dim3(kThreads), 0, st, a, role);
     if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_count, items, dim3(kThreads), 0, st, a, role);

@@ -216,6 +216,7 @@ __device__ __forceinline__ void make_lviews(const LinArgs& a, int g, LViews& v) 
   v.in.nA = v.out.nA = a.lay.n_ap;
   v.in.set_compact(a.lay, a.ints);      // (the column map moves to LDS with the automaton blob: stage_context)
   v.out.set_compact(a.lay, a.ints);
+  v.in.cyk_compact = a.cyk_compact;      // (the Viterbi pass sweeps band_in: TableView::ldm / stm)
   q.okbits_end = a.okbits_end ? a.okbits_end + p.bits_base : nullptr;
   v.row = a.seq_out + (size_t)n * a.out_stride;
   v.zs = a.zs + (size_t)g * 4;
@@ -2059,6 +2060,8 @@ __global__ __launch_bounds__(kBT, KOWN <= 2 ? ELEMDP_LB_CYK : 6) void k5_cyk(Lin
       if (x > 0 && x <= d && s1 < NU && s2 < NU) { po1[r] = c * NU + s1; po2[r] = c * NU + s2; }
     }
   }
+  const int kf = sm.act ? sm.r - sm.cell * NU : 0;      // the front state this lane stages
+  const int fc1 = a.cyk_compact ? v.in.col(ST_1, kf) : 0, fc2 = a.cyk_compact ? v.in.col(ST_2, kf) : 0;
   for (int q0 = (a.dbg & 256) ? d : a_lo; q0 < d; q0 += KC) {   // (dbg 256 / 512: timing experiments without the split / item sums)
     if (sm.act) {
 #pragma unroll
@@ -2066,8 +2069,16 @@ __global__ __launch_bounds__(kBT, KOWN <= 2 ? ELEMDP_LB_CYK : 6) void k5_cyk(Lin
         const int q = q0 + u * sm.nsub + sm.sub;
         const bool ok = q < d;
         const int aa = ok ? q : q0;
-        const double x1 = B[v.in.idx(ST_1, aa, i0, 0) + sm.goff];
-        const double x2 = B[v.in.idx(ST_2, d - aa, i0 + aa, 0) + sm.goff];
+        double x1, x2;
+        if (a.cyk_compact) {      // (rows of the compact layout: the lane's front state through its columns in planes 1 and 2)
+          x1 = B[fc1 >= 0 ? v.in.cidx(ST_1, aa, i0 + sm.cell, fc1) : 0u];
+          x2 = B[fc2 >= 0 ? v.in.cidx(ST_2, d - aa, i0 + aa + sm.cell, fc2) : 0u];
+          x1 = fc1 >= 0 ? x1 : NEG;
+          x2 = fc2 >= 0 ? x2 : NEG;
+        } else {
+          x1 = B[v.in.idx(ST_1, aa, i0, 0) + sm.goff];
+          x2 = B[v.in.idx(ST_2, d - aa, i0 + aa, 0) + sm.goff];
+        }
         st1[(u * sm.nsub + sm.sub) * CU + sm.r] = ok ? x1 : NEG;
         st2[(u * sm.nsub + sm.sub) * CU + sm.r] = ok ? x2 : NEG;
       }
@@ -2122,9 +2133,9 @@ __global__ __launch_bounds__(kBT, KOWN <= 2 ? ELEMDP_LB_CYK : 6) void k5_cyk(Lin
             const int i = i0 + c, j = i + d;
             const int tgs = G[A.quad_tgt + t];
             ok[u] = ok[u] && meta >= 0;   // (sign bit: not in the inside set)
-            x0[u] = B[v.in.idx(ST_P, it.l - it.k, it.k, G[A.quad_ent + 3 * t])];
-            x1[u] = B[v.in.idx(ST_L, it.k - i, i, G[A.quad_ent + 3 * t + 1])];
-            x2[u] = B[v.in.idx(ST_L, j - it.l, it.l, G[A.quad_ent + 3 * t + 2])];
+            x0[u] = v.in.ldm(ST_P, it.l - it.k, it.k, G[A.quad_ent + 3 * t]);
+            x1[u] = v.in.ldm(ST_L, it.k - i, i, G[A.quad_ent + 3 * t + 1]);
+            x2[u] = v.in.ldm(ST_L, j - it.l, it.l, G[A.quad_ent + 3 * t + 2]);
             lt[u] = ELEMDP_MUL_RN(v.m.lam(tgs), it.tsc);
             const int li = v.m.ints[A.st_li + tgs];
             ok[u] = ok[u] && li >= 0;
@@ -2233,6 +2244,7 @@ hipError_t launch_cyk_group(const LinArgs& full, int G, int Lmax, int Wmax, hipS
   a.ext_ring = G <= 1024 ? 1 : 0;
   a.lmax = Lmax;
   a.n_lin = kLinEth + nt; a.fast = 0; a.det = 0;
+  a.cyk_compact = getenv("ELEMDP_CYK_DENSE") ? 0 : 1;   // (the dense table only for comparisons)
   // cells per workgroup: a lane per (cell, live state) in the unary part, the front rows of all cells in one staging row, at most
   // four (cell, split tuple) products per lane
   const int NLc = std::max(a.lay.n_lane, 1);

@@ -60,7 +60,7 @@ ELEMDP_HD MaxAcc cyk_split_best(const ModelView& m, const SeqView& q, const Tabl
     if (dk == 0 || j - k < dk) continue;
     for (int t = G[A.split_off + s]; t < G[A.split_off + s + 1]; ++t) {
       const int s1 = G[A.split_ent + 2 * t], s2 = G[A.split_ent + 2 * t + 1];
-      aB.offer(T.at(ST_1, k - i, i, s1) + T.at(ST_2, j - k, k, s2), i, k, TT_B_12, ST_1, s1);
+      aB.offer(T.ldm(ST_1, k - i, i, s1) + T.ldm(ST_2, j - k, k, s2), i, k, TT_B_12, ST_1, s1);
     }
   }
   return aB;
@@ -78,7 +78,7 @@ ELEMDP_HD MaxAcc cyk_item_best(const ModelView& m, const SeqView& q, const Table
     const double lt = ELEMDP_MUL_RN(lam, x.tsc);
     for (int t = G[A.quad_off + s]; t < G[A.quad_off + s + 1]; ++t) {
       const int s1 = G[A.quad_ent + 3 * t], s2 = G[A.quad_ent + 3 * t + 1], s3 = G[A.quad_ent + 3 * t + 2];
-      aE.offer(T.at(ST_P, x.l - x.k, x.k, s1) + (T.at(ST_L, x.k - i, i, s2) + (T.at(ST_L, j - x.l, x.l, s3) + lt)), x.k,
+      aE.offer(T.ldm(ST_P, x.l - x.k, x.k, s1) + (T.ldm(ST_L, x.k - i, i, s2) + (T.ldm(ST_L, j - x.l, x.l, s3) + lt)), x.k,
                x.l, TT_E_P, ST_P, s1);
     }
   }
@@ -87,7 +87,7 @@ ELEMDP_HD MaxAcc cyk_item_best(const ModelView& m, const SeqView& q, const Table
 
 ELEMDP_HD void cyk_put(const TableView& T, const TraceView& R, int e, int d, int i, int s, const MaxAcc& a) {
   if (R.one) R.one[e] = a.tr;
-  else T.at(e, d, i, s) = a.best;
+  else T.stm(e, d, i, s, a.best);
 }
 
 // everything else of the target; hB = winner of rule 2 (used when left_ok), hE = winner of rule 6c (used when e_ok).
@@ -112,7 +112,7 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
         for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
           const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
           if (!allow_right(m, c, q.L, j, s, s1)) continue;
-          aL.offer(T.at(ST_L, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_L_L, ST_L, s1);
+          aL.offer(T.ldm(ST_L, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_L_L, ST_L, s1);
         }
     }
     cyk_put(T, R, ST_L, d, i, s, aL);
@@ -126,13 +126,13 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
       for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {  // all 1a candidates first ...
         const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
         if (!allow_pair(m, c, q.L, i, j, s, s1)) continue;
-        aP.offer(T.at(ST_E, d - 2, i + 1, s1) + w_pair(m, q, s, s1, tf, i, j - 1), i + 1, j - 1, TT_P_E, ST_E, s1);
+        aP.offer(T.ldm(ST_E, d - 2, i + 1, s1) + w_pair(m, q, s, s1, tf, i, j - 1), i + 1, j - 1, TT_P_E, ST_E, s1);
       }
       if (est != NEG)
         for (int t = I[A.pair_off + s]; t < I[A.pair_off + s + 1]; ++t) {  // ... then 1b
           const int s1 = I[A.pair_ent + 2 * t], tf = I[A.pair_ent + 2 * t + 1];
           if (!allow_pair(m, c, q.L, i, j, s, s1)) continue;
-          aP.offer(T.at(ST_P, d - 2, i + 1, s1) + (w_pair(m, q, s, s1, tf, i, j - 1) + ELEMDP_MUL_RN(lam, est)), i + 1, j - 1, TT_P_P,
+          aP.offer(T.ldm(ST_P, d - 2, i + 1, s1) + (w_pair(m, q, s, s1, tf, i, j - 1) + ELEMDP_MUL_RN(lam, est)), i + 1, j - 1, TT_P_P,
                    ST_P, s1);
         }
     }
@@ -152,15 +152,15 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
           for (int t = I[A.right_off + s]; t < I[A.right_off + s + 1]; ++t) {
             const int s1 = I[A.right_ent + 2 * t], tf = I[A.right_ent + 2 * t + 1];
             if (!allow_right(m, c, q.L, j, s, s1)) continue;
-            a2.offer(T.at(ST_2, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_2_2, ST_2, s1);
+            a2.offer(T.ldm(ST_2, d - 1, i, s1) + w_right(m, q, s, tf, j - 1), i, j - 1, TT_2_2, ST_2, s1);
           }
         if (pok) {
           const double eml = q.e_ml[q.cell(i, d)];
-          if (eml != NEG) a2.offer((all ? aP.best : T.at(ST_P, d, i, s)) + ELEMDP_MUL_RN(lam, eml), i, j, TT_2_P, ST_P, s);
+          if (eml != NEG) a2.offer((all ? aP.best : T.ldm(ST_P, d, i, s)) + ELEMDP_MUL_RN(lam, eml), i, j, TT_2_P, ST_P, s);
         }
       }
       if (want(ST_1)) {
-        a1.offer(all ? a2.best : T.at(ST_2, d, i, s), i, j, TT_1_2, ST_2, s);
+        a1.offer(all ? a2.best : T.ldm(ST_2, d, i, s), i, j, TT_1_2, ST_2, s);
         a1.offer(aB.best, i, j, TT_1_B, ST_B, s);
       }
     }
@@ -176,7 +176,7 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
         for (int t = I[A.left_off + s]; t < I[A.left_off + s + 1]; ++t) {
           const int s1 = I[A.left_ent + 2 * t], tf = I[A.left_ent + 2 * t + 1];
           if (!allow_left(m, c, i, s, s1)) continue;
-          aM.offer(T.at(ST_M, d - 1, i + 1, s1) + w_left(m, q, s1, tf, i), i + 1, j, TT_M_M, ST_M, s1);
+          aM.offer(T.ldm(ST_M, d - 1, i + 1, s1) + w_left(m, q, s1, tf, i), i + 1, j, TT_M_M, ST_M, s1);
         }
       if (lok) aM.offer(aB.best, i, j, TT_M_B, ST_B, s);
     }
@@ -187,8 +187,8 @@ ELEMDP_HD void cyk_target_u(const ModelView& m, const SeqView& q, const TableVie
     MaxAcc aE;
     if (q.e_ok(i, d)) {
       const int pc = q.cell(i - 1, d + 2);
-      if (mok) { const double t = q.e_close[pc]; if (t != NEG) aE.offer((all ? aM.best : T.at(ST_M, d, i, s)) + ELEMDP_MUL_RN(lam, t), i, j, TT_E_M, ST_M, s); }
-      if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) aE.offer((all ? aL.best : T.at(ST_L, d, i, s)) + ELEMDP_MUL_RN(lam, t), i, j, TT_E_H, ST_L, s); }
+      if (mok) { const double t = q.e_close[pc]; if (t != NEG) aE.offer((all ? aM.best : T.ldm(ST_M, d, i, s)) + ELEMDP_MUL_RN(lam, t), i, j, TT_E_M, ST_M, s); }
+      if (isloop) { const double t = q.e_hp[pc]; if (t != NEG) aE.offer((all ? aL.best : T.ldm(ST_L, d, i, s)) + ELEMDP_MUL_RN(lam, t), i, j, TT_E_H, ST_L, s); }
       if (aE.best < hE.best) aE = hE;   // (the item candidates come last; the first strictly greatest one wins)
     }
     cyk_put(T, R, ST_E, d, i, s, aE);
@@ -210,7 +210,7 @@ ELEMDP_HD TraceRec cyk_retrace(const ModelView& m, const SeqView& q, const Table
   MaxAcc hB, hE;
   if (q.left_ok(i, d)) {
     if (e == ST_B) hB = cyk_split_best(m, q, T, d, i, s);
-    else hB.best = T.at(ST_B, d, i, s);
+    else hB.best = T.ldm(ST_B, d, i, s);
   }
   if (e == ST_E && q.e_ok(i, d)) hE = cyk_item_best(m, q, T, d, i, s);
   TraceRec rec[kNumBandStates];
@@ -230,7 +230,7 @@ ELEMDP_HD void cyk_ext_pair(const ModelView& m, const TableView& T, MaxAcc& a, i
   const double lt = ELEMDP_MUL_RN(m.lam(s), t);
   for (int u = G[A.split_off + s]; u < G[A.split_off + s + 1]; ++u) {
     const int s2 = G[A.split_ent + 2 * u], s1 = G[A.split_ent + 2 * u + 1];
-    a.offer(T.o(i, s2) + (T.at(ST_P, d, i, s1) + lt), i, j, TT_O_OP, ST_P, s1);
+    a.offer(T.o(i, s2) + (T.ldm(ST_P, d, i, s1) + lt), i, j, TT_O_OP, ST_P, s1);
   }
 }
 // ... and rule 8 (the candidates behind those of rule 7), the value and the record

@@ -1052,7 +1052,11 @@ int emu_scan_seq_lin(void* h, const double* x, const uint8_t* seq, int L, const 
     for (int p = 0; p <= L; ++p) lPye[p] = tolog(Pye[p]);
     const int Ye = last_argmax(lPye.data(), L + 1);
     // K6: Viterbi parse in log space (scan_rules.h)
+    // (with the table-driven forms: the Viterbi pass on the COMPACT table, as launch_cyk_group runs it -- every entry starts as NaN,
+    // so a read of an entry nobody stored would show in the parse)
     Tab cyk(L, P.W, S);
+    LinTab cykc(L, P.W, m.lay, E.ints.data());
+    if (E.fast) { cyk.v = cykc.v; cyk.v.cyk_compact = 1; }
     std::vector<TraceRec> tro((size_t)(L + 1) * S);
     TraceView tv{tro.data()};
     Constraint c2{Ys, Ye, 1};
