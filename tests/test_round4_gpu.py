@@ -241,3 +241,27 @@ def test_deterministic_mode_on_other_automata(pattern, prune):
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3]
     assert a[0] == pytest.approx(ref[0], rel=1e-11)
     np.testing.assert_allclose(a[1], ref[1], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("pattern", ["((.*.))", "(.....)", ".(.).", "(.(.).)"])
+def test_viterbi_pass_on_the_compact_table_equals_the_dense_one(pattern, monkeypatch):
+    """k5_cyk / k5_cyk_ext / the traceback on the compact table layout (TableView::ldm / stm: every cell stored, a missing column
+    read as log 0) against the dense [e][d][i][s] table of round 3 (ELEMDP_CYK_DENSE, read at every launch): the same parse for
+    every sequence of a ragged batch with masked positions, poly-A stretches (ties) included -- CYKFun / trace_back,
+    motif_scanner.hpp:802-913, :262-362."""
+    seqs, quals = ragged(2100, ((33, 5), (150, 6), (300, 3), (71, 6)))
+    seqs.append(np.full(90, 1, dtype=np.uint8))                      # AAAA...: every parse ties with many others
+    quals.append(np.r_[np.full(90, 10, dtype=np.uint8), np.uint8(0)])
+    for k in range(0, len(quals), 4):
+        quals[k][len(quals[k]) // 3] = 5
+    eng = api.Engine(pattern, "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+    eng.load_batch(seqs, quals)
+    x = eng.initial_params(0.8)
+    x[:-2] += np.linspace(-0.35, 0.35, len(x) - 2)
+    monkeypatch.delenv("ELEMDP_CYK_DENSE", raising=False)
+    compact, _ = eng.scan(x)
+    monkeypatch.setenv("ELEMDP_CYK_DENSE", "1")
+    dense, _ = eng.scan(x)
+    for a_, b_ in zip(compact, dense):
+        assert (a_["Ys"], a_["Ye"]) == (b_["Ys"], b_["Ye"])
+        assert a_["rss"] == b_["rss"] and np.array_equal(a_["psihat"], b_["psihat"])
