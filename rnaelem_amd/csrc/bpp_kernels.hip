@@ -16,14 +16,18 @@
 // Same sums as k3_bpp_* (train_kernels.hip), which stay for spans beyond the linear range (W > kBppLinMaxSpan).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "kernels.h"
 #include "plan_rules.h"
 
 namespace elemdp {
 namespace {
 
-enum { BP_P = 0, BP_E, BP_M, BP_B, BP_1, BP_2, BP_A, BP_IN_PLANES };   // inside planes
-enum { BO_P = 0, BO_E, BO_M, BO_2, BO_A, BO_OUT_PLANES };              // outside planes (divided by Z)
+enum { BP_P = 0, BP_E, BP_M, BP_B, BP_1, BP_2, BP_A, BP_X, BP_IN_PLANES = BP_X + BC_CLASSES };   // inside planes; BP_X + c: P times the inner pair's factor of class c
+enum { BO_P = 0, BO_E, BO_M, BO_2, BO_A, BO_X, BO_OUT_PLANES = BO_X + BC_CLASSES };   // outside planes (divided by Z); BO_X + c: E times the closing pair's factor of class c
+static_assert(BP_IN_PLANES == kBppInPlanes && BO_OUT_PLANES == kBppOutPlanes, "plane counts of kernels.h");
 enum { XW_STACK = 0, XW_EXT, XW_ML, XW_CLOSE, XW_HP };
 
 struct Seq {
@@ -147,12 +151,12 @@ __host__ __device__ inline int bpp_mask_rows(int W) { return kC + W + kMaxLoop +
 __host__ __device__ inline int bpp_mask_words(int W) { return (bpp_mask_rows(W) * (W + 1) + 31) / 32 + 3; }
 
 // stage s[lo..hi] and return a pointer p with p[x] = s[x] for lo <= x <= hi (the plain pointer if the window is too long)
-__device__ __forceinline__ const uint8_t* stage_seq(const Seq& q, BppLds& sh, int lo, int hi) {
+__device__ __forceinline__ const uint8_t* stage_seq(const Seq& q, uint8_t* buf, int lo, int hi) {
   if (lo < 0) lo = 0;
   if (hi > q.L - 1) hi = q.L - 1;
   if (hi - lo + 1 > kWin) return q.seq;
-  for (int x = lo + (int)threadIdx.x; x <= hi; x += kThreads) sh.seq[x - lo] = q.seq[x];
-  return sh.seq - lo;
+  for (int x = lo + (int)threadIdx.x; x <= hi; x += kThreads) buf[x - lo] = q.seq[x];
+  return buf - lo;
 }
 // stage the mask rows [r_lo, r_hi] (clipped to the sequence) and return a pointer m with m[w] = ok[w] for their words
 __device__ __forceinline__ const uint32_t* stage_bits(const Seq& q, int r_lo, int r_hi) {
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void k6_in(BppLinArgs a) {
   if (i0 > q.L - d) return;
   const int W = q.W, L = q.L;
   const int nc = (kC < L - d - i0 + 1) ? kC : L - d - i0 + 1;
-  const uint8_t* sq = stage_seq(q, sh, i0 - 1, i0 + nc - 1 + d);
+  const uint8_t* sq = stage_seq(q, sh.seq, i0 - 1, i0 + nc - 1 + d);
   const Mask mk{stage_bits(q, i0 - 1, i0 + nc - 1 + d), L, W};
   if (tid < kC) sh.dmin[tid] = (tid < nc) ? q.dmin[i0 + tid] : 0;
   __syncthreads();
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
   if (i0 > q.L - d) return;
   const int W = q.W, L = q.L;
   const int nc = (kC < L - d - i0 + 1) ? kC : L - d - i0 + 1;
-  const uint8_t* sq = stage_seq(q, sh, i0 - q.C - 2, i0 + nc + W);
+  const uint8_t* sq = stage_seq(q, sh.seq, i0 - q.C - 2, i0 + nc + W);
   const int Cc = (q.C < kMaxLoop) ? q.C : kMaxLoop;
   const Mask mk{stage_bits(q, i0 - Cc - 2, i0 + nc - 1 + d), L, W};
   if (tid < kC) sh.dmin[tid] = (tid < nc) ? q.dmin[i0 + tid] : 0;
@@ -517,6 +521,332 @@ __global__ __launch_bounds__(kThreads) void k6_out(BppLinArgs a) {
   q.out(BO_P, d, i) = oP; q.out(BO_E, d, i) = oE; q.out(BO_M, d, i) = oM; q.out(BO_2, d, i) = o2; q.out(BO_A, d, i) = oA;
 }
 
+// ---- round 4: the interior loops of rule 6c from the candidate table (kernels.h: BppCandTable) instead of a walk over the
+// pair mask.  Lane = (cell that has loops, part): the parts of a cell deal the entries of a class among themselves, the cells
+// of a part are neighbours on the diagonal, so a wave's loads are row segments and every lane runs the same instructions; a
+// candidate that is no pair reads a zero from the plane (every cell of a plane is written).  The eight shapes that do not
+// factorise go through loop_weight, one per part.  Same sums as k6_in / k6_out in another (fixed) order.
+constexpr int kParts = 32;    // most parts per cell (parts = 256 / cells with loops, at least 8)
+struct BppLdsT {
+  double stem[kC][kStem + 1];
+  double stem2[kC][kStem + 1];
+  double loop[kC][kParts + 1];
+  BppCand cand[kBppCandMax];
+  int list[kC];
+  int n_list;
+  int dmin[kC];
+  uint8_t seq[kWin];
+};
+__constant__ int8_t kSpecialU1[kBppSpecial] = {0, 1, 1, 1, 2, 2, 2, 3};
+__constant__ int8_t kSpecialU2[kBppSpecial] = {1, 0, 1, 2, 1, 2, 3, 2};
+
+// stages the entries with u1 + u2 <= tmax of every class; n[c] = their number, off[c] = where the class starts in sh.cand
+__device__ __forceinline__ void stage_cand(const BppCandTable* __restrict__ tab, BppLdsT& sh, int tmax, int n[BC_CLASSES], int off[BC_CLASSES]) {
+  int tot = 0;
+#pragma unroll
+  for (int c = 0; c < BC_CLASSES; ++c) { n[c] = (tmax >= 0) ? tab->upto[c][tmax] : 0; off[c] = tot; tot += n[c]; }
+  for (int t = threadIdx.x; t < tot; t += kThreads) {
+    const int c = (t < off[1]) ? 0 : (t < off[2]) ? 1 : 2;
+    sh.cand[t] = tab->e[tab->base[c] + (t - off[c])];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k6_in_tab(BppLinArgs a) {
+  __shared__ BppLdsT sh;
+  const Seq q = make_seq(a, blockIdx.y);
+  const int d = a.d, tid = threadIdx.x;
+  if (d > q.W) return;
+  const int i0 = blockIdx.x * kC;
+  if (i0 > q.L - d) return;
+  const int W = q.W, L = q.L;
+  const int nc = (kC < L - d - i0 + 1) ? kC : L - d - i0 + 1;
+  const uint8_t* sq = stage_seq(q, sh.seq, i0 - 1, i0 + nc - 1 + d);
+  const Mask mk{stage_bits(q, i0 - 1, i0 + nc - 1 + d), L, W};
+  if (tid < kC) sh.dmin[tid] = (tid < nc) ? q.dmin[i0 + tid] : 0;
+  const int Cc = (q.C < kMaxLoop) ? q.C : kMaxLoop;
+  const int tmax = (Cc < d - 2) ? Cc : d - 2;          // inside set: (k - i) + (j - l) <= C, inner span >= 2
+  int cn[BC_CLASSES], co[BC_CLASSES];
+  stage_cand(a.cand, sh, tmax, cn, co);
+  __syncthreads();
+  if (tid < 64) {      // the cells with interior loops (E cells whose closing pair is allowed)
+    const int i = i0 + tid;
+    const bool e = tid < nc && i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
+    const unsigned long long m = __ballot(e);
+    if (e) sh.list[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+    if (tid == 0) sh.n_list = __popcll(m);
+  }
+  // rule 2, factorised: the stems (k, j) that end at j and start behind i + dmin[i]
+  {
+    const int ci = tid / kStem, ln = tid % kStem;
+    double A = 0.;
+    if (ci < nc) {
+      const int i = i0 + ci, j = i + d, dmi = sh.dmin[ci];
+      if (dmi > 0 && dmi < d) {
+        const int smax = d - dmi;
+        for (int sp0 = 1 + ln; sp0 <= smax; sp0 += kB * kStem) {
+          double x1[kB], xp[kB], xw[kB];
+          bool on[kB];
+#pragma unroll
+          for (int u = 0; u < kB; ++u) {
+            const int sp = sp0 + u * kStem;
+            on[u] = sp <= smax && mk.ok(j - sp, sp);
+            x1[u] = xp[u] = xw[u] = 0.;
+            if (on[u]) { x1[u] = q.in(BP_1, d - sp, i); xp[u] = q.in(BP_P, sp, j - sp); xw[u] = q.x(XW_ML, q.cell(j - sp, sp)); }
+          }
+#pragma unroll
+          for (int u = 0; u < kB; ++u)
+            if (on[u]) A = fma(x1[u], xp[u] * xw[u], A);
+        }
+      }
+      sh.stem[ci][ln] = A;
+    }
+  }
+  __syncthreads();
+  const int nE = sh.n_list;
+  const int parts = (nE > 0) ? ((kThreads / nE < kParts) ? kThreads / nE : kParts) : 1;
+  if (tmax >= 1 && tid < nE * parts) {
+    const EnergyTables& xet = *a.xet;
+    const int part = tid / nE, ci = sh.list[tid - part * nE];
+    const int i = i0 + ci, j = i + d;
+    // factors of the closing pair (i-1, j)
+    const int type = bp_type(sq[i - 1], sq[j]);
+    const int mi = type * 25 + sq[i] * 5 + sq[j - 1];
+    const double fac[BC_CLASSES] = {xet.mismatch_i[mi], xet.mismatch_1ni[mi], is_au(type) ? xet.term_au : 1.};
+    const size_t row = (size_t)(L + 1);
+    double HE = 0.;
+#pragma unroll
+    for (int c = 0; c < BC_CLASSES; ++c) {
+      const double* __restrict__ pl = q.tin + (size_t)(BP_X + c) * q.t_stride + (size_t)d * row + i;
+      const int end = co[c] + cn[c];
+      double acc = 0.;
+      for (int t0 = co[c] + part; t0 < end; t0 += kB * parts) {
+        double cf[kB], pv[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int t = t0 + u * parts;
+          cf[u] = 0.; pv[u] = 0.;
+          if (t < end) {
+            const BppCand e = sh.cand[t];
+            cf[u] = e.coef;
+            pv[u] = pl[(ptrdiff_t)e.u1 - (ptrdiff_t)e.T * (ptrdiff_t)row];        // plane[(d - T) * (L+1) + i + u1]
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) acc = fma(cf[u], pv[u], acc);
+      }
+      HE = fma(fac[c], acc, HE);
+    }
+    if (part < kBppSpecial) {
+      const int u1 = kSpecialU1[part], u2 = kSpecialU2[part];
+      const int k = i + u1, sp = d - u1 - u2;
+      if (u1 + u2 <= tmax && mk.ok(k, sp)) HE = fma(q.in(BP_P, sp, k), loop_weight(xet, sq, i - 1, j, k, k + sp - 1), HE);
+    }
+    sh.loop[ci][part] = HE;
+  }
+  __syncthreads();
+  if (tid >= nc) return;
+  const int i = i0 + tid, j = i + d;
+  const int dmi = sh.dmin[tid];
+  auto left_ok = [&](int dd) { return dd <= W && dd >= 0 && i + dd <= L && dmi > 0 && dd >= dmi; };
+  const bool pok = mk.ok(i, d), lok = left_ok(d), mok = q.m_ok(i, d, a.m_min);
+  const bool eok = i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
+  double A = 0., HE = 0.;
+#pragma unroll
+  for (int k = 0; k < kStem; ++k) A += sh.stem[tid][k];
+  if (eok && tmax >= 1)
+    for (int k = 0; k < parts; ++k) HE += sh.loop[tid][k];
+  if (dmi > 0 && dmi < d) A += q.in(BP_A, d - 1, i);      // the tail grows by the unpaired base j-1
+  const int c = q.cell(i, d), c_up = eok ? q.cell(i - 1, d + 2) : c;
+  double vP = 0.;
+  if (pok && d >= 2) vP = fma(q.in(BP_P, d - 2, i + 1), q.x(XW_STACK, c), q.in(BP_E, d - 2, i + 1));   // rules 1b, 1a
+  const double vB = lok ? A : 0.;
+  const double s2 = (lok && left_ok(d - 1)) ? q.in(BP_2, d - 1, i) : 0.;                                  // rule 3a
+  const double v2 = lok ? fma(vP, pok ? q.x(XW_ML, c) : 0., s2) : 0.;                                     // rule 3b
+  const double v1 = lok ? v2 + vB : 0.;                                                                   // rules 4a, 4b
+  const double sM = (mok && q.m_ok(i + 1, d - 1, a.m_min)) ? q.in(BP_M, d - 1, i + 1) : 0.;               // rule 5a
+  const double vM = mok ? sM + vB : 0.;                                                                   // rule 5b
+  const double vE = eok ? fma(vM, q.x(XW_CLOSE, c_up), q.x(XW_HP, c_up) + HE) : 0.;                       // rules 6a, 6b (L = 1), 6c
+  q.in(BP_P, d, i) = vP; q.in(BP_E, d, i) = vE; q.in(BP_M, d, i) = vM; q.in(BP_B, d, i) = vB;
+  q.in(BP_1, d, i) = v1; q.in(BP_2, d, i) = v2; q.in(BP_A, d, i) = A;
+  // P(i,j) as the INNER pair (i, j-1) of a loop: times its factor of every class (bases i-1 and j lie inside that loop)
+  double xI = 0., xN = 0., xB = 0.;
+  if (vP != 0.) {
+    const EnergyTables& xet = *a.xet;
+    const int type2 = bp_type(sq[j - 1], sq[i]);
+    xB = is_au(type2) ? vP * xet.term_au : vP;
+    if (i > 0 && j < L) {
+      const int mi = type2 * 25 + sq[j] * 5 + sq[i - 1];
+      xI = vP * xet.mismatch_i[mi];
+      xN = vP * xet.mismatch_1ni[mi];
+    }
+  }
+  q.in(BP_X + BC_I, d, i) = xI; q.in(BP_X + BC_N, d, i) = xN; q.in(BP_X + BC_B, d, i) = xB;
+}
+
+__global__ __launch_bounds__(kThreads) void k6_out_tab(BppLinArgs a) {
+  __shared__ BppLdsT sh;
+  const Seq q = make_seq(a, blockIdx.y);
+  const int d = a.d, tid = threadIdx.x;
+  if (d > q.W) return;
+  const int i0 = blockIdx.x * kC;
+  if (i0 > q.L - d) return;
+  const int W = q.W, L = q.L;
+  const int nc = (kC < L - d - i0 + 1) ? kC : L - d - i0 + 1;
+  const uint8_t* sq = stage_seq(q, sh.seq, i0 - q.C - 2, i0 + nc + W);
+  const int Cc = (q.C < kMaxLoop) ? q.C : kMaxLoop;
+  const Mask mk{stage_bits(q, i0 - Cc - 2, i0 + nc - 1 + d), L, W};
+  if (tid < kC) sh.dmin[tid] = (tid < nc) ? q.dmin[i0 + tid] : 0;
+  const int tmax = (kMaxLoop < W - 2 - d) ? kMaxLoop : W - 2 - d;     // outside set: the closing pair spans at most W
+  int cn[BC_CLASSES], co[BC_CLASSES];
+  stage_cand(a.cand, sh, tmax, cn, co);
+  __syncthreads();
+  if (tid < 64) {      // the stems P(i,j) that occur: they collect the interior loops around them
+    const int i = i0 + tid;
+    const bool e = tid < nc && mk.ok(i, d) && q.in(BP_P, d, i) != 0.;
+    const unsigned long long m = __ballot(e);
+    if (e) sh.list[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+    if (tid == 0) sh.n_list = __popcll(m);
+  }
+  {
+    const int ci = tid / kStem, ln = tid % kStem;
+    if (ci < nc) {
+      const int i = i0 + ci, j = i + d, dmi = sh.dmin[ci];
+      const bool lok = d <= W && i + d <= L && dmi > 0 && d >= dmi;
+      const bool pok = mk.ok(i, d);
+      const double in1 = lok ? q.in(BP_1, d, i) : 0.;
+      double H1 = 0., HA = 0.;
+      const int hi = (in1 != 0.) ? ((W - d < L - j) ? W - d : L - j) : 0;
+      const int bmax = pok ? ((W - d < i) ? W - d : i) : 0;
+      const int nmax = (hi > bmax) ? hi : bmax;
+      for (int n0 = 1 + ln; n0 <= nmax; n0 += kB * kStem) {
+        double oa[kB], xp[kB], xw[kB], ob[kB], x1[kB];
+        bool on[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int n = n0 + u * kStem;
+          on[u] = n <= hi && mk.ok(j, n);
+          oa[u] = xp[u] = xw[u] = ob[u] = x1[u] = 0.;
+          if (on[u]) { oa[u] = q.out(BO_A, d + n, i); xp[u] = q.in(BP_P, n, j); xw[u] = q.x(XW_ML, q.cell(j, n)); }
+          if (n <= bmax) { ob[u] = q.out(BO_A, d + n, i - n); x1[u] = q.in(BP_1, n, i - n); }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          if (on[u]) H1 = fma(oa[u], xp[u] * xw[u], H1);
+          if (n0 + u * kStem <= bmax) HA = fma(ob[u], x1[u], HA);
+        }
+      }
+      sh.stem[ci][ln] = H1;
+      sh.stem2[ci][ln] = HA;
+    }
+  }
+  __syncthreads();
+  // HP: the interior loops around the stem (i, j-1): outer E cells (i - u1, d + T), closing pair (i - u1 - 1, j + u2)
+  const int nP = sh.n_list;
+  const int parts = (nP > 0) ? ((kThreads / nP < kParts) ? kThreads / nP : kParts) : 1;
+  if (tmax >= 1 && tid < nP * parts) {
+    const EnergyTables& xet = *a.xet;
+    const int part = tid / nP, ci = sh.list[tid - part * nP];
+    const int i = i0 + ci, j = i + d;
+    const int amax = (Cc < i - 1) ? Cc : i - 1;          // k - i' <= C; the closing pair starts at i' - 1 >= 0
+    const int rmax = L - 1 - j;                          // .. and ends at j + u2 <= L - 1
+    // factors of the inner pair (i, j-1)
+    double fac[BC_CLASSES] = {0., 0., 0.};
+    {
+      const int type2 = bp_type(sq[j - 1], sq[i]);
+      fac[BC_B] = is_au(type2) ? xet.term_au : 1.;
+      if (i > 0 && j < L) {
+        const int mi = type2 * 25 + sq[j] * 5 + sq[i - 1];
+        fac[BC_I] = xet.mismatch_i[mi];
+        fac[BC_N] = xet.mismatch_1ni[mi];
+      }
+    }
+    const size_t row = (size_t)(L + 1);
+    double HP = 0.;
+#pragma unroll
+    for (int c = 0; c < BC_CLASSES; ++c) {
+      const double* __restrict__ pl = q.tout + (size_t)(BO_X + c) * q.t_stride + (size_t)d * row + i;
+      const int end = co[c] + cn[c];
+      double acc = 0.;
+      for (int t0 = co[c] + part; t0 < end; t0 += kB * parts) {
+        double cf[kB], ov[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int t = t0 + u * parts;
+          cf[u] = 0.; ov[u] = 0.;
+          if (t < end) {
+            const BppCand e = sh.cand[t];
+            if (e.u1 <= amax && e.T - e.u1 <= rmax) {
+              cf[u] = e.coef;
+              ov[u] = pl[(ptrdiff_t)e.T * (ptrdiff_t)row - (ptrdiff_t)e.u1];      // plane[(d + T) * (L+1) + i - u1]
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) acc = fma(cf[u], ov[u], acc);
+      }
+      HP = fma(fac[c], acc, HP);
+    }
+    if (part < kBppSpecial) {
+      const int u1 = kSpecialU1[part], u2 = kSpecialU2[part];
+      const int io = i - u1, jo = j + u2;
+      if (u1 + u2 <= tmax && u1 <= amax && u2 <= rmax && mk.ok(io - 1, jo - io + 2))
+        HP = fma(q.out(BO_E, jo - io, io), loop_weight(xet, sq, io - 1, jo, i, j - 1), HP);
+    }
+    sh.loop[ci][part] = HP;
+  }
+  __syncthreads();
+  if (tid >= nc) return;
+  const int i = i0 + tid, j = i + d;
+  const int dmi = sh.dmin[tid];
+  auto left_ok = [&](int dd) { return dd <= W && dd >= 0 && i + dd <= L && dmi > 0 && dd >= dmi; };
+  const bool pok = mk.ok(i, d), lok = left_ok(d), mok = q.m_ok(i, d, a.m_min);
+  const bool up_ok = i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
+  const double inP = q.in(BP_P, d, i), inA = q.in(BP_A, d, i), in1 = q.in(BP_1, d, i);
+  double H1 = 0., HA = 0., HP = 0.;
+  if (lok && in1 != 0.)
+#pragma unroll
+    for (int k = 0; k < kStem; ++k) H1 += sh.stem[tid][k];
+  if (pok && inP != 0.) {
+#pragma unroll
+    for (int k = 0; k < kStem; ++k) HA += sh.stem2[tid][k];
+    if (tmax >= 1)
+      for (int k = 0; k < parts; ++k) HP += sh.loop[tid][k];
+  }
+  const double inE = q.in(BP_E, d, i), inM = q.in(BP_M, d, i), inB = q.in(BP_B, d, i), in2 = q.in(BP_2, d, i);
+  const int c = q.cell(i, d), c_up = up_ok ? q.cell(i - 1, d + 2) : c;
+  const double opP = up_ok ? q.out(BO_P, d + 2, i - 1) : 0.;
+  const double oE = (up_ok && inE != 0.) ? opP : 0.;                                                        // rule 1a
+  const double oP1b = (up_ok && pok && inP != 0.) ? opP * q.x(XW_STACK, c_up) : 0.;                          // rule 1b
+  const bool doM = mok && q.m_ok(i - 1, d + 1, a.m_min);
+  const double sM = (doM && inM != 0.) ? q.out(BO_M, d + 1, i - 1) : 0.;                                     // rule 5a
+  const double oM = (inM != 0.) ? fma(oE, up_ok ? q.x(XW_CLOSE, c_up) : 0., sM) : 0.;                        // rule 6a
+  const double o1 = (in1 != 0.) ? H1 : 0.;
+  const double oB = (inB != 0.) ? (mok ? oM : 0.) + o1 : 0.;                                                 // rules 5b, 4b
+  const bool do2 = lok && left_ok(d + 1) && j < L;
+  const double s2 = (do2 && in2 != 0.) ? q.out(BO_2, d + 1, i) : 0.;                                         // rule 3a
+  const double o2 = (in2 != 0.) ? o1 + s2 : 0.;                                                              // rule 4a (direct part)
+  double oP = 0.;
+  if (inP != 0.) {
+    const double xe = pok ? q.x(XW_EXT, c) : 0.;
+    const double r7 = (xe != 0.) ? exp(q.lo_in[i] + q.lo_out[j]) * xe : 0.;                                  // rule 7 (lo_out holds - ln Z)
+    oP = r7 + oP1b + (o2 + HA) * (pok ? q.x(XW_ML, c) : 0.) + HP;                                            // rules 3b, 6c
+  }
+  double oA = 0.;
+  if (inA != 0.) oA = (lok ? oB : 0.) + ((d + 1 <= W && j < L) ? q.out(BO_A, d + 1, i) : 0.);
+  q.out(BO_P, d, i) = oP; q.out(BO_E, d, i) = oE; q.out(BO_M, d, i) = oM; q.out(BO_2, d, i) = o2; q.out(BO_A, d, i) = oA;
+  // E(i,j) as the region under the CLOSING pair (i-1, j) of a loop: times that pair's factor of every class
+  double xI = 0., xN = 0., xB = 0.;
+  if (oE != 0.) {
+    const EnergyTables& xet = *a.xet;
+    const int type = bp_type(sq[i - 1], sq[j]);
+    const int mi = type * 25 + sq[i] * 5 + sq[(d > 0) ? j - 1 : j];
+    xI = oE * xet.mismatch_i[mi];
+    xN = oE * xet.mismatch_1ni[mi];
+    xB = is_au(type) ? oE * xet.term_au : oE;
+  }
+  q.out(BO_X + BC_I, d, i) = xI; q.out(BO_X + BC_N, d, i) = xN; q.out(BO_X + BC_B, d, i) = xB;
+}
+
 // ---- ln BPP >= ln min_bpp: the filtered mask, the number of kept pairs, optionally ln BPP of every candidate
 __global__ __launch_bounds__(kThreads) void k6_threshold(BppLinArgs a) {
   __shared__ int cnt[kThreads / 64];
@@ -551,9 +881,34 @@ __global__ __launch_bounds__(kThreads) void k6_threshold(BppLinArgs a) {
 
 }  // namespace
 
+void build_bpp_cand(const EnergyTables& x, BppCandTable* t) {
+  std::memset(t, 0, sizeof(*t));
+  int n = 0;
+  for (int c = 0; c < BC_CLASSES; ++c) {
+    t->base[c] = n;
+    for (int T = 0; T <= kMaxLoop; ++T) {
+      for (int u1 = 0; u1 <= T; ++u1) {
+        const int u2 = T - u1, u = u1 > u2 ? u1 : u2;
+        int cls = -1;
+        double coef = 0.;
+        if (0 == u1 || 0 == u2) {
+          if (u >= 2) { cls = BC_B; coef = x.bulge[u]; }                                  // (u = 0: rule 1b; u = 1: special)
+        } else if (u > 2 && !(5 == T && (2 == u1 || 2 == u2))) {
+          cls = (1 == u1 || 1 == u2) ? BC_N : BC_I;
+          coef = x.interior[T] * x.ninio[u1 > u2 ? u1 - u2 : u2 - u1];
+        }
+        if (cls == c) { t->e[n].coef = coef; t->e[n].u1 = u1; t->e[n].T = T; ++n; }
+      }
+      t->upto[c][T] = n - t->base[c];
+    }
+  }
+}
+
 hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hipStream_t st) {
   if (G <= 0) return hipSuccess;
   BppLinArgs a = base;
+  // the candidate-table kernels need the loop energies (without them every loop weighs 1, whatever its size: the mask walk)
+  const bool tab = a.cand && !a.no_ene && !getenv("ELEMDP_BPP_WALK");
   const int ncell_max = (Lmax + 1) * (Wmax + 1);
   const size_t lds_bits = sizeof(uint32_t) * (size_t)bpp_mask_words(Wmax);
   hipLaunchKernelGGL(k6_terms, dim3((ncell_max + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
@@ -561,7 +916,8 @@ hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hip
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) break;
     a.d = d;
-    hipLaunchKernelGGL(k6_in, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), lds_bits, st, a);
+    if (tab) hipLaunchKernelGGL(k6_in_tab, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), lds_bits, st, a);
+    else hipLaunchKernelGGL(k6_in, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), lds_bits, st, a);
   }
   hipLaunchKernelGGL(k6_in_ext, dim3(G), dim3(64), 0, st, a);
   hipLaunchKernelGGL(k6_out_ext, dim3(G), dim3(64), 0, st, a);
@@ -569,7 +925,8 @@ hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hip
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) continue;
     a.d = d;
-    hipLaunchKernelGGL(k6_out, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), lds_bits, st, a);
+    if (tab) hipLaunchKernelGGL(k6_out_tab, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), lds_bits, st, a);
+    else hipLaunchKernelGGL(k6_out, dim3((ncell + kC - 1) / kC, G), dim3(kThreads), lds_bits, st, a);
   }
   hipLaunchKernelGGL(k6_threshold, dim3(G), dim3(kThreads), 0, st, a);
   return hipGetLastError();

@@ -392,7 +392,7 @@ class Engine {
   DevBuf d_bpp_band_in_, d_bpp_band_out_, d_bpp_ext_in_, d_bpp_ext_out_, d_bpp_tmp_;   // S = 1 tables of the BPP filter
   PlanSet bpp_plan_;   // plan over the unfiltered mask, chunk by chunk (only the filter reads it)
   DevBuf d_bpp_order_, d_bpp_rows_, d_bpp_kept_, d_okbits_end_, d_nitems_, d_plans_all_;   // scratch kept across loads
-  DevBuf d_bpp_plans_, d_bpp_xw_, d_bpp_dmin_;   // linear-semiring filter (bpp_kernels.hip)
+  DevBuf d_bpp_plans_, d_bpp_xw_, d_bpp_dmin_, d_bpp_cand_;   // linear-semiring filter (bpp_kernels.hip)
   bool opt_bpp_log_ = false;                      // option "bpp_log": the log-space filter over the unfiltered plan
  public:
   std::vector<long long> last_prof;
@@ -486,6 +486,10 @@ void Engine::init_device() {
     exp_tables(et_, x.get());
     d_xet_.alloc(sizeof(EnergyTables));
     HIP_OK(hipMemcpy(d_xet_.as<void>(), x.get(), sizeof(EnergyTables), hipMemcpyHostToDevice));
+    std::unique_ptr<BppCandTable> ct(new BppCandTable);
+    build_bpp_cand(*x, ct.get());
+    d_bpp_cand_.alloc(sizeof(BppCandTable));
+    HIP_OK(hipMemcpy(d_bpp_cand_.as<void>(), ct.get(), sizeof(BppCandTable), hipMemcpyHostToDevice));
   }
   d_ints0_.upload(ints0_, st_);
   upload_automaton();
@@ -925,7 +929,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
     if (opt_keep_lnbpp_) h_lnbpp_base_.assign(n + 1, 0);
     if (Wmax_ <= kBppLinMaxSpan && !opt_bpp_log_) {
       // ---- K1: BPP filter in the linear semiring (bpp_kernels.hip): no plan of the unfiltered mask; chunks by table memory
-      const int64_t cells_cap = 64LL * 1000 * 1000;     // 17 doubles per cell: ~9 GB per chunk
+      const int64_t cells_cap = 64LL * 1000 * 1000;     // 23 doubles per cell: ~12 GB per chunk
       int first = 0;
       while (first < n) {
         int count = 0;
@@ -944,8 +948,8 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         }
         d_bpp_plans_.upload(hp, st_);
         d_bpp_xw_.alloc(sizeof(double) * 5 * (size_t)cells, true);
-        d_bpp_band_in_.alloc(sizeof(double) * 7 * (size_t)cells, true);
-        d_bpp_band_out_.alloc(sizeof(double) * 5 * (size_t)cells, true);
+        d_bpp_band_in_.alloc(sizeof(double) * kBppInPlanes * (size_t)cells, true);
+        d_bpp_band_out_.alloc(sizeof(double) * kBppOutPlanes * (size_t)cells, true);
         d_bpp_ext_in_.alloc(sizeof(double) * (size_t)pos, true);
         d_bpp_ext_out_.alloc(sizeof(double) * (size_t)pos, true);
         d_bpp_dmin_.alloc(sizeof(int16_t) * (size_t)pos, true);
@@ -955,6 +959,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         std::memset(&a, 0, sizeof(a));
         a.et = d_et_.as<EnergyTables>();
         a.xet = d_xet_.as<EnergyTables>();
+        a.cand = d_bpp_cand_.as<BppCandTable>();
         a.plans = d_bpp_plans_.as<SeqPlan>();
         a.seq = d_seq_.as<uint8_t>();
         a.okbits = d_okbits0_.as<uint32_t>();

@@ -124,15 +124,34 @@ struct BppOut {
 // about e^(5.5 n) (3.4 kcal/mol per stack at kT = 0.616), and a span of W holds at most W / 2 of them -- e^550 at W = 200
 // against the limit e^709; wider bands go through the log-space filter (k3_bpp_*)
 constexpr int kBppLinMaxSpan = 200;
+// Candidate loops of rule 6c as a table (round 4).  A loop with u1 unpaired bases on the left and u2 on the right (T = u1 + u2 <=
+// kMaxLoop) weighs, in all but eight small shapes, g(u1, u2) * f(closing pair) * f(inner pair) (energy_param.hpp:775-792): the
+// factor of the pair that is NOT the cell being summed is folded into an extra plane of the band tables when that pair's value is
+// written (classes below), so a candidate costs one table load and one fma with a coefficient from this table; the lanes of a
+// workgroup walk the entries in the same order whatever the sequence (no mask walk, no branch per candidate).
+enum { BC_I = 0, BC_N, BC_B, BC_CLASSES };   // generic loops (mismatch_i); 1 x n loops (mismatch_1ni); bulges of two and more bases (term_au)
+struct BppCand { double coef; int32_t u1, T; };
+constexpr int kBppCandMax = 496;
+struct BppCandTable {
+  int32_t base[BC_CLASSES];                    // first entry of a class in e[]
+  int32_t upto[BC_CLASSES][kMaxLoop + 1];      // entries of the class with u1 + u2 <= T (entries are sorted by T)
+  int32_t pad_;
+  BppCand e[kBppCandMax];
+};
+void build_bpp_cand(const EnergyTables& xet, BppCandTable* t);
+// the eight shapes that do not factorise (stacked bulge, 1x1, 1x2, 2x1, 2x2, 2x3, 3x2): evaluated by loop_weight
+constexpr int kBppSpecial = 8;
+constexpr int kBppInPlanes = 7 + BC_CLASSES, kBppOutPlanes = 5 + BC_CLASSES;
 struct BppLinArgs {
   const EnergyTables* et;
   const EnergyTables* xet;         // the same tables exponentiated (exp_tables): interior loops through loop_weight
+  const BppCandTable* cand;        // candidate table of the interior loops (null: the mask walk of round 2)
   const SeqPlan* plans;
   const uint8_t* seq;
   const uint32_t* okbits;          // canonical pair mask
   int16_t* dmin;                   // [dmin_base + i]: smallest canonical span starting at i (0: none)
   double* xw; size_t xw_stride;    // exp of the five structural terms [term][cell_base + i * (W+1) + d]
-  double* tin; double* tout; size_t t_stride;   // band tables [plane][cell_base + d * (L+1) + i]: 7 inside / 5 outside planes
+  double* tin; double* tout; size_t t_stride;   // band tables [plane][cell_base + d * (L+1) + i]: kBppInPlanes inside / kBppOutPlanes outside planes
   double* lo_in; double* lo_out;   // exterior chains as logarithms [dmin_base + j]
   int32_t no_ene, min_span, m_min, d;
   uint32_t* okbits_out;            // filtered mask (bits_base indexing)
