@@ -14,6 +14,8 @@
 // The arithmetic of every rule is in dp_rules.h / scan_rules.h / plan_rules.h (device code here).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "dp_rules.h"
 #include "energy_rules.h"
 #include "kernels.h"
@@ -41,25 +43,30 @@ __device__ __forceinline__ int block_sum_int(int v, int* lds_tmp) {
   return tot;
 }
 
-// exclusive prefix sum of data[0..n) in place; data[n] receives the total.  One workgroup.
-__device__ void block_exclusive_scan(int32_t* data, int n, int* lds_tmp /* kThreads+1 ints */) {
-  const int tid = threadIdx.x;
-  const int chunk = (n + kThreads - 1) / kThreads;
-  const int a = tid * chunk;
-  const int b = (a + chunk < n) ? a + chunk : n;
-  int sum = 0;
-  for (int t = a; t < b; ++t) sum += data[t];
-  lds_tmp[tid] = sum;
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < kThreads; ++t) { int v = lds_tmp[t]; lds_tmp[t] = run; run += v; }
-    lds_tmp[kThreads] = run;
+// exclusive prefix sum of data[0..n) in place; data[n] receives the total.  One workgroup, tiles of one element per thread
+// (coalesced loads whatever the array length, a wave scan per tile; round 3 gave every thread a contiguous chunk: 60 strided
+// round trips per thread at 15 000 cells): `data` may be global or LDS memory, NT = threads of the workgroup (a multiple of 64),
+// lds_tmp = NT / 64 + 1 ints.
+template <int NT>
+__device__ __forceinline__ void block_exclusive_scan_tiled(int32_t* data, int n, int* lds_tmp) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int run = 0;
+  for (int base = 0; base < n; base += NT) {
+    const int t = base + tid;
+    const int v = (t < n) ? data[t] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    if (lane == 63) lds_tmp[wv] = inc;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { const int c = lds_tmp[w]; if (w < wv) before += c; tot += c; }
+    if (t < n) data[t] = run + before + inc - v;
+    run += tot;
+    __syncthreads();
   }
-  __syncthreads();
-  int run = lds_tmp[tid];
-  for (int t = a; t < b; ++t) { int v = data[t]; data[t] = run; run += v; }
-  if (tid == 0) data[n] = lds_tmp[kThreads];
+  if (tid == 0) data[n] = run;
   __syncthreads();
 }
 
@@ -232,9 +239,9 @@ __device__ __forceinline__ int32_t* role_idx(const PlanArrays& p, int role) {
 
 // counts -> offsets of one CSR array per sequence (role -1: by_outer)
 __global__ __launch_bounds__(kThreads) void k_plan_scan(PlanKernelArgs a, int role) {
-  __shared__ int tmp[kThreads + 1];
+  __shared__ int tmp[kThreads / 64 + 1];
   const SeqPlan p = a.plans[a.first + blockIdx.x];
-  block_exclusive_scan(role_off(a.p, role) + p.off_base, (p.L + 1) * (p.W + 1), tmp);
+  block_exclusive_scan_tiled<kThreads>(role_off(a.p, role) + p.off_base, (p.L + 1) * (p.W + 1), tmp);
 }
 
 __global__ __launch_bounds__(kThreads) void k_plan_fill(PlanKernelArgs a) {
@@ -320,6 +327,31 @@ __global__ __launch_bounds__(kThreads) void k_role_scatter3(PlanKernelArgs a) {
 #pragma unroll
   for (int role = 0; role < 3; ++role)
     role_idx(a.p, role)[p.item_base + role_off(a.p, role)[p.off_base + role_key(it, role, p.W)] + rank[role]] = t;
+}
+// One role of one sequence in ONE workgroup of 1024 threads (round 4): the counters of the keys live in LDS (4 bytes per cell: a
+// sequence of 300 with a band of 50 takes 61 KB), so the count pass is a pass of LDS atomics -- the global atomics of k_role_count3
+// serialise on the loop cells that hundreds of items share (32 ms per 10 000 x L=300) -- the scan runs on the LDS array, and the
+// scatter reads the offsets from LDS.  Ranks in the item-copy buffer as above.  grid = (3 roles, sequences); dynamic LDS =
+// (cells + 1) ints; the launcher falls back to the passes above for sequences whose counters do not fit.
+constexpr int kRoleThreads = 1024;
+__global__ __launch_bounds__(kRoleThreads) void k_role_build(PlanKernelArgs a) {
+  extern __shared__ int32_t s_cnt[];
+  __shared__ int tmp[kRoleThreads / 64 + 1];
+  const SeqPlan p = a.plans[a.first + blockIdx.y];
+  const int role = blockIdx.x;
+  const int ncell = (p.L + 1) * (p.W + 1), n_items = p.n_items, W = p.W;
+  const int tid = threadIdx.x;
+  for (int c = tid; c <= ncell; c += kRoleThreads) s_cnt[c] = 0;
+  __syncthreads();
+  const LoopItem* items = a.p.items + p.item_base;
+  int32_t* rank = reinterpret_cast<int32_t*>(a.p.items_inner + p.item_base) + role;
+  for (int t = tid; t < n_items; t += kRoleThreads) rank[(size_t)t * 3] = atomicAdd(&s_cnt[role_key(items[t], role, W)], 1);
+  __syncthreads();
+  block_exclusive_scan_tiled<kRoleThreads>(s_cnt, ncell, tmp);
+  int32_t* off = role_off(a.p, role) + p.off_base;
+  for (int c = tid; c <= ncell; c += kRoleThreads) off[c] = s_cnt[c];
+  int32_t* idx = role_idx(a.p, role) + p.item_base;
+  for (int t = tid; t < n_items; t += kRoleThreads) idx[s_cnt[role_key(items[t], role, W)] + rank[(size_t)t * 3]] = t;
 }
 // Sorts every segment of one role by item index (the scatter above leaves them in arbitrary order).  The segments of the
 // cells (i, 0..W) of one row are contiguous in the CSR array: a workgroup takes a row, builds the composite values
@@ -768,7 +800,13 @@ hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
   const dim3 cells((a.ncell_max + 1 + kThreads - 1) / kThreads, a.count), items((a.nitems_max + kThreads - 1) / kThreads, a.count);
   hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, -1);
   hipLaunchKernelGGL(k_plan_fill, dim3((a.ncell_max + kPlanTile * kThreads - 1) / (kPlanTile * kThreads), a.count), dim3(kThreads), 0, st, a);
-  if (a.n_roles == 3 && a.p.items_inner) {      // (ranks kept in the buffer of the item copies, which launch_permute_items fills later)
+  const size_t role_lds = sizeof(int32_t) * ((size_t)a.ncell_max + 1);
+  if (a.n_roles == 3 && a.p.items_inner && role_lds <= 150 * 1024 && !getenv("ELEMDP_ROLE_GLOBAL")) {
+    // (ranks kept in the buffer of the item copies, which launch_permute_items fills later)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_role_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)role_lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_role_build, dim3(3, a.count), dim3(kRoleThreads), role_lds, st, a);
+  } else if (a.n_roles == 3 && a.p.items_inner) {
     hipLaunchKernelGGL(k_role_zero3, cells, dim3(kThreads), 0, st, a);
     if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_count3, items, dim3(kThreads), 0, st, a);
     for (int role = 0; role < 3; ++role) hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, role);
