@@ -25,7 +25,8 @@
 namespace elemdp {
 namespace {
 
-enum { BP_P = 0, BP_E, BP_M, BP_B, BP_1, BP_2, BP_A, BP_X, BP_IN_PLANES = BP_X + BC_CLASSES };   // inside planes; BP_X + c: P times the inner pair's factor of class c
+enum { BP_P = 0, BP_E, BP_M, BP_B, BP_1, BP_2, BP_A, BP_X, BP_PM = BP_X + BC_CLASSES, BP_IN_PLANES };   // inside planes; BP_X + c: P times the inner
+                                                             // pair's factor of class c; BP_PM: P times the multiloop term of its pair (rule 2's stems)
 enum { BO_P = 0, BO_E, BO_M, BO_2, BO_A, BO_X, BO_OUT_PLANES = BO_X + BC_CLASSES };   // outside planes (divided by Z); BO_X + c: E times the closing pair's factor of class c
 static_assert(BP_IN_PLANES == kBppInPlanes && BO_OUT_PLANES == kBppOutPlanes, "plane counts of kernels.h");
 enum { XW_STACK = 0, XW_EXT, XW_ML, XW_CLOSE, XW_HP };
@@ -35,7 +36,7 @@ struct Seq {
   const uint8_t* seq;
   const uint32_t* ok;     // canonical pair mask, bit i * (W+1) + d
   const int16_t* dmin;
-  const double* xw;       // + term * xw_stride + cell
+  const double* xw;       // + term * xw_stride + d * (L+1) + i
   size_t xw_stride;
   double* tin;            // + plane * t_stride + d * (L+1) + i
   double* tout;
@@ -47,7 +48,7 @@ struct Seq {
     const int c = i * (W + 1) + d;
     return (ok[c >> 5] >> (c & 31)) & 1u;
   }
-  __device__ __forceinline__ int cell(int i, int d) const { return i * (W + 1) + d; }
+  __device__ __forceinline__ int cell(int i, int d) const { return d * (L + 1) + i; }   // (terms are stored by diagonal, like the tables)
   __device__ __forceinline__ double x(int term, int c) const { return xw[(size_t)term * xw_stride + c]; }
   __device__ __forceinline__ double& in(int plane, int d, int i) const { return tin[(size_t)plane * t_stride + (size_t)d * (L + 1) + i]; }
   __device__ __forceinline__ double& out(int plane, int d, int i) const { return tout[(size_t)plane * t_stride + (size_t)d * (L + 1) + i]; }
@@ -90,7 +91,8 @@ template <class F> __device__ __forceinline__ void for_bits(const uint32_t* m, i
   }
 }
 
-// ---- exp of the structural terms of every canonical pair, and dmin
+__device__ void build_pair_lists(const Seq& q, int16_t* plist, int32_t* poff, int* cnt);
+// ---- exp of the structural terms of every canonical pair, and dmin (and the pairs of every diagonal: build_pair_lists)
 __global__ __launch_bounds__(kThreads) void k6_terms(BppLinArgs a) {
   const SeqPlan p = a.plans[blockIdx.y];
   const int L = p.L, W = p.W;
@@ -105,10 +107,14 @@ __global__ __launch_bounds__(kThreads) void k6_terms(BppLinArgs a) {
         if (q.pair_ok(i, d)) { dm = d; break; }
       dmin[i] = (int16_t)dm;
     }
+    if (a.plist) {
+      __shared__ int cnt[kBppLinMaxSpan + 2];
+      build_pair_lists(q, a.plist + p.cell_base, a.poff + (size_t)blockIdx.y * a.poff_stride, cnt);
+    }
   }
   const int c = blockIdx.x * kThreads + threadIdx.x;
   if (c >= ncell) return;
-  const int i = c / (W + 1), d = c - i * (W + 1);
+  const int d = c / (L + 1), i = c - d * (L + 1);      // (terms are stored by diagonal: the sweeps read them along i)
   double v[5] = {0., 0., 0., 0., 0.};
   if (q.pair_ok(i, d)) {
     const PlanCfg cfg{a.no_ene, a.min_span, 0};
@@ -584,18 +590,18 @@ __global__ __launch_bounds__(kThreads) void k6_in_tab(BppLinArgs a) {
       if (dmi > 0 && dmi < d) {
         const int smax = d - dmi;
         for (int sp0 = 1 + ln; sp0 <= smax; sp0 += kB * kStem) {
-          double x1[kB], xp[kB], xw[kB];
+          double x1[kB], xp[kB];
           bool on[kB];
 #pragma unroll
           for (int u = 0; u < kB; ++u) {
             const int sp = sp0 + u * kStem;
             on[u] = sp <= smax && mk.ok(j - sp, sp);
-            x1[u] = xp[u] = xw[u] = 0.;
-            if (on[u]) { x1[u] = q.in(BP_1, d - sp, i); xp[u] = q.in(BP_P, sp, j - sp); xw[u] = q.x(XW_ML, q.cell(j - sp, sp)); }
+            x1[u] = xp[u] = 0.;
+            if (on[u]) { x1[u] = q.in(BP_1, d - sp, i); xp[u] = q.in(BP_PM, sp, j - sp); }
           }
 #pragma unroll
           for (int u = 0; u < kB; ++u)
-            if (on[u]) A = fma(x1[u], xp[u] * xw[u], A);
+            if (on[u]) A = fma(x1[u], xp[u], A);
         }
       }
       sh.stem[ci][ln] = A;
@@ -681,6 +687,7 @@ __global__ __launch_bounds__(kThreads) void k6_in_tab(BppLinArgs a) {
     }
   }
   q.in(BP_X + BC_I, d, i) = xI; q.in(BP_X + BC_N, d, i) = xN; q.in(BP_X + BC_B, d, i) = xB;
+  q.in(BP_PM, d, i) = (pok && vP != 0.) ? vP * q.x(XW_ML, c) : 0.;
 }
 
 __global__ __launch_bounds__(kThreads) void k6_out_tab(BppLinArgs a) {
@@ -719,19 +726,19 @@ __global__ __launch_bounds__(kThreads) void k6_out_tab(BppLinArgs a) {
       const int bmax = pok ? ((W - d < i) ? W - d : i) : 0;
       const int nmax = (hi > bmax) ? hi : bmax;
       for (int n0 = 1 + ln; n0 <= nmax; n0 += kB * kStem) {
-        double oa[kB], xp[kB], xw[kB], ob[kB], x1[kB];
+        double oa[kB], xp[kB], ob[kB], x1[kB];
         bool on[kB];
 #pragma unroll
         for (int u = 0; u < kB; ++u) {
           const int n = n0 + u * kStem;
           on[u] = n <= hi && mk.ok(j, n);
-          oa[u] = xp[u] = xw[u] = ob[u] = x1[u] = 0.;
-          if (on[u]) { oa[u] = q.out(BO_A, d + n, i); xp[u] = q.in(BP_P, n, j); xw[u] = q.x(XW_ML, q.cell(j, n)); }
+          oa[u] = xp[u] = ob[u] = x1[u] = 0.;
+          if (on[u]) { oa[u] = q.out(BO_A, d + n, i); xp[u] = q.in(BP_PM, n, j); }
           if (n <= bmax) { ob[u] = q.out(BO_A, d + n, i - n); x1[u] = q.in(BP_1, n, i - n); }
         }
 #pragma unroll
         for (int u = 0; u < kB; ++u) {
-          if (on[u]) H1 = fma(oa[u], xp[u] * xw[u], H1);
+          if (on[u]) H1 = fma(oa[u], xp[u], H1);
           if (n0 + u * kStem <= bmax) HA = fma(ob[u], x1[u], HA);
         }
       }
@@ -847,6 +854,395 @@ __global__ __launch_bounds__(kThreads) void k6_out_tab(BppLinArgs a) {
   q.out(BO_X + BC_I, d, i) = xI; q.out(BO_X + BC_N, d, i) = xN; q.out(BO_X + BC_B, d, i) = xB;
 }
 
+// ---- round 4: one workgroup per SEQUENCE sweeps all diagonals of a direction in one launch (k6_in_seq / k6_out_seq).  The
+// diagonal kernels above pay, per block of 32 cells and diagonal, a plan record, the staging of mask rows / bases / candidate
+// table and three barriers for a few hundred loads -- 13 dependent round trips per workgroup, 102 launches per chunk; here the
+// mask, the bases, the first-pair spans, the candidate table and the pairs of every diagonal (build_pair_lists) are staged ONCE, the
+// 512 threads take all cells of a diagonal together (stems: (cell, lane) items; loops: (pair of the diagonal, part) items), and
+// a diagonal costs two barriers.  A diagonal's values reach the next one through global memory: written and read by the same
+// workgroup, whose waves share the CU's vector L1 (write-through), with the barrier's workgroup-scope fence in between.
+// Same sums as the _tab kernels in the same order per cell (parts differ: the partial sums are added in another fixed order).
+constexpr int kSeqThreads = 512;
+#ifndef ELEMDP_SEQ_WAVES_IN
+#define ELEMDP_SEQ_WAVES_IN 6   // waves per SIMD the per-sequence kernels are compiled for (6: three workgroups of 512 per CU, 80 registers)
+#endif
+#ifndef ELEMDP_SEQ_WAVES_OUT
+#define ELEMDP_SEQ_WAVES_OUT 4
+#endif
+#ifndef ELEMDP_SEQ_BATCH
+#define ELEMDP_SEQ_BATCH 8
+#endif
+constexpr int kBL = ELEMDP_SEQ_BATCH;   // candidates per batch of loads in the loop sums
+constexpr int kSeqStem = 2;      // most lanes per cell for the stem sums
+struct SeqLdsLayout { int cand, part, stem, stem2, dmin, slot, plist, poff, seq, bits, total; };
+__host__ __device__ inline SeqLdsLayout seq_lds_layout(int lmax, int wmax, int pmax, bool out) {
+  SeqLdsLayout y;
+  int o = 0;
+  auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
+  const int ncm = lmax + 1;
+  y.cand = take((int)sizeof(BppCand) * kBppCandMax);
+  y.part = take(8 * ((kSeqThreads > ncm ? kSeqThreads : ncm) + kParts));
+  y.stem = take(8 * kSeqStem * ncm);
+  y.stem2 = out ? take(8 * kSeqStem * ncm) : y.stem;
+  y.dmin = take(2 * ncm);
+  y.slot = take(2 * ncm);
+  y.plist = take(2 * (pmax + 1));
+  y.poff = take(4 * (wmax + 3));
+  y.seq = take(lmax + 1);
+  y.bits = take(4 * (((ncm * (wmax + 1) + 31) >> 5) + 2));
+  y.total = o;
+  return y;
+}
+
+// pairs of every diagonal, ascending in i: plist[poff[d] .. poff[d+1]) = the i with (i, d) in the mask (block 0 of k6_terms)
+__device__ void build_pair_lists(const Seq& q, int16_t* plist, int32_t* poff, int* cnt /* LDS: W + 2 ints */) {
+  const int L = q.L, W = q.W, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = kThreads / 64;
+  for (int d = wv; d <= W; d += nw) {
+    int n = 0;
+    for (int i0 = 0; i0 + d <= L; i0 += 64) n += __popcll(__ballot(q.pair_ok(i0 + lane, d)));
+    if (lane == 0) cnt[d] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int d = 0; d <= W; ++d) { const int c = cnt[d]; cnt[d] = run; poff[d] = run; run += c; }
+    poff[W + 1] = run;
+  }
+  __syncthreads();
+  for (int d = wv; d <= W; d += nw) {
+    int at = cnt[d];
+    for (int i0 = 0; i0 + d <= L; i0 += 64) {
+      const bool e = q.pair_ok(i0 + lane, d);
+      const unsigned long long m = __ballot(e);
+      if (e) plist[at + __popcll(m & ((1ull << lane) - 1ull))] = (int16_t)(i0 + lane);
+      at += __popcll(m);
+    }
+  }
+}
+
+struct SeqCtx {
+  BppCand* cand; double* part; double* stem; double* stem2; int16_t* dmin; int16_t* slot; int16_t* plist; int32_t* poff;
+  uint8_t* seq; uint32_t* bits;
+};
+__device__ __forceinline__ SeqCtx seq_stage(const BppLinArgs& a, const Seq& q, int n, unsigned char* base, const SeqLdsLayout& y) {
+  SeqCtx c;
+  c.cand = reinterpret_cast<BppCand*>(base + y.cand); c.part = reinterpret_cast<double*>(base + y.part);
+  c.stem = reinterpret_cast<double*>(base + y.stem); c.stem2 = reinterpret_cast<double*>(base + y.stem2);
+  c.dmin = reinterpret_cast<int16_t*>(base + y.dmin); c.slot = reinterpret_cast<int16_t*>(base + y.slot);
+  c.plist = reinterpret_cast<int16_t*>(base + y.plist); c.poff = reinterpret_cast<int32_t*>(base + y.poff);
+  c.seq = base + y.seq; c.bits = reinterpret_cast<uint32_t*>(base + y.bits);
+  const int tid = threadIdx.x, L = q.L, W = q.W;
+  const SeqPlan p = a.plans[n];
+  for (int t = tid; t < kBppCandMax; t += kSeqThreads) c.cand[t] = a.cand->e[t];
+  const int nword = (int)((((long long)(L + 1) * (W + 1)) + 31) >> 5);
+  for (int t = tid; t < nword + 2; t += kSeqThreads) c.bits[t] = (t < nword) ? q.ok[t] : 0u;
+  for (int t = tid; t < L; t += kSeqThreads) c.seq[t] = q.seq[t];
+  for (int t = tid; t <= L; t += kSeqThreads) { c.dmin[t] = q.dmin[t]; c.slot[t] = -1; }
+  const int32_t* poff = a.poff + (size_t)n * a.poff_stride;
+  for (int t = tid; t <= W + 1; t += kSeqThreads) c.poff[t] = poff[t];
+  const int np = poff[W + 1];
+  const int16_t* pl = a.plist + p.cell_base;
+  for (int t = tid; t < np; t += kSeqThreads) c.plist[t] = pl[t];
+  return c;
+}
+
+__global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_IN) void k6_in_seq(BppLinArgs a) {
+  extern __shared__ __align__(16) unsigned char s_seq[];
+  const Seq q = make_seq(a, blockIdx.x);
+  const int tid = threadIdx.x, W = q.W, L = q.L;
+  const SeqLdsLayout y = seq_lds_layout(a.lmax, a.wmax, a.pmax, false);
+  const SeqCtx cx = seq_stage(a, q, blockIdx.x, s_seq, y);
+  const uint8_t* sq = cx.seq;
+  const Mask mk{cx.bits, L, W};
+  const EnergyTables& xet = *a.xet;
+  const int Cc = (q.C < kMaxLoop) ? q.C : kMaxLoop;
+  const size_t row = (size_t)(L + 1);
+  const int ncm = a.lmax + 1;
+  __syncthreads();
+  for (int d = 0; d <= W && d <= L; ++d) {
+    const int nc = L - d + 1;
+    const int tmax = (Cc < d - 2) ? Cc : d - 2;          // inside set: (k - i) + (j - l) <= C, inner span >= 2
+    // rule 2, factorised: the stems (k, j) that end at j and start behind i + dmin[i]; lanes of a cell take every ns-th
+    const int ns = (kSeqThreads / nc < 1) ? 1 : (kSeqThreads / nc < kSeqStem ? kSeqThreads / nc : kSeqStem);
+    for (int w = tid; w < nc * ns; w += kSeqThreads) {
+      const int ln = w / nc, i = w - ln * nc, j = i + d, dmi = cx.dmin[i];
+      double A = 0.;
+      if (dmi > 0 && dmi < d) {
+        const int smax = d - dmi;
+        for (int sp0 = 1 + ln; sp0 <= smax; sp0 += kB * ns) {
+          double x1[kB], xp[kB];
+          bool on[kB];
+#pragma unroll
+          for (int u = 0; u < kB; ++u) {
+            const int sp = sp0 + u * ns;
+            on[u] = sp <= smax && mk.ok(j - sp, sp);
+            x1[u] = xp[u] = 0.;
+            if (on[u]) { x1[u] = q.in(BP_1, d - sp, i); xp[u] = q.in(BP_PM, sp, j - sp); }
+          }
+#pragma unroll
+          for (int u = 0; u < kB; ++u)
+            if (on[u]) A = fma(x1[u], xp[u], A);
+        }
+      }
+      cx.stem[ln * ncm + i] = A;
+    }
+    // rule 6c: the E cells (i, d) whose closing pair (i-1, j) is allowed = the pairs of diagonal d + 2
+    const int lb = (tmax >= 1 && d + 2 <= W) ? cx.poff[d + 2] : 0;
+    const int nE = (tmax >= 1 && d + 2 <= W) ? cx.poff[d + 3] - lb : 0;
+    const int parts = (nE > 0) ? ((kSeqThreads / nE < 1) ? 1 : (kSeqThreads / nE < kParts ? kSeqThreads / nE : kParts)) : 1;
+    if (nE > 0) {
+      int cn[BC_CLASSES], co[BC_CLASSES];
+#pragma unroll
+      for (int c = 0; c < BC_CLASSES; ++c) { cn[c] = a.cand->upto[c][tmax]; co[c] = a.cand->base[c]; }
+      for (int w = tid; w < nE * parts; w += kSeqThreads) {
+        const int part = w / nE, ix = w - part * nE;
+        const int i = cx.plist[lb + ix] + 1, j = i + d;
+        const int type = bp_type(sq[i - 1], sq[j]);
+        const int mi = type * 25 + sq[i] * 5 + sq[j - 1];
+        const double fac[BC_CLASSES] = {xet.mismatch_i[mi], xet.mismatch_1ni[mi], is_au(type) ? xet.term_au : 1.};
+        double HE = 0.;
+#pragma unroll
+        for (int c = 0; c < BC_CLASSES; ++c) {
+          const double* __restrict__ pl = q.tin + (size_t)(BP_X + c) * q.t_stride + (size_t)d * row + i;
+          const int end = co[c] + cn[c];
+          double acc = 0.;
+          for (int t0 = co[c] + part; t0 < end; t0 += kBL * parts) {
+            double cf[kBL], pv[kBL];
+#pragma unroll
+            for (int u = 0; u < kBL; ++u) {
+              const int t = t0 + u * parts;
+              cf[u] = 0.; pv[u] = 0.;
+              if (t < end) {
+                const BppCand e = cx.cand[t];
+                cf[u] = e.coef;
+                pv[u] = pl[(ptrdiff_t)e.u1 - (ptrdiff_t)e.T * (ptrdiff_t)row];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < kBL; ++u) acc = fma(cf[u], pv[u], acc);
+          }
+          HE = fma(fac[c], acc, HE);
+        }
+        for (int sx = part; sx < kBppSpecial; sx += parts) {
+          const int u1 = kSpecialU1[sx], u2 = kSpecialU2[sx];
+          const int k = i + u1, sp = d - u1 - u2;
+          if (u1 + u2 <= tmax && mk.ok(k, sp)) HE = fma(q.in(BP_P, sp, k), loop_weight(xet, sq, i - 1, j, k, k + sp - 1), HE);
+        }
+        cx.part[w] = HE;
+        if (part == 0) cx.slot[i] = (int16_t)ix;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nc; i += kSeqThreads) {
+      const int j = i + d;
+      const int dmi = cx.dmin[i];
+      auto left_ok = [&](int dd) { return dd <= W && dd >= 0 && i + dd <= L && dmi > 0 && dd >= dmi; };
+      const bool pok = mk.ok(i, d), lok = left_ok(d), mok = q.m_ok(i, d, a.m_min);
+      const bool eok = i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
+      double A = 0., HE = 0.;
+      for (int k = 0; k < ns; ++k) A += cx.stem[k * ncm + i];
+      const int sl = cx.slot[i];
+      if (sl >= 0) {
+        for (int k = 0; k < parts; ++k) HE += cx.part[k * nE + sl];
+        cx.slot[i] = -1;
+      }
+      if (dmi > 0 && dmi < d) A += q.in(BP_A, d - 1, i);      // the tail grows by the unpaired base j-1
+      const int c = q.cell(i, d), c_up = eok ? q.cell(i - 1, d + 2) : c;
+      double vP = 0.;
+      if (pok && d >= 2) vP = fma(q.in(BP_P, d - 2, i + 1), q.x(XW_STACK, c), q.in(BP_E, d - 2, i + 1));   // rules 1b, 1a
+      const double vB = lok ? A : 0.;
+      const double s2 = (lok && left_ok(d - 1)) ? q.in(BP_2, d - 1, i) : 0.;                                  // rule 3a
+      const double v2 = lok ? fma(vP, pok ? q.x(XW_ML, c) : 0., s2) : 0.;                                     // rule 3b
+      const double v1 = lok ? v2 + vB : 0.;                                                                   // rules 4a, 4b
+      const double sM = (mok && q.m_ok(i + 1, d - 1, a.m_min)) ? q.in(BP_M, d - 1, i + 1) : 0.;               // rule 5a
+      const double vM = mok ? sM + vB : 0.;                                                                   // rule 5b
+      const double vE = eok ? fma(vM, q.x(XW_CLOSE, c_up), q.x(XW_HP, c_up) + HE) : 0.;                       // rules 6a, 6b (L = 1), 6c
+      q.in(BP_P, d, i) = vP; q.in(BP_E, d, i) = vE; q.in(BP_M, d, i) = vM; q.in(BP_B, d, i) = vB;
+      q.in(BP_1, d, i) = v1; q.in(BP_2, d, i) = v2; q.in(BP_A, d, i) = A;
+      double xI = 0., xN = 0., xB = 0.;
+      if (vP != 0.) {
+        const int type2 = bp_type(sq[j - 1], sq[i]);
+        xB = is_au(type2) ? vP * xet.term_au : vP;
+        if (i > 0 && j < L) {
+          const int mi = type2 * 25 + sq[j] * 5 + sq[i - 1];
+          xI = vP * xet.mismatch_i[mi];
+          xN = vP * xet.mismatch_1ni[mi];
+        }
+      }
+      q.in(BP_X + BC_I, d, i) = xI; q.in(BP_X + BC_N, d, i) = xN; q.in(BP_X + BC_B, d, i) = xB;
+      q.in(BP_PM, d, i) = (pok && vP != 0.) ? vP * q.x(XW_ML, c) : 0.;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_OUT) void k6_out_seq(BppLinArgs a) {
+  extern __shared__ __align__(16) unsigned char s_seq[];
+  const Seq q = make_seq(a, blockIdx.x);
+  const int tid = threadIdx.x, W = q.W, L = q.L;
+  const SeqLdsLayout y = seq_lds_layout(a.lmax, a.wmax, a.pmax, true);
+  const SeqCtx cx = seq_stage(a, q, blockIdx.x, s_seq, y);
+  const uint8_t* sq = cx.seq;
+  const Mask mk{cx.bits, L, W};
+  const EnergyTables& xet = *a.xet;
+  const int Cc = (q.C < kMaxLoop) ? q.C : kMaxLoop;
+  const size_t row = (size_t)(L + 1);
+  const int ncm = a.lmax + 1;
+  __syncthreads();
+  for (int d = (W < L) ? W : L; d >= 0; --d) {
+    const int nc = L - d + 1;
+    const int tmax = (kMaxLoop < W - 2 - d) ? kMaxLoop : W - 2 - d;     // outside set: the closing pair spans at most W
+    const int ns = (kSeqThreads / nc < 1) ? 1 : (kSeqThreads / nc < kSeqStem ? kSeqThreads / nc : kSeqStem);
+    // H1: 1(i,j) under B(i,l) through a stem (j, l) that starts at j;  HA: what reaches 2(i,j) through rule 2
+    for (int w = tid; w < nc * ns; w += kSeqThreads) {
+      const int ln = w / nc, i = w - ln * nc, j = i + d, dmi = cx.dmin[i];
+      const bool lok = dmi > 0 && d >= dmi;
+      const bool pok = mk.ok(i, d);
+      double H1 = 0., HA = 0.;
+      const int hi = lok ? ((W - d < L - j) ? W - d : L - j) : 0;
+      const int bmax = pok ? ((W - d < i) ? W - d : i) : 0;
+      for (int n0 = 1 + ln; n0 <= hi; n0 += kB * ns) {          // (two loops: five operands per candidate in one cost 40 registers)
+        double oa[kB], xp[kB];
+        bool on[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int n = n0 + u * ns;
+          on[u] = n <= hi && mk.ok(j, n);
+          oa[u] = xp[u] = 0.;
+          if (on[u]) { oa[u] = q.out(BO_A, d + n, i); xp[u] = q.in(BP_PM, n, j); }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+          if (on[u]) H1 = fma(oa[u], xp[u], H1);
+      }
+      for (int n0 = 1 + ln; n0 <= bmax; n0 += kB * ns) {
+        double ob[kB], x1[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int n = n0 + u * ns;
+          ob[u] = x1[u] = 0.;
+          if (n <= bmax) { ob[u] = q.out(BO_A, d + n, i - n); x1[u] = q.in(BP_1, n, i - n); }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+          if (n0 + u * ns <= bmax) HA = fma(ob[u], x1[u], HA);
+      }
+      cx.stem[ln * ncm + i] = H1;
+      cx.stem2[ln * ncm + i] = HA;
+    }
+    // HP: the interior loops around the stems (i, j-1) of this diagonal: outer E cells (i - u1, d + T)
+    const int lb = (tmax >= 1) ? cx.poff[d] : 0;
+    const int nP = (tmax >= 1) ? cx.poff[d + 1] - lb : 0;
+    const int parts = (nP > 0) ? ((kSeqThreads / nP < 1) ? 1 : (kSeqThreads / nP < kParts ? kSeqThreads / nP : kParts)) : 1;
+    if (nP > 0) {
+      int cn[BC_CLASSES], co[BC_CLASSES];
+#pragma unroll
+      for (int c = 0; c < BC_CLASSES; ++c) { cn[c] = a.cand->upto[c][tmax]; co[c] = a.cand->base[c]; }
+      for (int w = tid; w < nP * parts; w += kSeqThreads) {
+        const int part = w / nP, ix = w - part * nP;
+        const int i = cx.plist[lb + ix], j = i + d;
+        const int amax = (Cc < i - 1) ? Cc : i - 1;          // k - i' <= C; the closing pair starts at i' - 1 >= 0
+        const int rmax = L - 1 - j;                          // .. and ends at j + u2 <= L - 1
+        double fac[BC_CLASSES] = {0., 0., 0.};
+        {
+          const int type2 = bp_type(sq[j - 1], sq[i]);
+          fac[BC_B] = is_au(type2) ? xet.term_au : 1.;
+          if (i > 0 && j < L) {
+            const int mi = type2 * 25 + sq[j] * 5 + sq[i - 1];
+            fac[BC_I] = xet.mismatch_i[mi];
+            fac[BC_N] = xet.mismatch_1ni[mi];
+          }
+        }
+        double HP = 0.;
+#pragma unroll
+        for (int c = 0; c < BC_CLASSES; ++c) {
+          const double* __restrict__ pl = q.tout + (size_t)(BO_X + c) * q.t_stride + (size_t)d * row + i;
+          const int end = co[c] + cn[c];
+          double acc = 0.;
+          for (int t0 = co[c] + part; t0 < end; t0 += kBL * parts) {
+            double cf[kBL], ov[kBL];
+#pragma unroll
+            for (int u = 0; u < kBL; ++u) {
+              const int t = t0 + u * parts;
+              cf[u] = 0.; ov[u] = 0.;
+              if (t < end) {
+                const BppCand e = cx.cand[t];
+                if (e.u1 <= amax && e.T - e.u1 <= rmax) {
+                  cf[u] = e.coef;
+                  ov[u] = pl[(ptrdiff_t)e.T * (ptrdiff_t)row - (ptrdiff_t)e.u1];
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < kBL; ++u) acc = fma(cf[u], ov[u], acc);
+          }
+          HP = fma(fac[c], acc, HP);
+        }
+        for (int sx = part; sx < kBppSpecial; sx += parts) {
+          const int u1 = kSpecialU1[sx], u2 = kSpecialU2[sx];
+          const int io = i - u1, jo = j + u2;
+          if (u1 + u2 <= tmax && u1 <= amax && u2 <= rmax && mk.ok(io - 1, jo - io + 2))
+            HP = fma(q.out(BO_E, jo - io, io), loop_weight(xet, sq, io - 1, jo, i, j - 1), HP);
+        }
+        cx.part[w] = HP;
+        if (part == 0) cx.slot[i] = (int16_t)ix;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nc; i += kSeqThreads) {
+      const int j = i + d;
+      const int dmi = cx.dmin[i];
+      auto left_ok = [&](int dd) { return dd <= W && dd >= 0 && i + dd <= L && dmi > 0 && dd >= dmi; };
+      const bool pok = mk.ok(i, d), lok = left_ok(d), mok = q.m_ok(i, d, a.m_min);
+      const bool up_ok = i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
+      const double inP = q.in(BP_P, d, i), inA = q.in(BP_A, d, i), in1 = q.in(BP_1, d, i);
+      double H1 = 0., HA = 0., HP = 0.;
+      if (lok && in1 != 0.)
+        for (int k = 0; k < ns; ++k) H1 += cx.stem[k * ncm + i];
+      if (pok && inP != 0.)
+        for (int k = 0; k < ns; ++k) HA += cx.stem2[k * ncm + i];
+      const int sl = cx.slot[i];
+      if (sl >= 0) {
+        if (inP != 0.)
+          for (int k = 0; k < parts; ++k) HP += cx.part[k * nP + sl];
+        cx.slot[i] = -1;
+      }
+      const double inE = q.in(BP_E, d, i), inM = q.in(BP_M, d, i), inB = q.in(BP_B, d, i), in2 = q.in(BP_2, d, i);
+      const int c = q.cell(i, d), c_up = up_ok ? q.cell(i - 1, d + 2) : c;
+      const double opP = up_ok ? q.out(BO_P, d + 2, i - 1) : 0.;
+      const double oE = (up_ok && inE != 0.) ? opP : 0.;                                                        // rule 1a
+      const double oP1b = (up_ok && pok && inP != 0.) ? opP * q.x(XW_STACK, c_up) : 0.;                          // rule 1b
+      const bool doM = mok && q.m_ok(i - 1, d + 1, a.m_min);
+      const double sM = (doM && inM != 0.) ? q.out(BO_M, d + 1, i - 1) : 0.;                                     // rule 5a
+      const double oM = (inM != 0.) ? fma(oE, up_ok ? q.x(XW_CLOSE, c_up) : 0., sM) : 0.;                        // rule 6a
+      const double o1 = (in1 != 0.) ? H1 : 0.;
+      const double oB = (inB != 0.) ? (mok ? oM : 0.) + o1 : 0.;                                                 // rules 5b, 4b
+      const bool do2 = lok && left_ok(d + 1) && j < L;
+      const double s2 = (do2 && in2 != 0.) ? q.out(BO_2, d + 1, i) : 0.;                                         // rule 3a
+      const double o2 = (in2 != 0.) ? o1 + s2 : 0.;                                                              // rule 4a (direct part)
+      double oP = 0.;
+      if (inP != 0.) {
+        const double xe = pok ? q.x(XW_EXT, c) : 0.;
+        const double r7 = (xe != 0.) ? exp(q.lo_in[i] + q.lo_out[j]) * xe : 0.;                                  // rule 7 (lo_out holds - ln Z)
+        oP = r7 + oP1b + (o2 + HA) * (pok ? q.x(XW_ML, c) : 0.) + HP;                                            // rules 3b, 6c
+      }
+      double oA = 0.;
+      if (inA != 0.) oA = (lok ? oB : 0.) + ((d + 1 <= W && j < L) ? q.out(BO_A, d + 1, i) : 0.);
+      q.out(BO_P, d, i) = oP; q.out(BO_E, d, i) = oE; q.out(BO_M, d, i) = oM; q.out(BO_2, d, i) = o2; q.out(BO_A, d, i) = oA;
+      double xI = 0., xN = 0., xB = 0.;
+      if (oE != 0.) {
+        const int type = bp_type(sq[i - 1], sq[j]);
+        const int mi = type * 25 + sq[i] * 5 + sq[(d > 0) ? j - 1 : j];
+        xI = oE * xet.mismatch_i[mi];
+        xN = oE * xet.mismatch_1ni[mi];
+        xB = is_au(type) ? oE * xet.term_au : oE;
+      }
+      q.out(BO_X + BC_I, d, i) = xI; q.out(BO_X + BC_N, d, i) = xN; q.out(BO_X + BC_B, d, i) = xB;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- ln BPP >= ln min_bpp: the filtered mask, the number of kept pairs, optionally ln BPP of every candidate
 __global__ __launch_bounds__(kThreads) void k6_threshold(BppLinArgs a) {
   __shared__ int cnt[kThreads / 64];
@@ -909,9 +1305,19 @@ hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hip
   BppLinArgs a = base;
   // the candidate-table kernels need the loop energies (without them every loop weighs 1, whatever its size: the mask walk)
   const bool tab = a.cand && !a.no_ene && !getenv("ELEMDP_BPP_WALK");
+  // one workgroup per sequence for a whole direction where its LDS image fits twice per CU
+  a.lmax = Lmax; a.wmax = Wmax;
+  const SeqLdsLayout yi = seq_lds_layout(Lmax, Wmax, a.pmax, false), yo = seq_lds_layout(Lmax, Wmax, a.pmax, true);
+  const bool per_seq = tab && a.plist && a.poff && Lmax < 32767 && yo.total <= 80 * 1024 && !getenv("ELEMDP_BPP_DIAG");
+  if (!per_seq) a.plist = nullptr;
   const int ncell_max = (Lmax + 1) * (Wmax + 1);
   const size_t lds_bits = sizeof(uint32_t) * (size_t)bpp_mask_words(Wmax);
   hipLaunchKernelGGL(k6_terms, dim3((ncell_max + kThreads - 1) / kThreads, G), dim3(kThreads), 0, st, a);
+  if (per_seq) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k6_in_seq), hipFuncAttributeMaxDynamicSharedMemorySize, yi.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k6_in_seq, dim3(G), dim3(kSeqThreads), (size_t)yi.total, st, a);
+  } else
   for (int d = 0; d <= Wmax; ++d) {
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) break;
@@ -921,6 +1327,11 @@ hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hip
   }
   hipLaunchKernelGGL(k6_in_ext, dim3(G), dim3(64), 0, st, a);
   hipLaunchKernelGGL(k6_out_ext, dim3(G), dim3(64), 0, st, a);
+  if (per_seq) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k6_out_seq), hipFuncAttributeMaxDynamicSharedMemorySize, yo.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k6_out_seq, dim3(G), dim3(kSeqThreads), (size_t)yo.total, st, a);
+  } else
   for (int d = Wmax; d >= 0; --d) {
     const int ncell = Lmax - d + 1;
     if (ncell <= 0) continue;

@@ -392,7 +392,7 @@ class Engine {
   DevBuf d_bpp_band_in_, d_bpp_band_out_, d_bpp_ext_in_, d_bpp_ext_out_, d_bpp_tmp_;   // S = 1 tables of the BPP filter
   PlanSet bpp_plan_;   // plan over the unfiltered mask, chunk by chunk (only the filter reads it)
   DevBuf d_bpp_order_, d_bpp_rows_, d_bpp_kept_, d_okbits_end_, d_nitems_, d_plans_all_;   // scratch kept across loads
-  DevBuf d_bpp_plans_, d_bpp_xw_, d_bpp_dmin_, d_bpp_cand_;   // linear-semiring filter (bpp_kernels.hip)
+  DevBuf d_bpp_plans_, d_bpp_xw_, d_bpp_dmin_, d_bpp_cand_, d_bpp_plist_, d_bpp_poff_;   // linear-semiring filter (bpp_kernels.hip)
   bool opt_bpp_log_ = false;                      // option "bpp_log": the log-space filter over the unfiltered plan
  public:
   std::vector<long long> last_prof;
@@ -960,6 +960,10 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         a.et = d_et_.as<EnergyTables>();
         a.xet = d_xet_.as<EnergyTables>();
         a.cand = d_bpp_cand_.as<BppCandTable>();
+        d_bpp_plist_.alloc(sizeof(int16_t) * (size_t)cells, true);
+        d_bpp_poff_.alloc(sizeof(int32_t) * (size_t)count * (wmax + 2), true);
+        a.plist = d_bpp_plist_.as<int16_t>(); a.poff = d_bpp_poff_.as<int32_t>(); a.poff_stride = wmax + 2;
+        for (int k = 0; k < count; ++k) a.pmax = std::max(a.pmax, ncanon[first + k]);
         a.plans = d_bpp_plans_.as<SeqPlan>();
         a.seq = d_seq_.as<uint8_t>();
         a.okbits = d_okbits0_.as<uint32_t>();

@@ -141,16 +141,19 @@ struct BppCandTable {
 void build_bpp_cand(const EnergyTables& xet, BppCandTable* t);
 // the eight shapes that do not factorise (stacked bulge, 1x1, 1x2, 2x1, 2x2, 2x3, 3x2): evaluated by loop_weight
 constexpr int kBppSpecial = 8;
-constexpr int kBppInPlanes = 7 + BC_CLASSES, kBppOutPlanes = 5 + BC_CLASSES;
+constexpr int kBppInPlanes = 7 + BC_CLASSES + 1, kBppOutPlanes = 5 + BC_CLASSES;
 struct BppLinArgs {
   const EnergyTables* et;
   const EnergyTables* xet;         // the same tables exponentiated (exp_tables): interior loops through loop_weight
   const BppCandTable* cand;        // candidate table of the interior loops (null: the mask walk of round 2)
+  int16_t* plist; int32_t* poff;   // pairs of every diagonal of a sequence, ascending ([cell_base + ..], [seq * poff_stride + d]); null: diagonal launches
+  int32_t poff_stride, pmax;       // pmax = most canonical pairs of a sequence of the chunk
+  int32_t lmax, wmax;              // set by launch_bpp_lin
   const SeqPlan* plans;
   const uint8_t* seq;
   const uint32_t* okbits;          // canonical pair mask
   int16_t* dmin;                   // [dmin_base + i]: smallest canonical span starting at i (0: none)
-  double* xw; size_t xw_stride;    // exp of the five structural terms [term][cell_base + i * (W+1) + d]
+  double* xw; size_t xw_stride;    // exp of the five structural terms [term][cell_base + d * (L+1) + i]
   double* tin; double* tout; size_t t_stride;   // band tables [plane][cell_base + d * (L+1) + i]: kBppInPlanes inside / kBppOutPlanes outside planes
   double* lo_in; double* lo_out;   // exterior chains as logarithms [dmin_base + j]
   int32_t no_ene, min_span, m_min, d;

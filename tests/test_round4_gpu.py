@@ -268,13 +268,15 @@ def test_viterbi_pass_on_the_compact_table_equals_the_dense_one(pattern, monkeyp
 
 
 def test_filter_from_the_candidate_table_equals_the_mask_walk(monkeypatch):
-    """Rule 6c of the BPP filter from the candidate table (k6_in_tab / k6_out_tab: one load and one fma per candidate, the
-    factor of the other pair folded into extra planes) against round 2's walk over the pair mask (ELEMDP_BPP_WALK): identical kept
-    sets and kept fractions, ln BPP to 1e-10 -- ragged lengths (C = W - 7 < 30 for the short ones), N bases, max_iloop 0 .. 30."""
+    """Rule 6c of the BPP filter from the candidate table (one load and one fma per candidate, the factor of the other pair
+    folded into extra planes) -- as one workgroup per sequence sweeping all diagonals (k6_in_seq / k6_out_seq, the default) and as
+    one launch per diagonal (k6_in_tab / k6_out_tab, ELEMDP_BPP_DIAG) -- against round 2's walk over the pair mask
+    (ELEMDP_BPP_WALK): identical kept sets and kept fractions, ln BPP to 1e-10 -- ragged lengths (C = W - 7 < 30 for the short
+    ones), N bases, max_iloop 0 .. 30, a band of 120."""
     rng = np.random.default_rng(4)
     for W, C in ((50, 30), (50, 7), (24, 30), (120, 30), (50, 0), (50, 2), (50, 5)):
         seqs, quals = [], []
-        for L in (1, 5, 9, 20, 31, 33, 47, 64, 100, 150, 301):
+        for L in (1, 5, 9, 20, 31, 33, 47, 64, 100, 150, 301, 600):
             s_, q_ = synth.synth_batch(3, L, seed=int(rng.integers(1 << 30)))
             if L > 30:
                 s_[1] = s_[1].copy()
@@ -282,17 +284,19 @@ def test_filter_from_the_candidate_table_equals_the_mask_walk(monkeypatch):
             seqs += s_
             quals += q_
         res = {}
-        for walk in (0, 1):
-            if walk:
-                monkeypatch.setenv("ELEMDP_BPP_WALK", "1")
-            else:
-                monkeypatch.delenv("ELEMDP_BPP_WALK", raising=False)
+        for mode in ("", "ELEMDP_BPP_DIAG", "ELEMDP_BPP_WALK"):
+            for m in ("ELEMDP_BPP_DIAG", "ELEMDP_BPP_WALK"):
+                monkeypatch.delenv(m, raising=False)
+            if mode:
+                monkeypatch.setenv(mode, "1")
             eng = api.Engine("(.)", "~T2004~", W, C, 1e-4)
             eng.set_option("keep_lnbpp", 1)
             eng.load_batch(seqs, quals)
-            res[walk] = ([eng.pairs(k, with_lnbpp=True) for k in range(len(seqs))], eng.bpp_eff())
-        monkeypatch.delenv("ELEMDP_BPP_WALK", raising=False)
-        for k, ((ka, la), (kb, lb)) in enumerate(zip(res[0][0], res[1][0])):
-            assert np.array_equal(ka, kb), (W, C, k)
-            assert_log_close(la, lb, rtol=1e-10, atol=1e-10, what="lnbpp W=%d C=%d k=%d" % (W, C, k))
-        np.testing.assert_array_equal(res[0][1], res[1][1])
+            res[mode] = ([eng.pairs(k, with_lnbpp=True) for k in range(len(seqs))], eng.bpp_eff())
+        for m in ("ELEMDP_BPP_DIAG", "ELEMDP_BPP_WALK"):
+            monkeypatch.delenv(m, raising=False)
+        for mode in ("", "ELEMDP_BPP_DIAG"):
+            for k, ((ka, la), (kb, lb)) in enumerate(zip(res[mode][0], res["ELEMDP_BPP_WALK"][0])):
+                assert np.array_equal(ka, kb), (mode, W, C, k)
+                assert_log_close(la, lb, rtol=1e-10, atol=1e-10, what="lnbpp %s W=%d C=%d k=%d" % (mode, W, C, k))
+            np.testing.assert_array_equal(res[mode][1], res["ELEMDP_BPP_WALK"][1])
