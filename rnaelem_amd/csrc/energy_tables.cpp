@@ -115,6 +115,28 @@ void exp_tables(const EnergyTables& e, EnergyTables* x) {
   x->ml_base = std::exp(e.ml_base);
 }
 
+bool loop_tables_finite(const EnergyTables& e) {
+  auto fin = [](double v) { return std::isfinite(v); };
+  if (!fin(e.term_au)) return false;
+  for (int u = 1; u <= kMaxLoop; ++u) if (!fin(e.bulge[u])) return false;
+  for (int u = 4; u <= kMaxLoop; ++u) if (!fin(e.interior[u])) return false;
+  for (int u = 0; u <= kMaxLoop; ++u) if (!fin(e.ninio[u])) return false;
+  for (int t = 1; t <= 6; ++t) {
+    for (int b = 0; b < 25; ++b)
+      if (!fin(e.mismatch_i[t * 25 + b]) || !fin(e.mismatch_1ni[t * 25 + b]) || !fin(e.mismatch_23i[t * 25 + b])) return false;
+    for (int t2 = 1; t2 <= 6; ++t2) {
+      if (!fin(e.stack[t * 7 + t2])) return false;
+      for (int b = 0; b < 25; ++b) if (!fin(e.int11[(t * 8 + t2) * 25 + b])) return false;
+      for (int b = 0; b < 125; ++b) if (!fin(e.int21[(t * 8 + t2) * 125 + b])) return false;
+      for (int b = 0; b < 625; ++b) {       // (the 2x2 table has no entries for N: bases A .. U only)
+        if (b % 5 == 0 || (b / 5) % 5 == 0 || (b / 25) % 5 == 0 || b / 125 == 0) continue;
+        if (!fin(e.int22[(t * 8 + t2) * 625 + b])) return false;
+      }
+    }
+  }
+  return true;
+}
+
 double log_boltzmann(int dcal, bool smooth) {
   if (!smooth) return -dcal * 10. / kKT;
   // smooth(-z) (energy_param.hpp:94-106): a C1 clamp of stabilising energies at 0

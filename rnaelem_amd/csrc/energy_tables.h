@@ -50,6 +50,10 @@ struct EnergyTables {
 // special-loop keys and lxc37 are copied.  For loop_weight (energy_rules.h).
 void exp_tables(const EnergyTables& e, EnergyTables* x);
 
+// no entry loop_energy can reach for canonical pair types (1 .. 6) in a sequence WITHOUT N is log 0 (the 2x2 table has no N
+// entries): a candidate loop of such a sequence is then dropped by its size alone (count_interior_by_end, plan_rules.h)
+bool loop_tables_finite(const EnergyTables& e);
+
 // Parses ViennaRNA-2.0 format text (the shipped *.elempar files are a comment-free subset of it).
 // Throws std::runtime_error on malformed input.
 void parse_energy_text(const std::string& text, EnergyTables* out);

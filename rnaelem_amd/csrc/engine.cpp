@@ -149,6 +149,30 @@ class DevBuf {
   size_t bytes_ = 0;
 };
 
+// pinned host staging buffer, kept from load to load (a fresh std::vector of 24 MB costs its page faults -- 30 ms per
+// 10 000 x L=300 for the four arrays of load_batch -- and a pageable upload goes through the runtime's own staging copies)
+class HostBuf {
+ public:
+  HostBuf() = default;
+  ~HostBuf() { if (p_) (void)hipHostFree(p_); }
+  HostBuf(const HostBuf&) = delete;
+  HostBuf& operator=(const HostBuf&) = delete;
+  template <class T> T* get(size_t n) {
+    const size_t bytes = std::max<size_t>(n * sizeof(T), 8);
+    if (bytes > bytes_) {
+      if (p_) (void)hipHostFree(p_);
+      p_ = nullptr;
+      bytes_ = bytes + bytes / 8;
+      HIP_OK(hipHostMalloc(&p_, bytes_, hipHostMallocDefault));
+    }
+    return static_cast<T*>(p_);
+  }
+
+ private:
+  void* p_ = nullptr;
+  size_t bytes_ = 0;
+};
+
 std::string default_data_dir() {
   if (!g_data_dir.empty()) return g_data_dir;
   if (const char* e = std::getenv("ELEMDP_DATA_DIR")) return e;
@@ -327,6 +351,7 @@ class Engine {
   std::vector<int32_t> ints_, ints0_, intsr_;
   bool linear_ok_ = true;
   int flags_, max_span_, max_iloop_;
+  bool loops_finite_ = false;   // loop_tables_finite(et_)
   double min_bpp_, tau_;
   int device_ = -1, n_cu_ = 256;   // device_ < 0: no HIP device (host-only handle)
   hipStream_t st_ = nullptr;
@@ -378,6 +403,7 @@ class Engine {
   std::vector<double> last_x_;           // parameters of the last train evaluation (debug_tables repeats it with the generic kernels)
   std::vector<double> h_lin_, h_lins_;   // linear parameter block of the last evaluation (plain automaton / with the shadow state)
   std::vector<uint8_t> h_seq_;           // base codes of the batch (table export)
+  HostBuf hb_ws_, hb_ews_, hb_unp_;      // staging of load_batch
   int64_t n_cells_total_ = 0;
   bool tables_linear_ = false;           // the resident tables hold scaled linear values (debug_tables converts)
   int n_flagged_last_ = 0;
@@ -481,6 +507,7 @@ void Engine::init_device() {
   gev_[0][0] = ev2_[0]; gev_[0][1] = ev2_[1];
   d_et_.alloc(sizeof(EnergyTables));
   HIP_OK(hipMemcpyAsync(d_et_.as<void>(), &et_, sizeof(EnergyTables), hipMemcpyHostToDevice, st_));
+  loops_finite_ = loop_tables_finite(et_);
   {   // Boltzmann weights of the loop tables, for the BPP filter (energy_rules.h: loop_weight)
     std::unique_ptr<EnergyTables> x(new EnergyTables);
     exp_tables(et_, x.get());
@@ -695,6 +722,7 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   a.no_ene = (flags_ & ELEMDP_NO_ENERGY) ? 1 : 0;
   a.min_span = (flags_ & ELEMDP_DBG_NO_TURN) ? 1 : 5;
   a.fix_rss = (flags_ & ELEMDP_DBG_FIX_RSS) ? 1 : 0;
+  a.count_fast = (loops_finite_ && !a.fix_rss && !getenv("ELEMDP_PLAN_ENUM_COUNT")) ? 1 : 0;
   HIP_OK(launch_plan_cells(a, d_nitems.as<int32_t>(), st_));
   std::vector<int32_t> n_items(count);
   HIP_OK(hipMemcpyAsync(n_items.data(), d_nitems.as<void>(), sizeof(int32_t) * count, hipMemcpyDeviceToHost, st_));
@@ -718,7 +746,7 @@ void Engine::build_planset(PlanSet& ps, int first, int count, const uint32_t* d_
   // ensure_sorted_plan when the option arrives after the batch).
   a.sort_roles = (ps.inner_only || opt_det_ || opt_pipeline_ != 4 || opt_sorted_plan_) ? 1 : 0;
   HIP_OK(launch_plan_items(a, st_));
-  if (ps.permuted) HIP_OK(launch_permute_items(a, st_));
+  if (ps.permuted && !plan_copies_fused(a)) HIP_OK(launch_permute_items(a, st_));
   HIP_OK(hipStreamSynchronize(st_));
   ps.sorted = a.sort_roles != 0;
   ps.ka = a;
@@ -830,8 +858,12 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   if ((double)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1) * au_.S() >= 2147483648.0)
     throw ArgError("load_batch: sequence too long for this pattern (band table exceeds 2^31 entries)");
   // static arrays
-  std::vector<uint8_t> h_seq((size_t)seq_b), h_unp((size_t)pos_b, 1);
-  std::vector<double> h_ws((size_t)pos_b);
+  h_seq_.resize((size_t)seq_b);
+  std::vector<uint8_t>& h_seq = h_seq_;
+  uint8_t* h_unp = hb_unp_.get<uint8_t>((size_t)pos_b);
+  double* h_ws = hb_ws_.get<double>((size_t)pos_b);
+  double* h_ews = hb_ews_.get<double>((size_t)pos_b);
+  std::memset(h_unp, 1, (size_t)pos_b);
   std::vector<int32_t> h_ndot;
   std::vector<uint32_t> h_bits;
   if (fixmode) { h_ndot.assign((size_t)pos_b, 0); h_bits.assign((size_t)bits_b, 0u); }
@@ -842,7 +874,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
       if (c > 4) throw ArgError("load_batch: base code out of range");
       h_seq[p.seq_base + t] = c;
     }
-    position_weights(qual + qoff[k], p.L + 1, &h_ws[p.pos_base]);
+    position_weights(qual + qoff[k], p.L + 1, &h_ws[p.pos_base], &h_ews[p.pos_base]);
     if (fixmode) {
       const char* f = fix + off[k];
       nondot_prefix(f, p.L, &h_ndot[p.pos_base]);
@@ -868,17 +900,14 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
   std::iota(h_order_.begin(), h_order_.end(), 0);
   std::stable_sort(h_order_.begin(), h_order_.end(), [&](int a, int b) { return h_plans_[a].L > h_plans_[b].L; });
   d_seq_.upload(h_seq, st_);
-  d_ws_.upload(h_ws, st_);
-  {
-    std::vector<double> h_ews(h_ws.size());
-    for (size_t k = 0; k < h_ws.size(); ++k) h_ews[k] = std::exp(h_ws[k]);
-    d_ews_.upload(h_ews, st_);
-    HIP_OK(hipStreamSynchronize(st_));
-  }
-  h_seq_ = h_seq;
+  d_ws_.alloc(sizeof(double) * pos_b);
+  HIP_OK(hipMemcpyAsync(d_ws_.as<void>(), h_ws, sizeof(double) * pos_b, hipMemcpyHostToDevice, st_));
+  d_ews_.alloc(sizeof(double) * pos_b);
+  HIP_OK(hipMemcpyAsync(d_ews_.as<void>(), h_ews, sizeof(double) * pos_b, hipMemcpyHostToDevice, st_));
   d_zero_ws_.alloc(sizeof(double) * pos_b);
   HIP_OK(hipMemsetAsync(d_zero_ws_.as<void>(), 0, sizeof(double) * pos_b, st_));
-  d_unp_.upload(h_unp, st_);
+  d_unp_.alloc((size_t)pos_b);
+  HIP_OK(hipMemcpyAsync(d_unp_.as<void>(), h_unp, (size_t)pos_b, hipMemcpyHostToDevice, st_));
   if (fixmode) d_ndot_.upload(h_ndot, st_);
   d_okbits0_.alloc(sizeof(uint32_t) * bits_b);
   d_okbits1_.alloc(sizeof(uint32_t) * bits_b);

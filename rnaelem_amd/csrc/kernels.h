@@ -46,6 +46,7 @@ struct PlanKernelArgs {
   int32_t wmax1 = 0;     // largest W + 1 of the set
   int32_t n_roles = 3;   // 1: only the by_inner order (plan of the BPP filter)
   int32_t sort_roles = 1;   // sort every segment of the role lists by item index (reproducible summation order of the gathers)
+  int32_t count_fast = 0;   // loop_tables_finite and no imposed structure: the count pass takes popcounts (count_interior_by_end)
 };
 
 // byte offsets of the dynamic LDS regions of the DP kernels
@@ -248,6 +249,7 @@ hipError_t launch_plan_cells(const PlanKernelArgs& a, int32_t* n_items_out, hipS
 hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st);
 hipError_t launch_plan_sort(const PlanKernelArgs& a, hipStream_t st);   // the sort of launch_plan_items alone (sort_roles = 0 before)
 hipError_t launch_permute_items(const PlanKernelArgs& a, hipStream_t st);
+bool plan_copies_fused(const PlanKernelArgs& a);   // launch_plan_items has written the item copies already (no launch_permute_items)
 hipError_t launch_dp(int kind, const DpArgs& a, int n_blocks, hipStream_t st);
 hipError_t launch_reduce(const double* seq_out, int out_stride, int n_seq, int n_theta, double* partial, hipStream_t st);
 const char* dp_kernel_name(int kind);

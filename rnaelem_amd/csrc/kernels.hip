@@ -207,12 +207,19 @@ __global__ __launch_bounds__(kThreads) void k_plan_cells(PlanKernelArgs a, int32
     if (!has_loops(c)) cnt[c] = 0;
   }
   const int n_act = compact_loop_cells(sh, ncell, has_loops);
+  bool fast = a.count_fast != 0;      // (an N next to a pair makes a 2x2 loop log 0: such sequences are enumerated)
+  if (fast) {
+    int has_n = 0;
+    for (int t = threadIdx.x; t < L; t += kThreads) has_n |= (seq[t] == 0);
+    fast = !__syncthreads_or(has_n);
+  }
   int n_mine = 0;
   for (int t = threadIdx.x; t < n_act; t += kThreads) {
     const int c = sh.list[t];
     const int i = c / (W + 1), d = c - i * (W + 1);
     int n = 0;
-    enum_interior_by_end(*a.et, cfg, seq, L, W, p.C, ndot, words, i, d, [&](int, int, double, bool) { ++n; });
+    if (fast) n = count_interior_by_end(a.no_ene != 0, L, W, p.C, words, i, d);
+    else enum_interior_by_end(*a.et, cfg, seq, L, W, p.C, ndot, words, i, d, [&](int, int, double, bool) { ++n; });
     cnt[c] = n;
     n_mine += n;
   }
@@ -331,9 +338,12 @@ __global__ __launch_bounds__(kThreads) void k_role_scatter3(PlanKernelArgs a) {
 // One role of one sequence in ONE workgroup of 1024 threads (round 4): the counters of the keys live in LDS (4 bytes per cell: a
 // sequence of 300 with a band of 50 takes 61 KB), so the count pass is a pass of LDS atomics -- the global atomics of k_role_count3
 // serialise on the loop cells that hundreds of items share (32 ms per 10 000 x L=300) -- the scan runs on the LDS array, and the
-// scatter reads the offsets from LDS.  Ranks in the item-copy buffer as above.  grid = (3 roles, sequences); dynamic LDS =
-// (cells + 1) ints; the launcher falls back to the passes above for sequences whose counters do not fit.
+// scatter takes its positions from a second pass of LDS atomics on the scanned array (offsets written out before it).  COPY: the
+// scatter also writes the item's copy in the role's order (k_permute_items: a scattered 16-byte read per item and role otherwise).
+// grid = (3 roles, sequences); dynamic LDS = (cells + 1) ints; the launcher falls back to the passes above for sequences whose
+// counters do not fit.
 constexpr int kRoleThreads = 1024;
+template <bool COPY>
 __global__ __launch_bounds__(kRoleThreads) void k_role_build(PlanKernelArgs a) {
   extern __shared__ int32_t s_cnt[];
   __shared__ int tmp[kRoleThreads / 64 + 1];
@@ -344,14 +354,20 @@ __global__ __launch_bounds__(kRoleThreads) void k_role_build(PlanKernelArgs a) {
   for (int c = tid; c <= ncell; c += kRoleThreads) s_cnt[c] = 0;
   __syncthreads();
   const LoopItem* items = a.p.items + p.item_base;
-  int32_t* rank = reinterpret_cast<int32_t*>(a.p.items_inner + p.item_base) + role;
-  for (int t = tid; t < n_items; t += kRoleThreads) rank[(size_t)t * 3] = atomicAdd(&s_cnt[role_key(items[t], role, W)], 1);
+  for (int t = tid; t < n_items; t += kRoleThreads) atomicAdd(&s_cnt[role_key(items[t], role, W)], 1);
   __syncthreads();
   block_exclusive_scan_tiled<kRoleThreads>(s_cnt, ncell, tmp);
   int32_t* off = role_off(a.p, role) + p.off_base;
   for (int c = tid; c <= ncell; c += kRoleThreads) off[c] = s_cnt[c];
+  __syncthreads();
   int32_t* idx = role_idx(a.p, role) + p.item_base;
-  for (int t = tid; t < n_items; t += kRoleThreads) idx[s_cnt[role_key(items[t], role, W)] + rank[(size_t)t * 3]] = t;
+  LoopItem* copy = (role == 0 ? a.p.items_inner : role == 1 ? a.p.items_left : a.p.items_right) + p.item_base;
+  for (int t = tid; t < n_items; t += kRoleThreads) {
+    const LoopItem it = items[t];
+    const int pos = atomicAdd(&s_cnt[role_key(it, role, W)], 1);
+    idx[pos] = t;
+    if (COPY) copy[pos] = it;
+  }
 }
 // Sorts every segment of one role by item index (the scatter above leaves them in arbitrary order).  The segments of the
 // cells (i, 0..W) of one row are contiguous in the CSR array: a workgroup takes a row, builds the composite values
@@ -790,6 +806,12 @@ hipError_t launch_plan_cells(const PlanKernelArgs& a, int32_t* n_items_out, hipS
   hipLaunchKernelGGL(k_plan_cells, dim3((a.ncell_max + kPlanTile * kThreads - 1) / (kPlanTile * kThreads), a.count), dim3(kThreads), 0, st, a, n_items_out);
   return hipGetLastError();
 }
+// the three role lists of a sequence by one workgroup per role with its counters in LDS (k_role_build)?
+static bool plan_roles_in_lds(const PlanKernelArgs& a) {
+  return a.n_roles == 3 && a.p.items_inner && sizeof(int32_t) * ((size_t)a.ncell_max + 1) <= 150 * 1024 && !getenv("ELEMDP_ROLE_GLOBAL");
+}
+// .. which then also writes the item copies in the role orders, unless the segments are sorted afterwards
+bool plan_copies_fused(const PlanKernelArgs& a) { return plan_roles_in_lds(a) && !a.sort_roles; }
 hipError_t launch_permute_items(const PlanKernelArgs& a, hipStream_t st) {
   if (a.count <= 0 || !a.p.items_inner || a.nitems_max <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_permute_items, dim3((a.nitems_max + kThreads - 1) / kThreads, a.count), dim3(kThreads), 0, st, a);
@@ -800,12 +822,13 @@ hipError_t launch_plan_items(const PlanKernelArgs& a, hipStream_t st) {
   const dim3 cells((a.ncell_max + 1 + kThreads - 1) / kThreads, a.count), items((a.nitems_max + kThreads - 1) / kThreads, a.count);
   hipLaunchKernelGGL(k_plan_scan, dim3(a.count), dim3(kThreads), 0, st, a, -1);
   hipLaunchKernelGGL(k_plan_fill, dim3((a.ncell_max + kPlanTile * kThreads - 1) / (kPlanTile * kThreads), a.count), dim3(kThreads), 0, st, a);
-  const size_t role_lds = sizeof(int32_t) * ((size_t)a.ncell_max + 1);
-  if (a.n_roles == 3 && a.p.items_inner && role_lds <= 150 * 1024 && !getenv("ELEMDP_ROLE_GLOBAL")) {
-    // (ranks kept in the buffer of the item copies, which launch_permute_items fills later)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_role_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)role_lds);
+  if (plan_roles_in_lds(a)) {
+    const size_t role_lds = sizeof(int32_t) * ((size_t)a.ncell_max + 1);
+    const void* fn = plan_copies_fused(a) ? reinterpret_cast<const void*>(&k_role_build<true>) : reinterpret_cast<const void*>(&k_role_build<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)role_lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_role_build, dim3(3, a.count), dim3(kRoleThreads), role_lds, st, a);
+    if (plan_copies_fused(a)) hipLaunchKernelGGL(k_role_build<true>, dim3(3, a.count), dim3(kRoleThreads), role_lds, st, a);
+    else hipLaunchKernelGGL(k_role_build<false>, dim3(3, a.count), dim3(kRoleThreads), role_lds, st, a);
   } else if (a.n_roles == 3 && a.p.items_inner) {
     hipLaunchKernelGGL(k_role_zero3, cells, dim3(kThreads), 0, st, a);
     if (a.nitems_max > 0) hipLaunchKernelGGL(k_role_count3, items, dim3(kThreads), 0, st, a);

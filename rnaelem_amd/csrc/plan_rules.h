@@ -97,4 +97,38 @@ ELEMDP_HD void enum_interior_by_end(const EnergyTables& e, const PlanCfg& cfg, c
   }
 }
 
+// The NUMBER of candidates enum_interior_by_end visits, from popcounts of the same bit runs -- valid when no loop term is log 0
+// except by size (loop_tables_finite, energy_tables.h; a sequence without N) and no structure is imposed (ndot == nullptr): then a kept pair (k, l) is
+// dropped only where the loop would hold more than kMaxLoop unpaired bases (loop_energy, energy_rules.h:77).  The count pass of
+// the plan builder (k_plan_cells) evaluated the energy of every candidate just to test it against log 0.
+template <class WordFn>
+ELEMDP_HD int count_interior_by_end(bool no_ene, int L, int W, int C, const WordFn& word, int i, int d) {
+  const int j = i + d;
+  int n = 0;
+  for (int l = j; l >= i + 2; --l) {
+    int kmax = (l - 2 < i + C) ? l - 2 : i + C;
+    if (!no_ene) {
+      const int kcap = i + kMaxLoop - (j - l);
+      if (kcap < kmax) kmax = kcap;
+      if (kmax < i) break;            // (the right side alone exceeds kMaxLoop from here on)
+    }
+    const int dhi = (l - i < W) ? l - i : W, dlo = l - kmax;
+    for (int top = dhi; top >= dlo; top -= 32) {
+      const int lo = (top - 31 > dlo) ? top - 31 : dlo;
+      const int len = top - lo + 1;
+      const long long b0 = (long long)l * (W + 1) + lo;
+      const int w = (int)(b0 >> 5), sh = (int)(b0 & 31);
+      const unsigned long long two = ((unsigned long long)word(w + 1) << 32) | (unsigned long long)word(w);
+      uint32_t m = (uint32_t)(two >> sh);
+      if (len < 32) m &= (1u << len) - 1u;
+      n += __builtin_popcount(m);
+    }
+  }
+  if (d <= W && d >= 2) {             // (k, l) = (i, j): the closing pair's stack (rule 1b), not a loop
+    const long long b = (long long)j * (W + 1) + d;
+    if ((word((int)(b >> 5)) >> (b & 31)) & 1u) --n;
+  }
+  return n;
+}
+
 }  // namespace elemdp

@@ -169,6 +169,11 @@ void plan_finish(const Emu& E, HostPlan& P) {
     for (int i = 0; i <= L; ++i)
       for (int d = 0; d <= W && i + d <= L; ++d) {
         if (!(i > 0 && d + 2 <= W && P.ok(i - 1, d + 2))) continue;
+        if (!ndot && loop_tables_finite(E.et) && std::find(P.seq.begin(), P.seq.end(), (uint8_t)0) == P.seq.end()) {   // the count pass of the product (popcounts): as many as the enumeration visits
+          size_t m = 0;
+          enum_interior_by_end(E.et, cfg, P.seq.data(), L, W, P.C, ndot, word, i, d, [&](int, int, double, bool) { ++m; });
+          if ((size_t)count_interior_by_end(cfg.no_ene != 0, L, W, P.C, word, i, d) != m) ++g_enum_mismatch;
+        }
         enum_interior_by_end(E.et, cfg, P.seq.data(), L, W, P.C, ndot, word, i, d, [&](int k, int l, double tsc, bool in) {
           if (n >= P.items.size()) { ++g_enum_mismatch; return; }
           const LoopItem& it = P.items[n];
