@@ -873,14 +873,34 @@ constexpr int kSeqThreads = 512;
 #define ELEMDP_SEQ_BATCH 8
 #endif
 constexpr int kBL = ELEMDP_SEQ_BATCH;   // candidates per batch of loads in the loop sums
+#ifndef ELEMDP_SEQ_QUADS
+#define ELEMDP_SEQ_QUADS 2
+#endif
+constexpr int kBQ = ELEMDP_SEQ_QUADS;   // quads of the generic class per batch of loads
+#ifndef ELEMDP_SEQ_KO
+#define ELEMDP_SEQ_KO 0         // timing experiments: 1 no class loops, 2 no special shapes, 4 no stems (inside sweep)
+#endif
+#ifndef ELEMDP_SEQ_STEM_BATCH
+#define ELEMDP_SEQ_STEM_BATCH 6
+#endif
+constexpr int kBS = ELEMDP_SEQ_STEM_BATCH;   // stems per batch of loads (inside sweep)
 constexpr int kSeqStem = 2;      // most lanes per cell for the stem sums
-struct SeqLdsLayout { int cand, part, stem, stem2, dmin, slot, plist, poff, seq, bits, total; };
+// a candidate as the per-sequence kernels stage it: the offset of its plane entry from the lane's base pointer is formed once per
+// sequence (inside sweep: (kMaxLoop - T) * (L+1) + u1 from the row kMaxLoop diagonals below the cell's; outside: T * (L+1) - u1),
+// so a candidate costs an LDS read, one 64-bit shift-add, the load and the fma
+struct SeqCand { double coef; uint32_t off; int16_t u1, u2; };
+static_assert(sizeof(SeqCand) == 16, "one ds_read_b128 per candidate");
+struct __attribute__((packed, aligned(8))) Dbl2 { double x, y; };     // two neighbours of a plane row: one 16-byte load
+struct SeqLdsLayout { int cand, runc, runo, qoff, part, stem, stem2, dmin, slot, plist, poff, seq, bits, total; };
 __host__ __device__ inline SeqLdsLayout seq_lds_layout(int lmax, int wmax, int pmax, bool out) {
   SeqLdsLayout y;
   int o = 0;
   auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
   const int ncm = lmax + 1;
-  y.cand = take((int)sizeof(BppCand) * kBppCandMax);
+  y.cand = take((int)sizeof(SeqCand) * kBppCandMax);
+  y.runc = take(8 * kBppRunMax);
+  y.runo = take(4 * (kMaxLoop + 2));
+  y.qoff = take(4 * (kBppRunMax / 4));
   y.part = take(8 * ((kSeqThreads > ncm ? kSeqThreads : ncm) + kParts));
   y.stem = take(8 * kSeqStem * ncm);
   y.stem2 = out ? take(8 * kSeqStem * ncm) : y.stem;
@@ -921,19 +941,35 @@ __device__ void build_pair_lists(const Seq& q, int16_t* plist, int32_t* poff, in
 }
 
 struct SeqCtx {
-  BppCand* cand; double* part; double* stem; double* stem2; int16_t* dmin; int16_t* slot; int16_t* plist; int32_t* poff;
+  SeqCand* cand; double* runc; int32_t* runo; uint32_t* qoff; double* part; double* stem; double* stem2; int16_t* dmin; int16_t* slot; int16_t* plist; int32_t* poff;
   uint8_t* seq; uint32_t* bits;
 };
+template <bool OUT>
 __device__ __forceinline__ SeqCtx seq_stage(const BppLinArgs& a, const Seq& q, int n, unsigned char* base, const SeqLdsLayout& y) {
   SeqCtx c;
-  c.cand = reinterpret_cast<BppCand*>(base + y.cand); c.part = reinterpret_cast<double*>(base + y.part);
+  c.cand = reinterpret_cast<SeqCand*>(base + y.cand);
+  c.runc = reinterpret_cast<double*>(base + y.runc); c.runo = reinterpret_cast<int32_t*>(base + y.runo);
+  c.qoff = reinterpret_cast<uint32_t*>(base + y.qoff); c.part = reinterpret_cast<double*>(base + y.part);
   c.stem = reinterpret_cast<double*>(base + y.stem); c.stem2 = reinterpret_cast<double*>(base + y.stem2);
   c.dmin = reinterpret_cast<int16_t*>(base + y.dmin); c.slot = reinterpret_cast<int16_t*>(base + y.slot);
   c.plist = reinterpret_cast<int16_t*>(base + y.plist); c.poff = reinterpret_cast<int32_t*>(base + y.poff);
   c.seq = base + y.seq; c.bits = reinterpret_cast<uint32_t*>(base + y.bits);
   const int tid = threadIdx.x, L = q.L, W = q.W;
   const SeqPlan p = a.plans[n];
-  for (int t = tid; t < kBppCandMax; t += kSeqThreads) c.cand[t] = a.cand->e[t];
+  for (int t = tid; t < kBppCandMax; t += kSeqThreads) {
+    const BppCand e = a.cand->e[t];
+    SeqCand s;
+    s.coef = e.coef; s.u1 = (int16_t)e.u1; s.u2 = (int16_t)(e.T - e.u1);
+    s.off = OUT ? (uint32_t)(e.T * (L + 1) - e.u1) : (uint32_t)((kMaxLoop - e.T) * (L + 1) + e.u1);
+    c.cand[t] = s;
+  }
+  for (int t = tid; t < kBppRunMax; t += kSeqThreads) c.runc[t] = a.cand->run_coef[t];
+  for (int t = tid; t < kMaxLoop + 2; t += kSeqThreads) c.runo[t] = a.cand->run_off[t];
+  for (int t = tid; t < kBppRunMax / 4; t += kSeqThreads) {     // where a quad starts, from the lane's base (low 20 bits) | T << 20 | m << 25
+    const uint32_t T = a.cand->quad_T[t], m = a.cand->quad_m[t];
+    const uint32_t off = OUT ? T * (uint32_t)(L + 1) - T + 2u + m : (kMaxLoop - T) * (uint32_t)(L + 1) + 2u + m;
+    c.qoff[t] = off | (T << 20) | (m << 25);
+  }
   const int nword = (int)((((long long)(L + 1) * (W + 1)) + 31) >> 5);
   for (int t = tid; t < nword + 2; t += kSeqThreads) c.bits[t] = (t < nword) ? q.ok[t] : 0u;
   for (int t = tid; t < L; t += kSeqThreads) c.seq[t] = q.seq[t];
@@ -946,19 +982,29 @@ __device__ __forceinline__ SeqCtx seq_stage(const BppLinArgs& a, const Seq& q, i
   return c;
 }
 
+// debug clock of the per-sequence kernels (BppLinArgs::prof): thread 0 adds the cycles since its last mark to a phase
+struct SeqClock {
+  unsigned long long* row; unsigned long long t0;
+  __device__ __forceinline__ void start(unsigned long long* r) { row = (threadIdx.x == 0) ? r : nullptr; if (row) t0 = __builtin_readcyclecounter(); }
+  __device__ __forceinline__ void mark(int k) {
+    if (row) { const unsigned long long t = __builtin_readcyclecounter(); atomicAdd(row + k, t - t0); t0 = t; }
+  }
+};
 __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_IN) void k6_in_seq(BppLinArgs a) {
   extern __shared__ __align__(16) unsigned char s_seq[];
   const Seq q = make_seq(a, blockIdx.x);
   const int tid = threadIdx.x, W = q.W, L = q.L;
   const SeqLdsLayout y = seq_lds_layout(a.lmax, a.wmax, a.pmax, false);
-  const SeqCtx cx = seq_stage(a, q, blockIdx.x, s_seq, y);
+  const SeqCtx cx = seq_stage<false>(a, q, blockIdx.x, s_seq, y);
   const uint8_t* sq = cx.seq;
   const Mask mk{cx.bits, L, W};
   const EnergyTables& xet = *a.xet;
   const int Cc = (q.C < kMaxLoop) ? q.C : kMaxLoop;
   const size_t row = (size_t)(L + 1);
   const int ncm = a.lmax + 1;
+  SeqClock clk; clk.start(a.prof ? a.prof + 0 : nullptr);
   __syncthreads();
+  clk.mark(0);
   for (int d = 0; d <= W && d <= L; ++d) {
     const int nc = L - d + 1;
     const int tmax = (Cc < d - 2) ? Cc : d - 2;          // inside set: (k - i) + (j - l) <= C, inner span >= 2
@@ -967,25 +1013,25 @@ __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_IN) void k6_in_seq(Bp
     for (int w = tid; w < nc * ns; w += kSeqThreads) {
       const int ln = w / nc, i = w - ln * nc, j = i + d, dmi = cx.dmin[i];
       double A = 0.;
-      if (dmi > 0 && dmi < d) {
+      if (!(ELEMDP_SEQ_KO & 4) && dmi > 0 && dmi < d) {
         const int smax = d - dmi;
-        for (int sp0 = 1 + ln; sp0 <= smax; sp0 += kB * ns) {
-          double x1[kB], xp[kB];
-          bool on[kB];
+        // (no mask test: BP_PM of a cell that is no pair is 0, and a test per stem is an LDS round trip in front of its loads)
+        for (int sp0 = 1 + ln; sp0 <= smax; sp0 += kBS * ns) {
+          double x1[kBS], xp[kBS];
 #pragma unroll
-          for (int u = 0; u < kB; ++u) {
-            const int sp = sp0 + u * ns;
-            on[u] = sp <= smax && mk.ok(j - sp, sp);
-            x1[u] = xp[u] = 0.;
-            if (on[u]) { x1[u] = q.in(BP_1, d - sp, i); xp[u] = q.in(BP_PM, sp, j - sp); }
+          for (int u = 0; u < kBS; ++u) {
+            const int sp = sp0 + u * ns, spc = (sp <= smax) ? sp : smax;
+            x1[u] = q.in(BP_1, d - spc, i);
+            const double pm = q.in(BP_PM, spc, j - spc);
+            xp[u] = (sp <= smax) ? pm : 0.;
           }
 #pragma unroll
-          for (int u = 0; u < kB; ++u)
-            if (on[u]) A = fma(x1[u], xp[u], A);
+          for (int u = 0; u < kBS; ++u) A = fma(x1[u], xp[u], A);
         }
       }
       cx.stem[ln * ncm + i] = A;
     }
+    clk.mark(1);
     // rule 6c: the E cells (i, d) whose closing pair (i-1, j) is allowed = the pairs of diagonal d + 2
     const int lb = (tmax >= 1 && d + 2 <= W) ? cx.poff[d + 2] : 0;
     const int nE = (tmax >= 1 && d + 2 <= W) ? cx.poff[d + 3] - lb : 0;
@@ -1001,29 +1047,57 @@ __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_IN) void k6_in_seq(Bp
         const int mi = type * 25 + sq[i] * 5 + sq[j - 1];
         const double fac[BC_CLASSES] = {xet.mismatch_i[mi], xet.mismatch_1ni[mi], is_au(type) ? xet.term_au : 1.};
         double HE = 0.;
+        if (!(ELEMDP_SEQ_KO & 1) && tmax >= kBppRunMin) {
+          // generic loops: the entries of one T are a run of the row d - T: quads of four neighbours (two 16-byte loads), the parts
+          // of a cell deal the quads, four quads' loads in flight together; past the end of its list a lane takes the zero quad
+          const double* __restrict__ pb = reinterpret_cast<const double*>(reinterpret_cast<uintptr_t>(q.tin) +
+              8 * ((size_t)(BP_X + BC_I) * q.t_stride + (size_t)i) + 8 * (ptrdiff_t)row * ((ptrdiff_t)d - kMaxLoop));
+          const int nq = cx.runo[tmax + 1] >> 2;
+          double acc = 0., acc2 = 0.;
+          for (int q0 = part; q0 < nq; q0 += kBQ * parts) {
+            Dbl2 v0[kBQ], v1[kBQ];
+            int qq[kBQ];
 #pragma unroll
-        for (int c = 0; c < BC_CLASSES; ++c) {
-          const double* __restrict__ pl = q.tin + (size_t)(BP_X + c) * q.t_stride + (size_t)d * row + i;
+            for (int u = 0; u < kBQ; ++u) {
+              const int qi = q0 + u * parts;
+              qq[u] = (qi < nq) ? qi : kBppRunMax / 4 - 1;
+              const double* src = pb + (cx.qoff[qq[u]] & 0xFFFFFu);
+              v0[u] = *reinterpret_cast<const Dbl2*>(src); v1[u] = *reinterpret_cast<const Dbl2*>(src + 2);
+            }
+#pragma unroll
+            for (int u = 0; u < kBQ; ++u) {
+              const double* cf = cx.runc + 4 * qq[u];
+              const double2 c0 = *reinterpret_cast<const double2*>(cf), c1 = *reinterpret_cast<const double2*>(cf + 2);
+              acc = fma(c0.x, v0[u].x, acc); acc2 = fma(c0.y, v0[u].y, acc2);
+              acc = fma(c1.x, v1[u].x, acc); acc2 = fma(c1.y, v1[u].y, acc2);
+            }
+          }
+          HE = fac[BC_I] * (acc + acc2);
+        }
+        clk.mark(2);
+#pragma unroll
+        for (int c = BC_I + 1; c < ((ELEMDP_SEQ_KO & 1) ? 0 : BC_CLASSES); ++c) {
+          // (base kMaxLoop rows below the cell's: the offsets of the entries are unsigned; only those of valid entries are added)
+          const double* __restrict__ pl = reinterpret_cast<const double*>(reinterpret_cast<uintptr_t>(q.tin) +
+              8 * ((size_t)(BP_X + c) * q.t_stride + (size_t)i) + 8 * (ptrdiff_t)row * ((ptrdiff_t)d - kMaxLoop));
           const int end = co[c] + cn[c];
           double acc = 0.;
           for (int t0 = co[c] + part; t0 < end; t0 += kBL * parts) {
             double cf[kBL], pv[kBL];
 #pragma unroll
-            for (int u = 0; u < kBL; ++u) {
+            for (int u = 0; u < kBL; ++u) {      // (past the end: the last entry again, with coefficient 0 -- no branch per candidate)
               const int t = t0 + u * parts;
-              cf[u] = 0.; pv[u] = 0.;
-              if (t < end) {
-                const BppCand e = cx.cand[t];
-                cf[u] = e.coef;
-                pv[u] = pl[(ptrdiff_t)e.u1 - (ptrdiff_t)e.T * (ptrdiff_t)row];
-              }
+              const SeqCand e = cx.cand[(t < end) ? t : end - 1];
+              cf[u] = (t < end) ? e.coef : 0.;
+              pv[u] = pl[e.off];
             }
 #pragma unroll
             for (int u = 0; u < kBL; ++u) acc = fma(cf[u], pv[u], acc);
           }
           HE = fma(fac[c], acc, HE);
         }
-        for (int sx = part; sx < kBppSpecial; sx += parts) {
+        clk.mark(3);
+        for (int sx = part; sx < ((ELEMDP_SEQ_KO & 2) ? 0 : kBppSpecial); sx += parts) {
           const int u1 = kSpecialU1[sx], u2 = kSpecialU2[sx];
           const int k = i + u1, sp = d - u1 - u2;
           if (u1 + u2 <= tmax && mk.ok(k, sp)) HE = fma(q.in(BP_P, sp, k), loop_weight(xet, sq, i - 1, j, k, k + sp - 1), HE);
@@ -1032,13 +1106,25 @@ __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_IN) void k6_in_seq(Bp
         if (part == 0) cx.slot[i] = (int16_t)ix;
       }
     }
+    clk.mark(4);
     __syncthreads();
+    clk.mark(5);
     for (int i = tid; i < nc; i += kSeqThreads) {
       const int j = i + d;
       const int dmi = cx.dmin[i];
       auto left_ok = [&](int dd) { return dd <= W && dd >= 0 && i + dd <= L && dmi > 0 && dd >= dmi; };
       const bool pok = mk.ok(i, d), lok = left_ok(d), mok = q.m_ok(i, d, a.m_min);
       const bool eok = i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
+      // every operand is fetched unconditionally (valid addresses: the conditions below only select): one round of loads per cell
+      // instead of a dependent one per rule
+      const int c = q.cell(i, d), c_up = eok ? q.cell(i - 1, d + 2) : c;
+      const int d1 = (d >= 1) ? d - 1 : 0, d2 = (d >= 2) ? d - 2 : 0, i1 = (d >= 1) ? i + 1 : i;
+      const double lA = q.in(BP_A, d1, i), l2 = q.in(BP_2, d1, i), lM = q.in(BP_M, d1, i1);
+      const double lP = q.in(BP_P, d2, i1), lE = q.in(BP_E, d2, i1);
+      const double xS = q.x(XW_STACK, c), xM = q.x(XW_ML, c), xC = q.x(XW_CLOSE, c_up), xH = q.x(XW_HP, c_up);
+      const int type2 = bp_type(sq[(d >= 1) ? j - 1 : i], sq[i]);
+      const int mi = type2 * 25 + sq[(j < L) ? j : L - 1] * 5 + sq[(i > 0) ? i - 1 : 0];
+      const double fI = xet.mismatch_i[mi], fN = xet.mismatch_1ni[mi];
       double A = 0., HE = 0.;
       for (int k = 0; k < ns; ++k) A += cx.stem[k * ncm + i];
       const int sl = cx.slot[i];
@@ -1046,33 +1132,29 @@ __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_IN) void k6_in_seq(Bp
         for (int k = 0; k < parts; ++k) HE += cx.part[k * nE + sl];
         cx.slot[i] = -1;
       }
-      if (dmi > 0 && dmi < d) A += q.in(BP_A, d - 1, i);      // the tail grows by the unpaired base j-1
-      const int c = q.cell(i, d), c_up = eok ? q.cell(i - 1, d + 2) : c;
+      if (dmi > 0 && dmi < d) A += lA;      // the tail grows by the unpaired base j-1
       double vP = 0.;
-      if (pok && d >= 2) vP = fma(q.in(BP_P, d - 2, i + 1), q.x(XW_STACK, c), q.in(BP_E, d - 2, i + 1));   // rules 1b, 1a
+      if (pok && d >= 2) vP = fma(lP, xS, lE);                                                                // rules 1b, 1a
       const double vB = lok ? A : 0.;
-      const double s2 = (lok && left_ok(d - 1)) ? q.in(BP_2, d - 1, i) : 0.;                                  // rule 3a
-      const double v2 = lok ? fma(vP, pok ? q.x(XW_ML, c) : 0., s2) : 0.;                                     // rule 3b
+      const double s2 = (lok && left_ok(d - 1)) ? l2 : 0.;                                                    // rule 3a
+      const double v2 = lok ? fma(vP, pok ? xM : 0., s2) : 0.;                                                // rule 3b
       const double v1 = lok ? v2 + vB : 0.;                                                                   // rules 4a, 4b
-      const double sM = (mok && q.m_ok(i + 1, d - 1, a.m_min)) ? q.in(BP_M, d - 1, i + 1) : 0.;               // rule 5a
+      const double sM = (mok && q.m_ok(i + 1, d - 1, a.m_min)) ? lM : 0.;                                     // rule 5a
       const double vM = mok ? sM + vB : 0.;                                                                   // rule 5b
-      const double vE = eok ? fma(vM, q.x(XW_CLOSE, c_up), q.x(XW_HP, c_up) + HE) : 0.;                       // rules 6a, 6b (L = 1), 6c
+      const double vE = eok ? fma(vM, xC, xH + HE) : 0.;                                                      // rules 6a, 6b (L = 1), 6c
       q.in(BP_P, d, i) = vP; q.in(BP_E, d, i) = vE; q.in(BP_M, d, i) = vM; q.in(BP_B, d, i) = vB;
       q.in(BP_1, d, i) = v1; q.in(BP_2, d, i) = v2; q.in(BP_A, d, i) = A;
       double xI = 0., xN = 0., xB = 0.;
       if (vP != 0.) {
-        const int type2 = bp_type(sq[j - 1], sq[i]);
         xB = is_au(type2) ? vP * xet.term_au : vP;
-        if (i > 0 && j < L) {
-          const int mi = type2 * 25 + sq[j] * 5 + sq[i - 1];
-          xI = vP * xet.mismatch_i[mi];
-          xN = vP * xet.mismatch_1ni[mi];
-        }
+        if (i > 0 && j < L) { xI = vP * fI; xN = vP * fN; }
       }
       q.in(BP_X + BC_I, d, i) = xI; q.in(BP_X + BC_N, d, i) = xN; q.in(BP_X + BC_B, d, i) = xB;
-      q.in(BP_PM, d, i) = (pok && vP != 0.) ? vP * q.x(XW_ML, c) : 0.;
+      q.in(BP_PM, d, i) = (pok && vP != 0.) ? vP * xM : 0.;
     }
+    clk.mark(6);
     __syncthreads();
+    clk.mark(7);
   }
 }
 
@@ -1081,14 +1163,16 @@ __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_OUT) void k6_out_seq(
   const Seq q = make_seq(a, blockIdx.x);
   const int tid = threadIdx.x, W = q.W, L = q.L;
   const SeqLdsLayout y = seq_lds_layout(a.lmax, a.wmax, a.pmax, true);
-  const SeqCtx cx = seq_stage(a, q, blockIdx.x, s_seq, y);
+  const SeqCtx cx = seq_stage<true>(a, q, blockIdx.x, s_seq, y);
   const uint8_t* sq = cx.seq;
   const Mask mk{cx.bits, L, W};
   const EnergyTables& xet = *a.xet;
   const int Cc = (q.C < kMaxLoop) ? q.C : kMaxLoop;
   const size_t row = (size_t)(L + 1);
   const int ncm = a.lmax + 1;
+  SeqClock clk; clk.start(a.prof ? a.prof + 8 : nullptr);
   __syncthreads();
+  clk.mark(0);
   for (int d = (W < L) ? W : L; d >= 0; --d) {
     const int nc = L - d + 1;
     const int tmax = (kMaxLoop < W - 2 - d) ? kMaxLoop : W - 2 - d;     // outside set: the closing pair spans at most W
@@ -1101,35 +1185,35 @@ __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_OUT) void k6_out_seq(
       double H1 = 0., HA = 0.;
       const int hi = lok ? ((W - d < L - j) ? W - d : L - j) : 0;
       const int bmax = pok ? ((W - d < i) ? W - d : i) : 0;
-      for (int n0 = 1 + ln; n0 <= hi; n0 += kB * ns) {          // (two loops: five operands per candidate in one cost 40 registers)
-        double oa[kB], xp[kB];
-        bool on[kB];
+      // (two loops: five operands per candidate in one cost 40 registers; no mask test: BP_PM of a cell that is no pair is 0)
+      for (int n0 = 1 + ln; n0 <= hi; n0 += kBS * ns) {
+        double oa[kBS], xp[kBS];
 #pragma unroll
-        for (int u = 0; u < kB; ++u) {
-          const int n = n0 + u * ns;
-          on[u] = n <= hi && mk.ok(j, n);
-          oa[u] = xp[u] = 0.;
-          if (on[u]) { oa[u] = q.out(BO_A, d + n, i); xp[u] = q.in(BP_PM, n, j); }
+        for (int u = 0; u < kBS; ++u) {
+          const int n = n0 + u * ns, nn = (n <= hi) ? n : hi;
+          oa[u] = q.out(BO_A, d + nn, i);
+          const double pm = q.in(BP_PM, nn, j);
+          xp[u] = (n <= hi) ? pm : 0.;
         }
 #pragma unroll
-        for (int u = 0; u < kB; ++u)
-          if (on[u]) H1 = fma(oa[u], xp[u], H1);
+        for (int u = 0; u < kBS; ++u) H1 = fma(oa[u], xp[u], H1);
       }
-      for (int n0 = 1 + ln; n0 <= bmax; n0 += kB * ns) {
-        double ob[kB], x1[kB];
+      for (int n0 = 1 + ln; n0 <= bmax; n0 += kBS * ns) {
+        double ob[kBS], x1[kBS];
 #pragma unroll
-        for (int u = 0; u < kB; ++u) {
-          const int n = n0 + u * ns;
-          ob[u] = x1[u] = 0.;
-          if (n <= bmax) { ob[u] = q.out(BO_A, d + n, i - n); x1[u] = q.in(BP_1, n, i - n); }
+        for (int u = 0; u < kBS; ++u) {
+          const int n = n0 + u * ns, nn = (n <= bmax) ? n : bmax;
+          ob[u] = q.out(BO_A, d + nn, i - nn);
+          const double v = q.in(BP_1, nn, i - nn);
+          x1[u] = (n <= bmax) ? v : 0.;
         }
 #pragma unroll
-        for (int u = 0; u < kB; ++u)
-          if (n0 + u * ns <= bmax) HA = fma(ob[u], x1[u], HA);
+        for (int u = 0; u < kBS; ++u) HA = fma(ob[u], x1[u], HA);
       }
       cx.stem[ln * ncm + i] = H1;
       cx.stem2[ln * ncm + i] = HA;
     }
+    clk.mark(1);
     // HP: the interior loops around the stems (i, j-1) of this diagonal: outer E cells (i - u1, d + T)
     const int lb = (tmax >= 1) ? cx.poff[d] : 0;
     const int nP = (tmax >= 1) ? cx.poff[d + 1] - lb : 0;
@@ -1154,30 +1238,60 @@ __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_OUT) void k6_out_seq(
           }
         }
         double HP = 0.;
+        if (tmax >= kBppRunMin) {
+          // generic loops: the entries of one T are a run of the row d + T, walked from u1 = T - 2 down (the coefficients are symmetric):
+          // element m of the run is (u1, u2) = (T - 2 - m, 2 + m)
+          const double* __restrict__ pb = q.tout + (size_t)(BO_X + BC_I) * q.t_stride + (size_t)d * row + i;
+          const int nq = cx.runo[tmax + 1] >> 2;
+          const int mhi = rmax - 2;
+          double acc = 0., acc2 = 0.;
+          for (int q0 = part; q0 < nq; q0 += kBQ * parts) {
+            Dbl2 v0[kBQ], v1[kBQ];
+            int qq[kBQ];
+            uint32_t qo[kBQ];
 #pragma unroll
-        for (int c = 0; c < BC_CLASSES; ++c) {
+            for (int u = 0; u < kBQ; ++u) {
+              const int qi = q0 + u * parts;
+              qq[u] = (qi < nq) ? qi : kBppRunMax / 4 - 1;
+              qo[u] = cx.qoff[qq[u]];
+              const double* src = pb + (qo[u] & 0xFFFFFu);
+              v0[u] = *reinterpret_cast<const Dbl2*>(src); v1[u] = *reinterpret_cast<const Dbl2*>(src + 2);
+            }
+#pragma unroll
+            for (int u = 0; u < kBQ; ++u) {
+              const double* cf = cx.runc + 4 * qq[u];
+              const double2 c0 = *reinterpret_cast<const double2*>(cf), c1 = *reinterpret_cast<const double2*>(cf + 2);
+              const int T = (int)((qo[u] >> 20) & 31u), m = (int)(qo[u] >> 25);
+              const int mlo = T - 2 - amax;
+              acc = fma((m >= mlo && m <= mhi) ? c0.x : 0., v0[u].x, acc);
+              acc2 = fma((m + 1 >= mlo && m + 1 <= mhi) ? c0.y : 0., v0[u].y, acc2);
+              acc = fma((m + 2 >= mlo && m + 2 <= mhi) ? c1.x : 0., v1[u].x, acc);
+              acc2 = fma((m + 3 >= mlo && m + 3 <= mhi) ? c1.y : 0., v1[u].y, acc2);
+            }
+          }
+          HP = fac[BC_I] * (acc + acc2);
+        }
+        clk.mark(2);
+#pragma unroll
+        for (int c = BC_I + 1; c < BC_CLASSES; ++c) {
           const double* __restrict__ pl = q.tout + (size_t)(BO_X + c) * q.t_stride + (size_t)d * row + i;
           const int end = co[c] + cn[c];
           double acc = 0.;
           for (int t0 = co[c] + part; t0 < end; t0 += kBL * parts) {
             double cf[kBL], ov[kBL];
 #pragma unroll
-            for (int u = 0; u < kBL; ++u) {
-              const int t = t0 + u * parts;
-              cf[u] = 0.; ov[u] = 0.;
-              if (t < end) {
-                const BppCand e = cx.cand[t];
-                if (e.u1 <= amax && e.T - e.u1 <= rmax) {
-                  cf[u] = e.coef;
-                  ov[u] = pl[(ptrdiff_t)e.T * (ptrdiff_t)row - (ptrdiff_t)e.u1];
-                }
-              }
+            for (int u = 0; u < kBL; ++u) {      // (an entry outside the sequence reads some finite entry of the plane -- the
+              const int t = t0 + u * parts;      //  planes are cleared when they are allocated -- with coefficient 0)
+              const SeqCand e = cx.cand[(t < end) ? t : end - 1];
+              cf[u] = (t < end && e.u1 <= amax && e.u2 <= rmax) ? e.coef : 0.;
+              ov[u] = pl[e.off];
             }
 #pragma unroll
             for (int u = 0; u < kBL; ++u) acc = fma(cf[u], ov[u], acc);
           }
           HP = fma(fac[c], acc, HP);
         }
+        clk.mark(3);
         for (int sx = part; sx < kBppSpecial; sx += parts) {
           const int u1 = kSpecialU1[sx], u2 = kSpecialU2[sx];
           const int io = i - u1, jo = j + u2;
@@ -1188,14 +1302,28 @@ __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_OUT) void k6_out_seq(
         if (part == 0) cx.slot[i] = (int16_t)ix;
       }
     }
+    clk.mark(4);
     __syncthreads();
+    clk.mark(5);
     for (int i = tid; i < nc; i += kSeqThreads) {
       const int j = i + d;
       const int dmi = cx.dmin[i];
       auto left_ok = [&](int dd) { return dd <= W && dd >= 0 && i + dd <= L && dmi > 0 && dd >= dmi; };
       const bool pok = mk.ok(i, d), lok = left_ok(d), mok = q.m_ok(i, d, a.m_min);
       const bool up_ok = i > 0 && d + 2 <= W && mk.ok(i - 1, d + 2);
+      // every operand is fetched unconditionally (valid addresses: the conditions below only select)
       const double inP = q.in(BP_P, d, i), inA = q.in(BP_A, d, i), in1 = q.in(BP_1, d, i);
+      const double inE = q.in(BP_E, d, i), inM = q.in(BP_M, d, i), inB = q.in(BP_B, d, i), in2 = q.in(BP_2, d, i);
+      const int c = q.cell(i, d), c_up = up_ok ? q.cell(i - 1, d + 2) : c;
+      const bool v2u = i > 0 && d + 2 <= W && j + 1 <= L, v1l = i > 0 && d + 1 <= W, v1r = d + 1 <= W && j + 1 <= L;
+      const double lP2 = q.out(BO_P, v2u ? d + 2 : d, v2u ? i - 1 : i);
+      const double lM1 = q.out(BO_M, v1l ? d + 1 : d, v1l ? i - 1 : i);
+      const double l21 = q.out(BO_2, v1r ? d + 1 : d, i), lA1 = q.out(BO_A, v1r ? d + 1 : d, i);
+      const double xS = q.x(XW_STACK, c_up), xC = q.x(XW_CLOSE, c_up), xE = q.x(XW_EXT, c), xM = q.x(XW_ML, c);
+      const double r7l = q.lo_in[i] + q.lo_out[j];
+      const int typeo = bp_type(sq[(i > 0) ? i - 1 : 0], sq[(j < L) ? j : L - 1]);
+      const int mio = typeo * 25 + sq[i < L ? i : L - 1] * 5 + sq[(d > 0) ? j - 1 : ((j < L) ? j : L - 1)];
+      const double fI = xet.mismatch_i[mio], fN = xet.mismatch_1ni[mio];
       double H1 = 0., HA = 0., HP = 0.;
       if (lok && in1 != 0.)
         for (int k = 0; k < ns; ++k) H1 += cx.stem[k * ncm + i];
@@ -1207,39 +1335,37 @@ __global__ __launch_bounds__(kSeqThreads, ELEMDP_SEQ_WAVES_OUT) void k6_out_seq(
           for (int k = 0; k < parts; ++k) HP += cx.part[k * nP + sl];
         cx.slot[i] = -1;
       }
-      const double inE = q.in(BP_E, d, i), inM = q.in(BP_M, d, i), inB = q.in(BP_B, d, i), in2 = q.in(BP_2, d, i);
-      const int c = q.cell(i, d), c_up = up_ok ? q.cell(i - 1, d + 2) : c;
-      const double opP = up_ok ? q.out(BO_P, d + 2, i - 1) : 0.;
+      const double opP = up_ok ? lP2 : 0.;
       const double oE = (up_ok && inE != 0.) ? opP : 0.;                                                        // rule 1a
-      const double oP1b = (up_ok && pok && inP != 0.) ? opP * q.x(XW_STACK, c_up) : 0.;                          // rule 1b
+      const double oP1b = (up_ok && pok && inP != 0.) ? opP * xS : 0.;                                          // rule 1b
       const bool doM = mok && q.m_ok(i - 1, d + 1, a.m_min);
-      const double sM = (doM && inM != 0.) ? q.out(BO_M, d + 1, i - 1) : 0.;                                     // rule 5a
-      const double oM = (inM != 0.) ? fma(oE, up_ok ? q.x(XW_CLOSE, c_up) : 0., sM) : 0.;                        // rule 6a
+      const double sM = (doM && inM != 0.) ? lM1 : 0.;                                                           // rule 5a
+      const double oM = (inM != 0.) ? fma(oE, up_ok ? xC : 0., sM) : 0.;                                         // rule 6a
       const double o1 = (in1 != 0.) ? H1 : 0.;
       const double oB = (inB != 0.) ? (mok ? oM : 0.) + o1 : 0.;                                                 // rules 5b, 4b
       const bool do2 = lok && left_ok(d + 1) && j < L;
-      const double s2 = (do2 && in2 != 0.) ? q.out(BO_2, d + 1, i) : 0.;                                         // rule 3a
+      const double s2 = (do2 && in2 != 0.) ? l21 : 0.;                                                           // rule 3a
       const double o2 = (in2 != 0.) ? o1 + s2 : 0.;                                                              // rule 4a (direct part)
       double oP = 0.;
       if (inP != 0.) {
-        const double xe = pok ? q.x(XW_EXT, c) : 0.;
-        const double r7 = (xe != 0.) ? exp(q.lo_in[i] + q.lo_out[j]) * xe : 0.;                                  // rule 7 (lo_out holds - ln Z)
-        oP = r7 + oP1b + (o2 + HA) * (pok ? q.x(XW_ML, c) : 0.) + HP;                                            // rules 3b, 6c
+        const double xe = pok ? xE : 0.;
+        const double r7 = (xe != 0.) ? exp(r7l) * xe : 0.;                                                       // rule 7 (lo_out holds - ln Z)
+        oP = r7 + oP1b + (o2 + HA) * (pok ? xM : 0.) + HP;                                                       // rules 3b, 6c
       }
       double oA = 0.;
-      if (inA != 0.) oA = (lok ? oB : 0.) + ((d + 1 <= W && j < L) ? q.out(BO_A, d + 1, i) : 0.);
+      if (inA != 0.) oA = (lok ? oB : 0.) + ((d + 1 <= W && j < L) ? lA1 : 0.);
       q.out(BO_P, d, i) = oP; q.out(BO_E, d, i) = oE; q.out(BO_M, d, i) = oM; q.out(BO_2, d, i) = o2; q.out(BO_A, d, i) = oA;
       double xI = 0., xN = 0., xB = 0.;
       if (oE != 0.) {
-        const int type = bp_type(sq[i - 1], sq[j]);
-        const int mi = type * 25 + sq[i] * 5 + sq[(d > 0) ? j - 1 : j];
-        xI = oE * xet.mismatch_i[mi];
-        xN = oE * xet.mismatch_1ni[mi];
-        xB = is_au(type) ? oE * xet.term_au : oE;
+        xI = oE * fI;
+        xN = oE * fN;
+        xB = is_au(typeo) ? oE * xet.term_au : oE;
       }
       q.out(BO_X + BC_I, d, i) = xI; q.out(BO_X + BC_N, d, i) = xN; q.out(BO_X + BC_B, d, i) = xB;
     }
+    clk.mark(6);
     __syncthreads();
+    clk.mark(7);
   }
 }
 
@@ -1298,6 +1424,15 @@ void build_bpp_cand(const EnergyTables& x, BppCandTable* t) {
       t->upto[c][T] = n - t->base[c];
     }
   }
+  int r = 0;
+  for (int T = 0; T <= kMaxLoop + 1; ++T) {
+    t->run_off[T] = r;
+    if (T < kBppRunMin || T > kMaxLoop) continue;
+    for (int u1 = 2; u1 <= T - 2; ++u1) t->run_coef[r++] = x.interior[T] * x.ninio[u1 > T - u1 ? 2 * u1 - T : T - 2 * u1];
+    while (r & 3) t->run_coef[r++] = 0.;
+    for (int q = t->run_off[T] / 4; q < r / 4; ++q) { t->quad_T[q] = (uint8_t)T; t->quad_m[q] = (uint8_t)(4 * q - t->run_off[T]); }
+  }
+  t->quad_T[kBppRunMax / 4 - 1] = kBppRunMin; t->quad_m[kBppRunMax / 4 - 1] = 0;      // the zero quad: any valid address
 }
 
 hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hipStream_t st) {

@@ -352,6 +352,7 @@ class Engine {
   bool linear_ok_ = true;
   int flags_, max_span_, max_iloop_;
   bool loops_finite_ = false;   // loop_tables_finite(et_)
+  bool bpp_planes_finite_ = false;   // the linear filter's planes hold nothing but finite values (cleared at allocation)
   double min_bpp_, tau_;
   int device_ = -1, n_cu_ = 256;   // device_ < 0: no HIP device (host-only handle)
   hipStream_t st_ = nullptr;
@@ -977,8 +978,17 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         }
         d_bpp_plans_.upload(hp, st_);
         d_bpp_xw_.alloc(sizeof(double) * 5 * (size_t)cells, true);
-        d_bpp_band_in_.alloc(sizeof(double) * kBppInPlanes * (size_t)cells, true);
-        d_bpp_band_out_.alloc(sizeof(double) * kBppOutPlanes * (size_t)cells, true);
+        // (the per-sequence sweeps read plane entries outside a sequence's triangle with coefficient 0: they must be finite, so a
+        // fresh allocation is cleared once; later loads leave finite values of theirs)
+        for (auto pb : {std::make_pair(&d_bpp_band_in_, sizeof(double) * kBppInPlanes * (size_t)cells),
+                        std::make_pair(&d_bpp_band_out_, sizeof(double) * kBppOutPlanes * (size_t)cells)}) {
+          const void* before = pb.first->as<void>();
+          const size_t before_b = pb.first->bytes();
+          pb.first->alloc(pb.second, true);
+          if (pb.first->as<void>() != before || pb.first->bytes() != before_b || !bpp_planes_finite_)
+            HIP_OK(hipMemsetAsync(pb.first->as<void>(), 0, pb.first->bytes(), st_));
+        }
+        bpp_planes_finite_ = true;
         d_bpp_ext_in_.alloc(sizeof(double) * (size_t)pos, true);
         d_bpp_ext_out_.alloc(sizeof(double) * (size_t)pos, true);
         d_bpp_dmin_.alloc(sizeof(int16_t) * (size_t)pos, true);
@@ -1006,6 +1016,12 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         a.okbits_out = d_okbits1_.as<uint32_t>();
         a.kept = d_bpp_kept_.as<int32_t>();
         a.log_min_bpp = std::log(min_bpp_);
+        DevBuf d_prof;
+        if (getenv("ELEMDP_BPP_PROF")) {
+          d_prof.alloc(sizeof(unsigned long long) * 16);
+          HIP_OK(hipMemsetAsync(d_prof.as<void>(), 0, sizeof(unsigned long long) * 16, st_));
+          a.prof = d_prof.as<unsigned long long>();
+        }
         if (opt_keep_lnbpp_) { d_lnbpp.alloc(sizeof(double) * cells); a.lnbpp = d_lnbpp.as<double>(); }
         HIP_OK(launch_bpp_lin(a, count, lmax, wmax, st_));
         std::vector<int32_t> kept(count);
@@ -1013,6 +1029,18 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
         HIP_OK(hipStreamSynchronize(st_));
         for (int k = 0; k < count; ++k) h_plans_[first + k].bpp_eff = (double)kept[k] / (double)ncanon[first + k];
         dbg_lap("load: BPP filter, linear (chunk)");
+        if (a.prof) {
+          unsigned long long h[16];
+          HIP_OK(hipMemcpy(h, a.prof, sizeof(h), hipMemcpyDeviceToHost));
+          static const char* nm[8] = {"stage", "stems", "loops generic", "loops 1xn / bulge", "special shapes", "barrier 1", "unary", "barrier 2"};
+          for (int dir = 0; dir < 2; ++dir) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < 8; ++k) tot += h[dir * 8 + k];
+            for (int k = 0; k < 8; ++k)
+              fprintf(stderr, "[elemdp bpp prof] %s %-18s %6.2f %%  %.3g cycles per sequence\n", dir ? "out" : "in ", nm[k],
+                      tot ? 100. * (double)h[dir * 8 + k] / (double)tot : 0., (double)h[dir * 8 + k] / count);
+          }
+        }
         if (opt_keep_lnbpp_) {
           const size_t base = h_lnbpp_.size();
           h_lnbpp_.resize(base + cells);
@@ -1041,6 +1069,7 @@ void Engine::load_batch(const uint8_t* seq, const int32_t* off, const uint8_t* q
       // evaluation pipelines survive a load_batch -- the mini-batch training mode loads before every evaluation
       {
         const size_t band1 = (size_t)kNumBandStates * (Wmax_ + 1) * (Lmax_ + 1), ext1 = (size_t)(Lmax_ + 1);
+        bpp_planes_finite_ = false;   // (log-space values: log 0 = -inf)
         d_bpp_band_in_.alloc(band1 * count * sizeof(double), true);
         d_bpp_band_out_.alloc(band1 * count * sizeof(double), true);
         d_bpp_ext_in_.alloc(ext1 * count * sizeof(double), true);

@@ -133,11 +133,18 @@ constexpr int kBppLinMaxSpan = 200;
 enum { BC_I = 0, BC_N, BC_B, BC_CLASSES };   // generic loops (mismatch_i); 1 x n loops (mismatch_1ni); bulges of two and more bases (term_au)
 struct BppCand { double coef; int32_t u1, T; };
 constexpr int kBppCandMax = 496;
+constexpr int kBppRunMin = 6;                  // from T = 6 on every (u1, T - u1), u1 = 2 .. T - 2, is a generic loop
+constexpr int kBppRunMax = 416;
 struct BppCandTable {
   int32_t base[BC_CLASSES];                    // first entry of a class in e[]
   int32_t upto[BC_CLASSES][kMaxLoop + 1];      // entries of the class with u1 + u2 <= T (entries are sorted by T)
-  int32_t pad_;
+  // the generic class once more as RUNS: the entries u1 = 2 .. T - 2 of one T are neighbours in a plane row, so the per-sequence
+  // kernels take them with 16-byte loads: run_coef[run_off[T] + m] = g(2 + m, T - 2 - m) (symmetric in its arguments: the outside
+  // sweep walks the row the other way with the same array), each run padded with zeros to a multiple of four
+  int32_t run_off[kMaxLoop + 2];
   BppCand e[kBppCandMax];
+  double run_coef[kBppRunMax];                 // (the last four are zeros: the quad a lane takes past the end of its list)
+  uint8_t quad_T[kBppRunMax / 4], quad_m[kBppRunMax / 4];   // quad q = run_coef[4q .. 4q+3] belongs to T = quad_T[q], starts at m = quad_m[q]
 };
 void build_bpp_cand(const EnergyTables& xet, BppCandTable* t);
 // the eight shapes that do not factorise (stacked bulge, 1x1, 1x2, 2x1, 2x2, 2x3, 3x2): evaluated by loop_weight
@@ -150,6 +157,7 @@ struct BppLinArgs {
   int16_t* plist; int32_t* poff;   // pairs of every diagonal of a sequence, ascending ([cell_base + ..], [seq * poff_stride + d]); null: diagonal launches
   int32_t poff_stride, pmax;       // pmax = most canonical pairs of a sequence of the chunk
   int32_t lmax, wmax;              // set by launch_bpp_lin
+  unsigned long long* prof;        // debug (ELEMDP_BPP_PROF): cycles of wave 0 of every workgroup per phase [direction][8], or null
   const SeqPlan* plans;
   const uint8_t* seq;
   const uint32_t* okbits;          // canonical pair mask
