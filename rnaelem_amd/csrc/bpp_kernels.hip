@@ -862,7 +862,10 @@ __global__ __launch_bounds__(kThreads) void k6_out_tab(BppLinArgs a) {
 // a diagonal costs two barriers.  A diagonal's values reach the next one through global memory: written and read by the same
 // workgroup, whose waves share the CU's vector L1 (write-through), with the barrier's workgroup-scope fence in between.
 // Same sums as the _tab kernels in the same order per cell (parts differ: the partial sums are added in another fixed order).
-constexpr int kSeqThreads = 512;
+#ifndef ELEMDP_SEQ_THREADS
+#define ELEMDP_SEQ_THREADS 512
+#endif
+constexpr int kSeqThreads = ELEMDP_SEQ_THREADS;
 #ifndef ELEMDP_SEQ_WAVES_IN
 #define ELEMDP_SEQ_WAVES_IN 6   // waves per SIMD the per-sequence kernels are compiled for (6: three workgroups of 512 per CU, 80 registers)
 #endif

@@ -90,7 +90,8 @@ T_trace, T_b = (L + 1) * (W + 1) * 7 * S * 20, (L + 1) * (W + 1) * 7 * 8
 # train: 5 T = inside writes T, the outside sweep reads it and writes its own table for both passes of the reference (4 T);
 # scan: 7 T + T_trace + 3 T_b = two sum insides (2 T), two sum outsides (4 T), the Viterbi pass (T + its trace), the filter (3 T_b)
 # (per kernel INSTANCE: the scan runs two instances of k4_in and of k4_out, each one pass)
-alg = {"k4_in": T, "k4_out": 4 * T} if not a.scan else {"k4_in": T, "k4_out": 2 * T, "k5_cyk": T + T_trace, "k6_in": T_b, "k6_out": 2 * T_b}
+alg = {"k4_in": T, "k4_out": 4 * T} if not a.scan else {"k4_in": T, "k4_out": 2 * T, "k5_cyk": T + T_trace, "k6_in": T_b, "k6_out": 2 * T_b,
+                                                           "k6_in_seq": T_b, "k6_out_seq": 2 * T_b, "k6_in_tab": T_b, "k6_out_tab": 2 * T_b}
 pipeline = ("k4_", "k_reduce") if not a.scan else ("k4_", "k5_", "k6_")
 rows, tot_f, tot_w, tot_ms = {}, 0.0, 0.0, 0.0
 for k in sorted(set(fetch) | set(write)):
