@@ -300,3 +300,50 @@ def test_filter_from_the_candidate_table_equals_the_mask_walk(monkeypatch):
                 assert np.array_equal(ka, kb), (mode, W, C, k)
                 assert_log_close(la, lb, rtol=1e-10, atol=1e-10, what="lnbpp %s W=%d C=%d k=%d" % (mode, W, C, k))
             np.testing.assert_array_equal(res[mode][1], res["ELEMDP_BPP_WALK"][1])
+
+
+def test_plan_builder_forms_agree(monkeypatch):
+    """The plan of a batch built three ways gives the same evaluation: role lists by one workgroup per (sequence, role) with LDS
+    counters + popcount count pass (default), role lists by global atomics in separate passes (ELEMDP_ROLE_GLOBAL; also what a
+    sequence too long for the LDS counters forces: L = 900), count pass by enumeration (ELEMDP_PLAN_ENUM_COUNT; also what a
+    sequence with N bases takes).  Default mode (atomic sums: 1e-11) and deterministic mode (sorted segments, item copies by
+    k_permute_items: bit-identical)."""
+    rng = np.random.default_rng(12)
+    seqs, quals = ragged(300, ((60, 5), (200, 6), (131, 4), (33, 3)))
+    seqs[2] = seqs[2].copy()
+    seqs[2][rng.integers(0, len(seqs[2]), size=6)] = 0          # N bases: the enumerating count pass for this sequence
+    long_s, long_q = synth.synth_batch(1, 900, seed=77)
+    res = {}
+    for det in (0, 1):
+        for mode in ("", "ELEMDP_ROLE_GLOBAL", "ELEMDP_PLAN_ENUM_COUNT", "long"):
+            for m in ("ELEMDP_ROLE_GLOBAL", "ELEMDP_PLAN_ENUM_COUNT"):
+                monkeypatch.delenv(m, raising=False)
+            if mode.startswith("ELEMDP"):
+                monkeypatch.setenv(mode, "1")
+            eng = api.Engine("((.*.))", "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+            if det:
+                eng.set_option("deterministic", 1)
+            if mode == "long":     # the long sequence takes the whole plan set to the global passes; its own terms are subtracted below
+                eng.load_batch(seqs + long_s, quals + long_q)
+            else:
+                eng.load_batch(seqs, quals)
+            x = eng.initial_params(1.0)
+            fn, gr, eff, nsk = eng.train_eval(x)
+            res[(det, mode)] = (fn, gr, eng.seq_stats()[:len(seqs)].copy(), eng.bpp_eff()[:len(seqs)].copy())
+        for m in ("ELEMDP_ROLE_GLOBAL", "ELEMDP_PLAN_ENUM_COUNT"):
+            monkeypatch.delenv(m, raising=False)
+        ref = res[(det, "")]
+        for mode in ("ELEMDP_ROLE_GLOBAL", "ELEMDP_PLAN_ENUM_COUNT"):
+            got = res[(det, mode)]
+            if det:
+                assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+            else:
+                assert got[0] == pytest.approx(ref[0], rel=1e-11)
+                np.testing.assert_allclose(got[1], ref[1], rtol=1e-10, atol=1e-11)
+            np.testing.assert_array_equal(got[3], ref[3])
+        got = res[(det, "long")]           # per-sequence rows of the shared sequences are the same whatever else is in the batch
+        if det:
+            assert np.array_equal(got[2], ref[2])
+        else:
+            np.testing.assert_allclose(got[2], ref[2], rtol=1e-10, atol=1e-11)
+        np.testing.assert_array_equal(got[3], ref[3])
