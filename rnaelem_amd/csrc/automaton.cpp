@@ -305,7 +305,7 @@ Automaton::Liveness Automaton::liveness() const {
 }
 
 void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0, bool prune, bool shadow,
-                        int row_pad) const {
+                        int row_pad, bool cell_major) const {
   const int S_ = S(), m = M();
   const int ST = S_ + (shadow ? 1 : 0);   // states of the flattened automaton (the shadow of (0,0) is the last one)
   Liveness lv;
@@ -513,7 +513,8 @@ void Automaton::flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool o
       A.tab_cs[e] = cs;
       cs += A.tab_rs[e];
     }
-    A.tab_row = cs;
+    A.tab_row = cell_major ? ((cs + 7) / 8) * 8 : cs;     // (cell records start on 64-byte lines)
+    A.tab_cell = cell_major ? 1 : 0;
     A.ap_rs = std::max(pad, ((A.n_ap + pad - 1) / pad) * pad);
   }
   // table-driven unary phases (device_layout.h: fp_*): programs per state, static attributes per forward transition.  They
@@ -781,7 +782,7 @@ void flatten_trivial(AutomatonLayout* lay, std::vector<int32_t>* ints) {
   csr(1, &A.ap_by_s1_off, &A.ap_by_s1_ent); csr(1, &A.ap_by_t_off, &A.ap_by_t_ent);
   A.tab_cmap = (int32_t)ints->size();
   for (int e = 0; e < 7; ++e) { ints->push_back(0); A.tab_rs[e] = 1; A.tab_cs[e] = e; }
-  A.tab_row = 7; A.ap_rs = 1;
+  A.tab_row = 7; A.ap_rs = 1; A.tab_cell = 0;
   A.fp_ok = 0; A.fp_in = A.fp_out = A.fe_r = A.fe_p = 0; A.n_wr = A.n_wp = A.n_wl = 0;
   A.fb_in = A.fb_in_n = A.fb_out = A.fb_out_n = A.fqc_in = A.fpr_in = A.fqc_out = A.fpr_out = A.fs_in = A.fs_out = 0;
   A.qd_in = A.qd_out = A.fqd_in = A.fqd_out = 0;

@@ -79,6 +79,9 @@ struct AutomatonLayout {
   // lines.  ap_rs: row stride of the pair tables of the factorised rule 2 (>= n_ap).
   int32_t tab_cmap;
   int32_t tab_rs[7], tab_cs[7], tab_row;
+  // tab_cell: the seven rows of a cell lie side by side in one record of tab_row doubles (entry = cell * tab_row + tab_cs[e] + column)
+  // instead of plane after plane (entry = tab_cs[e] * cells + cell * tab_rs[e] + column): TableView::set_compact
+  int32_t tab_cell;
   int32_t ap_rs;
   // ---- Table-driven train kernels (lin_fast.h, k4_in / k4_out with FAST).  They stage only their own FAST BLOB -- ints
   // [fb_in, fb_in + fb_in_n) resp. [fb_out, fb_out + fb_out_n) behind n_ints -- instead of the generic lists:

@@ -208,7 +208,10 @@ struct TableView {
   ELEMDP_HD void set_compact(const AutomatonLayout& A, const int32_t* ints) {
     const uint32_t cells = (uint32_t)(W + 1) * (uint32_t)(L + 1);
 #pragma unroll
-    for (int e = 0; e < 7; ++e) { pb[e] = (uint32_t)A.tab_cs[e] * cells; rs[e] = A.tab_rs[e]; }
+    for (int e = 0; e < 7; ++e) {
+      pb[e] = A.tab_cell ? (uint32_t)A.tab_cs[e] : (uint32_t)A.tab_cs[e] * cells;
+      rs[e] = A.tab_cell ? A.tab_row : A.tab_rs[e];
+    }
     cm = ints + A.tab_cmap;
     nAs = A.ap_rs;
   }

@@ -282,7 +282,8 @@ class Engine {
   void lin_weights(int first = 0, int count = 0);
   void upload_automaton();
   bool opt_prune_ = true;   // transition lists pruned to the transitions of complete parses (Automaton::flatten)
-  int opt_row_pad_ = 8;     // rows of the compact tables padded to a multiple of this many doubles (8 = 64-byte lines)
+  int opt_row_pad_ = 1;     // rows of the compact tables padded to a multiple of this many doubles (8 = 64-byte lines; 1 = none)
+  bool opt_cell_major_ = false;   // compact tables cell by cell (the seven rows of a cell side by side) instead of plane by plane
   // a train evaluation covers the records [eval_first, eval_first + eval_count) of the resident batch only (count 0: all): the
   // mini-batch trainer loads the records + negatives of several coming evaluations as ONE batch -- the filter and the plan do not
   // depend on x, and a load of 128 sequences costs as much as one of 1024 (launch-bound) -- and evaluates them range by range
@@ -466,9 +467,9 @@ Engine::Engine(const elemdp_model_desc& d)
 // the flat transition lists of the pattern automaton (pruned to the transitions that can occur in a complete parse unless
 // option "prune" = 0) and of its restriction to state (0,0)
 void Engine::flatten_automaton() {
-  au_.flatten(&lay_, &ints_, false, opt_prune_, false, opt_row_pad_);
-  au_.flatten(&layr_, &intsr_, true, opt_prune_, false, opt_row_pad_);
-  if (linear_ok_ && au_.S() < 127) au_.flatten(&lays_, &intss_, false, opt_prune_, true, opt_row_pad_);
+  au_.flatten(&lay_, &ints_, false, opt_prune_, false, opt_row_pad_, opt_cell_major_);
+  au_.flatten(&layr_, &intsr_, true, opt_prune_, false, opt_row_pad_, opt_cell_major_);
+  if (linear_ok_ && au_.S() < 127) au_.flatten(&lays_, &intss_, false, opt_prune_, true, opt_row_pad_, opt_cell_major_);
   else { lays_ = lay_; lays_.shadow = -1; intss_ = ints_; }
   lin_slots_ = 0;   // (the pair tables of the linear pipeline are sized by the automaton's pair list)
 }
@@ -596,8 +597,9 @@ void Engine::set_option(const std::string& key, double v) {
   else if (key == "sorted_plan") opt_sorted_plan_ = v != 0;
   else if (key == "eval_first") opt_eval_first_ = (int)v;
   else if (key == "eval_count") opt_eval_count_ = (int)v;
-  else if (key == "prune" || key == "row_pad") {
+  else if (key == "prune" || key == "row_pad" || key == "cell_major") {
     if (key == "prune") opt_prune_ = v != 0;
+    else if (key == "cell_major") opt_cell_major_ = v != 0;
     else opt_row_pad_ = std::max(1, (int)v);
     n_slots_ = 0;
     flatten_automaton();
@@ -1749,6 +1751,7 @@ void Engine::debug_tables(double* inside, double* outside, double* inside_o, dou
     if (!lin) return t[(((size_t)e * (W + 1) + d) * (L + 1) + i) * S + s2];
     const int c = TI[TL.tab_cmap + e * S + s2];
     if (c < 0 || !cell_live(e, d, i)) return 0.;
+    if (TL.tab_cell) return t[((size_t)d * (L + 1) + i) * TL.tab_row + TL.tab_cs[e] + c];
     return t[(size_t)TL.tab_cs[e] * cells + ((size_t)d * (L + 1) + i) * TL.tab_rs[e] + c];
   };
   auto reorder = [&](const std::vector<double>& t, const std::vector<double>* plus2, double* dst, bool outside_tab) {  // -> [i][d][e][s]

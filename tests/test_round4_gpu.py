@@ -347,3 +347,37 @@ def test_plan_builder_forms_agree(monkeypatch):
         else:
             np.testing.assert_allclose(got[2], ref[2], rtol=1e-10, atol=1e-11)
         np.testing.assert_array_equal(got[3], ref[3])
+
+
+@pytest.mark.parametrize("pattern", ["((.*.))", "(.....)"])
+def test_table_layouts_agree(pattern):
+    """The compact tables without row padding (the default since round 4), with rows padded to 64-byte lines (row_pad = 8, the
+    layout of round 3) and cell by cell (cell_major: the seven rows of a cell side by side) hold the same values: a deterministic
+    train evaluation is bit-identical, a default one agrees to 1e-11, and the scan's records are the same."""
+    seqs, quals = ragged(500, ((70, 4), (200, 5), (33, 3), (121, 4)))
+    res = {}
+    for name, opts in (("plain", {}), ("pad8", {"row_pad": 8}), ("cell", {"cell_major": 1}), ("cell8", {"cell_major": 1, "row_pad": 8})):
+        for det in (0, 1):
+            eng = api.Engine(pattern, "~T2004~", 50, 30, 1e-4, 0.1, 0, 0)
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            if det:
+                eng.set_option("deterministic", 1)
+            eng.load_batch(seqs, quals)
+            x = eng.initial_params(1.0)
+            res[(name, det)] = eng.train_eval(x)[:2] + (eng.seq_stats().copy(),)
+            if det:
+                res[(name, "scan")] = eng.scan(x)
+    for name in ("pad8", "cell", "cell8"):
+        a, b = res[(name, 1)], res[("plain", 1)]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), name
+        a, b = res[(name, 0)], res[("plain", 0)]
+        assert a[0] == pytest.approx(b[0], rel=1e-11)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-10, atol=1e-11)
+        (ra, ea), (rb, eb) = res[(name, "scan")], res[("plain", "scan")]
+        for p, q in zip(ra, rb):
+            assert (p["Ys"], p["Ye"], p["rss"]) == (q["Ys"], q["Ye"], q["rss"]) and list(p["psihat"]) == list(q["psihat"])
+            np.testing.assert_allclose(p["start"], q["start"], rtol=1e-10, atol=1e-300)
+            np.testing.assert_allclose(p["end"], q["end"], rtol=1e-10, atol=1e-300)
+            assert p["exist_prob"] == pytest.approx(q["exist_prob"], rel=1e-10)
+        np.testing.assert_allclose(ea, eb, rtol=1e-10, atol=1e-12)

@@ -12,7 +12,7 @@ for p in sys.argv[2:]:
         k = name.replace("elemdp::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         acc[k][cn] += val
 names = sorted({cn for k in acc for cn in acc[k]})
-for k in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", acc[k].get("GRBM_GUI_ACTIVE", 0)))[:4]:
+for k in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", acc[k].get("GRBM_GUI_ACTIVE", max(acc[k].values()))))[:int(os.environ.get("PMC_TABLE_TOP", "4"))]:
     print("==", k)
     for cn in names:
         if cn in acc[k]:
