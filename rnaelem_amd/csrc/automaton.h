@@ -57,7 +57,7 @@ class Automaton {
   // state (requires that state 0 is closed, Engine::linear_ok_).  One outside sweep with the "has motif" terminals on the
   // states of the pattern and the "no motif" terminal on the shadow then yields both outside passes of the train schedule.
   // row_pad: the rows of the compact tables of the scaled-linear pipeline (AutomatonLayout::tab_*) are padded to a multiple of
-  // row_pad doubles (8 = every row starts on a 64-byte line; 1, the default since round 4 = no padding: 68 instead of 104 doubles
+  // row_pad doubles (8 = every row starts on a 64-byte line; 1, the default since round 4 = no padding: 70 instead of 104 doubles
   // per cell for ((.*.)), and 4.7 % off the train evaluation -- the memory system is bound by requests).  cell_major: the seven rows of a cell lie side by side (one record of
   // tab_row doubles per cell, padded to a multiple of 8) instead of one plane after the other (AutomatonLayout::tab_cell).
   void flatten(AutomatonLayout* lay, std::vector<int32_t>* ints, bool only_state0 = false, bool prune = false,

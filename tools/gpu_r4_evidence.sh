@@ -3,7 +3,7 @@
 # (10 000 x L=200, default groups; separate --pmc passes, no tracing domains), the same for the scan (10 000 x L=300, (.....)).
 # tools/pmc_traffic.py reads the number of evaluations / scans / loads of every pass from its own dispatch counts and refuses a
 # per-kernel sum that exceeds the bench line's step.  Outputs under gpurun_out/r4ev/ -- the summaries are copied to profiles/.
-O=$GRAFT_REPO_ROOT/gpurun_out/r4ev2
+O=$GRAFT_REPO_ROOT/gpurun_out/r4ev3
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout -k 10 1000 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc $?"; cut -c1-400 $O/bench.json
