@@ -103,7 +103,8 @@ int elemdp_describe(const elemdp_handle* h, char* buf, int32_t cap);
  *                       "two_streams": second outside pass of schedule 0 on a second stream (default 1); "slots": table slots
  *     "keep_lnbpp"      keep ln BPP of the filter for elemdp_batch_pairs; "bpp_log": 1 = log-space BPP filter for every band
  *     "sorted_plan"     1: role lists of the plan sorted per cell (reproducible summation order of the log-space pipeline)
- *     "row_pad"         padding of the compact table rows in doubles (default 8 = 64-byte lines)
+ *     "row_pad"         padding of the compact table rows in doubles (default 1 = none; 8 = rows start on 64-byte lines)
+ *     "cell_major"      1 = the seven rows of a cell side by side in one record instead of plane after plane (default 0)
  *   measurement / tests
  *     "profile"         in-kernel phase clocks for elemdp_debug_profile; "dbg": switch phases off (results invalid);
  *     "poison"          1: every table is filled with NaN before an evaluation (an unmasked read of an entry nobody stored shows) */
