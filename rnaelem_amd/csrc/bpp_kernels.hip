@@ -545,6 +545,10 @@ struct BppLdsT {
 };
 __constant__ int8_t kSpecialU1[kBppSpecial] = {0, 1, 1, 1, 2, 2, 2, 3};
 __constant__ int8_t kSpecialU2[kBppSpecial] = {1, 0, 1, 2, 1, 2, 3, 2};
+static_assert(kBppSpecialU1[0] == 0 && kBppSpecialU1[1] == 1 && kBppSpecialU1[2] == 1 && kBppSpecialU1[3] == 1 && kBppSpecialU1[4] == 2 &&
+              kBppSpecialU1[5] == 2 && kBppSpecialU1[6] == 2 && kBppSpecialU1[7] == 3 && kBppSpecialU2[0] == 1 && kBppSpecialU2[1] == 0 &&
+              kBppSpecialU2[2] == 1 && kBppSpecialU2[3] == 2 && kBppSpecialU2[4] == 1 && kBppSpecialU2[5] == 2 && kBppSpecialU2[6] == 3 &&
+              kBppSpecialU2[7] == 2, "the special shapes of bpp_cand.h (which the CPU check walks)");
 
 // stages the entries with u1 + u2 <= tmax of every class; n[c] = their number, off[c] = where the class starts in sh.cand
 __device__ __forceinline__ void stage_cand(const BppCandTable* __restrict__ tab, BppLdsT& sh, int tmax, int n[BC_CLASSES], int off[BC_CLASSES]) {
@@ -1405,38 +1409,6 @@ __global__ __launch_bounds__(kThreads) void k6_threshold(BppLinArgs a) {
 }
 
 }  // namespace
-
-void build_bpp_cand(const EnergyTables& x, BppCandTable* t) {
-  std::memset(t, 0, sizeof(*t));
-  int n = 0;
-  for (int c = 0; c < BC_CLASSES; ++c) {
-    t->base[c] = n;
-    for (int T = 0; T <= kMaxLoop; ++T) {
-      for (int u1 = 0; u1 <= T; ++u1) {
-        const int u2 = T - u1, u = u1 > u2 ? u1 : u2;
-        int cls = -1;
-        double coef = 0.;
-        if (0 == u1 || 0 == u2) {
-          if (u >= 2) { cls = BC_B; coef = x.bulge[u]; }                                  // (u = 0: rule 1b; u = 1: special)
-        } else if (u > 2 && !(5 == T && (2 == u1 || 2 == u2))) {
-          cls = (1 == u1 || 1 == u2) ? BC_N : BC_I;
-          coef = x.interior[T] * x.ninio[u1 > u2 ? u1 - u2 : u2 - u1];
-        }
-        if (cls == c) { t->e[n].coef = coef; t->e[n].u1 = u1; t->e[n].T = T; ++n; }
-      }
-      t->upto[c][T] = n - t->base[c];
-    }
-  }
-  int r = 0;
-  for (int T = 0; T <= kMaxLoop + 1; ++T) {
-    t->run_off[T] = r;
-    if (T < kBppRunMin || T > kMaxLoop) continue;
-    for (int u1 = 2; u1 <= T - 2; ++u1) t->run_coef[r++] = x.interior[T] * x.ninio[u1 > T - u1 ? 2 * u1 - T : T - 2 * u1];
-    while (r & 3) t->run_coef[r++] = 0.;
-    for (int q = t->run_off[T] / 4; q < r / 4; ++q) { t->quad_T[q] = (uint8_t)T; t->quad_m[q] = (uint8_t)(4 * q - t->run_off[T]); }
-  }
-  t->quad_T[kBppRunMax / 4 - 1] = kBppRunMin; t->quad_m[kBppRunMax / 4 - 1] = 0;      // the zero quad: any valid address
-}
 
 hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hipStream_t st) {
   if (G <= 0) return hipSuccess;

@@ -7,6 +7,7 @@
 
 #include "device_layout.h"
 #include "energy_tables.h"
+#include "bpp_cand.h"
 
 namespace elemdp {
 
@@ -125,30 +126,6 @@ struct BppOut {
 // about e^(5.5 n) (3.4 kcal/mol per stack at kT = 0.616), and a span of W holds at most W / 2 of them -- e^550 at W = 200
 // against the limit e^709; wider bands go through the log-space filter (k3_bpp_*)
 constexpr int kBppLinMaxSpan = 200;
-// Candidate loops of rule 6c as a table (round 4).  A loop with u1 unpaired bases on the left and u2 on the right (T = u1 + u2 <=
-// kMaxLoop) weighs, in all but eight small shapes, g(u1, u2) * f(closing pair) * f(inner pair) (energy_param.hpp:775-792): the
-// factor of the pair that is NOT the cell being summed is folded into an extra plane of the band tables when that pair's value is
-// written (classes below), so a candidate costs one table load and one fma with a coefficient from this table; the lanes of a
-// workgroup walk the entries in the same order whatever the sequence (no mask walk, no branch per candidate).
-enum { BC_I = 0, BC_N, BC_B, BC_CLASSES };   // generic loops (mismatch_i); 1 x n loops (mismatch_1ni); bulges of two and more bases (term_au)
-struct BppCand { double coef; int32_t u1, T; };
-constexpr int kBppCandMax = 496;
-constexpr int kBppRunMin = 6;                  // from T = 6 on every (u1, T - u1), u1 = 2 .. T - 2, is a generic loop
-constexpr int kBppRunMax = 416;
-struct BppCandTable {
-  int32_t base[BC_CLASSES];                    // first entry of a class in e[]
-  int32_t upto[BC_CLASSES][kMaxLoop + 1];      // entries of the class with u1 + u2 <= T (entries are sorted by T)
-  // the generic class once more as RUNS: the entries u1 = 2 .. T - 2 of one T are neighbours in a plane row, so the per-sequence
-  // kernels take them with 16-byte loads: run_coef[run_off[T] + m] = g(2 + m, T - 2 - m) (symmetric in its arguments: the outside
-  // sweep walks the row the other way with the same array), each run padded with zeros to a multiple of four
-  int32_t run_off[kMaxLoop + 2];
-  BppCand e[kBppCandMax];
-  double run_coef[kBppRunMax];                 // (the last four are zeros: the quad a lane takes past the end of its list)
-  uint8_t quad_T[kBppRunMax / 4], quad_m[kBppRunMax / 4];   // quad q = run_coef[4q .. 4q+3] belongs to T = quad_T[q], starts at m = quad_m[q]
-};
-void build_bpp_cand(const EnergyTables& xet, BppCandTable* t);
-// the eight shapes that do not factorise (stacked bulge, 1x1, 1x2, 2x1, 2x2, 2x3, 3x2): evaluated by loop_weight
-constexpr int kBppSpecial = 8;
 constexpr int kBppInPlanes = 7 + BC_CLASSES + 1, kBppOutPlanes = 5 + BC_CLASSES;
 struct BppLinArgs {
   const EnergyTables* et;

@@ -8,6 +8,7 @@
 // (pytest -m "not gpu").  The thread mapping, LDS staging, barriers and reductions of the real
 // kernels are covered by the -m gpu tests.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -19,10 +20,12 @@
 #include "../../rnaelem_amd/csrc/energy_tables.h"
 #include "../../rnaelem_amd/csrc/host_prep.h"
 #include <limits>
+#include <memory>
 #include "../../rnaelem_amd/csrc/lin_rules.h"
 #include "../../rnaelem_amd/csrc/lin_fast.h"
 #include "../../rnaelem_amd/csrc/plan_rules.h"
 #include "../../rnaelem_amd/csrc/scan_rules.h"
+#include "../../rnaelem_amd/csrc/bpp_cand.h"
 
 using namespace elemdp;
 static long g_enum_checked = 0, g_enum_mismatch = 0;
@@ -538,6 +541,69 @@ thread_local std::string g_err;
 
 extern "C" {
 // plans built so far / differences between the two interior-loop enumerators (must stay 0)
+// The candidate table of the BPP filter (bpp_cand.h) against loop_weight, shape by shape and context by context: every (u1, u2) with
+// u1 + u2 <= kMaxLoop except (0, 0) is either one of the eight special shapes or exactly one table entry whose coefficient times the
+// closing pair's factor times the inner pair's factor is loop_weight (to a few ulp: the same products in another order); the runs
+// of the generic class repeat the entries' coefficients.  Returns the number of violations; *max_rel = largest relative deviation.
+long emu_check_bpp_cand(void* h, double* max_rel) {
+  Emu& E = *static_cast<Emu*>(h);
+  std::unique_ptr<EnergyTables> xp(new EnergyTables);
+  exp_tables(E.et, xp.get());
+  const EnergyTables& x = *xp;
+  std::unique_ptr<BppCandTable> tp(new BppCandTable);
+  build_bpp_cand(x, tp.get());
+  const BppCandTable& t = *tp;
+  long bad = 0;
+  double worst = 0.;
+  static const char pl[7][2] = {{0, 0}, {2, 3}, {3, 2}, {3, 4}, {4, 3}, {1, 4}, {4, 1}};   // bases of pair type 1 .. 6 (bp_type)
+  for (int ty = 1; ty <= 6; ++ty)
+    if (bp_type(pl[ty][0], pl[ty][1]) != ty) ++bad;
+  int seen[kMaxLoop + 1][kMaxLoop + 1] = {};
+  for (int c = 0; c < BC_CLASSES; ++c) {
+    const int n = t.upto[c][kMaxLoop];
+    for (int k = 0; k < n; ++k) {
+      const BppCand& e = t.e[t.base[c] + k];
+      if (e.T < 0 || e.T > kMaxLoop || e.u1 < 0 || e.u1 > e.T) { ++bad; continue; }
+      seen[e.u1][e.T - e.u1] += 1 + 10 * c;
+      if (k > 0 && t.e[t.base[c] + k - 1].T > e.T) ++bad;                       // sorted by T
+      if (t.upto[c][e.T] <= k || (e.T > 0 && t.upto[c][e.T - 1] > k)) ++bad;    // the prefix counts
+    }
+  }
+  for (int u1 = 0; u1 <= kMaxLoop; ++u1)
+    for (int u2 = 0; u1 + u2 <= kMaxLoop; ++u2) {
+      bool special = (u1 == 0 && u2 == 0);
+      for (int k = 0; k < kBppSpecial; ++k) special = special || (kBppSpecialU1[k] == u1 && kBppSpecialU2[k] == u2);
+      if (special) { if (seen[u1][u2] != 0) ++bad; continue; }
+      const int c = (seen[u1][u2] - 1) / 10;
+      if (seen[u1][u2] != 1 + 10 * c || c < 0 || c >= BC_CLASSES) { ++bad; continue; }
+      double coef = 0.;
+      for (int k = 0; k < t.upto[c][kMaxLoop]; ++k) { const BppCand& e = t.e[t.base[c] + k]; if (e.u1 == u1 && e.T == u1 + u2) coef = e.coef; }
+      if (c == BC_I) {
+        const int T = u1 + u2;
+        if (T < kBppRunMin || t.run_coef[t.run_off[T] + (u1 - 2)] != coef || t.quad_T[(t.run_off[T] + (u1 - 2)) / 4] != T) ++bad;
+      }
+      // closing pair (i, j), inner pair (p, q); the four neighbours get every base incl. N
+      uint8_t s[2 * kMaxLoop + 16];
+      const int i = 0, pp = u1 + 1, qq = pp + 3, j = qq + u2 + 1;
+      for (int ty = 1; ty <= 6; ++ty)
+        for (int ty2 = 1; ty2 <= 6; ++ty2)
+          for (int nb = 0; nb < 625; ++nb) {
+            for (int z = 0; z <= j; ++z) s[z] = 1;
+            s[i + 1] = nb % 5; s[j - 1] = (nb / 5) % 5; s[pp - 1] = (nb / 25) % 5; s[qq + 1] = nb / 125;
+            s[i] = pl[ty][0]; s[j] = pl[ty][1]; s[qq] = pl[ty2][0]; s[pp] = pl[ty2][1];     // type2 = bp_type(s[q], s[p])
+            const double ref = loop_weight(x, s, i, j, pp, qq);
+            const int mo = ty * 25 + s[i + 1] * 5 + s[j - 1], mi = ty2 * 25 + s[qq + 1] * 5 + s[pp - 1];
+            const double fo = c == BC_I ? x.mismatch_i[mo] : c == BC_N ? x.mismatch_1ni[mo] : (is_au(ty) ? x.term_au : 1.);
+            const double fi = c == BC_I ? x.mismatch_i[mi] : c == BC_N ? x.mismatch_1ni[mi] : (is_au(ty2) ? x.term_au : 1.);
+            const double got = coef * fo * fi;
+            const double rel = ref == got ? 0. : std::fabs(got - ref) / std::max(std::fabs(ref), 1e-300);
+            worst = std::max(worst, rel);
+            if (!(rel <= 1e-14)) ++bad;
+          }
+    }
+  if (max_rel) *max_rel = worst;
+  return bad;
+}
 long emu_enum_checked() { return g_enum_checked; }
 long emu_enum_mismatches() { return g_enum_mismatch; }
 long emu_fast_cells() { return g_fast_cells; }

@@ -3,6 +3,8 @@ weight tables, cell records, ScanFlag words; the pair records and tuple column r
 outside sweep on the automaton with the shadow copy of state (0,0), compiled into the serial test driver (tests/emul) and
 pinned to the oracle on the same cases as the generic rule code.  The GPU-less container thereby checks the path the bench
 measures, not only the rules it was derived from."""
+import os
+
 import numpy as np
 import pytest
 
@@ -129,3 +131,24 @@ def test_deterministic_mode_tuple_lists(pattern, prune):
     e = Emul(pattern, PAR)
     e.set_prune(prune)
     assert lib().emu_check_det_lists(e.h) == 0
+
+
+def test_candidate_table_of_the_filter_reproduces_loop_weight():
+    """The BPP filter's candidate table (bpp_cand.h: coefficient per shape, the other factors folded into planes by the kernels)
+    against loop_weight for every shape u1 + u2 <= 30, every pair of pair types and every choice of the four neighbour bases
+    incl. N, for both parameter sets: each shape is a special one or exactly one entry, entries sorted by size with the right
+    prefix counts, the runs of the generic class repeat the entries, and coefficient x closing factor x inner factor =
+    loop_weight to 1e-14 (the same products in another order)."""
+    import ctypes
+    from tests.emul import pyemul
+    from oracle import pyoracle as po
+    L = pyemul.lib()
+    L.emu_check_bpp_cand.restype = ctypes.c_long
+    L.emu_check_bpp_cand.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+    for par in (po.DEFAULT_PAR, os.path.join(os.path.dirname(po.DEFAULT_PAR), "andronescu2007.elempar")):
+        if not os.path.exists(par):
+            continue
+        e = pyemul.Emul("(.)", open(par).read())
+        worst = ctypes.c_double(0.)
+        assert L.emu_check_bpp_cand(e.h, ctypes.byref(worst)) == 0
+        assert worst.value <= 1e-14
