@@ -381,3 +381,35 @@ def test_table_layouts_agree(pattern):
             np.testing.assert_allclose(p["end"], q["end"], rtol=1e-10, atol=1e-300)
             assert p["exist_prob"] == pytest.approx(q["exist_prob"], rel=1e-10)
         np.testing.assert_allclose(ea, eb, rtol=1e-10, atol=1e-12)
+
+
+def test_filter_forms_on_random_lengths(monkeypatch):
+    """The per-sequence filter kernels (default) against the mask walk on 150 sequences of random lengths 1 .. 600 in one batch
+    (the LDS image of the per-sequence kernels is sized by the longest -- 62 KB here, inside their 80 KB; beyond it a batch takes
+    the launches per diagonal, which the 900 of the second round does; short sequences take C = W - 7 < 30; every tenth has N
+    bases; a band of 50 and one of 33): identical kept sets and kept fractions, ln BPP to 1e-10."""
+    rng = np.random.default_rng(77)
+    for W, lmax in ((50, 600), (33, 600), (50, 900)):
+        seqs, quals = [], []
+        for k in range(150):
+            L = int(rng.integers(1, lmax + 1)) if k % 3 else int(rng.integers(1, 70))
+            (s_,), (q_,) = synth.synth_batch(1, L, seed=int(rng.integers(1 << 30)))
+            if k % 10 == 0 and L > 10:
+                s_ = s_.copy()
+                s_[rng.integers(0, L, size=max(1, L // 20))] = 0
+            seqs.append(s_)
+            quals.append(q_)
+        res = {}
+        for mode in ("", "ELEMDP_BPP_WALK"):
+            monkeypatch.delenv("ELEMDP_BPP_WALK", raising=False)
+            if mode:
+                monkeypatch.setenv(mode, "1")
+            eng = api.Engine("(.)", "~T2004~", W, 30, 1e-4)
+            eng.set_option("keep_lnbpp", 1)
+            eng.load_batch(seqs, quals)
+            res[mode] = ([eng.pairs(k, with_lnbpp=True) for k in range(len(seqs))], eng.bpp_eff())
+        monkeypatch.delenv("ELEMDP_BPP_WALK", raising=False)
+        for k, ((ka, la), (kb, lb)) in enumerate(zip(res[""][0], res["ELEMDP_BPP_WALK"][0])):
+            assert np.array_equal(ka, kb), (W, k, len(seqs[k]))
+            assert_log_close(la, lb, rtol=1e-10, atol=1e-10, what="lnbpp W=%d k=%d L=%d" % (W, k, len(seqs[k])))
+        np.testing.assert_array_equal(res[""][1], res["ELEMDP_BPP_WALK"][1])
