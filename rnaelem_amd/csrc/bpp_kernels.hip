@@ -1415,10 +1415,12 @@ hipError_t launch_bpp_lin(const BppLinArgs& base, int G, int Lmax, int Wmax, hip
   BppLinArgs a = base;
   // the candidate-table kernels need the loop energies (without them every loop weighs 1, whatever its size: the mask walk)
   const bool tab = a.cand && !a.no_ene && !getenv("ELEMDP_BPP_WALK");
-  // one workgroup per sequence for a whole direction where its LDS image fits twice per CU
+  // one workgroup per sequence for a whole direction where its LDS image fits a CU (two or three per CU up to L ~ 600)
   a.lmax = Lmax; a.wmax = Wmax;
   const SeqLdsLayout yi = seq_lds_layout(Lmax, Wmax, a.pmax, false), yo = seq_lds_layout(Lmax, Wmax, a.pmax, true);
-  const bool per_seq = tab && a.plist && a.poff && Lmax < 32767 && yo.total <= 80 * 1024 && !getenv("ELEMDP_BPP_DIAG");
+  const char* cap_env = getenv("ELEMDP_BPP_SEQ_KB");      // (experiments: the largest LDS image the per-sequence kernels take)
+  const int cap_kb = cap_env ? atoi(cap_env) : 150;        // (one workgroup per CU still beats the launches per diagonal: 2 000 x L=1000 load 0.140 -> 0.108 s)
+  const bool per_seq = tab && a.plist && a.poff && Lmax < 32767 && yo.total <= cap_kb * 1024 && !getenv("ELEMDP_BPP_DIAG");
   if (!per_seq) a.plist = nullptr;
   const int ncell_max = (Lmax + 1) * (Wmax + 1);
   const size_t lds_bits = sizeof(uint32_t) * (size_t)bpp_mask_words(Wmax);

@@ -385,8 +385,8 @@ def test_table_layouts_agree(pattern):
 
 def test_filter_forms_on_random_lengths(monkeypatch):
     """The per-sequence filter kernels (default) against the mask walk on 150 sequences of random lengths 1 .. 600 in one batch
-    (the LDS image of the per-sequence kernels is sized by the longest -- 62 KB here, inside their 80 KB; beyond it a batch takes
-    the launches per diagonal, which the 900 of the second round does; short sequences take C = W - 7 < 30; every tenth has N
+    (the LDS image of the per-sequence kernels is sized by the longest: 62 KB, three workgroups per CU -- and 88 KB with the 900 of
+    the third round, one per CU; short sequences take C = W - 7 < 30; every tenth has N
     bases; a band of 50 and one of 33): identical kept sets and kept fractions, ln BPP to 1e-10."""
     rng = np.random.default_rng(77)
     for W, lmax in ((50, 600), (33, 600), (50, 900)):
